@@ -1,0 +1,145 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of librox_oracle.so (the plain-C
+CPU restatement in rox_oracle.c).  Imported by tests/, by
+__graft_entry__.smoke() and by bench.py's cpu_baseline leg, never by the
+product package.  Struct definitions are shared with the product because they
+are the data format under test."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from rayoptics_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', _HERE, 'librox_oracle.so'])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, 'librox_oracle.so')
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        P = C.POINTER
+        L.rox_oracle_trace_rays.restype = C.c_int
+        L.rox_oracle_trace_rays.argtypes = [P(abi.Surface), i32, vp, i32, i64,
+                                            vp, vp, vp, i32, P(abi.Opts), P(abi.Out)]
+        L.rox_oracle_trace_pupil_grid.restype = C.c_int
+        L.rox_oracle_trace_pupil_grid.argtypes = [P(abi.Surface), i32, vp, i32,
+                                                  P(abi.Field), P(abi.Grid), i32,
+                                                  P(abi.Opts), P(abi.Out)]
+        L.rox_oracle_trace_pupil_list.restype = C.c_int
+        L.rox_oracle_trace_pupil_list.argtypes = [P(abi.Surface), i32, vp, i32,
+                                                  P(abi.Field), i64, vp, vp, i32,
+                                                  P(abi.Opts), P(abi.Out)]
+        L.rox_oracle_intersect.restype = C.c_int
+        L.rox_oracle_intersect.argtypes = [P(abi.Surface), vp, vp, C.c_double,
+                                           C.c_double, P(C.c_double), vp, vp]
+        _LIB = L
+    return _LIB
+
+
+class HostResult:
+    """numpy-backed SoA result buffers in the product's output layout,
+    NaN / 0xff pre-filled so untouched slots compare equal."""
+
+    def __init__(self, n_seg_rows, R, out_mode, want_pupil=False):
+        self.R = R
+        self.out_mode = out_mode
+        if out_mode == abi.OUT_FULL:
+            shape = (n_seg_rows, abi.SEG_DOUBLES, R)
+        elif out_mode == abi.OUT_LAST:
+            shape = (abi.SEG_DOUBLES, R)
+        else:
+            shape = (2, R)
+        self.seg = np.full(shape, np.nan)
+        self.op = np.full(R, np.nan)
+        self.status = np.full(R, 255, dtype=np.uint8)
+        self.fail_surf = np.full(R, -2, dtype=np.int16)
+        self.pupil = np.full((2, R), np.nan) if want_pupil else None
+
+    def out_struct(self):
+        o = abi.Out()
+        o.seg = self.seg.ctypes.data
+        o.op = self.op.ctypes.data
+        o.status = self.status.ctypes.data
+        o.fail_surf = self.fail_surf.ctypes.data
+        o.pupil = self.pupil.ctypes.data if self.pupil is not None else None
+        o.ld = self.R
+        return o
+
+
+def make_opts(flags=abi.INTERSECT_OBJ, out_mode=abi.OUT_FULL, first_surf=0,
+              last_surf=-1, eps=1.0e-12, fuzz=1e-5, foc=0.0, image_pt=(0., 0.)):
+    o = abi.Opts()
+    o.flags, o.out_mode = flags, out_mode
+    o.first_surf, o.last_surf = first_surf, last_surf
+    o.eps, o.fuzz, o.foc = eps, fuzz, foc
+    o.image_pt[0], o.image_pt[1] = image_pt
+    return o
+
+
+def trace_rays(table, pt0, dir0, wvl_idx, opts):
+    """pt0, dir0: float64 [3][R]; wvl_idx: int or int32[R]"""
+    pt0 = np.ascontiguousarray(pt0, dtype=np.float64)
+    dir0 = np.ascontiguousarray(dir0, dtype=np.float64)
+    R = pt0.shape[1]
+    res = HostResult(table.n_ifcs, R, opts.out_mode)
+    out = res.out_struct()
+    if np.ndim(wvl_idx) == 0:
+        wi_ptr, wi_all = None, int(wvl_idx)
+    else:
+        wi = np.ascontiguousarray(wvl_idx, dtype=np.int32)
+        wi_ptr, wi_all = wi.ctypes.data, 0
+    rc = lib().rox_oracle_trace_rays(table.rows, table.n_ifcs,
+                                     table.n_table.ctypes.data, len(table.wvls),
+                                     R, pt0.ctypes.data, dir0.ctypes.data,
+                                     wi_ptr, wi_all, C.byref(opts), C.byref(out))
+    if rc:
+        raise RuntimeError(f'oracle error {rc}')
+    return res
+
+
+def trace_pupil_grid(table, fld, grid, wvl_idx, opts):
+    R = grid.num if grid.kind == abi.GRID_FAN else grid.num * grid.num
+    res = HostResult(table.n_ifcs, R, opts.out_mode, want_pupil=True)
+    out = res.out_struct()
+    rc = lib().rox_oracle_trace_pupil_grid(table.rows, table.n_ifcs,
+                                           table.n_table.ctypes.data,
+                                           len(table.wvls), C.byref(fld),
+                                           C.byref(grid), wvl_idx,
+                                           C.byref(opts), C.byref(out))
+    if rc:
+        raise RuntimeError(f'oracle error {rc}')
+    return res
+
+
+def trace_pupil_list(table, fld, px, py, wvl_idx, opts):
+    px = np.ascontiguousarray(px, dtype=np.float64)
+    py = np.ascontiguousarray(py, dtype=np.float64)
+    R = px.shape[0]
+    res = HostResult(table.n_ifcs, R, opts.out_mode, want_pupil=True)
+    out = res.out_struct()
+    rc = lib().rox_oracle_trace_pupil_list(table.rows, table.n_ifcs,
+                                           table.n_table.ctypes.data,
+                                           len(table.wvls), C.byref(fld), R,
+                                           px.ctypes.data, py.ctypes.data,
+                                           wvl_idx, C.byref(opts), C.byref(out))
+    if rc:
+        raise RuntimeError(f'oracle error {rc}')
+    return res
+
+
+def make_grid(start, stop, num, kind=abi.GRID_PRODUCT):
+    g = abi.Grid()
+    g.start[0], g.start[1] = start
+    g.stop[0], g.stop[1] = stop
+    g.num, g.kind = num, kind
+    return g

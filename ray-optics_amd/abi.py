@@ -1,0 +1,123 @@
+"""ctypes mirror of include/roxtrace.h (the C ABI of libroxtrace.so).
+
+Only plain structs and constants live here; loading the HIP library is done
+by :mod:`rayoptics_amd.engine`, which fails loudly when it is missing.
+"""
+import ctypes as C
+
+ABI_VERSION = 1
+MAX_COEF = 10
+MAX_AP = 4
+SEG_DOUBLES = 10
+
+# interact_mode  (rayoptics/raytr/raytrace.py:211-221)
+TRANSMIT, REFLECT, DUMMY, PHANTOM = 0, 1, 2, 3
+MODE_NAMES = {'transmit': TRANSMIT, 'reflect': REFLECT, 'dummy': DUMMY,
+              'phantom': PHANTOM}
+# profile kinds  (rayoptics/elem/profiles.py)
+SPHERICAL, CONIC, EVENPOLY, RADIALPOLY = 0, 1, 2, 3
+PROFILE_NAMES = {'Spherical': SPHERICAL, 'Conic': CONIC,
+                 'EvenPolynomial': EVENPOLY, 'RadialPolynomial': RADIALPOLY}
+# aperture kinds (rayoptics/elem/surface.py:398-494)
+AP_CIRCULAR, AP_RECTANGULAR, AP_ALWAYS_BLOCK = 0, 1, 2
+# per-ray status (rayoptics/raytr/traceerror.py)
+OK, MISSED_SURFACE, TIR, BLOCKED, EVANESCENT = 0, 1, 2, 3, 4
+# output modes
+OUT_FULL, OUT_LAST, OUT_HITS = 0, 1, 2
+# flags
+CHECK_APERTURES = 1
+INTERSECT_OBJ = 2
+FILTER_PHANTOMS = 4
+APPLY_VIGNETTING = 8
+HOST_POINTERS = 16
+# grid kinds
+GRID_PRODUCT, GRID_FAN = 0, 1
+
+
+class Aperture(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('is_obscuration', C.c_int32),
+                ('x_offset', C.c_double), ('y_offset', C.c_double),
+                ('a', C.c_double), ('b', C.c_double)]
+
+
+class Surface(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('profile', C.c_int32),
+                ('ncoef', C.c_int32), ('n_ap', C.c_int32),
+                ('cv', C.c_double), ('cc', C.c_double), ('ec', C.c_double),
+                ('coefs', C.c_double * MAX_COEF),
+                ('rt', C.c_double * 9), ('t', C.c_double * 3),
+                ('z_dir', C.c_double), ('max_aperture', C.c_double),
+                ('ap', Aperture * MAX_AP)]
+
+
+class Opts(C.Structure):
+    _fields_ = [('flags', C.c_uint32), ('out_mode', C.c_int32),
+                ('first_surf', C.c_int32), ('last_surf', C.c_int32),
+                ('eps', C.c_double), ('fuzz', C.c_double),
+                ('foc', C.c_double), ('image_pt', C.c_double * 2)]
+
+
+class Field(C.Structure):
+    _fields_ = [('pt0', C.c_double * 3), ('aim', C.c_double * 2),
+                ('eprad', C.c_double), ('z_enp', C.c_double),
+                ('vlx', C.c_double), ('vux', C.c_double),
+                ('vly', C.c_double), ('vuy', C.c_double),
+                ('z_dir0', C.c_double)]
+
+
+class Grid(C.Structure):
+    _fields_ = [('start', C.c_double * 2), ('stop', C.c_double * 2),
+                ('num', C.c_int32), ('kind', C.c_int32)]
+
+
+class Out(C.Structure):
+    _fields_ = [('seg', C.c_void_p), ('op', C.c_void_p),
+                ('status', C.c_void_p), ('fail_surf', C.c_void_p),
+                ('pupil', C.c_void_p), ('ld', C.c_int64)]
+
+
+assert C.sizeof(Aperture) == 40
+assert C.sizeof(Surface) == 392
+assert C.sizeof(Opts) == 56
+assert C.sizeof(Field) == 96
+assert C.sizeof(Grid) == 40
+assert C.sizeof(Out) == 48
+
+# every symbol include/roxtrace.h declares (checked by tests/test_abi.py)
+EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
+           'rox_last_error', 'rox_system_create', 'rox_system_destroy',
+           'rox_system_num_segments', 'rox_trace_rays',
+           'rox_trace_pupil_grid', 'rox_trace_pupil_list',
+           'rox_time_pupil_grid')
+
+
+def declare(lib):
+    """attach argtypes/restype for every export of libroxtrace.so"""
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    P = C.POINTER
+    lib.rox_abi_version.restype = C.c_int
+    lib.rox_abi_version.argtypes = []
+    lib.rox_device_count.restype = C.c_int
+    lib.rox_device_count.argtypes = [P(C.c_int)]
+    lib.rox_set_device.restype = C.c_int
+    lib.rox_set_device.argtypes = [C.c_int]
+    lib.rox_last_error.restype = C.c_char_p
+    lib.rox_last_error.argtypes = []
+    lib.rox_system_create.restype = C.c_int
+    lib.rox_system_create.argtypes = [P(Surface), i32, vp, i32, P(vp)]
+    lib.rox_system_destroy.restype = C.c_int
+    lib.rox_system_destroy.argtypes = [vp]
+    lib.rox_system_num_segments.restype = C.c_int
+    lib.rox_system_num_segments.argtypes = [vp, C.c_uint32, P(i32)]
+    lib.rox_trace_rays.restype = C.c_int
+    lib.rox_trace_rays.argtypes = [vp, i64, vp, vp, vp, i32, P(Opts), P(Out), vp]
+    lib.rox_trace_pupil_grid.restype = C.c_int
+    lib.rox_trace_pupil_grid.argtypes = [vp, P(Field), P(Grid), i32, P(Opts),
+                                         P(Out), vp]
+    lib.rox_trace_pupil_list.restype = C.c_int
+    lib.rox_trace_pupil_list.argtypes = [vp, P(Field), i64, vp, vp, i32,
+                                         P(Opts), P(Out), vp]
+    lib.rox_time_pupil_grid.restype = C.c_int
+    lib.rox_time_pupil_grid.argtypes = [vp, P(Field), P(Grid), i32, P(Opts),
+                                        P(Out), vp, i32, P(dbl)]
+    return lib

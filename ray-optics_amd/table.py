@@ -1,0 +1,288 @@
+"""Flat surface table: the read-only model data the trace kernels consume.
+
+The reference hands ``trace_raw`` a per-wavelength list of path tuples
+``(Intfc, Gap, Tfrm, Indx, Zdir)`` (rayoptics/seq/sequential.py:149-202,
+rayoptics/optical/model_constants.py:12).  :class:`SurfaceTable` flattens that
+list into ``rox_surface`` rows (include/roxtrace.h) plus an ``n_table[W][N]``
+of refractive indices, by *reading* a live reference ``SequentialModel`` --
+nothing is re-derived: transforms come from ``seq_model.lcl_tfrms``, indices
+from ``seq_model.rndx``, ``max_nonzero_coef`` from the profile.
+
+Interfaces the kernels do not implement (phase elements, thin lenses, toroids,
+unknown aperture classes) raise :class:`UnsupportedModelError` so that callers
+keep such models on the reference's own CPU path.
+"""
+import json
+import numpy as np
+
+from . import abi
+
+
+class UnsupportedModelError(Exception):
+    """the model uses an interface kind the device kernels do not cover"""
+
+
+def _profile_row(row, prof):
+    kind = type(prof).__name__
+    if kind not in abi.PROFILE_NAMES:
+        raise UnsupportedModelError(f'profile {kind} is not supported')
+    row.profile = abi.PROFILE_NAMES[kind]
+    row.cv = float(prof.cv)
+    if kind == 'Spherical':
+        row.cc, row.ec = 0.0, 1.0
+    elif kind == 'RadialPolynomial':
+        # stores ec; cc is the derived property (profiles.py:930-937)
+        row.ec = float(prof.ec)
+        row.cc = float(prof.cc)
+    else:
+        row.cc = float(prof.cc)
+        row.ec = float(prof.ec)         # property: cc + 1.0 (profiles.py:515-517)
+    if kind in ('EvenPolynomial', 'RadialPolynomial'):
+        coefs = [float(c) for c in prof.coefs]
+        # profiles.py:827-832 calc_max_nonzero_coef (refreshed by update())
+        mnc = getattr(prof, 'max_nonzero_coef', None)
+        if mnc is None:
+            mnc = 0
+            for i, c in enumerate(coefs):
+                if c != 0.0:
+                    mnc = i + 1
+        if mnc > abi.MAX_COEF:
+            raise UnsupportedModelError(
+                f'{kind} with {mnc} coefficients (max {abi.MAX_COEF})')
+        row.ncoef = int(mnc)
+        for i in range(mnc):
+            row.coefs[i] = coefs[i]
+
+
+def _aperture_rows(row, ifc):
+    cas = getattr(ifc, 'clear_apertures', None) or []
+    if len(cas) > abi.MAX_AP:
+        raise UnsupportedModelError(f'{len(cas)} clear apertures on one surface')
+    row.n_ap = len(cas)
+    for k, ca in enumerate(cas):
+        a = row.ap[k]
+        kind = type(ca).__name__
+        a.is_obscuration = 1 if getattr(ca, 'is_obscuration', False) else 0
+        a.x_offset = float(getattr(ca, 'x_offset', 0.0))
+        a.y_offset = float(getattr(ca, 'y_offset', 0.0))
+        if kind == 'Circular':
+            a.kind, a.a, a.b = abi.AP_CIRCULAR, float(ca.radius), 0.0
+        elif kind == 'Rectangular':
+            a.kind = abi.AP_RECTANGULAR
+            a.a, a.b = float(ca.x_half_width), float(ca.y_half_width)
+        elif kind == 'Elliptical':
+            # no point_inside() in the reference (surface.py:472-494): the base
+            # class returns None, so every ray is blocked
+            a.kind = abi.AP_ALWAYS_BLOCK
+            a.a, a.b = float(ca.x_half_width), float(ca.y_half_width)
+        else:
+            raise UnsupportedModelError(f'aperture {kind} is not supported')
+
+
+class SurfaceTable:
+    """rows[N] of ``rox_surface`` + n_table[W][N] + the wavelengths (nm)."""
+
+    def __init__(self, rows, n_table, wvls, stop_idx=None):
+        self.rows = rows
+        self.n_table = np.ascontiguousarray(n_table, dtype=np.float64)
+        self.wvls = [float(w) for w in wvls]
+        self.stop_idx = stop_idx
+        assert self.n_table.shape == (len(self.wvls), len(rows))
+
+    @property
+    def n_ifcs(self):
+        return len(self.rows)
+
+    def wvl_index(self, wvl):
+        """rayoptics/seq/sequential.py:281-285 index_for_wavelength: the
+        wavelength must be an exact member of the spectral region."""
+        return self.wvls.index(float(wvl))
+
+    def has_phantoms(self):
+        return any(r.mode == abi.PHANTOM for r in self.rows)
+
+    # -- builders ---------------------------------------------------------
+    @classmethod
+    def from_paths(cls, paths, wvls, stop_idx=None):
+        """paths[w] = list of reference path tuples for wavelength wvls[w]."""
+        N = len(paths[0])
+        rows = (abi.Surface * N)()
+        n_table = np.ones((len(wvls), N))
+        prev_zdir = 1.0
+        for i, seg in enumerate(paths[0]):
+            ifc, _gap, tfrm, _n, zdir = seg
+            row = rows[i]
+            if hasattr(ifc, 'phase_element'):
+                raise UnsupportedModelError('phase elements stay on the CPU path')
+            if not hasattr(ifc, 'profile'):
+                raise UnsupportedModelError(
+                    f'interface {type(ifc).__name__} has no surface profile')
+            row.mode = abi.MODE_NAMES.get(ifc.interact_mode, abi.DUMMY)
+            _profile_row(row, ifc.profile)
+            _aperture_rows(row, ifc)
+            row.max_aperture = float(ifc.max_aperture)
+            if tfrm is None:
+                rt, t = np.identity(3), np.zeros(3)
+            else:
+                rt, t = tfrm
+            for a in range(3):
+                for b in range(3):
+                    row.rt[3 * a + b] = float(rt[a][b])
+                row.t[a] = float(t[a])
+            if zdir is None:
+                zdir = prev_zdir
+            row.z_dir = float(zdir)
+            prev_zdir = float(zdir)
+        for w, path in enumerate(paths):
+            assert len(path) == N
+            for i, seg in enumerate(path):
+                n = seg[3]
+                n_table[w, i] = 1.0 if n is None else float(n)
+        return cls(rows, n_table, wvls, stop_idx)
+
+    @classmethod
+    def from_seq_model(cls, seq_model, wvls=None):
+        """read a live reference ``SequentialModel`` (duck-typed)."""
+        if wvls is None:
+            wvls = list(seq_model.opt_model['osp']['wvls'].wavelengths)
+        paths = [list(seq_model.path(wl=w)) for w in wvls]
+        return cls.from_paths(paths, wvls, getattr(seq_model, 'stop_surface', None))
+
+    @classmethod
+    def from_prescription(cls, surfaces, wvls=(587.6,), stop_idx=None):
+        """standalone builder for centred systems, no reference needed.
+
+        surfaces: one dict per interface (object first, image last) with keys
+        ``cv, thi, n`` (n: float or per-wavelength list; the medium *after*
+        the interface) and optional ``mode, profile, cc, ec, coefs,
+        max_aperture``.  Transforms follow rayoptics/elem/transform.py:143-166
+        for undecentered surfaces: Rt = I, t = (0, 0, thi); z_dir flips after
+        each mirror as in rayoptics/seq/sequential.py:640-655.
+        """
+        N = len(surfaces)
+        rows = (abi.Surface * N)()
+        n_table = np.ones((len(wvls), N))
+        zdir = 1.0
+        for i, s in enumerate(surfaces):
+            row = rows[i]
+            mode = s.get('mode', 'dummy' if i in (0, N - 1) else 'transmit')
+            row.mode = abi.MODE_NAMES[mode]
+            prof = s.get('profile', 'Spherical')
+            row.profile = abi.PROFILE_NAMES[prof]
+            row.cv = float(s.get('cv', 0.0))
+            if prof == 'RadialPolynomial':
+                row.ec = float(s.get('ec', 1.0))
+                row.cc = row.ec - 1.0
+            else:
+                row.cc = float(s.get('cc', 0.0))
+                row.ec = row.cc + 1.0
+            coefs = list(s.get('coefs', []))
+            mnc = 0
+            for k, c in enumerate(coefs):
+                if c != 0.0:
+                    mnc = k + 1
+            if mnc > abi.MAX_COEF:
+                raise UnsupportedModelError('too many coefficients')
+            row.ncoef = mnc
+            for k in range(mnc):
+                row.coefs[k] = float(coefs[k])
+            for a in range(3):
+                row.rt[4 * a] = 1.0
+            row.t[2] = float(s.get('thi', 0.0)) if i < N - 1 else 0.0
+            if mode == 'reflect':
+                zdir = -zdir
+            row.z_dir = zdir
+            row.max_aperture = float(s.get('max_aperture', 1.0))
+            n = s.get('n', 1.0)
+            for w in range(len(wvls)):
+                n_table[w, i] = float(n[w]) if isinstance(n, (list, tuple)) else float(n)
+        return cls(rows, n_table, wvls, stop_idx)
+
+    # -- (de)serialisation for golden fixtures ------------------------------
+    def to_dict(self):
+        rows = []
+        for r in self.rows:
+            rows.append(dict(
+                mode=r.mode, profile=r.profile, ncoef=r.ncoef, n_ap=r.n_ap,
+                cv=r.cv, cc=r.cc, ec=r.ec, coefs=list(r.coefs),
+                rt=list(r.rt), t=list(r.t), z_dir=r.z_dir,
+                max_aperture=r.max_aperture,
+                ap=[dict(kind=a.kind, is_obscuration=a.is_obscuration,
+                         x_offset=a.x_offset, y_offset=a.y_offset, a=a.a, b=a.b)
+                    for a in r.ap[:r.n_ap]]))
+        return dict(wvls=self.wvls, stop_idx=self.stop_idx,
+                    n_table=self.n_table.tolist(), rows=rows)
+
+    @classmethod
+    def from_dict(cls, d):
+        N = len(d['rows'])
+        rows = (abi.Surface * N)()
+        for row, s in zip(rows, d['rows']):
+            row.mode, row.profile = s['mode'], s['profile']
+            row.ncoef, row.n_ap = s['ncoef'], s['n_ap']
+            row.cv, row.cc, row.ec = s['cv'], s['cc'], s['ec']
+            for k, c in enumerate(s['coefs']):
+                row.coefs[k] = c
+            for k, v in enumerate(s['rt']):
+                row.rt[k] = v
+            for k, v in enumerate(s['t']):
+                row.t[k] = v
+            row.z_dir, row.max_aperture = s['z_dir'], s['max_aperture']
+            for k, a in enumerate(s['ap']):
+                ap = row.ap[k]
+                ap.kind, ap.is_obscuration = a['kind'], a['is_obscuration']
+                ap.x_offset, ap.y_offset = a['x_offset'], a['y_offset']
+                ap.a, ap.b = a['a'], a['b']
+        return cls(rows, np.array(d['n_table'], dtype=np.float64), d['wvls'],
+                   d.get('stop_idx'))
+
+    def save(self, path):
+        with open(path, 'w') as f:
+            json.dump(self.to_dict(), f)
+
+    @classmethod
+    def load(cls, path):
+        with open(path) as f:
+            return cls.from_dict(json.load(f))
+
+
+def field_struct(pt0, aim, eprad, z_enp, vig=(0., 0., 0., 0.), z_dir0=1.0):
+    """fill a ``rox_field`` (vig = (vlx, vux, vly, vuy))."""
+    f = abi.Field()
+    for i in range(3):
+        f.pt0[i] = float(pt0[i])
+    f.aim[0], f.aim[1] = float(aim[0]), float(aim[1])
+    f.eprad, f.z_enp = float(eprad), float(z_enp)
+    f.vlx, f.vux, f.vly, f.vuy = (float(v) for v in vig)
+    f.z_dir0 = float(z_dir0)
+    return f
+
+
+def field_from_model(opt_model, fld):
+    """per-field constants of the 'epd', non-wide-angle branch of
+    ``OpticalSpecs.ray_start_from_osp`` (rayoptics/raytr/opticalspec.py:289-366).
+
+    Raises :class:`UnsupportedModelError` for the branches that stay on the
+    host (angular pupil keys, wide-angle fields, telecentric pupils)."""
+    osp = opt_model['optical_spec']
+    fod = opt_model['analysis_results']['parax_data'].fod
+    if osp['fov'].is_wide_angle:
+        raise UnsupportedModelError('wide-angle fields are generated on the host')
+    pupil_oi_key, pupil_value_key = osp['pupil'].key
+    pupil_value = osp['pupil'].value
+    if pupil_oi_key == 'image':                      # :311-325
+        if abs(fod.m) < 1e-10 or not abs(fod.enp_dist) > 1e10:
+            pupil_value_key, pupil_value = 'epd', 2 * fod.enp_radius
+        else:
+            raise UnsupportedModelError('telecentric entrance pupil')
+    if pupil_value_key != 'epd':
+        raise UnsupportedModelError(f"pupil key {pupil_value_key!r} is generated on the host")
+    _p0, d0 = osp['fov'].obj_coords(fld)              # :308
+    aim_info = getattr(fld, 'aim_info', None)
+    aim_pt = [0., 0.] if aim_info is None else aim_info          # :359
+    z_enp = fod.enp_dist
+    obj2enp_dist = -(fod.obj_dist + z_enp)                       # :360
+    pt0 = obj2enp_dist * np.array([d0[0] / d0[2], d0[1] / d0[2], 0.])   # :364
+    return field_struct(pt0, aim_pt, pupil_value / 2, fod.obj_dist + z_enp,
+                        (fld.vlx, fld.vux, fld.vly, fld.vuy),
+                        opt_model['seq_model'].z_dir[0])

@@ -1,0 +1,359 @@
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE ITSELF
+(mjhoptics/ray-optics at /root/reference, imported through oracle/refshim.py).
+
+    python tests/golden/make_golden.py
+
+Runs only in the build container.  Each fixture holds
+  * the flat surface table (JSON, rayoptics_amd.SurfaceTable.to_dict) read
+    from the live reference SequentialModel,
+  * the inputs (explicit rays, or the per-field constants + grid definition),
+  * the reference's outputs, converted to the SoA layout of include/roxtrace.h
+    (seg[K][10][R], NaN where the reference produced nothing).
+The outputs come from the reference's own drivers:
+  rays  -> rayoptics.raytr.raytrace.trace            (raytrace.py:51-80)
+  grid  -> rayoptics.raytr.trace.trace_grid          (trace.py:563-605), every
+           RayResult recorded by wrapping trace.trace_safe
+  fan   -> rayoptics.raytr.trace.trace_fan           (trace.py:537-560)
+  spot  -> rayoptics.mpl.axisarrayfigure.SpotDiagramFigure.update_data
+           (axisarrayfigure.py:222-263) -> SequentialModel.trace_grid
+  list  -> rayoptics.raytr.analyses.trace_list_of_rays (analyses.py:458-510)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
+
+import refmodels as rm  # noqa: E402  (installs the reference shim)
+import rayoptics_amd as ra  # noqa: E402
+from rayoptics_amd import abi  # noqa: E402
+from rayoptics_amd.table import field_from_model  # noqa: E402
+
+import rayoptics.raytr.raytrace as rt  # noqa: E402
+import rayoptics.raytr.trace as trace  # noqa: E402
+import rayoptics.raytr.analyses as analyses  # noqa: E402
+from rayoptics.raytr import traceerror as terr  # noqa: E402
+from rayoptics.seq.sequential import gen_sequence  # noqa: E402
+
+SEED = 20260925
+
+
+def status_of(err):
+    if err is None:
+        return abi.OK
+    if isinstance(err, terr.TraceMissedSurfaceError):
+        return abi.MISSED_SURFACE
+    if isinstance(err, terr.TraceTIRError):
+        return abi.TIR
+    if isinstance(err, terr.TraceRayBlockedError):
+        return abi.BLOCKED
+    if isinstance(err, terr.TraceEvanescentRayError):
+        return abi.EVANESCENT
+    raise err
+
+
+class SoA:
+    """reference RayPkgs -> seg[K][10][R] + op + status + fail_surf"""
+
+    def __init__(self, K, R):
+        self.seg = np.full((K, 10, R), np.nan)
+        self.op = np.full(R, np.nan)
+        self.status = np.full(R, 255, dtype=np.uint8)
+        self.fail_surf = np.full(R, -2, dtype=np.int16)
+
+    def put(self, r, pkg, err):
+        self.status[r] = status_of(err)
+        self.fail_surf[r] = -1 if err is None else err.surf
+        if pkg is None:
+            return
+        ray, op, _wvl = pkg[0], pkg[1], pkg[2]
+        self.op[r] = op
+        for k, s in enumerate(ray):
+            self.seg[k, 0:3, r] = s[0]
+            self.seg[k, 3:6, r] = s[1]
+            self.seg[k, 6, r] = s[2]
+            self.seg[k, 7:10, r] = s[3]
+
+    def arrays(self, prefix=''):
+        return {prefix + 'seg': self.seg, prefix + 'op': self.op,
+                prefix + 'status': self.status,
+                prefix + 'fail_surf': self.fail_surf}
+
+
+def field_arr(f):
+    return np.array(list(f.pt0) + list(f.aim) + [f.eprad, f.z_enp, f.vlx, f.vux,
+                                                  f.vly, f.vuy, f.z_dir0])
+
+
+def trace_with_errors(sm, pt0, dir0, wvl, **kw):
+    try:
+        return rt.trace(sm, pt0, dir0, wvl, **kw), None
+    except terr.TraceError as e:
+        return e.ray_pkg, e
+
+
+def case_rays(opm, R, rng, check_apertures, pupil_scale=1.15):
+    """explicit (pt0, dir0, wvl) rays through raytrace.trace()"""
+    sm, osp = opm['seq_model'], opm['optical_spec']
+    wvls = list(osp['wvls'].wavelengths)
+    flds = osp['fov'].fields
+    N = len(sm.ifcs)
+    pt0 = np.zeros((3, R))
+    dir0 = np.zeros((3, R))
+    wi = rng.integers(0, len(wvls), R).astype(np.int32)
+    out = SoA(N, R)
+    for r in range(R):
+        fld = flds[rng.integers(0, len(flds))]
+        pupil = rng.uniform(-pupil_scale, pupil_scale, 2)
+        p, d = osp.ray_start_from_osp(pupil, fld, 'rel pupil')
+        if d[2] * sm.z_dir[0] < 0:
+            d = -d
+        pt0[:, r], dir0[:, r] = p, d
+        pkg, err = trace_with_errors(sm, p.copy(), d.copy(), wvls[wi[r]],
+                                     check_apertures=check_apertures)
+        out.put(r, pkg, err)
+    d = dict(pt0=pt0, dir0=dir0, wvl_idx=wi,
+             flags=np.int64(abi.INTERSECT_OBJ |
+                            (abi.CHECK_APERTURES if check_apertures else 0)),
+             first_surf=np.int64(1), last_surf=np.int64(N - 2))
+    d.update(out.arrays())
+    return d
+
+
+class Recorder:
+    """wraps rayoptics.raytr.trace.trace_safe to keep every RayResult and the
+    (vignetted, mutated-in-place) pupil array the driver passed."""
+
+    def __init__(self):
+        self.results = []
+        self._orig = trace.trace_safe
+
+    def __enter__(self):
+        def wrapped(opt_model, pupil, *a, **k):
+            res = self._orig(opt_model, pupil, *a, **k)
+            self.results.append((np.array(pupil, dtype=float), res))
+            return res
+        trace.trace_safe = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        trace.trace_safe = self._orig
+
+
+def case_grid(opm, fi, wvl, num, kind='grid', start=(-1., -1.), stop=(1., 1.)):
+    """the reference's trace_grid / trace_fan driver loop, FULL packets"""
+    sm, osp = opm['seq_model'], opm['optical_spec']
+    fld = osp['fov'].fields[fi]
+    foc = osp['focus'].focus_shift
+    N = len(sm.ifcs)
+    rng_def = [np.array(start), np.array(stop), num]
+    with Recorder() as rec:
+        if kind == 'grid':
+            # img_filter returns a scalar so that np.array(grid) at
+            # trace.py:605 stays homogeneous under NumPy 2 (ragged partial
+            # packets otherwise raise); the packets are kept by the Recorder
+            trace.trace_grid(opm, rng_def, fld, wvl, foc,
+                             img_filter=lambda p, pkg: 0.0,
+                             form='list', append_if_none=True,
+                             rayerr_filter='full')
+        else:
+            trace.trace_fan(opm, rng_def, fld, wvl, foc, img_filter=None,
+                            rayerr_filter='full', check_apertures=True)
+    R = len(rec.results)
+    out = SoA(N, R)
+    pupil = np.zeros((2, R))
+    for r, (pup, res) in enumerate(rec.results):
+        pupil[:, r] = pup
+        out.put(r, res.pkg, res.err)
+    d = dict(field=field_arr(field_from_model(opm, fld)),
+             wvl_idx=np.int64(list(osp['wvls'].wavelengths).index(wvl)),
+             start=np.array(start), stop=np.array(stop), num=np.int64(num),
+             kind=np.int64(abi.GRID_PRODUCT if kind == 'grid' else abi.GRID_FAN),
+             flags=np.int64(abi.INTERSECT_OBJ | abi.CHECK_APERTURES |
+                            abi.APPLY_VIGNETTING),
+             first_surf=np.int64(1), last_surf=np.int64(N - 2), pupil=pupil)
+    d.update(out.arrays())
+    return d
+
+
+def case_spot(opm, num_rays):
+    """SpotDiagramFigure's own data path: per field, per wavelength, the
+    (R_ok, 2) arrays of transverse aberrations"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    from rayoptics.mpl.axisarrayfigure import SpotDiagramFigure
+    osp = opm['optical_spec']
+    fig = plt.figure(FigureClass=SpotDiagramFigure, opt_model=opm,
+                     num_rays=num_rays)
+    fig.update_data()
+    d = dict(num=np.int64(num_rays), foc=np.float64(osp['focus'].focus_shift))
+    nf = len(osp['fov'].fields)
+    # axis_data_array is filled in reversed(range(num_rows)) order
+    for row_i, row in enumerate(fig.axis_data_array):
+        fi = nf - 1 - row_i
+        grids, _max_val, _rc = row[0]
+        fld = osp['fov'].fields[fi]
+        d[f'f{fi}_field'] = field_arr(field_from_model(opm, fld))
+        d[f'f{fi}_image_pt'] = np.array(fld.ref_sphere[0][:2])
+        for wi, g in enumerate(grids):
+            d[f'f{fi}_w{wi}_hits'] = np.array(g, dtype=float).reshape(-1, 2)
+    plt.close(fig)
+    return d
+
+
+def case_list_of_rays(opm, R, rng):
+    """analyses.trace_list_of_rays with output_filter='last'"""
+    sm, osp = opm['seq_model'], opm['optical_spec']
+    wvls = list(osp['wvls'].wavelengths)
+    fld = osp['fov'].fields[-1]
+    rays = []
+    for r in range(R):
+        pupil = rng.uniform(-0.9, 0.9, 2)
+        p, d = osp.ray_start_from_osp(pupil, fld, 'rel pupil')
+        rays.append((p, d, wvls[r % len(wvls)]))
+    res = analyses.trace_list_of_rays(opm, rays, output_filter='last',
+                                      rayerr_filter='summary',
+                                      check_apertures=True)
+    last = np.full((10, R), np.nan)
+    op = np.full(R, np.nan)
+    status = np.zeros(R, dtype=np.uint8)
+    for r, item in enumerate(res):
+        if isinstance(item[1], terr.TraceError):
+            status[r] = status_of(item[1])
+        else:
+            seg, op_r, _w = item
+            last[0:3, r], last[3:6, r], last[6, r], last[7:10, r] = seg[0], seg[1], seg[2], seg[3]
+            op[r] = op_r
+    return dict(pt0=np.array([r[0] for r in rays]).T.copy(),
+                dir0=np.array([r[1] for r in rays]).T.copy(),
+                wvl_idx=np.array([i % len(wvls) for i in range(R)], dtype=np.int32),
+                last=last, op=op, status=status)
+
+
+def save(name, table, cases):
+    flat = {'table_json': np.array(json.dumps(table.to_dict()))}
+    for cname, d in cases.items():
+        for k, v in d.items():
+            flat[f'{cname}/{k}'] = v
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **flat)
+    print(f'{name}: {os.path.getsize(path) / 1024:.0f} KiB, cases {list(cases)}')
+
+
+def kat_dblgauss_seq():
+    """the reference's only end-to-end KAT: test_sequential.py + marginal_ray.py
+    (CODE V axial marginal ray, 6 decimals) on gen_sequence(ag_dblgauss)."""
+    import copy
+    sys.path.insert(0, os.path.join(rm.REF_SRC, 'rayoptics', 'raytr', 'tests'))
+    import ag_dblgauss_s as dblg
+    import marginal_ray as f1r2
+    from rayoptics.util.misc_math import normalize
+    d = copy.deepcopy(dblg.ag_dblgauss)
+    d[-2][1] += d[-1][1]            # test_sequential.py:26-27
+    d[-1][1] = 0.
+    # the CODE V truth was computed with the listed n_d at 587.6 nm: keep the
+    # indices exactly as listed (constant-index media), not through the shim's
+    # synthetic dispersion
+    d = [row[:3] for row in d]
+    path = list(gen_sequence(d, wvl=587.6, radius_mode=False))
+    table = ra.SurfaceTable.from_paths([path], [587.6])
+    p0 = np.array([0., 0., 0.])
+    p1 = np.array([0., 0., d[0][1]])
+    epd = np.array([25., 0., 0.])
+    d0 = normalize((p1 + epd) - p0)
+    ray, op, _ = rt.trace_raw(iter(path), p0, d0, 587.6)
+    out = SoA(len(path), 1)
+    out.put(0, (ray, op, 587.6), None)
+    codev = np.array([[*r[0], *r[1], r[2]] for r in f1r2.rayf1r2])
+    # a random bundle through the same hand-built path (no apertures)
+    rng = np.random.default_rng(SEED)
+    R = 256
+    tgt = np.stack([rng.uniform(-32, 32, R), rng.uniform(-32, 32, R),
+                    np.full(R, d[0][1])])
+    pt0 = np.zeros((3, R))
+    dir0 = tgt / np.linalg.norm(tgt, axis=0)
+    bundle = SoA(len(path), R)
+    for r in range(R):
+        try:
+            pkg, err = rt.trace_raw(iter(path), pt0[:, r].copy(), dir0[:, r].copy(),
+                                    587.6, first_surf=1, last_surf=11), None
+        except terr.TraceError as e:
+            pkg, err = e.ray_pkg, e
+        bundle.put(r, pkg, err)
+    cases = {'marginal': dict(pt0=p0.reshape(3, 1), dir0=d0.reshape(3, 1),
+                              codev=codev, **out.arrays()),
+             'bundle': dict(pt0=pt0, dir0=dir0, first_surf=np.int64(1),
+                            last_surf=np.int64(11), **bundle.arrays())}
+    save('dblgauss_seq', table, cases)
+
+
+def main():
+    rng = np.random.default_rng(SEED)
+    kat_dblgauss_seq()
+
+    # C2: double Gauss (13 interfaces)
+    opm = rm.dblgauss()
+    table = ra.SurfaceTable.from_seq_model(opm['seq_model'])
+    save('dblgauss', table, {
+        'rays_ap': case_rays(opm, 384, rng, True),
+        'rays_noap': case_rays(opm, 128, rng, False),
+        'grid_f0': case_grid(opm, 0, 587.6, 12),
+        'grid_f2': case_grid(opm, 2, 486.1, 12),
+        'fan_f1': case_grid(opm, 1, 656.3, 21, kind='fan', start=(0., -1.), stop=(0., 1.)),
+        'spot': case_spot(opm, 16),
+        'list_last': case_list_of_rays(opm, 64, rng),
+    })
+    # finite-conjugate variant separates kernel bugs from the 1e10 cancellation
+    opm = rm.dblgauss(obj_thi=1.0e3)
+    save('dblgauss_finite', ra.SurfaceTable.from_seq_model(opm['seq_model']), {
+        'rays_ap': case_rays(opm, 256, rng, True),
+        'grid_f2': case_grid(opm, 2, 587.6, 10),
+    })
+
+    # C1: singlet, 64x64 grid through the reference trace_grid (CPU plumbing)
+    opm = rm.singlet()
+    save('singlet', ra.SurfaceTable.from_seq_model(opm['seq_model']), {
+        'grid64': case_grid(opm, 0, 650.0, 64),
+        'grid_f1': case_grid(opm, 1, 650.0, 9),
+        'spot': case_spot(opm, 12),
+    })
+
+    # C4: Ritchey-Chretien mirrors + field stop
+    opm = rm.rc_telescope()
+    save('rc_telescope', ra.SurfaceTable.from_seq_model(opm['seq_model']), {
+        'rays_ap': case_rays(opm, 256, rng, True, pupil_scale=1.3),
+        'grid_f0': case_grid(opm, 0, 550.0, 10),
+        'grid_f4': case_grid(opm, 4, 550.0, 10),
+        'spot': case_spot(opm, 10),
+    })
+
+    # C3 stand-in: 29 interfaces, 4 even aspheres
+    opm = rm.nikkor()
+    save('nikkor', ra.SurfaceTable.from_seq_model(opm['seq_model']), {
+        'rays_ap': case_rays(opm, 192, rng, True),
+        'grid_f1': case_grid(opm, 1, 587.5618, 8),
+        'spot': case_spot(opm, 8),
+    })
+
+    # RadialPolynomial aspheres (the reference's timed asphere model)
+    opm = rm.cell_phone()
+    save('cell_phone', ra.SurfaceTable.from_seq_model(opm['seq_model']), {
+        'rays_ap': case_rays(opm, 192, rng, True),
+        'grid_f2': case_grid(opm, 2, list(opm['osp']['wvls'].wavelengths)[0], 8),
+    })
+
+    # decenters / tilts / phantom / rectangular + obscuration
+    opm = rm.tilted_singlet()
+    save('tilted_singlet', ra.SurfaceTable.from_seq_model(opm['seq_model']), {
+        'rays_ap': case_rays(opm, 256, rng, True, pupil_scale=1.6),
+        'grid_f1': case_grid(opm, 1, 650.0, 10),
+    })
+
+
+if __name__ == '__main__':
+    main()

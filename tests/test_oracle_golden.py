@@ -1,0 +1,145 @@
+"""Pins the CPU oracle (oracle/rox_oracle.c) against
+  (a) the reference's own golden vectors / known answers, and
+  (b) fixtures produced by running the reference itself
+      (tests/golden/make_golden.py).
+CPU only: this is the `-m "not gpu"` half of the parity story; the `-m gpu`
+tests then hold the HIP kernels to the oracle bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rayoptics_amd import abi
+from oracle import oracle
+import helpers as H
+
+
+def test_codev_marginal_ray_kat():
+    """rayoptics/raytr/tests/test_sequential.py:34-77 with
+    rayoptics/raytr/tests/marginal_ray.py (CODE V, 6 decimals)"""
+    fx = H.fixture('dblgauss_seq')
+    c = fx['marginal']
+    res = oracle.trace_rays(fx.table, c['pt0'], c['dir0'], 0, oracle.make_opts())
+    assert res.status[0] == abi.OK
+    codev = c['codev']          # rows: x y z tanX tanY dist
+    seg = res.seg[:, :, 0]
+    for i in range(13):
+        np.testing.assert_allclose(seg[i, 0:3], codev[i, 0:3], rtol=3e-6, atol=2e-6)
+        np.testing.assert_allclose([seg[i, 3] / seg[i, 5], seg[i, 4] / seg[i, 5]],
+                                   codev[i, 3:5], rtol=3e-6, atol=1e-6)
+        if 1 < i < 12:      # test_sequential.py:73 skips object/image space
+            np.testing.assert_allclose(seg[i, 6], codev[i, 5], rtol=3e-6)
+    # and bit-for-bit against what the reference code itself produced
+    assert H.assert_result_matches(c, res, require_exact=True) == 1.0
+
+
+def test_profiles_kat():
+    """rayoptics/elem/tests/test_profiles.py:127-154: double-Gauss S1,
+    Spherical closed form vs Spencer-Murty Newton, s = 5.866433424372758"""
+    r1 = 56.20238                       # test_profiles.py:128-133
+    cv = 1 / r1
+    p0 = np.array([0., 25.0, 0.])
+    d = np.array([0., 0., 1.])
+    sag1 = r1 - np.sqrt(r1 * r1 - 25.0 * 25.0)
+    L = oracle.lib()
+    out = {}
+    for prof in (abi.SPHERICAL, abi.EVENPOLY):
+        sf = abi.Surface()
+        sf.profile, sf.cv, sf.cc, sf.ec = prof, cv, 0.0, 1.0
+        s = C.c_double()
+        p1 = np.zeros(3)
+        nrm = np.zeros(3)
+        st = L.rox_oracle_intersect(C.byref(sf), p0.ctypes.data, d.ctypes.data,
+                                    1e-12, 1.0, C.byref(s), p1.ctypes.data,
+                                    nrm.ctypes.data)
+        assert st == 0
+        out[prof] = (s.value, p1, nrm)
+    np.testing.assert_allclose(out[abi.SPHERICAL][0], 5.866433424372758, rtol=1e-14)
+    np.testing.assert_allclose(out[abi.SPHERICAL][1], [0., 25.0, sag1], rtol=1e-14)
+    nrm_truth = -(np.array([0., 25.0, sag1]) - np.array([0, 0, r1]))
+    nrm_truth /= np.linalg.norm(nrm_truth)
+    np.testing.assert_allclose(out[abi.SPHERICAL][2], nrm_truth, rtol=1e-14)
+    np.testing.assert_allclose(out[abi.EVENPOLY][0], 5.866433424372758, rtol=1e-13)
+    np.testing.assert_allclose(out[abi.SPHERICAL][1], out[abi.EVENPOLY][1], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(out[abi.SPHERICAL][2], out[abi.EVENPOLY][2], rtol=1e-13, atol=1e-13)
+
+
+RAY_CASES = [('dblgauss_seq', 'bundle'), ('dblgauss', 'rays_ap'),
+             ('dblgauss', 'rays_noap'), ('dblgauss_finite', 'rays_ap'),
+             ('rc_telescope', 'rays_ap'), ('nikkor', 'rays_ap'),
+             ('cell_phone', 'rays_ap'), ('tilted_singlet', 'rays_ap')]
+
+
+@pytest.mark.parametrize('name,case', RAY_CASES)
+def test_explicit_rays_vs_reference(name, case):
+    fx = H.fixture(name)
+    c = fx[case]
+    wi = c['wvl_idx'] if 'wvl_idx' in c else 0
+    res = oracle.trace_rays(fx.table, c['pt0'], c['dir0'], wi, H.make_opts(c))
+    exact = H.assert_result_matches(c, res)
+    # centred systems: the FMA-chain dot model makes the restatement bit-exact
+    if name != 'tilted_singlet':
+        assert exact == 1.0, f'{name}/{case}: bit-exact fraction {exact}'
+    assert len(set(c['status'].tolist())) >= 1
+
+
+GRID_CASES = [('dblgauss', 'grid_f0'), ('dblgauss', 'grid_f2'), ('dblgauss', 'fan_f1'),
+              ('dblgauss_finite', 'grid_f2'), ('singlet', 'grid64'),
+              ('singlet', 'grid_f1'), ('rc_telescope', 'grid_f0'),
+              ('rc_telescope', 'grid_f4'), ('nikkor', 'grid_f1'),
+              ('cell_phone', 'grid_f2'), ('tilted_singlet', 'grid_f1')]
+
+
+@pytest.mark.parametrize('name,case', GRID_CASES)
+def test_pupil_grid_vs_reference_driver(name, case):
+    """trace.trace_grid / trace_fan -> trace_safe -> trace_base ->
+    apply_vignetting + ray_start_from_osp -> rt.trace, all reference code"""
+    fx = H.fixture(name)
+    c = fx[case]
+    fld = H.field_from_arr(c['field'])
+    grid = oracle.make_grid(c['start'], c['stop'], int(c['num']), int(c['kind']))
+    res = oracle.trace_pupil_grid(fx.table, fld, grid, int(c['wvl_idx']), H.make_opts(c))
+    np.testing.assert_array_equal(res.pupil, c['pupil'])    # accumulate-by-step + vignetting
+    exact = H.assert_result_matches(c, res)
+    if name != 'tilted_singlet':
+        assert exact == 1.0, f'{name}/{case}: bit-exact fraction {exact}'
+
+
+@pytest.mark.parametrize('name', ['dblgauss', 'singlet', 'rc_telescope', 'nikkor'])
+def test_spot_diagram_vs_reference_figure(name):
+    """HITS output == what SpotDiagramFigure.update_data() computed"""
+    fx = H.fixture(name)
+    c = fx['spot']
+    num = int(c['num'])
+    N = fx.table.n_ifcs
+    nchecked = 0
+    for key in c:
+        if not key.endswith('_hits'):
+            continue
+        fi, wi = key.split('_')[0], int(key.split('_')[1][1:])
+        fld = H.field_from_arr(c[f'{fi}_field'])
+        opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING,
+                                out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
+                                foc=float(c['foc']), image_pt=tuple(c[f'{fi}_image_pt']))
+        grid = oracle.make_grid((-1., -1.), (1., 1.), num)
+        res = oracle.trace_pupil_grid(fx.table, fld, grid, wi, opts)
+        ok = res.status == abi.OK
+        got = res.seg[:, ok].T          # form='list', append_if_none=False
+        exp = c[key]
+        assert got.shape == exp.shape, (key, got.shape, exp.shape)
+        H.assert_soa_close(exp, got, key, require_exact=True)
+        nchecked += 1
+    assert nchecked >= 2
+
+
+def test_list_of_rays_last_segment():
+    """analyses.trace_list_of_rays(output_filter='last')"""
+    fx = H.fixture('dblgauss')
+    c = fx['list_last']
+    N = fx.table.n_ifcs
+    opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES,
+                            out_mode=abi.OUT_LAST, first_surf=1, last_surf=N - 2)
+    res = oracle.trace_rays(fx.table, c['pt0'], c['dir0'], c['wvl_idx'], opts)
+    np.testing.assert_array_equal(res.status, c['status'])
+    H.assert_soa_close(c['last'], res.seg, 'last', require_exact=True)
+    H.assert_soa_close(c['op'], np.where(res.status == 0, res.op, np.nan), 'op', require_exact=True)
