@@ -1,0 +1,1061 @@
+// roxtrace.hip -- sequential real-ray trace for gfx950 (MI355X, CDNA4).
+//
+// Hot path of mjhoptics/ray-optics restated as hand-written HIP (reference
+// paths relative to /root/reference/src/):
+//   rayoptics/raytr/raytrace.py:83-264   trace_raw   -> trace_kernel (the loop)
+//   rayoptics/raytr/raytrace.py:19-38    bend/reflect -> refract(), mirror()
+//   rayoptics/elem/profiles.py:310-336   Spherical.intersect  \  quadric_hit()
+//   rayoptics/elem/profiles.py:569-593   Conic.intersect      /
+//   rayoptics/elem/profiles.py:155-186   intersect_spencer    -> newton_hit()
+//   rayoptics/elem/profiles.py:849-885   EvenPolynomial.sag/df \ poly_eval()
+//   rayoptics/elem/profiles.py:1070-1113 RadialPolynomial.sag/df/
+//   rayoptics/elem/surface.py:198-208, 416-457 point_inside    -> inside_aperture()
+//   rayoptics/raytr/opticalspec.py:358-366, 1339-1353; trace.py:298-308
+//                                         pupil -> (pt0, dir0) -> launch_ray()
+//   rayoptics/raytr/trace.py:563-605, 537-560 grid / fan pupil coordinates
+//                                         -> pupil_axes_kernel (repeated +=)
+//
+// Execution model: one wavefront lane = one ray; 256-thread workgroups
+// grid-stride over the ray batch.  Every per-surface parameter is
+// wave-uniform: the surface table is staged once per workgroup in LDS and read
+// with same-address (broadcast, conflict-free) ds_reads.  Ray packets are SoA
+// [segment][component][ray]: each store is 64 lanes x 8 B = 512 B contiguous.
+// All arithmetic is IEEE binary64 with the reference's operation order:
+// this file is compiled with -ffp-contract=off, NumPy's BLAS dot sites are
+// spelled as explicit fma chains (dot3), division and sqrt are the correctly
+// rounded ones.  No MFMA: this is 3-vector arithmetic, not a contraction.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/roxtrace.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kRowDoubles = sizeof(rox_surface) / sizeof(double);   // 49
+static_assert(sizeof(rox_surface) == 392, "rox_surface layout");
+static_assert(sizeof(rox_aperture) == 40, "rox_aperture layout");
+
+enum { GEN_RAYS = 0, GEN_PUPIL = 1 };
+enum { AXIS_LIST = 0, AXIS_PRODUCT = 1 };
+
+struct v3 { double x, y, z; };
+
+// ---------------------------------------------------------------- kernel args
+struct TraceArgs {
+    const double *rows;        // [N][49] raw rox_surface rows
+    const double *n_table;     // [W][N]
+    const int32_t *slots;      // [2][N]: slot[s] (-1 = filtered phantom), nslots_before[s]
+    int32_t n_ifcs, n_wvls;
+    int64_t n_rays;
+    // explicit rays
+    const double *pt0, *dir0;  // SoA [3][n_rays]
+    const int32_t *wvl_idx;    // per ray or nullptr
+    int32_t wvl_idx_all;
+    // pupil rays
+    const double *px, *py;     // axis / list coordinates
+    int32_t axis_kind;         // AXIS_LIST: px[r],py[r]; AXIS_PRODUCT: px[r/num], py[r%num]
+    int32_t axis_num;
+    rox_field fld;
+    rox_opts opts;
+    rox_out out;
+};
+
+// ---------------------------------------------------------------- arithmetic
+// np.dot / ndarray.dot / np.linalg.norm on float64[3] = OpenBLAS ddot:
+// acc = 0; acc = fma(a_i, b_i, acc), i = 0, 1, 2.
+__device__ __forceinline__ double dot3(const v3 &a, const v3 &b)
+{
+    double acc = fma(a.x, b.x, 0.0);
+    acc = fma(a.y, b.y, acc);
+    return fma(a.z, b.z, acc);
+}
+
+// Rt.dot(v): same chain per output row (dgemv on the F-ordered transpose view)
+__device__ __forceinline__ v3 rotate(const double *rt, const v3 &v)
+{
+    v3 r;
+    r.x = fma(rt[2], v.z, fma(rt[1], v.y, fma(rt[0], v.x, 0.0)));
+    r.y = fma(rt[5], v.z, fma(rt[4], v.y, fma(rt[3], v.x, 0.0)));
+    r.z = fma(rt[8], v.z, fma(rt[7], v.y, fma(rt[6], v.x, 0.0)));
+    return r;
+}
+
+// misc_math.py:48-54 normalize
+__device__ __forceinline__ v3 unit(const v3 &v)
+{
+    const double len = sqrt(dot3(v, v));
+    if (len == 0.0)
+        return v;
+    return v3{v.x / len, v.y / len, v.z / len};
+}
+
+// raytrace.py:19-30.  false = TIR (math.sqrt ValueError)
+__device__ __forceinline__ bool refract(const v3 &d, const v3 &nrm, double n_in,
+                                        double n_out, v3 &out)
+{
+    const double nlen = sqrt(dot3(nrm, nrm));
+    const double cosI = dot3(d, nrm) / nlen;
+    const double sin2 = 1.0 - cosI * cosI;
+    const double rad = n_out * n_out - n_in * n_in * sin2;
+    if (rad < 0.0)
+        return false;
+    const double n_cosIp = copysign(sqrt(rad), cosI);
+    const double alpha = n_cosIp - n_in * cosI;
+    out.x = (n_in * d.x + alpha * nrm.x) / n_out;
+    out.y = (n_in * d.y + alpha * nrm.y) / n_out;
+    out.z = (n_in * d.z + alpha * nrm.z) / n_out;
+    return true;
+}
+
+// raytrace.py:33-38 (not renormalised)
+__device__ __forceinline__ v3 mirror(const v3 &d, const v3 &nrm)
+{
+    const double nlen = sqrt(dot3(nrm, nrm));
+    const double cosI = dot3(d, nrm) / nlen;
+    const double k = 2.0 * cosI;
+    return v3{d.x - k * nrm.x, d.y - k * nrm.y, d.z - k * nrm.z};
+}
+
+// profiles.py:321-336 / 580-593: s = cx2 / (z_dir*sqrt(b*b - ax2*cx2) - b)
+__device__ __forceinline__ bool quadric_root(double ax2, double cx2, double b,
+                                             double z_dir, double &s)
+{
+    if ((b != 0) || (cx2 != 0) || (ax2 != 0)) {
+        const double rad = b * b - ax2 * cx2;
+        if (rad < 0.0)
+            return false;                       // TraceMissedSurfaceError
+        const double den = z_dir * sqrt(rad) - b;
+        // np.errstate(divide='raise') -> FloatingPointError -> s = 0 only for a
+        // finite non-zero numerator; 0/0 and nan/0 stay NaN
+        if (den == 0.0 && cx2 != 0.0 && isfinite(cx2))
+            s = 0.0;
+        else
+            s = cx2 / den;
+    } else {
+        s = 0.0;
+    }
+    return true;
+}
+
+// Spherical (conic == false) / Conic closed-form intersection
+__device__ __forceinline__ bool quadric_hit(bool conic, double cv, double cc, double ec,
+                                            const v3 &p, const v3 &d, double z_dir,
+                                            double &s, v3 &hit)
+{
+    double ax2, cx2, b;
+    if (!conic) {
+        ax2 = cv;
+        cx2 = cv * dot3(p, p) - 2 * p.z;
+        b = cv * dot3(d, p) - d.z;
+    } else {
+        ax2 = cv * (1. + cc * d.z * d.z);
+        cx2 = cv * (p.x * p.x + p.y * p.y + ec * p.z * p.z) - 2.0 * p.z;
+        b = cv * (d.x * p.x + d.y * p.y + ec * d.z * p.z) - d.z;
+    }
+    if (!quadric_root(ax2, cx2, b, z_dir, s))
+        return false;
+    hit = v3{p.x + s * d.x, p.y + s * d.y, p.z + s * d.z};
+    return true;
+}
+
+// One evaluation of f(p) and df(p) for the polynomial aspheres
+// (profiles.py:849-885 even, 1070-1113 radial; forward accumulation of the
+// powers, not Horner).  Returns false when the sag square root goes negative.
+template <bool WANT_F>
+__device__ __forceinline__ bool poly_eval(bool radial, double cv, double cc1, double ec,
+                                          int ncoef, const double *coefs,
+                                          const v3 &p, double &f, v3 &df)
+{
+    const double r2 = p.x * p.x + p.y * p.y;
+    double e_tot;
+    if (!radial) {
+        if (WANT_F) {
+            const double rad = 1. - cc1 * cv * cv * r2;     // (cc + 1.0)*cv*cv*r2
+            if (rad < 0.0)
+                return false;
+            const double z = cv * r2 / (1. + sqrt(rad));
+            double z_asp = 0.0, r_pow = r2;
+            for (int i = 0; i < ncoef; ++i) {
+                z_asp += coefs[i] * r_pow;
+                r_pow *= r2;
+            }
+            f = p.z - (z + z_asp);
+        }
+        const double e = cv / sqrt(1. - ec * cv * cv * r2);
+        double r_pow = 1, e_asp = 0.0, c_coef = 2.0;
+        for (int i = 0; i < ncoef; ++i) {
+            e_asp += c_coef * coefs[i] * r_pow;
+            c_coef += 2.0;
+            r_pow *= r2;
+        }
+        e_tot = e + e_asp;
+    } else {
+        const double r = sqrt(r2);
+        if (WANT_F) {
+            const double rad = 1. - ec * cv * cv * r2;
+            if (rad < 0.0)
+                return false;
+            const double z = cv * r2 / (1. + sqrt(rad));
+            double z_asp = 0.0, r_pow = r;
+            for (int i = 0; i < ncoef; ++i) {
+                z_asp += coefs[i] * r_pow;
+                r_pow *= r;
+            }
+            f = p.z - (z + z_asp);
+        }
+        const double e = cv / sqrt(1. - ec * cv * cv * r2);
+        double e_asp = 0.0, c_coef = 1.0;
+        double r_pow = (r == 0.0) ? 1.0 : 1 / r;
+        for (int i = 0; i < ncoef; ++i) {
+            e_asp += c_coef * coefs[i] * r_pow;
+            c_coef += 1.0;
+            r_pow *= r;
+        }
+        e_tot = e + e_asp;
+    }
+    df = v3{-e_tot * p.x, -e_tot * p.y, 1.0};
+    return true;
+}
+
+// profiles.py:155-186 Spencer & Murty Newton iteration.  Returns the last
+// *evaluated* iterate as the hit point (p0 itself when |s1| <= eps at once).
+__device__ __forceinline__ bool newton_hit(bool radial, double cv, double cc1, double ec,
+                                           int ncoef, const double *coefs,
+                                           const v3 &p0, const v3 &d, double eps,
+                                           double &s, v3 &hit, v3 &df)
+{
+    v3 p = p0;
+    double f;
+    if (!poly_eval<true>(radial, cv, cc1, ec, ncoef, coefs, p, f, df))
+        return false;
+    double s1 = -f / dot3(d, df);
+    double delta = fabs(s1);
+    int iter = 0;
+    while (delta > eps && iter < 1000) {
+        p = v3{p0.x + s1 * d.x, p0.y + s1 * d.y, p0.z + s1 * d.z};
+        if (!poly_eval<true>(radial, cv, cc1, ec, ncoef, coefs, p, f, df))
+            return false;
+        const double s2 = s1 - f / dot3(d, df);
+        delta = fabs(s2 - s1);
+        s1 = s2;
+        ++iter;
+    }
+    s = s1;
+    hit = p;        // df already holds df(hit): normal() re-evaluates the same expression
+    return true;
+}
+
+// surface.py:198-208 (+ interface.py:113-122, surface.py:416-419, 453-457)
+__device__ __forceinline__ bool inside_aperture(const double *row, int n_ap, double x,
+                                                double y, double fuzz)
+{
+    if (n_ap > 0) {
+        const double *ap = row + (offsetof(rox_surface, ap) / sizeof(double));
+        for (int k = 0; k < n_ap; ++k, ap += sizeof(rox_aperture) / sizeof(double)) {
+            const int2 ki = *reinterpret_cast<const int2 *>(ap);    // kind, is_obscuration
+            const double xx = x - ap[1];
+            const double yy = y - ap[2];
+            bool ans;
+            if (ki.x == ROX_AP_CIRCULAR)
+                ans = sqrt(xx * xx + yy * yy) <= ap[3] + fuzz;
+            else if (ki.x == ROX_AP_RECTANGULAR)
+                ans = (fabs(xx) <= ap[3] + fuzz) && (fabs(yy) <= ap[4] + fuzz);
+            else
+                return false;               // Elliptical: point_inside() returns None
+            if (ki.y)
+                ans = !ans;
+            if (!ans)
+                return false;
+        }
+        return true;
+    }
+    return sqrt(x * x + y * y) <= row[offsetof(rox_surface, max_aperture) / sizeof(double)] + fuzz;
+}
+
+// ------------------------------------------------------------------ stores
+__device__ __forceinline__ void st(double *p, double v) { __builtin_nontemporal_store(v, p); }
+
+__device__ __forceinline__ void store_pdn(double *seg, int64_t ld, int slot, int64_t r,
+                                          const v3 &p, const v3 &d, const v3 &n)
+{
+    double *b = seg + (int64_t)slot * ROX_SEG_DOUBLES * ld + r;
+    st(b + 0 * ld, p.x); st(b + 1 * ld, p.y); st(b + 2 * ld, p.z);
+    st(b + 3 * ld, d.x); st(b + 4 * ld, d.y); st(b + 5 * ld, d.z);
+    st(b + 7 * ld, n.x); st(b + 8 * ld, n.y); st(b + 9 * ld, n.z);
+}
+
+__device__ __forceinline__ void store_dst(double *seg, int64_t ld, int slot, int64_t r, double dst)
+{
+    st(seg + ((int64_t)slot * ROX_SEG_DOUBLES + 6) * ld + r, dst);
+}
+
+// ------------------------------------------------------------------ the kernel
+template <int OUT_MODE, int GEN, bool PER_RAY_WVL>
+__global__ void __launch_bounds__(kBlock)
+trace_kernel(const TraceArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int N = a.n_ifcs;
+    double *tbl = lds;                               // [N][49]
+    double *ntab = tbl + (size_t)N * kRowDoubles;    // [W][N] (or [N] for one wavelength)
+    int32_t *slot = reinterpret_cast<int32_t *>(ntab + (PER_RAY_WVL ? (size_t)a.n_wvls * N : N));
+    int32_t *nslots_before = slot + N;
+
+    // stage the surface table once per workgroup
+    for (int i = threadIdx.x; i < N * kRowDoubles; i += kBlock)
+        tbl[i] = a.rows[i];
+    if (PER_RAY_WVL) {
+        for (int i = threadIdx.x; i < a.n_wvls * N; i += kBlock)
+            ntab[i] = a.n_table[i];
+    } else {
+        for (int i = threadIdx.x; i < N; i += kBlock)
+            ntab[i] = a.n_table[(size_t)a.wvl_idx_all * N + i];
+    }
+    for (int i = threadIdx.x; i < 2 * N; i += kBlock)
+        slot[i] = a.slots[i];
+    __syncthreads();
+
+    const uint32_t flags = a.opts.flags;
+    const bool check_ap = flags & ROX_CHECK_APERTURES;
+    const bool intersect_obj = flags & ROX_INTERSECT_OBJ;
+    const bool filter_ph = flags & ROX_FILTER_PHANTOMS;
+    const int first_surf = a.opts.first_surf, last_surf = a.opts.last_surf;
+    const double eps = a.opts.eps, fuzz = a.opts.fuzz;
+    const int64_t ld = a.out.ld;
+    double *const seg = a.out.seg;
+
+    constexpr int O_CV = offsetof(rox_surface, cv) / 8, O_CC = offsetof(rox_surface, cc) / 8,
+                  O_EC = offsetof(rox_surface, ec) / 8, O_COEF = offsetof(rox_surface, coefs) / 8,
+                  O_RT = offsetof(rox_surface, rt) / 8, O_T = offsetof(rox_surface, t) / 8,
+                  O_ZDIR = offsetof(rox_surface, z_dir) / 8;
+
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < a.n_rays;
+         r += (int64_t)gridDim.x * kBlock) {
+        // ---- ray start -------------------------------------------------------
+        v3 pt0, dir0;
+        if (GEN == GEN_PUPIL) {
+            double px, py;
+            if (a.axis_kind == AXIS_PRODUCT) {
+                px = a.px[r / a.axis_num];
+                py = a.py[r % a.axis_num];
+            } else {
+                px = a.px[r];
+                py = a.py[r];
+            }
+            if (flags & ROX_APPLY_VIGNETTING) {         // opticalspec.py:1339-1353
+                if (px < 0.0) { if (a.fld.vlx != 0.0) px *= (1.0 - a.fld.vlx); }
+                else          { if (a.fld.vux != 0.0) px *= (1.0 - a.fld.vux); }
+                if (py < 0.0) { if (a.fld.vly != 0.0) py *= (1.0 - a.fld.vly); }
+                else          { if (a.fld.vuy != 0.0) py *= (1.0 - a.fld.vuy); }
+            }
+            if (a.out.pupil) {
+                st(a.out.pupil + r, px);
+                st(a.out.pupil + ld + r, py);
+            }
+            // opticalspec.py:358-366
+            const v3 pt1{a.fld.eprad * px + a.fld.aim[0], a.fld.eprad * py + a.fld.aim[1],
+                         a.fld.z_enp};
+            pt0 = v3{a.fld.pt0[0], a.fld.pt0[1], a.fld.pt0[2]};
+            dir0 = unit(v3{pt1.x - pt0.x, pt1.y - pt0.y, pt1.z - pt0.z});
+            if (dir0.z * a.fld.z_dir0 < 0)              // trace.py:307-308
+                dir0 = v3{-dir0.x, -dir0.y, -dir0.z};
+        } else {
+            pt0 = v3{a.pt0[r], a.pt0[a.n_rays + r], a.pt0[2 * a.n_rays + r]};
+            dir0 = v3{a.dir0[r], a.dir0[a.n_rays + r], a.dir0[2 * a.n_rays + r]};
+        }
+        const double *nw = ntab;
+        if (PER_RAY_WVL)
+            nw = ntab + (size_t)a.wvl_idx[r] * N;
+
+        // ---- object surface, raytrace.py:145-158 -----------------------------
+        int status = ROX_OK, fail_surf = -1;
+        v3 bp, bn, bd = dir0;               // before_pt, before_normal, before_dir
+        int b4_mode = ROX_DUMMY;
+        {
+            const double *row = tbl;
+            if (intersect_obj) {
+                const int2 mp = *reinterpret_cast<const int2 *>(row);       // mode, profile
+                const int2 na = *reinterpret_cast<const int2 *>(row + 1);   // ncoef, n_ap
+                b4_mode = mp.x;
+                double s_;
+                v3 df;
+                bool ok;
+                if (mp.y <= ROX_CONIC) {
+                    ok = quadric_hit(mp.y == ROX_CONIC, row[O_CV], row[O_CC], row[O_EC], pt0, dir0,
+                                     row[O_ZDIR], s_, bp);
+                    if (ok) {
+                        const double k = (mp.y == ROX_CONIC) ? (row[O_CC] + 1.0) * row[O_CV] : row[O_CV];
+                        df = v3{-row[O_CV] * bp.x, -row[O_CV] * bp.y, 1.0 - k * bp.z};
+                    }
+                } else {
+                    ok = newton_hit(mp.y == ROX_RADIALPOLY, row[O_CV], row[O_CC] + 1.0, row[O_EC],
+                                    na.x, row + O_COEF, pt0, dir0, eps, s_, bp, df);
+                }
+                if (!ok) {              // raised outside the try block: no packet
+                    status = ROX_MISSED_SURFACE;
+                    fail_surf = 0;
+                } else {
+                    bn = unit(df);
+                }
+            } else {
+                bp = pt0;
+                bn = v3{0., 0., 1.};
+            }
+        }
+        double z_dir_before = tbl[O_ZDIR];
+        double opl = 0.0;
+        double acc_dst = 0.0;           // dst of the most recently appended segment
+        int acc_slot = 0;
+        v3 inc{0, 0, 0}, nrm{0, 0, 0}, ad = dir0;
+        bool alive = (status == ROX_OK);
+        if (OUT_MODE == ROX_OUT_FULL && alive)
+            store_pdn(seg, ld, 0, r, bp, bd, bn);
+
+        // ---- remaining surfaces, raytrace.py:164-229 -------------------------
+        for (int surf = 1; surf < N && alive; ++surf) {
+            const double *prow = tbl + (size_t)(surf - 1) * kRowDoubles;    // `before`
+            const double *row = tbl + (size_t)surf * kRowDoubles;            // `after`
+            const int2 mp = *reinterpret_cast<const int2 *>(row);
+            const int2 na = *reinterpret_cast<const int2 *>(row + 1);
+            const int mode = mp.x, prof = mp.y;
+            const double cv = row[O_CV];
+
+            // :170-174 transform to the new vertex frame, closest approach
+            const v3 b4p = rotate(prow + O_RT, v3{bp.x - prow[O_T], bp.y - prow[O_T + 1],
+                                                  bp.z - prow[O_T + 2]});
+            const v3 b4d = rotate(prow + O_RT, bd);
+            const double pp_dst = -dot3(b4p, b4d);
+            const v3 pp{b4p.x + pp_dst * b4d.x, b4p.y + pp_dst * b4d.y, b4p.z + pp_dst * b4d.z};
+
+            // :181-183 intersect
+            double s;
+            v3 df;
+            bool ok;
+            if (prof <= ROX_CONIC) {
+                ok = quadric_hit(prof == ROX_CONIC, cv, row[O_CC], row[O_EC], pp, b4d,
+                                 z_dir_before, s, inc);
+            } else {
+                ok = newton_hit(prof == ROX_RADIALPOLY, cv, row[O_CC] + 1.0, row[O_EC], na.x,
+                                row + O_COEF, pp, b4d, eps, s, inc, df);
+            }
+            const bool b4_filtered = (b4_mode == ROX_PHANTOM) && filter_ph;
+            if (!ok) {                                  // :231-237
+                status = ROX_MISSED_SURFACE;
+                fail_surf = surf;
+                alive = false;
+                if (OUT_MODE == ROX_OUT_FULL) {
+                    const int sl = b4_filtered ? nslots_before[surf - 1] : slot[surf - 1];
+                    if (b4_filtered)
+                        store_pdn(seg, ld, sl, r, bp, bd, bn);
+                    store_dst(seg, ld, sl, r, pp_dst);
+                }
+                break;
+            }
+            const double dst_b4 = pp_dst + s;
+            // :185-191 the *previous* segment is completed only now
+            if (b4_filtered) {
+                acc_dst += dst_b4;
+            } else {
+                acc_dst = dst_b4;
+                acc_slot = slot[surf - 1];
+            }
+            if (OUT_MODE == ROX_OUT_FULL)
+                store_dst(seg, ld, acc_slot, r, acc_dst);
+
+            // :193-194 (in_gap_range, :123-132)
+            {
+                const int g = surf - 1;
+                const bool in_gap = !(last_surf >= 0 && first_surf == last_surf) && g >= first_surf &&
+                                    (last_surf < 0 || g < last_surf);
+                if (in_gap)
+                    opl += nw[surf - 1] * dst_b4;
+            }
+
+            // :196 normal = normalize(df(inc_pt))
+            if (prof == ROX_SPHERICAL)
+                df = v3{-cv * inc.x, -cv * inc.y, 1.0 - cv * inc.z};
+            else if (prof == ROX_CONIC)
+                df = v3{-cv * inc.x, -cv * inc.y, 1.0 - (row[O_CC] + 1.0) * cv * inc.z};
+            nrm = unit(df);
+
+            // :198-202 aperture test (in_surface_range, :134-142)
+            if (check_ap && surf >= first_surf && (last_surf < 0 || surf <= last_surf) &&
+                mode != ROX_PHANTOM) {
+                if (!inside_aperture(row, na.y, inc.x, inc.y, fuzz)) {
+                    status = ROX_BLOCKED;               // :247-251
+                    fail_surf = surf;
+                    alive = false;
+                }
+            }
+
+            // :211-221 refract / reflect / pass through
+            if (alive) {
+                if (mode == ROX_REFLECT) {
+                    ad = mirror(b4d, nrm);
+                } else if (mode == ROX_TRANSMIT) {
+                    if (!refract(b4d, nrm, nw[surf - 1], nw[surf], ad)) {
+                        status = ROX_TIR;               // :239-245
+                        fail_surf = surf;
+                        alive = false;
+                    }
+                } else {
+                    ad = b4d;
+                }
+            }
+            if (!alive) {
+                // partial packet: [inc_pt, before_dir, 0.0, normal] in the next slot
+                if (OUT_MODE == ROX_OUT_FULL) {
+                    const int sl = nslots_before[surf];
+                    store_pdn(seg, ld, sl, r, inc, bd, nrm);
+                    store_dst(seg, ld, sl, r, 0.0);
+                }
+                break;
+            }
+
+            // :223-229 roll
+            bp = inc; bn = nrm; bd = ad;
+            z_dir_before = row[O_ZDIR];
+            b4_mode = mode;
+            if (OUT_MODE == ROX_OUT_FULL) {
+                const bool cur_filtered = (mode == ROX_PHANTOM) && filter_ph && surf < N - 1;
+                if (!cur_filtered)
+                    store_pdn(seg, ld, slot[surf], r, inc, ad, nrm);
+            }
+        }
+
+        // ---- epilogue ---------------------------------------------------------
+        if (status == ROX_OK) {                         // :259-262
+            if (OUT_MODE == ROX_OUT_FULL) {
+                store_dst(seg, ld, slot[N - 1], r, 0.0);
+            } else if (OUT_MODE == ROX_OUT_LAST) {      // trace.py:214-217
+                store_pdn(seg, ld, 0, r, inc, ad, nrm);
+                store_dst(seg, ld, 0, r, 0.0);
+            } else {                                    // axisarrayfigure.py:229-238
+                const double dist = a.opts.foc / ad.z;
+                const double dx = inc.x + dist * ad.x;
+                const double dy = inc.y + dist * ad.y;
+                st(seg + r, dx - a.opts.image_pt[0]);
+                st(seg + ld + r, dy - a.opts.image_pt[1]);
+            }
+        }
+        if (a.out.op)
+            st(a.out.op + r, opl);      // op_delta = 0 + opl on success; opl on failure (:236)
+        if (a.out.status)
+            a.out.status[r] = (uint8_t)status;
+        if (a.out.fail_surf)
+            a.out.fail_surf[r] = (int16_t)fail_surf;
+    }
+}
+
+// trace.py:563-605 / 537-560: pupil coordinates by repeated `+=` of the step.
+// lane 0 walks the x axis, lane 1 the y axis (both are sequential by
+// definition: k-th value = start after k separately rounded additions).
+__global__ void pupil_axes_kernel(double x0, double y0, double sx, double sy, int num,
+                                  double *px, double *py)
+{
+    if (threadIdx.x > 1)
+        return;
+    double v = threadIdx.x == 0 ? x0 : y0;
+    const double step = threadIdx.x == 0 ? sx : sy;
+    double *out = threadIdx.x == 0 ? px : py;
+    for (int k = 0; k < num; ++k) {
+        out[k] = v;
+        v += step;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(ROX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));              \
+    } while (0)
+
+}  // namespace
+
+struct rox_system {
+    int device = 0;
+    int32_t n_ifcs = 0, n_wvls = 0;
+    std::vector<rox_surface> rows;      // host copy (immutable)
+    double *d_rows = nullptr;
+    double *d_ntab = nullptr;
+    int32_t *d_slots[2] = {nullptr, nullptr};   // [0]: no phantom filtering, [1]: filtered
+    int32_t n_seg[2] = {0, 0};
+    double *d_axes = nullptr;           // scratch for pupil axes [2][axes_cap]
+    int32_t axes_cap = 0;
+    int num_cus = 256;
+};
+
+namespace {
+
+void slot_map(const rox_system *s, bool filter, std::vector<int32_t> &m, int32_t &n_seg)
+{
+    const int N = s->n_ifcs;
+    m.assign(2 * N, 0);
+    int next = 0;
+    for (int i = 0; i < N; ++i) {
+        // a phantom's segment is dropped when the *following* surface sees
+        // b4_interact_mode == 'phantom' (raytrace.py:185-188); the last
+        // interface has no follower, and the object is 'dummy' unless
+        // intersect_obj reads its own mode
+        const bool filtered = filter && s->rows[i].mode == ROX_PHANTOM && i > 0 && i < N - 1;
+        m[N + i] = next;                // nslots_before[i]
+        m[i] = filtered ? -1 : next++;
+    }
+    n_seg = next;
+}
+
+size_t lds_bytes(const rox_system *s, bool per_ray_wvl)
+{
+    const size_t N = s->n_ifcs;
+    size_t b = N * sizeof(rox_surface) + (per_ray_wvl ? (size_t)s->n_wvls * N : N) * sizeof(double) +
+               2 * N * sizeof(int32_t);
+    return (b + 15) & ~size_t(15);
+}
+
+int check_opts(const rox_system *sys, const rox_opts *o, const rox_out *out, int64_t n_rays)
+{
+    if (!sys || !o || !out)
+        return fail(ROX_E_ARG, "null argument");
+    if (o->out_mode < ROX_OUT_FULL || o->out_mode > ROX_OUT_HITS)
+        return fail(ROX_E_ARG, "bad out_mode %d", o->out_mode);
+    if (out->ld < n_rays)
+        return fail(ROX_E_ARG, "out.ld (%lld) < n_rays (%lld)", (long long)out->ld, (long long)n_rays);
+    if (!out->seg && n_rays > 0)
+        return fail(ROX_E_ARG, "out.seg is null");
+    if ((o->flags & ROX_FILTER_PHANTOMS) && sys->rows[0].mode == ROX_PHANTOM)
+        return fail(ROX_E_UNSUPPORTED, "phantom object surface with filter_out_phantoms");
+    return 0;
+}
+
+template <int GEN, bool PRW>
+void launch_mode(int out_mode, dim3 grid, size_t lds, hipStream_t st, const TraceArgs &a)
+{
+    switch (out_mode) {
+    case ROX_OUT_FULL:
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_FULL, GEN, PRW>), grid, dim3(kBlock), lds, st, a);
+        break;
+    case ROX_OUT_LAST:
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_LAST, GEN, PRW>), grid, dim3(kBlock), lds, st, a);
+        break;
+    default:
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_HITS, GEN, PRW>), grid, dim3(kBlock), lds, st, a);
+        break;
+    }
+}
+
+int launch(const rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
+{
+    if (a.n_rays == 0)
+        return 0;
+    const bool prw = a.wvl_idx != nullptr;
+    a.rows = sys->d_rows;
+    a.n_table = sys->d_ntab;
+    a.slots = sys->d_slots[(a.opts.flags & ROX_FILTER_PHANTOMS) ? 1 : 0];
+    a.n_ifcs = sys->n_ifcs;
+    a.n_wvls = sys->n_wvls;
+    const size_t lds = lds_bytes(sys, prw);
+    if (lds > 160 * 1024)
+        return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS (max 163840)", lds);
+    // enough workgroups to fill 256 CUs several times over, grid-stride the rest
+    int64_t blocks = (a.n_rays + kBlock - 1) / kBlock;
+    const int64_t cap = (int64_t)sys->num_cus * 8;
+    if (blocks > cap)
+        blocks = cap;
+    const dim3 grid((unsigned)blocks);
+    if (gen == GEN_PUPIL)
+        launch_mode<GEN_PUPIL, false>(a.opts.out_mode, grid, lds, st, a);
+    else if (prw)
+        launch_mode<GEN_RAYS, true>(a.opts.out_mode, grid, lds, st, a);
+    else
+        launch_mode<GEN_RAYS, false>(a.opts.out_mode, grid, lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int64_t seg_rows(const rox_system *sys, const rox_opts *o)
+{
+    if (o->out_mode == ROX_OUT_FULL)
+        return (int64_t)sys->n_seg[(o->flags & ROX_FILTER_PHANTOMS) ? 1 : 0] * ROX_SEG_DOUBLES;
+    return o->out_mode == ROX_OUT_LAST ? ROX_SEG_DOUBLES : 2;
+}
+
+// ROX_HOST_POINTERS: stage outputs through HBM
+struct Staged {
+    rox_out dev{};          // device-side buffers
+    rox_out host{};         // caller's host buffers
+    int64_t n = 0, rows = 0;
+    bool want_pupil = false;
+    ~Staged()
+    {
+        (void)hipFree(dev.seg); (void)hipFree(dev.op); (void)hipFree(dev.status); (void)hipFree(dev.fail_surf);
+        (void)hipFree(dev.pupil);
+    }
+};
+
+int stage_out(Staged &s, const rox_system *sys, const rox_opts *o, const rox_out *out, int64_t n)
+{
+    s.host = *out;
+    s.n = n;
+    s.rows = seg_rows(sys, o);
+    s.dev.ld = n;
+    HIP_TRY(hipMalloc(&s.dev.seg, sizeof(double) * s.rows * n));
+    // untouched slots keep the caller's bytes
+    HIP_TRY(hipMemcpy2D(s.dev.seg, sizeof(double) * n, out->seg, sizeof(double) * out->ld,
+                        sizeof(double) * n, s.rows, hipMemcpyHostToDevice));
+    if (out->op) {
+        HIP_TRY(hipMalloc(&s.dev.op, sizeof(double) * n));
+    }
+    if (out->status) {
+        HIP_TRY(hipMalloc(&s.dev.status, n));
+    }
+    if (out->fail_surf) {
+        HIP_TRY(hipMalloc(&s.dev.fail_surf, sizeof(int16_t) * n));
+    }
+    if (out->pupil) {
+        HIP_TRY(hipMalloc(&s.dev.pupil, sizeof(double) * 2 * n));
+    }
+    return 0;
+}
+
+int unstage_out(Staged &s, hipStream_t st)
+{
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy2D(s.host.seg, sizeof(double) * s.host.ld, s.dev.seg, sizeof(double) * s.n,
+                        sizeof(double) * s.n, s.rows, hipMemcpyDeviceToHost));
+    if (s.host.op)
+        HIP_TRY(hipMemcpy(s.host.op, s.dev.op, sizeof(double) * s.n, hipMemcpyDeviceToHost));
+    if (s.host.status)
+        HIP_TRY(hipMemcpy(s.host.status, s.dev.status, s.n, hipMemcpyDeviceToHost));
+    if (s.host.fail_surf)
+        HIP_TRY(hipMemcpy(s.host.fail_surf, s.dev.fail_surf, sizeof(int16_t) * s.n,
+                          hipMemcpyDeviceToHost));
+    if (s.host.pupil)
+        HIP_TRY(hipMemcpy2D(s.host.pupil, sizeof(double) * s.host.ld, s.dev.pupil,
+                            sizeof(double) * s.n, sizeof(double) * s.n, 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ensure_axes(rox_system *sys, int32_t num)
+{
+    if (num <= sys->axes_cap)
+        return 0;
+    if (sys->d_axes)
+        HIP_TRY(hipFree(sys->d_axes));
+    sys->d_axes = nullptr;
+    sys->axes_cap = 0;
+    HIP_TRY(hipMalloc(&sys->d_axes, sizeof(double) * 2 * (size_t)num));
+    sys->axes_cap = num;
+    return 0;
+}
+
+int prepare_grid(rox_system *sys, const rox_field *fld, const rox_grid *grid, int32_t wvl_idx,
+                 const rox_opts *opts, const rox_out *out, hipStream_t st, TraceArgs &a)
+{
+    if (!fld || !grid)
+        return fail(ROX_E_ARG, "null argument");
+    if (grid->num < 1)
+        return fail(ROX_E_ARG, "grid.num must be >= 1");
+    if (wvl_idx < 0 || wvl_idx >= sys->n_wvls)
+        return fail(ROX_E_ARG, "wvl_idx %d out of range", wvl_idx);
+    const int64_t R = grid->kind == ROX_GRID_FAN ? grid->num : (int64_t)grid->num * grid->num;
+    int rc = check_opts(sys, opts, out, R);
+    if (rc)
+        return rc;
+    rc = ensure_axes(sys, grid->num);
+    if (rc)
+        return rc;
+    // trace.py:566-570 step = (stop - start)/(num - 1)
+    const double sx = (grid->stop[0] - grid->start[0]) / (grid->num - 1);
+    const double sy = (grid->stop[1] - grid->start[1]) / (grid->num - 1);
+    double *px = sys->d_axes, *py = sys->d_axes + sys->axes_cap;
+    hipLaunchKernelGGL(pupil_axes_kernel, dim3(1), dim3(64), 0, st, grid->start[0], grid->start[1],
+                       sx, sy, grid->num, px, py);
+    HIP_TRY(hipGetLastError());
+    a = TraceArgs{};
+    a.n_rays = R;
+    a.px = px;
+    a.py = py;
+    a.axis_kind = grid->kind == ROX_GRID_FAN ? AXIS_LIST : AXIS_PRODUCT;
+    a.axis_num = grid->num;
+    a.wvl_idx_all = wvl_idx;
+    a.fld = *fld;
+    a.opts = *opts;
+    a.out = *out;
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------- C ABI
+extern "C" {
+
+int rox_abi_version(void) { return ROX_ABI_VERSION; }
+
+const char *rox_last_error(void) { return g_err; }
+
+int rox_device_count(int *count)
+{
+    if (!count)
+        return fail(ROX_E_ARG, "null argument");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(ROX_E_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+
+int rox_set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_table,
+                      int32_t n_wvls, rox_system **out_sys)
+{
+    if (!rows || !n_table || !out_sys || n_ifcs < 2 || n_wvls < 1)
+        return fail(ROX_E_ARG, "rox_system_create: bad argument");
+    for (int i = 0; i < n_ifcs; ++i) {
+        const rox_surface &s = rows[i];
+        if (s.mode < ROX_TRANSMIT || s.mode > ROX_PHANTOM || s.profile < ROX_SPHERICAL ||
+            s.profile > ROX_RADIALPOLY || s.ncoef < 0 || s.ncoef > ROX_MAX_COEF || s.n_ap < 0 ||
+            s.n_ap > ROX_MAX_AP)
+            return fail(ROX_E_ARG, "rox_system_create: row %d is malformed", i);
+    }
+    rox_system *sys = new (std::nothrow) rox_system;
+    if (!sys)
+        return fail(ROX_E_NOMEM, "out of host memory");
+    sys->n_ifcs = n_ifcs;
+    sys->n_wvls = n_wvls;
+    sys->rows.assign(rows, rows + n_ifcs);
+    hipError_t e = hipGetDevice(&sys->device);
+    if (e != hipSuccess) {
+        delete sys;
+        return fail(ROX_E_NO_DEVICE, "hipGetDevice: %s", hipGetErrorString(e));
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, sys->device) == hipSuccess && prop.multiProcessorCount > 0)
+        sys->num_cus = prop.multiProcessorCount;
+    int rc = 0;
+    do {
+        const size_t rb = sizeof(rox_surface) * n_ifcs, nb = sizeof(double) * n_wvls * n_ifcs;
+        if (hipMalloc(&sys->d_rows, rb) != hipSuccess || hipMalloc(&sys->d_ntab, nb) != hipSuccess) {
+            rc = fail(ROX_E_HIP, "hipMalloc failed for the surface table");
+            break;
+        }
+        if (hipMemcpy(sys->d_rows, rows, rb, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(sys->d_ntab, n_table, nb, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(ROX_E_HIP, "hipMemcpy failed for the surface table");
+            break;
+        }
+        for (int f = 0; f < 2 && !rc; ++f) {
+            std::vector<int32_t> m;
+            slot_map(sys, f == 1, m, sys->n_seg[f]);
+            if (hipMalloc(&sys->d_slots[f], sizeof(int32_t) * m.size()) != hipSuccess ||
+                hipMemcpy(sys->d_slots[f], m.data(), sizeof(int32_t) * m.size(),
+                          hipMemcpyHostToDevice) != hipSuccess)
+                rc = fail(ROX_E_HIP, "slot map upload failed");
+        }
+    } while (0);
+    if (rc) {
+        rox_system_destroy(sys);
+        return rc;
+    }
+    *out_sys = sys;
+    return 0;
+}
+
+int rox_system_destroy(rox_system *sys)
+{
+    if (!sys)
+        return 0;
+    (void)hipFree(sys->d_rows);
+    (void)hipFree(sys->d_ntab);
+    (void)hipFree(sys->d_slots[0]);
+    (void)hipFree(sys->d_slots[1]);
+    (void)hipFree(sys->d_axes);
+    delete sys;
+    return 0;
+}
+
+int rox_system_num_segments(const rox_system *sys, uint32_t flags, int32_t *n_seg)
+{
+    if (!sys || !n_seg)
+        return fail(ROX_E_ARG, "null argument");
+    *n_seg = sys->n_seg[(flags & ROX_FILTER_PHANTOMS) ? 1 : 0];
+    return 0;
+}
+
+int rox_trace_rays(rox_system *sys, int64_t n_rays, const double *pt0, const double *dir0,
+                   const int32_t *wvl_idx, int32_t wvl_idx_all, const rox_opts *opts,
+                   const rox_out *out, void *stream)
+{
+    int rc = check_opts(sys, opts, out, n_rays);
+    if (rc)
+        return rc;
+    if (n_rays < 0 || (n_rays > 0 && (!pt0 || !dir0)))
+        return fail(ROX_E_ARG, "rox_trace_rays: bad ray buffers");
+    if (!wvl_idx && (wvl_idx_all < 0 || wvl_idx_all >= sys->n_wvls))
+        return fail(ROX_E_ARG, "wvl_idx %d out of range", wvl_idx_all);
+    hipStream_t st = (hipStream_t)stream;
+    TraceArgs a{};
+    a.n_rays = n_rays;
+    a.wvl_idx_all = wvl_idx_all;
+    a.opts = *opts;
+    if (!(opts->flags & ROX_HOST_POINTERS)) {
+        a.pt0 = pt0; a.dir0 = dir0; a.wvl_idx = wvl_idx; a.out = *out;
+        return launch(sys, a, GEN_RAYS, st);
+    }
+    if (wvl_idx)
+        for (int64_t i = 0; i < n_rays; ++i)
+            if (wvl_idx[i] < 0 || wvl_idx[i] >= sys->n_wvls)
+                return fail(ROX_E_ARG, "wvl_idx[%lld] = %d out of range", (long long)i, wvl_idx[i]);
+    Staged s;
+    rc = stage_out(s, sys, opts, out, n_rays);
+    if (rc)
+        return rc;
+    double *d_in = nullptr;
+    int32_t *d_w = nullptr;
+    const size_t vb = sizeof(double) * 3 * (size_t)n_rays;
+    hipError_t e = hipMalloc(&d_in, 2 * vb + 16);
+    if (e == hipSuccess && wvl_idx)
+        e = hipMalloc(&d_w, sizeof(int32_t) * (size_t)n_rays + 16);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_in, pt0, vb, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_in + 3 * n_rays, dir0, vb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && wvl_idx)
+        e = hipMemcpy(d_w, wvl_idx, sizeof(int32_t) * (size_t)n_rays, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        a.pt0 = d_in; a.dir0 = d_in + 3 * n_rays; a.wvl_idx = d_w; a.out = s.dev;
+        rc = launch(sys, a, GEN_RAYS, st);
+        if (!rc)
+            rc = unstage_out(s, st);
+    } else {
+        rc = fail(ROX_E_HIP, "staging inputs: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_w);
+    return rc;
+}
+
+int rox_trace_pupil_grid(rox_system *sys, const rox_field *fld, const rox_grid *grid,
+                         int32_t wvl_idx, const rox_opts *opts, const rox_out *out, void *stream)
+{
+    if (!sys)
+        return fail(ROX_E_ARG, "null system");
+    hipStream_t st = (hipStream_t)stream;
+    TraceArgs a;
+    int rc = prepare_grid(sys, fld, grid, wvl_idx, opts, out, st, a);
+    if (rc)
+        return rc;
+    if (!(opts->flags & ROX_HOST_POINTERS))
+        return launch(sys, a, GEN_PUPIL, st);
+    Staged s;
+    rc = stage_out(s, sys, opts, out, a.n_rays);
+    if (rc)
+        return rc;
+    a.out = s.dev;
+    rc = launch(sys, a, GEN_PUPIL, st);
+    return rc ? rc : unstage_out(s, st);
+}
+
+int rox_trace_pupil_list(rox_system *sys, const rox_field *fld, int64_t n_rays, const double *px,
+                         const double *py, int32_t wvl_idx, const rox_opts *opts,
+                         const rox_out *out, void *stream)
+{
+    int rc = check_opts(sys, opts, out, n_rays);
+    if (rc)
+        return rc;
+    if (!fld || n_rays < 0 || (n_rays > 0 && (!px || !py)))
+        return fail(ROX_E_ARG, "rox_trace_pupil_list: bad argument");
+    if (wvl_idx < 0 || wvl_idx >= sys->n_wvls)
+        return fail(ROX_E_ARG, "wvl_idx %d out of range", wvl_idx);
+    hipStream_t st = (hipStream_t)stream;
+    TraceArgs a{};
+    a.n_rays = n_rays;
+    a.axis_kind = AXIS_LIST;
+    a.axis_num = 1;
+    a.wvl_idx_all = wvl_idx;
+    a.fld = *fld;
+    a.opts = *opts;
+    if (!(opts->flags & ROX_HOST_POINTERS)) {
+        a.px = px; a.py = py; a.out = *out;
+        return launch(sys, a, GEN_PUPIL, st);
+    }
+    Staged s;
+    rc = stage_out(s, sys, opts, out, n_rays);
+    if (rc)
+        return rc;
+    double *d_p = nullptr;
+    hipError_t e = hipMalloc(&d_p, sizeof(double) * 2 * (size_t)n_rays + 16);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_p, px, sizeof(double) * n_rays, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_p + n_rays, py, sizeof(double) * n_rays, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        a.px = d_p; a.py = d_p + n_rays; a.out = s.dev;
+        rc = launch(sys, a, GEN_PUPIL, st);
+        if (!rc)
+            rc = unstage_out(s, st);
+    } else {
+        rc = fail(ROX_E_HIP, "staging pupil coordinates: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_p);
+    return rc;
+}
+
+int rox_time_pupil_grid(rox_system *sys, const rox_field *fld, const rox_grid *grid,
+                        int32_t wvl_idx, const rox_opts *opts, const rox_out *out, void *stream,
+                        int32_t launches, double *mean_ms)
+{
+    if (!sys || !mean_ms || launches < 1)
+        return fail(ROX_E_ARG, "rox_time_pupil_grid: bad argument");
+    if (opts && (opts->flags & ROX_HOST_POINTERS))
+        return fail(ROX_E_ARG, "rox_time_pupil_grid needs device buffers");
+    hipStream_t st = (hipStream_t)stream;
+    TraceArgs a;
+    int rc = prepare_grid(sys, fld, grid, wvl_idx, opts, out, st, a);
+    if (rc)
+        return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int i = 0; i < launches && !rc; ++i)
+        rc = launch(sys, a, GEN_PUPIL, st);
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *mean_ms = (double)ms / launches;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,229 @@
+"""Launch wrappers over the C ABI of libroxtrace.so (include/roxtrace.h).
+
+PyTorch is used only as plumbing: device buffers and the current HIP stream.
+There is no CPU fallback -- a missing library, or a missing GPU, raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .table import SurfaceTable
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libroxtrace.so')
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libroxtrace.so; never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                f'{LIB_PATH} is missing: build it with `python ray-optics_amd/build.py` '
+                '(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+        lib = abi.declare(C.CDLL(LIB_PATH))
+        if lib.rox_abi_version() != abi.ABI_VERSION:
+            raise EngineError('libroxtrace.so ABI version mismatch')
+        _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().rox_last_error().decode(errors='replace')
+        raise EngineError(f'{what} failed ({rc}): {msg}')
+
+
+def make_opts(flags=abi.INTERSECT_OBJ, out_mode=abi.OUT_FULL, first_surf=0,
+              last_surf=-1, eps=1.0e-12, fuzz=1e-5, foc=0.0, image_pt=(0., 0.)):
+    o = abi.Opts()
+    o.flags, o.out_mode = int(flags), int(out_mode)
+    o.first_surf, o.last_surf = int(first_surf), int(last_surf)
+    o.eps, o.fuzz, o.foc = float(eps), float(fuzz), float(foc)
+    o.image_pt[0], o.image_pt[1] = float(image_pt[0]), float(image_pt[1])
+    return o
+
+
+def make_grid(start, stop, num, kind=abi.GRID_PRODUCT):
+    g = abi.Grid()
+    g.start[0], g.start[1] = float(start[0]), float(start[1])
+    g.stop[0], g.stop[1] = float(stop[0]), float(stop[1])
+    g.num, g.kind = int(num), int(kind)
+    return g
+
+
+class DeviceResult:
+    """SoA trace results resident in HBM (torch tensors on the engine's device).
+
+    seg: FULL [n_seg, 10, R] | LAST [10, R] | HITS [2, R];  op [R] f64;
+    status [R] u8;  fail_surf [R] i16;  pupil [2, R] f64 or None.
+    Slots the trace does not write (segments past a failure, LAST/HITS rows of
+    failed rays) keep the buffer's prior contents: NaN when ``nan_fill``.
+    """
+
+    def __init__(self, torch, device, n_seg, R, out_mode, want_pupil, nan_fill):
+        if out_mode == abi.OUT_FULL:
+            shape = (n_seg, abi.SEG_DOUBLES, R)
+        elif out_mode == abi.OUT_LAST:
+            shape = (abi.SEG_DOUBLES, R)
+        else:
+            shape = (2, R)
+        new = (lambda s: torch.full(s, float('nan'), dtype=torch.float64, device=device)) \
+            if nan_fill else (lambda s: torch.empty(s, dtype=torch.float64, device=device))
+        self.R = R
+        self.out_mode = out_mode
+        self.seg = new(shape)
+        self.op = new((R,))
+        self.status = torch.empty((R,), dtype=torch.uint8, device=device)
+        self.fail_surf = torch.empty((R,), dtype=torch.int16, device=device)
+        self.pupil = new((2, R)) if want_pupil else None
+
+    def out_struct(self):
+        o = abi.Out()
+        o.seg = self.seg.data_ptr()
+        o.op = self.op.data_ptr()
+        o.status = self.status.data_ptr()
+        o.fail_surf = self.fail_surf.data_ptr()
+        o.pupil = self.pupil.data_ptr() if self.pupil is not None else None
+        o.ld = max(self.R, 1)
+        return o
+
+    def to_host(self):
+        """numpy copies (synchronises)"""
+        class _H:
+            pass
+        h = _H()
+        h.R, h.out_mode = self.R, self.out_mode
+        h.seg = self.seg.cpu().numpy()
+        h.op = self.op.cpu().numpy()
+        h.status = self.status.cpu().numpy()
+        h.fail_surf = self.fail_surf.cpu().numpy()
+        h.pupil = self.pupil.cpu().numpy() if self.pupil is not None else None
+        return h
+
+
+class TraceEngine:
+    """one immutable surface table on one GPU.
+
+    A model edit means a new engine, as ``path_sequence.cache_clear()`` does in
+    the reference (rayoptics/seq/sequential.py:666-668)."""
+
+    def __init__(self, table: SurfaceTable, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise EngineError('no GPU visible: the trace engine has no CPU fallback')
+        self.torch = torch
+        self.lib = load_library()
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None
+                                   else torch.device(device).index or 0)
+        self.table = table
+        self._handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.rox_set_device(self.device.index), 'rox_set_device')
+            _check(self.lib.rox_system_create(table.rows, table.n_ifcs,
+                                              table.n_table.ctypes.data,
+                                              len(table.wvls), C.byref(self._handle)),
+                   'rox_system_create')
+
+    def close(self):
+        if self._handle:
+            self.lib.rox_system_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ------------------------------------------------------------
+    def num_segments(self, flags=0):
+        n = C.c_int32()
+        _check(self.lib.rox_system_num_segments(self._handle, int(flags), C.byref(n)),
+               'rox_system_num_segments')
+        return n.value
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, x, dtype):
+        t = self.torch
+        if isinstance(x, t.Tensor):
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        return t.from_numpy(np.ascontiguousarray(x)).to(device=self.device, dtype=dtype)
+
+    def _result(self, R, opts, want_pupil, nan_fill, out):
+        if out is not None:
+            return out
+        return DeviceResult(self.torch, self.device, self.num_segments(opts.flags), R,
+                            opts.out_mode, want_pupil, nan_fill)
+
+    # -- entries --------------------------------------------------------------
+    def trace_rays(self, pt0, dir0, wvl_idx=0, opts=None, nan_fill=False, out=None):
+        """pt0, dir0: [3, R] (numpy or torch); wvl_idx: int or int32[R]"""
+        t = self.torch
+        opts = opts or make_opts()
+        pt0 = self._dev(pt0, t.float64)
+        dir0 = self._dev(dir0, t.float64)
+        R = pt0.shape[1]
+        if np.ndim(wvl_idx) == 0 and not isinstance(wvl_idx, t.Tensor):
+            wi, wi_ptr, wi_all = None, None, int(wvl_idx)
+        else:
+            wi = self._dev(wvl_idx, t.int32)
+            wi_ptr, wi_all = wi.data_ptr(), 0
+        res = self._result(R, opts, False, nan_fill, out)
+        o = res.out_struct()
+        with t.cuda.device(self.device):
+            _check(self.lib.rox_trace_rays(self._handle, R, pt0.data_ptr(), dir0.data_ptr(),
+                                           wi_ptr, wi_all, C.byref(opts), C.byref(o),
+                                           self._stream()), 'rox_trace_rays')
+        res._keep = (pt0, dir0, wi)     # inputs must outlive the async launch
+        return res
+
+    def trace_pupil_grid(self, fld, grid, wvl_idx=0, opts=None, want_pupil=True,
+                         nan_fill=False, out=None):
+        opts = opts or make_opts()
+        R = grid.num if grid.kind == abi.GRID_FAN else grid.num * grid.num
+        res = self._result(R, opts, want_pupil, nan_fill, out)
+        o = res.out_struct()
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_trace_pupil_grid(self._handle, C.byref(fld), C.byref(grid),
+                                                 int(wvl_idx), C.byref(opts), C.byref(o),
+                                                 self._stream()), 'rox_trace_pupil_grid')
+        return res
+
+    def trace_pupil_list(self, fld, px, py, wvl_idx=0, opts=None, want_pupil=True,
+                         nan_fill=False, out=None):
+        t = self.torch
+        opts = opts or make_opts()
+        px = self._dev(px, t.float64)
+        py = self._dev(py, t.float64)
+        R = px.shape[0]
+        res = self._result(R, opts, want_pupil, nan_fill, out)
+        o = res.out_struct()
+        with t.cuda.device(self.device):
+            _check(self.lib.rox_trace_pupil_list(self._handle, C.byref(fld), R, px.data_ptr(),
+                                                 py.data_ptr(), int(wvl_idx), C.byref(opts),
+                                                 C.byref(o), self._stream()),
+                   'rox_trace_pupil_list')
+        res._keep = (px, py)
+        return res
+
+    def time_pupil_grid(self, fld, grid, wvl_idx, opts, out, launches):
+        """mean duration (ms) of the trace kernel over `launches` launches,
+        from HIP events recorded on the launch stream"""
+        ms = C.c_double()
+        o = out.out_struct()
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_time_pupil_grid(self._handle, C.byref(fld), C.byref(grid),
+                                                int(wvl_idx), C.byref(opts), C.byref(o),
+                                                self._stream(), int(launches), C.byref(ms)),
+                   'rox_time_pupil_grid')
+        return ms.value

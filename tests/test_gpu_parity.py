@@ -1,0 +1,223 @@
+"""-m gpu: the HIP kernels, called through the C ABI, against
+  * the CPU oracle on the same inputs -- BIT-EXACT (binary64, same operation
+    order, explicit fma at the BLAS sites), and
+  * the reference's own outputs stored in tests/golden -- within 1e-10
+    (north_star's tolerance on ray intercepts, applied relative to max(1,|ref|)).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rayoptics_amd import abi
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engines():
+    from rayoptics_amd.engine import TraceEngine
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = TraceEngine(H.fixture(name).table)
+        return cache[name]
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+def bit_equal(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f'{what}: {np.count_nonzero(~same)} of {same.size} entries differ, first at {np.argwhere(~same)[:3].tolist()}'
+    # signed zeros too
+    assert np.array_equal(np.signbit(a[~np.isnan(a)]), np.signbit(b[~np.isnan(b)])), f'{what}: zero signs differ'
+
+
+def assert_same_as_oracle(dev, orc, what):
+    np.testing.assert_array_equal(dev.status, orc.status, err_msg=what)
+    np.testing.assert_array_equal(dev.fail_surf, orc.fail_surf, err_msg=what)
+    bit_equal(dev.seg, orc.seg, what + ' seg')
+    bit_equal(dev.op, orc.op, what + ' op')
+    if getattr(orc, 'pupil', None) is not None and dev.pupil is not None:
+        bit_equal(dev.pupil, orc.pupil, what + ' pupil')
+
+
+from test_oracle_golden import RAY_CASES, GRID_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize('name,case', RAY_CASES)
+def test_explicit_rays(engines, name, case):
+    from oracle import oracle
+    fx = H.fixture(name)
+    c = fx[case]
+    wi = c['wvl_idx'] if 'wvl_idx' in c else 0
+    opts = H.make_opts(c)
+    dev = engines(name).trace_rays(c['pt0'], c['dir0'], wi, opts, nan_fill=True).to_host()
+    orc = oracle.trace_rays(fx.table, c['pt0'], c['dir0'], wi, opts)
+    assert_same_as_oracle(dev, orc, f'{name}/{case}')
+    H.assert_result_matches(c, dev)                 # and vs the reference itself
+
+
+@pytest.mark.parametrize('name,case', GRID_CASES)
+def test_pupil_grid(engines, name, case):
+    from oracle import oracle
+    fx = H.fixture(name)
+    c = fx[case]
+    fld = H.field_from_arr(c['field'])
+    grid = oracle.make_grid(c['start'], c['stop'], int(c['num']), int(c['kind']))
+    opts = H.make_opts(c)
+    dev = engines(name).trace_pupil_grid(fld, grid, int(c['wvl_idx']), opts, nan_fill=True).to_host()
+    orc = oracle.trace_pupil_grid(fx.table, fld, grid, int(c['wvl_idx']), opts)
+    assert_same_as_oracle(dev, orc, f'{name}/{case}')
+    np.testing.assert_array_equal(dev.pupil, c['pupil'])
+    H.assert_result_matches(c, dev)
+
+
+@pytest.mark.parametrize('name', ['dblgauss', 'singlet', 'rc_telescope', 'nikkor'])
+def test_spot_hits(engines, name):
+    """HITS mode == SpotDiagramFigure's data (reference consumer, unchanged)"""
+    from oracle import oracle
+    fx = H.fixture(name)
+    c = fx['spot']
+    num = int(c['num'])
+    N = fx.table.n_ifcs
+    for key in [k for k in c if k.endswith('_hits')]:
+        fi, wi = key.split('_')[0], int(key.split('_')[1][1:])
+        fld = H.field_from_arr(c[f'{fi}_field'])
+        opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING,
+                                out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
+                                foc=float(c['foc']), image_pt=tuple(c[f'{fi}_image_pt']))
+        grid = oracle.make_grid((-1., -1.), (1., 1.), num)
+        dev = engines(name).trace_pupil_grid(fld, grid, wi, opts, nan_fill=True).to_host()
+        ok = dev.status == abi.OK
+        H.assert_soa_close(c[key], dev.seg[:, ok].T, key, require_exact=True)
+
+
+@pytest.mark.parametrize('out_mode', [abi.OUT_LAST, abi.OUT_HITS])
+def test_reduced_outputs_match_full(engines, out_mode):
+    from oracle import oracle
+    fx = H.fixture('dblgauss')
+    c = fx['rays_ap']
+    N = fx.table.n_ifcs
+    opts = oracle.make_opts(flags=int(c['flags']), out_mode=out_mode, first_surf=1,
+                            last_surf=N - 2, foc=0.0125, image_pt=(0.01, -0.02))
+    dev = engines('dblgauss').trace_rays(c['pt0'], c['dir0'], c['wvl_idx'], opts, nan_fill=True).to_host()
+    orc = oracle.trace_rays(fx.table, c['pt0'], c['dir0'], c['wvl_idx'], opts)
+    assert_same_as_oracle(dev, orc, f'out_mode {out_mode}')
+
+
+def test_list_of_rays_last(engines):
+    fx = H.fixture('dblgauss')
+    c = fx['list_last']
+    N = fx.table.n_ifcs
+    from oracle import oracle
+    opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES,
+                            out_mode=abi.OUT_LAST, first_surf=1, last_surf=N - 2)
+    dev = engines('dblgauss').trace_rays(c['pt0'], c['dir0'], c['wvl_idx'], opts, nan_fill=True).to_host()
+    np.testing.assert_array_equal(dev.status, c['status'])
+    H.assert_soa_close(c['last'], dev.seg, 'last', require_exact=True)
+
+
+def test_filter_out_phantoms(engines):
+    """raytrace.py:185-188: the coordinate break's segment is dropped and its
+    path length folded into the previous segment"""
+    from oracle import oracle
+    fx = H.fixture('tilted_singlet')
+    c = fx['rays_ap']
+    assert fx.table.has_phantoms()
+    opts = H.make_opts(c)
+    opts.flags |= abi.FILTER_PHANTOMS
+    eng = engines('tilted_singlet')
+    assert eng.num_segments(opts.flags) == fx.table.n_ifcs - 1
+    dev = eng.trace_rays(c['pt0'], c['dir0'], c['wvl_idx'], opts, nan_fill=True).to_host()
+    orc = oracle.trace_rays(fx.table, c['pt0'], c['dir0'], c['wvl_idx'], opts)
+    np.testing.assert_array_equal(dev.status, orc.status)
+    bit_equal(dev.seg, orc.seg[:dev.seg.shape[0]], 'filtered seg')
+    bit_equal(dev.op, orc.op, 'filtered op')
+
+
+def test_intersect_obj_false_and_surface_ranges(engines):
+    """wide-angle entry (trace.py:302-303) and non-default first/last_surf"""
+    from oracle import oracle
+    fx = H.fixture('dblgauss_finite')
+    c = fx['rays_ap']
+    for flags, fs, ls in [(abi.CHECK_APERTURES, 0, -1), (abi.INTERSECT_OBJ, 2, 7),
+                          (abi.INTERSECT_OBJ | abi.CHECK_APERTURES, 3, 3)]:
+        opts = oracle.make_opts(flags=flags, first_surf=fs, last_surf=ls)
+        dev = engines('dblgauss_finite').trace_rays(c['pt0'], c['dir0'], c['wvl_idx'], opts, nan_fill=True).to_host()
+        orc = oracle.trace_rays(fx.table, c['pt0'], c['dir0'], c['wvl_idx'], opts)
+        assert_same_as_oracle(dev, orc, f'flags={flags} fs={fs} ls={ls}')
+
+
+def test_empty_and_ragged_batches(engines):
+    from oracle import oracle
+    fx = H.fixture('dblgauss')
+    c = fx['rays_ap']
+    eng = engines('dblgauss')
+    opts = H.make_opts(c)
+    res = eng.trace_rays(np.zeros((3, 0)), np.zeros((3, 0)), 0, opts)
+    assert res.seg.shape[-1] == 0
+    for R in (1, 63, 65, 257):
+        dev = eng.trace_rays(c['pt0'][:, :R], c['dir0'][:, :R], c['wvl_idx'][:R], opts, nan_fill=True).to_host()
+        orc = oracle.trace_rays(fx.table, c['pt0'][:, :R], c['dir0'][:, :R], c['wvl_idx'][:R], opts)
+        assert_same_as_oracle(dev, orc, f'R={R}')
+
+
+def test_host_pointer_mode(engines):
+    """ROX_HOST_POINTERS: plain numpy buffers straight through the C ABI"""
+    from oracle import oracle
+    from rayoptics_amd.engine import load_library
+    fx = H.fixture('rc_telescope')
+    c = fx['grid_f4']
+    eng = engines('rc_telescope')
+    fld = H.field_from_arr(c['field'])
+    grid = oracle.make_grid(c['start'], c['stop'], int(c['num']), int(c['kind']))
+    opts = H.make_opts(c)
+    orc = oracle.trace_pupil_grid(fx.table, fld, grid, int(c['wvl_idx']), opts)
+    opts.flags |= abi.HOST_POINTERS
+    res = oracle.HostResult(fx.table.n_ifcs, orc.R, abi.OUT_FULL, want_pupil=True)
+    out = res.out_struct()
+    rc = load_library().rox_trace_pupil_grid(eng._handle, C.byref(fld), C.byref(grid),
+                                             int(c['wvl_idx']), C.byref(opts), C.byref(out), None)
+    assert rc == 0, load_library().rox_last_error()
+    assert_same_as_oracle(res, orc, 'host pointers')
+
+
+def test_full_size_grid_bit_exact_vs_oracle(engines):
+    """BASELINE.json config 2 at full size: 1024x1024 pupil grid through the
+    13-interface double Gauss, every ray compared with the oracle (HITS and
+    status), plus size-independent properties."""
+    from oracle import oracle
+    fx = H.fixture('dblgauss')
+    c = fx['grid_f2']
+    N = fx.table.n_ifcs
+    fld = H.field_from_arr(c['field'])
+    grid = oracle.make_grid((-1., -1.), (1., 1.), 1024)
+    opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING,
+                            out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2)
+    dev = engines('dblgauss').trace_pupil_grid(fld, grid, 1, opts, nan_fill=True).to_host()
+    orc = oracle.trace_pupil_grid(fx.table, fld, grid, 1, opts)
+    assert_same_as_oracle(dev, orc, '1024x1024 HITS')
+    # properties: the system is symmetric in x for a y-field, so the spot is too
+    ok = (dev.status == 0).reshape(1024, 1024)
+    assert 0.3 < ok.mean() < 0.9
+    # FULL packets of the same grid: every segment chain is geometrically
+    # consistent (next point = point + dst * direction, in the next frame)
+    opts.out_mode = abi.OUT_FULL
+    full = engines('dblgauss').trace_pupil_grid(fld, grid, 1, opts, nan_fill=True)
+    seg = full.seg
+    import torch
+    good = (full.status == 0)
+    t_z = torch.tensor([fx.table.rows[k].t[2] for k in range(N)], dtype=torch.float64, device=seg.device)
+    for k in range(1, N - 1):
+        p, d, dst = seg[k, 0:3][:, good], seg[k, 3:6][:, good], seg[k, 6][good]
+        nxt = seg[k + 1, 0:3][:, good].clone()
+        nxt[2] += t_z[k]
+        err = (p + dst * d - nxt).abs().max().item()
+        assert err < 1e-9, (k, err)
+        assert ((d * d).sum(0) - 1).abs().max().item() < 1e-12
