@@ -24,6 +24,10 @@ def load_library():
     """dlopen libroxtrace.so; never falls back to anything else."""
     global _lib
     if _lib is None:
+        # torch ships its own libamdhip64; it must be the HIP runtime of the
+        # process *before* libroxtrace.so (linked against the same SONAME)
+        # is dlopen'ed, or the two sides would not share device pointers
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise EngineError(
                 f'{LIB_PATH} is missing: build it with `python ray-optics_amd/build.py` '

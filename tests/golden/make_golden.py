@@ -292,9 +292,44 @@ def kat_dblgauss_seq():
     save('dblgauss_seq', table, cases)
 
 
+def workload_file(opm, name, desc):
+    """ray-optics_amd/data/<name>.json: what bench.py / smoke() need to run a
+    BASELINE.json configuration where the reference is absent (the GPU box):
+    the surface table plus, per field, the ray-start constants and the
+    central-wavelength chief-ray image point (fld.ref_sphere[0], set by
+    SequentialModel.trace_grid -> trace.setup_pupil_coords)."""
+    sm, osp = opm['seq_model'], opm['optical_spec']
+    table = ra.SurfaceTable.from_seq_model(sm)
+    foc = osp['focus'].focus_shift
+    wvl = sm.central_wavelength()
+    flds = []
+    for fld in osp['fov'].fields:
+        rs_pkg, cr_pkg = trace.setup_pupil_coords(opm, fld, wvl, foc)
+        fld.chief_ray, fld.ref_sphere = cr_pkg, rs_pkg
+        flds.append(dict(field=field_arr(field_from_model(opm, fld)).tolist(),
+                         image_pt=[float(v) for v in rs_pkg[0][:2]]))
+    d = dict(description=desc, table=table.to_dict(), fields=flds, foc=float(foc),
+             ref_wvl_idx=int(osp['wvls'].reference_wvl))
+    path = os.path.join(HERE, '..', '..', 'ray-optics_amd', 'data', name + '.json')
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, 'w') as f:
+        json.dump(d, f)
+    print(f'data/{name}.json: {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def main():
     rng = np.random.default_rng(SEED)
     kat_dblgauss_seq()
+    workload_file(rm.dblgauss(), 'dblgauss_c2',
+                  'BASELINE.json configs[1]: double Gauss, 13 interfaces (K=12 '
+                  'intersections/ray), rayoptics/raytr/tests/ag_dblgauss_s.py; '
+                  'EPD 50, fields 0/10/14 deg, 656.3/587.6/486.1 nm')
+    workload_file(rm.rc_telescope(), 'rc_telescope_c4',
+                  'BASELINE.json configs[3]: Ritchey-Chretien mirror pair + field '
+                  'stop, 5 fields (rayoptics/models/Ritchey_Chretien.roa)')
+    workload_file(rm.nikkor(), 'nikkor_c3',
+                  'BASELINE.json configs[2] stand-in: 29-interface zoom with 4 '
+                  'even aspheres (rayoptics/optical/tests/Nikon Nikkor Z 14-30mm f-4 S.roa)')
 
     # C2: double Gauss (13 interfaces)
     opm = rm.dblgauss()

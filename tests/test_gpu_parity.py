@@ -205,7 +205,7 @@ def test_full_size_grid_bit_exact_vs_oracle(engines):
     assert_same_as_oracle(dev, orc, '1024x1024 HITS')
     # properties: the system is symmetric in x for a y-field, so the spot is too
     ok = (dev.status == 0).reshape(1024, 1024)
-    assert 0.3 < ok.mean() < 0.9
+    assert 0.3 < ok.mean() < 0.99
     # FULL packets of the same grid: every segment chain is geometrically
     # consistent (next point = point + dst * direction, in the next frame)
     opts.out_mode = abi.OUT_FULL
