@@ -1,0 +1,113 @@
+"""Drop-ins for the list / grid / fan drivers of ``rayoptics.raytr.analyses``.
+
+  trace_list_of_rays <- rayoptics/raytr/analyses.py:458-510
+  trace_ray_list     <- rayoptics/raytr/analyses.py:437-455
+  trace_ray_grid     <- rayoptics/raytr/analyses.py:666-696
+  trace_ray_fan      <- rayoptics/raytr/analyses.py:212-230
+"""
+import numpy as np
+
+from . import abi, session
+from .engine import make_grid
+from .raypkg import HostPackets
+from .trace import opts_from_kwargs, emit, _trace_pupil
+
+
+def trace_list_of_rays(opt_model, rays, output_filter=None, rayerr_filter=None,
+                       **kwargs):
+    """explicit (pt0, dir0, wvl) rays; per-ray wavelengths allowed"""
+    rays = list(rays)
+    eng = session.engine_for(opt_model)
+    tbl = eng.table
+    R = len(rays)
+    pt0 = np.empty((3, R))
+    dir0 = np.empty((3, R))
+    wvls = np.empty(R)
+    wi = np.empty(R, dtype=np.int32)
+    for r, (p, d, w) in enumerate(rays):
+        pt0[:, r], dir0[:, r], wvls[r] = p, d, w
+        wi[r] = tbl.wvl_index(w)
+    # partial packets (rayerr_filter='full') need the FULL layout
+    out_mode = (abi.OUT_LAST if output_filter == 'last' and rayerr_filter != 'full'
+                else abi.OUT_FULL)
+    opts = opts_from_kwargs(tbl.n_ifcs, kwargs, out_mode)
+    res = eng.trace_rays(pt0, dir0, wi, opts)
+    pk = HostPackets(res.to_host(), tbl, opts.flags, out_mode, wvls)
+    ifcs = opt_model['seq_model'].ifcs
+    named = True        # trace.trace() wraps in RayPkg (trace.py:250)
+    ray_list = []
+    for r, ray in enumerate(rays):
+        if pk.status[r] != abi.OK:
+            if rayerr_filter == 'full':
+                ray_list.append((ray, pk.error(r, ifcs, with_pkg=True, named=False)))
+            elif rayerr_filter == 'summary':
+                ray_list.append((ray, pk.error(r, ifcs, with_pkg=False)))
+            continue
+        pkg = pk.pkg(r, named)
+        if output_filter is None:
+            ray_list.append(pkg)
+        elif output_filter == 'last':
+            seg, op_delta, wvl = pkg
+            ray_list.append((seg[-1], op_delta, wvl))
+        else:
+            ray_list.append(output_filter(pkg))
+    return ray_list
+
+
+def trace_ray_list(opt_model, pupil_coords, fld, wvl, foc, append_if_none=False,
+                   output_filter=None, rayerr_filter=None, **kwargs):
+    kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', True)
+    named = kwargs.get('use_named_tuples', False)
+    items = pupil_coords if isinstance(pupil_coords, (list, np.ndarray)) else list(pupil_coords)
+    pc = np.array([[p[0], p[1]] for p in items], dtype=float).reshape(-1, 2)
+    pk = _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter,
+                      pupil_list=(pc[:, 0].copy(), pc[:, 1].copy()))
+    ifcs = opt_model['seq_model'].ifcs
+    ray_list = []
+    for r, p in enumerate(items):
+        # Field.apply_vignetting scales `pupil[:]`: a view for an ndarray (the
+        # caller's coordinates change in place), a copy for a list or tuple
+        if isinstance(p, np.ndarray):
+            p[0], p[1] = pk.pupil[0, r], pk.pupil[1, r]
+        pkg, _err = emit(pk, r, output_filter, rayerr_filter, named, ifcs)
+        if pkg is not None:
+            ray_list.append([p[0], p[1], pkg])
+        elif append_if_none:
+            ray_list.append([p[0], p[1], None])
+    return ray_list
+
+
+def trace_ray_grid(opt_model, grid_rng, fld, wvl, foc, append_if_none=True,
+                   output_filter=None, rayerr_filter=None, **kwargs):
+    kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', False)   # :674
+    named = kwargs.get('use_named_tuples', False)
+    num = grid_rng[2]
+    pk = _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter,
+                      grid=make_grid(grid_rng[0], grid_rng[1], num))
+    ifcs = opt_model['seq_model'].ifcs
+    grid = []
+    for i in range(num):
+        row = []
+        for j in range(num):
+            r = i * num + j
+            pkg, _err = emit(pk, r, output_filter, rayerr_filter, named, ifcs)
+            if pkg is not None:
+                row.append([pk.pupil[0, r], pk.pupil[1, r], pkg])
+            elif append_if_none:
+                row.append([pk.pupil[0, r], pk.pupil[1, r], None])
+        grid.append(row)
+    return grid
+
+
+def trace_ray_fan(opt_model, fan_rng, fld, wvl, foc, output_filter=None,
+                  rayerr_filter=None, **kwargs):
+    kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', True)
+    pk = _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter,
+                      grid=make_grid(fan_rng[0], fan_rng[1], fan_rng[2], abi.GRID_FAN))
+    ifcs = opt_model['seq_model'].ifcs
+    fan = []
+    for r in range(fan_rng[2]):
+        pkg, _err = emit(pk, r, output_filter, rayerr_filter, True, ifcs)   # :222
+        if pkg is not None:
+            fan.append([pk.pupil[0, r], pk.pupil[1, r], pkg])
+    return fan

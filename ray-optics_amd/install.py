@@ -1,0 +1,57 @@
+"""Rebinds the reference's module-level seams to the
+device-backed drop-ins.  Every caller in ray-optics reaches these functions
+through a module-qualified name (``trace.trace_grid(...)``,
+``seq_model.trace_grid(...)``), so rebinding the attribute is a true drop-in:
+SpotDiagramFigure, RayFan, RayList and RayGrid consume the results unchanged.
+
+    import rayoptics_amd.install as roxi
+    roxi.install()              # unsupported models raise
+    roxi.install('reference')   # unsupported models use the reference's own code
+    roxi.uninstall()
+"""
+import functools
+
+from . import session
+from . import trace as _t
+from . import analyses as _a
+from .table import UnsupportedModelError
+
+_saved = {}
+
+
+def _guard(ours, theirs):
+    @functools.wraps(theirs)
+    def call(*args, **kwargs):
+        try:
+            return ours(*args, **kwargs)
+        except UnsupportedModelError:
+            if session.FALLBACK == 'reference':
+                return theirs(*args, **kwargs)
+            raise
+    return call
+
+
+def install(fallback='raise'):
+    import rayoptics.raytr.trace as rtrace
+    import rayoptics.raytr.analyses as ranalyses
+    from rayoptics.seq.sequential import SequentialModel
+    if _saved:
+        uninstall()
+    session.FALLBACK = fallback
+    seams = [(rtrace, 'trace_grid', _t.trace_grid), (rtrace, 'trace_fan', _t.trace_fan),
+             (ranalyses, 'trace_list_of_rays', _a.trace_list_of_rays),
+             (ranalyses, 'trace_ray_list', _a.trace_ray_list),
+             (ranalyses, 'trace_ray_grid', _a.trace_ray_grid),
+             (ranalyses, 'trace_ray_fan', _a.trace_ray_fan),
+             (SequentialModel, 'trace_grid', _t.seq_trace_grid)]
+    for owner, name, ours in seams:
+        theirs = getattr(owner, name)
+        _saved[(owner, name)] = theirs
+        setattr(owner, name, _guard(ours, theirs))
+
+
+def uninstall():
+    for (owner, name), theirs in _saved.items():
+        setattr(owner, name, theirs)
+    _saved.clear()
+    session.clear()

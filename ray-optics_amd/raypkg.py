@@ -1,0 +1,119 @@
+"""Lazy RayPkg / RaySeg views over SoA trace results.
+
+The reference returns, per ray, a Python list of N lists
+``[p(ndarray3), d(ndarray3), dst(float), nrml(ndarray3)]`` plus ``op_delta`` and
+``wvl`` (rayoptics/raytr/raytrace.py:191, 260-264;
+rayoptics/raytr/__init__.py:24-40).  Materialising that for a million rays is
+tens of millions of Python objects, so the host side keeps the SoA arrays and
+hands out sequence views that build a segment only when it is indexed.  Every
+access pattern reference consumers use works on them: ``pkg[mc.ray]``,
+``ray[-1][mc.p]``, ``ray[k][mc.d][2]``, ``len(ray)``, iteration, tuple
+unpacking ``ray, op, wvl = pkg`` and ``RaySeg(*rs)``.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from . import abi
+
+try:
+    from rayoptics.raytr import RayPkg, RaySeg, RayResult
+except Exception:
+    RayResult = namedtuple('RayResult', ['pkg', 'err'])
+    RayPkg = namedtuple('RayPkg', ['ray', 'op', 'wvl'])
+    RaySeg = namedtuple('RaySeg', ['p', 'd', 'dst', 'nrml'])
+
+
+class LazyRay:
+    """sequence of ray segments of one ray; segment k is built on access"""
+    __slots__ = ('_seg', '_r', '_n', '_named')
+
+    def __init__(self, seg, r, nseg, named=False):
+        self._seg = seg         # numpy [K, 10, R] (FULL) or [1, 10, R]
+        self._r = r
+        self._n = nseg
+        self._named = named
+
+    def __len__(self):
+        return self._n
+
+    def _make(self, k):
+        s = self._seg[k, :, self._r]
+        item = [s[0:3].copy(), s[3:6].copy(), float(s[6]), s[7:10].copy()]
+        return RaySeg(*item) if self._named else item
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self._make(i) for i in range(*k.indices(self._n))]
+        if k < 0:
+            k += self._n
+        if not 0 <= k < self._n:
+            raise IndexError('ray segment index out of range')
+        return self._make(k)
+
+    def __iter__(self):
+        for k in range(self._n):
+            yield self._make(k)
+
+    def to_list(self):
+        return [self._make(k) for k in range(self._n)]
+
+    def __repr__(self):
+        return f'LazyRay({self._n} segments, ray {self._r})'
+
+
+class HostPackets:
+    """host-side (numpy) copy of one trace call's outputs + the bookkeeping
+    needed to serve reference-shaped results for ray ``r``"""
+
+    def __init__(self, host, table, flags, out_mode, wvl_of_ray):
+        self.seg = host.seg if host.seg.ndim == 3 else host.seg[None]
+        self.op = host.op
+        self.status = host.status
+        self.fail_surf = host.fail_surf
+        self.pupil = host.pupil
+        self.table = table
+        self.out_mode = out_mode
+        self.flags = flags
+        self._wvl = wvl_of_ray          # float or array of floats
+        N = table.n_ifcs
+        filt = bool(flags & abi.FILTER_PHANTOMS)
+        nb, nxt = [], 0
+        for i, row in enumerate(table.rows):
+            nb.append(nxt)
+            if not (filt and row.mode == abi.PHANTOM and 0 < i < N - 1):
+                nxt += 1
+        self._nslots_before = nb
+        self._n_full = nxt
+
+    def wvl(self, r):
+        return float(self._wvl if np.ndim(self._wvl) == 0 else self._wvl[r])
+
+    def nseg(self, r):
+        st = self.status[r]
+        if self.out_mode != abi.OUT_FULL:
+            return 1 if st == abi.OK else 0
+        if st == abi.OK:
+            return self._n_full
+        s = int(self.fail_surf[r])
+        if s <= 0:
+            return 0
+        if st == abi.MISSED_SURFACE:        # raytrace.py:231-237
+            return self._nslots_before[s - 1] + 1
+        return self._nslots_before[s] + 1   # raytrace.py:239-257
+
+    def pkg(self, r, named=False):
+        ray = LazyRay(self.seg, r, self.nseg(r), named)
+        op, wvl = float(self.op[r]), self.wvl(r)
+        return RayPkg(ray, op, wvl) if named else (ray, op, wvl)
+
+    def error(self, r, ifcs=None, with_pkg=True, named=True):
+        """the exception object trace_safe would report for a failed ray"""
+        from .traceerror import make_error
+        st, s = int(self.status[r]), int(self.fail_surf[r])
+        ifc = ifcs[s] if ifcs is not None and 0 <= s < len(ifcs) else None
+        pkg = self.pkg(r, named) if with_pkg and self.out_mode == abi.OUT_FULL else None
+        int_pt = None
+        if pkg is not None and st != abi.MISSED_SURFACE and len(pkg[0]):
+            int_pt = pkg[0][-1][0]
+        return make_error(st, s, ifc, pkg, int_pt)

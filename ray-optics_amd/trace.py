@@ -1,0 +1,187 @@
+"""Drop-ins for the fan / grid drivers of ``rayoptics.raytr.trace`` and for
+``SequentialModel.trace_grid``: same names, arguments and return shapes, with
+the per-ray Python loop replaced by one device launch.
+
+  trace_grid      <- rayoptics/raytr/trace.py:563-605
+  trace_fan       <- rayoptics/raytr/trace.py:537-560
+  seq_trace_grid  <- rayoptics/seq/sequential.py:1058-1085 (method)
+Result filtering follows trace_safe, rayoptics/raytr/trace.py:160-221.
+"""
+import numpy as np
+
+from . import abi, session
+from .engine import make_opts, make_grid
+from .raypkg import HostPackets, RayPkg, RaySeg
+from .table import field_from_model, UnsupportedModelError
+
+
+def opts_from_kwargs(n_ifcs, kwargs, out_mode, foc=0.0, image_pt=(0., 0.)):
+    """kwargs threaded through the reference's layers (trace.py:116-146,
+    raytrace.py:83-99) -> the C ABI's flags word + scalars.  first/last_surf
+    default as in raytrace.trace (raytrace.py:77-79)."""
+    flags = 0
+    if kwargs.get('check_apertures', False):
+        flags |= abi.CHECK_APERTURES
+    if kwargs.get('intersect_obj', True):
+        flags |= abi.INTERSECT_OBJ
+    if kwargs.get('filter_out_phantoms', False):
+        flags |= abi.FILTER_PHANTOMS
+    if kwargs.get('apply_vignetting', False):
+        flags |= abi.APPLY_VIGNETTING
+    last = kwargs.get('last_surf', n_ifcs - 2)
+    fuzz = kwargs.get('pt_inside_fuzz', None)
+    return make_opts(flags=flags, out_mode=out_mode,
+                     first_surf=kwargs.get('first_surf', 1),
+                     last_surf=-1 if last is None else last,
+                     eps=kwargs.get('eps', 1.0e-12),
+                     fuzz=1e-5 if fuzz is None else fuzz, foc=foc, image_pt=image_pt)
+
+
+def emit(pk, r, output_filter, rayerr_filter, named, ifcs):
+    """(pkg, err) for ray r, as trace_safe would return it (trace.py:186-221)"""
+    if pk.status[r] != abi.OK:
+        if rayerr_filter == 'full':
+            err = pk.error(r, ifcs, with_pkg=True, named=True)
+            return err.ray_pkg, err
+        if rayerr_filter == 'summary':
+            return None, pk.error(r, ifcs, with_pkg=False)
+        return None, None
+    pkg = pk.pkg(r, named)
+    if output_filter is None:
+        return pkg, None
+    if output_filter == 'last':
+        ray, op, wvl = pkg
+        return RayPkg([ray[-1]], op, wvl), None
+    return output_filter(pkg), None
+
+
+def _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter, grid=None,
+                 pupil_list=None,
+                 out_mode=None, foc=0.0, image_pt=(0., 0.)):
+    pupil_type = kwargs.get('pupil_type', 'rel pupil')
+    if pupil_type != 'rel pupil':
+        raise UnsupportedModelError(f'pupil_type {pupil_type!r} is generated on the host')
+    eng = session.engine_for(opt_model)
+    tbl = eng.table
+    f = field_from_model(opt_model, fld)
+    if out_mode is None:
+        # partial packets (rayerr_filter='full') need the FULL layout
+        out_mode = (abi.OUT_LAST if output_filter == 'last' and rayerr_filter != 'full'
+                    else abi.OUT_FULL)
+    opts = opts_from_kwargs(tbl.n_ifcs, kwargs, out_mode, foc, image_pt)
+    wi = tbl.wvl_index(wvl)
+    if grid is not None:
+        res = eng.trace_pupil_grid(f, grid, wi, opts)
+    else:
+        res = eng.trace_pupil_list(f, pupil_list[0], pupil_list[1], wi, opts)
+    return HostPackets(res.to_host(), tbl, opts.flags, out_mode, wvl)
+
+
+def trace_grid(opt_model, grid_rng, fld, wvl, foc, img_filter=None,
+               form='grid', append_if_none=True, **kwargs):
+    """rayoptics/raytr/trace.py:563-605"""
+    output_filter = kwargs.pop('output_filter', None)
+    rayerr_filter = kwargs.pop('rayerr_filter', None)
+    named = kwargs.get('use_named_tuples', False)
+    num = grid_rng[2]
+    kwargs['check_apertures'] = True                                 # :583
+    kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', True)   # trace_base default
+    pk = _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter,
+                      grid=make_grid(grid_rng[0], grid_rng[1], num))
+    ifcs = opt_model['seq_model'].ifcs
+    grid = []
+    for i in range(num):
+        working_grid = grid if form == 'list' else []
+        for j in range(num):
+            r = i * num + j
+            pupil = np.array([pk.pupil[0, r], pk.pupil[1, r]])
+            pkg, _err = emit(pk, r, output_filter, rayerr_filter, named, ifcs)
+            if pkg is not None:
+                if img_filter:
+                    working_grid.append(img_filter(pupil, pkg))
+                else:
+                    working_grid.append([pupil[0], pupil[1], pkg])
+            else:
+                if img_filter:
+                    result = img_filter(pupil, None)
+                    if result is not None or append_if_none:
+                        working_grid.append(result)
+                elif append_if_none:
+                    working_grid.append([pupil[0], pupil[1], None])
+        if form == 'grid':
+            grid.append(working_grid)
+    try:
+        return np.array(grid)
+    except ValueError:      # ragged packets under NumPy >= 1.24
+        return np.array(grid, dtype=object)
+
+
+def trace_fan(opt_model, fan_rng, fld, wvl, foc, img_filter=None, **kwargs):
+    """rayoptics/raytr/trace.py:537-560"""
+    output_filter = kwargs.pop('output_filter', None)
+    rayerr_filter = kwargs.pop('rayerr_filter', None)
+    named = kwargs.get('use_named_tuples', False)
+    kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', True)
+    pk = _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter,
+                      grid=make_grid(fan_rng[0], fan_rng[1], fan_rng[2], abi.GRID_FAN))
+    ifcs = opt_model['seq_model'].ifcs
+    fan = []
+    for r in range(fan_rng[2]):
+        pupil = np.array([pk.pupil[0, r], pk.pupil[1, r]])
+        pkg, _err = emit(pk, r, output_filter, rayerr_filter, named, ifcs)
+        if pkg is not None:
+            fan.append([pupil, img_filter(pupil, pkg) if img_filter else pkg])
+    return fan
+
+
+def trace_grid_spot(opt_model, grid_rng, fld, wvl, foc, image_pt, **kwargs):
+    """fused spot diagram: the transverse aberrations SpotDiagramFigure's
+    ``spot`` filter computes (rayoptics/mpl/axisarrayfigure.py:229-238), for the
+    rays that get through, as one (R_ok, 2) array; HITS output mode."""
+    kwargs['check_apertures'] = True
+    kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', True)
+    pk = _trace_pupil(opt_model, fld, wvl, kwargs, None, None,
+                      grid=make_grid(grid_rng[0], grid_rng[1], grid_rng[2]),
+                      out_mode=abi.OUT_HITS, foc=foc, image_pt=image_pt[:2])
+    ok = pk.status == abi.OK
+    return np.ascontiguousarray(pk.seg[0][:, ok].T)
+
+
+def _is_spot_filter(fct):
+    return getattr(fct, '__qualname__', '').endswith(
+        'SpotDiagramFigure.__init__.<locals>.spot')
+
+
+def seq_trace_grid(self, fct, fi, wl=None, num_rays=21, form='grid',
+                   append_if_none=True, **kwargs):
+    """rayoptics/seq/sequential.py:1058-1085, as a replacement *method* of
+    SequentialModel.  Chief-ray / reference-sphere setup stays the reference's
+    (a handful of iterated single rays); the num_rays**2 loop goes to the GPU.
+    SpotDiagramFigure's own ``spot`` callback is recognised and fused."""
+    from rayoptics.raytr import trace as ref_trace
+    osp = self.opt_model.optical_spec
+    wvls = osp.spectral_region
+    wvl = self.central_wavelength()
+    wv_list = wvls.wavelengths if wl is None else [wl]
+    fld = osp.field_of_view.fields[fi]
+    foc = osp.defocus.get_focus()
+
+    rs_pkg, cr_pkg = ref_trace.setup_pupil_coords(self.opt_model, fld, wvl, foc)
+    fld.chief_ray = cr_pkg
+    fld.ref_sphere = rs_pkg
+
+    grids = []
+    grid_def = [np.array([-1., -1.]), np.array([1., 1.]), num_rays]
+    fused = _is_spot_filter(fct) and form == 'list' and not append_if_none
+    for wi, wvl in enumerate(wv_list):
+        if fused:
+            grid = trace_grid_spot(self.opt_model, grid_def, fld, wvl, foc,
+                                   fld.ref_sphere[0], **dict(kwargs))
+        else:
+            grid = trace_grid(self.opt_model, grid_def, fld, wvl, foc,
+                              form=form, append_if_none=append_if_none,
+                              img_filter=lambda p, ray_pkg, wi=wi, wvl=wvl:
+                              fct(p, wi, ray_pkg, fld, wvl, foc),
+                              **dict(kwargs))
+        grids.append(grid)
+    return grids, wvls.render_colors

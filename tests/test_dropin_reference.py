@@ -1,0 +1,245 @@
+"""Host logic of the drop-in layer against the LIVE reference (build container
+only): with rayoptics_amd.install active, the reference's own consumers
+(SpotDiagramFigure, RayFan, RayList, RayGrid, trace_grid callbacks ...) must
+see exactly what the reference's per-ray Python loop gives them.
+
+No GPU here, so launches are served by the oracle-backed test double
+(tests/oracle_engine.py); on the GPU box the same host logic runs over the HIP
+engine in tests/test_gpu_dropin.py against stored reference outputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.needs_reference
+
+
+@pytest.fixture(scope='module')
+def ref():
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    import refmodels as rm
+    return rm
+
+
+@pytest.fixture()
+def installed(ref):
+    from rayoptics_amd import session, install
+    from oracle_engine import OracleEngine
+    session.ENGINE_FACTORY = OracleEngine
+    install.install()
+    yield install
+    install.uninstall()
+    session.ENGINE_FACTORY = None
+
+
+def both(install, fn):
+    """run fn() with the drop-ins active, then with the original reference"""
+    ours = fn()
+    install.uninstall()
+    theirs = fn()
+    install.install()
+    return ours, theirs
+
+
+def same_pkg(a, b):
+    ra, opa, wa = a
+    rb, opb, wb = b
+    assert len(ra) == len(rb)
+    assert opa == opb and wa == wb
+    for sa, sb in zip(ra, rb):
+        for k in (0, 1, 3):
+            np.testing.assert_array_equal(sa[k], sb[k])
+        assert sa[2] == sb[2]
+
+
+def test_spot_diagram_figure_unchanged(ref, installed):
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    from rayoptics.mpl.axisarrayfigure import SpotDiagramFigure
+    opm = ref.dblgauss()
+
+    def run():
+        fig = plt.figure(FigureClass=SpotDiagramFigure, opt_model=opm, num_rays=14)
+        fig.update_data()
+        data = [[np.array(g) for g in row[0][0]] for row in fig.axis_data_array]
+        plt.close(fig)
+        return data
+    ours, theirs = both(installed, run)
+    assert len(ours) == 3
+    for ro, rt_ in zip(ours, theirs):
+        for go, gt in zip(ro, rt_):
+            assert go.shape == gt.shape and go.shape[1] == 2
+            np.testing.assert_array_equal(go, gt)
+
+
+def test_trace_grid_callback_forms(ref, installed):
+    import rayoptics.raytr.trace as trace
+    opm = ref.dblgauss()
+    fld = opm['osp']['fov'].fields[2]
+    seen = []
+
+    def filt(pupil, pkg):
+        seen.append(None if pkg is None else len(pkg[0]))
+        if pkg is None:
+            # (a None entry would make np.array(grid) at trace.py:605 ragged,
+            # which NumPy >= 1.24 refuses in the reference itself)
+            return None if not keep_none else np.full(4, np.nan)
+        return np.array([pupil[0], pupil[1], pkg[0][-1][0][1], pkg[1]])
+
+    for form, ain in (('list', False), ('grid', True)):
+        keep_none = ain
+
+        def run():
+            seen.clear()
+            g = trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 9],
+                                 fld, 587.6, 0.0, img_filter=filt, form=form,
+                                 append_if_none=ain)
+            return g, list(seen)
+        (go, so), (gt, st) = both(installed, run)
+        assert so == st
+        if form == 'list':
+            np.testing.assert_array_equal(go, gt)
+        else:
+            assert go.shape == gt.shape == (9, 9, 4)
+            np.testing.assert_array_equal(go, gt)
+
+
+def test_trace_fan_and_seq_trace_grid_generic(ref, installed):
+    import rayoptics.raytr.trace as trace
+    opm = ref.rc_telescope()
+    sm = opm['seq_model']
+    fld = opm['osp']['fov'].fields[4]
+
+    def fan():
+        return trace.trace_fan(opm, [np.array([0., -1.]), np.array([0., 1.]), 15],
+                               fld, 550.0, 0.0,
+                               img_filter=lambda p, pkg: pkg[0][-1][0][1],
+                               check_apertures=True)
+    fo, ft = both(installed, fan)
+    assert len(fo) == len(ft) > 3
+    for (po, vo), (pt_, vt) in zip(fo, ft):
+        np.testing.assert_array_equal(po, pt_)
+        assert vo == vt
+
+    def fct(p, wi, ray_pkg, fld, wvl, foc):     # not the figure's `spot`: generic path
+        return None if ray_pkg is None else np.array([ray_pkg[0][-1][0][0], ray_pkg[0][-1][0][1]])
+
+    def grid():
+        return sm.trace_grid(fct, 2, num_rays=8, form='list', append_if_none=False)[0]
+    go, gt = both(installed, grid)
+    for a, b in zip(go, gt):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_trace_list_of_rays_filters(ref, installed):
+    import rayoptics.raytr.analyses as analyses
+    from rayoptics.raytr.traceerror import TraceError
+    opm = ref.dblgauss()
+    osp = opm['osp']
+    rng = np.random.default_rng(5)
+    wv = list(osp['wvls'].wavelengths)
+    rays = []
+    for r in range(40):
+        p, d = osp.ray_start_from_osp(rng.uniform(-1.2, 1.2, 2), osp['fov'].fields[r % 3], 'rel pupil')
+        rays.append((p, d, wv[r % 3]))
+    for of in (None, 'last', lambda pkg: pkg[1]):
+        for ef in (None, 'full', 'summary'):
+            def run():
+                return analyses.trace_list_of_rays(opm, rays, output_filter=of,
+                                                   rayerr_filter=ef, check_apertures=True)
+            lo, lt = both(installed, run)
+            assert len(lo) == len(lt)
+            for a, b in zip(lo, lt):
+                if isinstance(b, tuple) and len(b) == 2 and isinstance(b[1], TraceError):
+                    assert type(a[1]) is type(b[1]) and a[1].surf == b[1].surf
+                    if ef == 'full':
+                        same_pkg(a[1].ray_pkg, b[1].ray_pkg)
+                    else:
+                        assert a[1].ray_pkg is None
+                elif of is None:
+                    same_pkg(a, b)
+                elif of == 'last':
+                    for k in (0, 1, 3):
+                        np.testing.assert_array_equal(a[0][k], b[0][k])
+                    assert a[0][2] == b[0][2] and a[1] == b[1] and a[2] == b[2]
+                else:
+                    assert a == b
+
+
+def test_ray_list_grid_fan_containers(ref, installed):
+    """the reference's analysis containers, unchanged, over the drop-ins"""
+    import rayoptics.raytr.analyses as analyses
+    opm = ref.dblgauss()
+    fld = opm['osp']['fov'].fields[1]
+    foc = 0.0
+
+    def ray_list():
+        pc = np.array([[0., 0.], [0.5, 0.5], [-0.9, 0.2], [0.1, -1.0], [1.0, 1.0]])
+        out = analyses.trace_ray_list(opm, pc, fld, 587.6, foc, append_if_none=True,
+                                      check_apertures=True)
+        return out, pc
+    (lo, pco), (lt, pct) = both(installed, ray_list)
+    np.testing.assert_array_equal(pco, pct)        # in-place vignetting of the caller's array
+    assert len(lo) == len(lt)
+    for a, b in zip(lo, lt):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert (a[2] is None) == (b[2] is None)
+        if a[2] is not None:
+            same_pkg(a[2], b[2])
+
+    def ray_grid():
+        return analyses.trace_ray_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 7],
+                                       fld, 486.1, foc, check_apertures=True)
+    go, gt = both(installed, ray_grid)
+    for ro, rt_ in zip(go, gt):
+        assert len(ro) == len(rt_)
+        for a, b in zip(ro, rt_):
+            assert a[0] == b[0] and a[1] == b[1] and (a[2] is None) == (b[2] is None)
+            if a[2] is not None:
+                same_pkg(a[2], b[2])
+
+    def ray_fan():
+        return analyses.trace_ray_fan(opm, [np.array([0., -1.]), np.array([0., 1.]), 11],
+                                      fld, 656.3, foc, check_apertures=True)
+    fo, ft = both(installed, ray_fan)
+    assert len(fo) == len(ft)
+    for a, b in zip(fo, ft):
+        assert a[0] == b[0] and a[1] == b[1]
+        same_pkg(a[2], b[2])
+        assert a[2].op == b[2].op          # named tuples, analyses.py:222
+
+
+def test_rayfan_raylist_classes(ref, installed):
+    import rayoptics.raytr.analyses as analyses
+    opm = ref.dblgauss()
+
+    def run():
+        rf = analyses.RayFan(opm, f=2, wl=587.6, xyfan='y', num_rays=9)
+        rl = analyses.RayList(opm, num_rays=8, f=1, wl=587.6)
+        # fan entries: ((px, py), (dx, dy, opd)) -- dx/dy from the ray packets,
+        # opd through waveabr.wave_abr_pre_calc/_calc on the lazy views
+        cols = [analyses.select_plot_data(rf.fan, 1, k) for k in range(3)]
+        return (np.array([c[0] for c in cols]), np.array([c[1] for c in cols]),
+                np.array(rl.ray_abr))
+    ours, theirs = both(installed, run)
+    for a, b in zip(ours, theirs):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_unsupported_model_policy(ref, installed):
+    """models outside the kernels' scope raise by default; with
+    install('reference') they run through the reference's own code"""
+    import rayoptics.raytr.trace as trace
+    from rayoptics_amd import UnsupportedModelError
+    from rayoptics.elem import profiles
+    opm = ref.singlet()
+    sm = opm['seq_model']
+    sm.ifcs[1].profile = profiles.YToroid(c=0.01)
+    fld = opm['osp']['fov'].fields[0]
+    args = (opm, [np.array([-1., -1.]), np.array([1., 1.]), 3], fld, 650.0, 0.0)
+    with pytest.raises(UnsupportedModelError):
+        trace.trace_grid(*args, img_filter=lambda p, pkg: 0.0)
+    installed.install('reference')
+    g = trace.trace_grid(*args, img_filter=lambda p, pkg: 0.0)
+    assert g.shape == (3, 3)
