@@ -129,7 +129,9 @@ typedef struct rox_grid {
     double stop[2];          /* grid_rng[1]                                    */
     int32_t num;             /* grid_rng[2]                                    */
     int32_t kind;            /* ROX_GRID_PRODUCT | ROX_GRID_FAN                */
-} rox_grid;
+    int32_t row_begin;       /* PRODUCT only: trace pupil rows (x index i)     */
+    int32_t row_count;       /*   [row_begin, row_begin+row_count); 0 = all    */
+} rox_grid;                  /* (row blocks are the multi-GPU sharding unit)   */
 
 typedef struct rox_out {
     double *seg;             /* see ROX_OUT_*; may be NULL only if unused      */

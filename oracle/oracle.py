@@ -108,7 +108,7 @@ def trace_rays(table, pt0, dir0, wvl_idx, opts):
 
 
 def trace_pupil_grid(table, fld, grid, wvl_idx, opts):
-    R = grid.num if grid.kind == abi.GRID_FAN else grid.num * grid.num
+    R = grid.num if grid.kind == abi.GRID_FAN else (grid.row_count or grid.num) * grid.num
     res = HostResult(table.n_ifcs, R, opts.out_mode, want_pupil=True)
     out = res.out_struct()
     rc = lib().rox_oracle_trace_pupil_grid(table.rows, table.n_ifcs,
@@ -137,9 +137,10 @@ def trace_pupil_list(table, fld, px, py, wvl_idx, opts):
     return res
 
 
-def make_grid(start, stop, num, kind=abi.GRID_PRODUCT):
+def make_grid(start, stop, num, kind=abi.GRID_PRODUCT, row_begin=0, row_count=0):
     g = abi.Grid()
     g.start[0], g.start[1] = start
     g.stop[0], g.stop[1] = stop
     g.num, g.kind = num, kind
+    g.row_begin, g.row_count = row_begin, row_count
     return g

@@ -67,7 +67,8 @@ class Field(C.Structure):
 
 class Grid(C.Structure):
     _fields_ = [('start', C.c_double * 2), ('stop', C.c_double * 2),
-                ('num', C.c_int32), ('kind', C.c_int32)]
+                ('num', C.c_int32), ('kind', C.c_int32),
+                ('row_begin', C.c_int32), ('row_count', C.c_int32)]
 
 
 class Out(C.Structure):
@@ -80,7 +81,7 @@ assert C.sizeof(Aperture) == 40
 assert C.sizeof(Surface) == 392
 assert C.sizeof(Opts) == 56
 assert C.sizeof(Field) == 96
-assert C.sizeof(Grid) == 40
+assert C.sizeof(Grid) == 48
 assert C.sizeof(Out) == 48
 
 # every symbol include/roxtrace.h declares (checked by tests/test_abi.py)

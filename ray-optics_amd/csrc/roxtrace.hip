@@ -64,6 +64,7 @@ struct TraceArgs {
     const double *px, *py;     // axis / list coordinates
     int32_t axis_kind;         // AXIS_LIST: px[r],py[r]; AXIS_PRODUCT: px[r/num], py[r%num]
     int32_t axis_num;
+    int32_t row_begin;         // AXIS_PRODUCT: first pupil row of this launch
     rox_field fld;
     rox_opts opts;
     rox_out out;
@@ -345,7 +346,7 @@ trace_kernel(const TraceArgs a)
         if (GEN == GEN_PUPIL) {
             double px, py;
             if (a.axis_kind == AXIS_PRODUCT) {
-                px = a.px[r / a.axis_num];
+                px = a.px[a.row_begin + r / a.axis_num];
                 py = a.py[r % a.axis_num];
             } else {
                 px = a.px[r];
@@ -779,7 +780,14 @@ int prepare_grid(rox_system *sys, const rox_field *fld, const rox_grid *grid, in
         return fail(ROX_E_ARG, "grid.num must be >= 1");
     if (wvl_idx < 0 || wvl_idx >= sys->n_wvls)
         return fail(ROX_E_ARG, "wvl_idx %d out of range", wvl_idx);
-    const int64_t R = grid->kind == ROX_GRID_FAN ? grid->num : (int64_t)grid->num * grid->num;
+    int32_t rows = grid->num, row0 = 0;
+    if (grid->kind != ROX_GRID_FAN && grid->row_count > 0) {
+        rows = grid->row_count;
+        row0 = grid->row_begin;
+    }
+    if (row0 < 0 || row0 + rows > grid->num)
+        return fail(ROX_E_ARG, "grid row block [%d, %d) outside [0, %d)", row0, row0 + rows, grid->num);
+    const int64_t R = grid->kind == ROX_GRID_FAN ? grid->num : (int64_t)rows * grid->num;
     int rc = check_opts(sys, opts, out, R);
     if (rc)
         return rc;
@@ -799,6 +807,7 @@ int prepare_grid(rox_system *sys, const rox_field *fld, const rox_grid *grid, in
     a.py = py;
     a.axis_kind = grid->kind == ROX_GRID_FAN ? AXIS_LIST : AXIS_PRODUCT;
     a.axis_num = grid->num;
+    a.row_begin = row0;
     a.wvl_idx_all = wvl_idx;
     a.fld = *fld;
     a.opts = *opts;

@@ -55,12 +55,20 @@ def make_opts(flags=abi.INTERSECT_OBJ, out_mode=abi.OUT_FULL, first_surf=0,
     return o
 
 
-def make_grid(start, stop, num, kind=abi.GRID_PRODUCT):
+def make_grid(start, stop, num, kind=abi.GRID_PRODUCT, row_begin=0, row_count=0):
     g = abi.Grid()
     g.start[0], g.start[1] = float(start[0]), float(start[1])
     g.stop[0], g.stop[1] = float(stop[0]), float(stop[1])
     g.num, g.kind = int(num), int(kind)
+    g.row_begin, g.row_count = int(row_begin), int(row_count)
     return g
+
+
+def grid_rays(grid):
+    """number of rays a rox_grid describes"""
+    if grid.kind == abi.GRID_FAN:
+        return grid.num
+    return (grid.row_count or grid.num) * grid.num
 
 
 class DeviceResult:
@@ -194,7 +202,7 @@ class TraceEngine:
     def trace_pupil_grid(self, fld, grid, wvl_idx=0, opts=None, want_pupil=True,
                          nan_fill=False, out=None):
         opts = opts or make_opts()
-        R = grid.num if grid.kind == abi.GRID_FAN else grid.num * grid.num
+        R = grid_rays(grid)
         res = self._result(R, opts, want_pupil, nan_fill, out)
         o = res.out_struct()
         with self.torch.cuda.device(self.device):

@@ -11,11 +11,23 @@ from rayoptics_amd import abi
 
 
 class _Res:
+    """DeviceResult look-alike: numpy on to_host(), torch views for dist.py"""
+
     def __init__(self, host):
         self._h = host
 
     def to_host(self):
         return self._h
+
+    @property
+    def seg(self):
+        import torch
+        return torch.from_numpy(self._h.seg)
+
+    @property
+    def status(self):
+        import torch
+        return torch.from_numpy(self._h.status)
 
 
 class OracleEngine:

@@ -221,3 +221,48 @@ def test_full_size_grid_bit_exact_vs_oracle(engines):
         err = (p + dst * d - nxt).abs().max().item()
         assert err < 1e-9, (k, err)
         assert ((d * d).sum(0) - 1).abs().max().item() < 1e-12
+
+
+def test_row_blocks_tile_the_full_grid(engines):
+    """multi-GPU sharding unit: pupil row blocks reproduce the full grid's rays
+    bit for bit (coordinates still come from the full accumulate-by-step axis)"""
+    from oracle import oracle
+    fx = H.fixture('dblgauss')
+    c = fx['grid_f2']
+    N = fx.table.n_ifcs
+    fld = H.field_from_arr(c['field'])
+    opts = H.make_opts(c)
+    num = 37
+    eng = engines('dblgauss')
+    full = eng.trace_pupil_grid(fld, oracle.make_grid((-1., -1.), (1., 1.), num), 2, opts,
+                                nan_fill=True).to_host()
+    for r0, rc in [(0, 5), (5, 20), (25, 12)]:
+        g = oracle.make_grid((-1., -1.), (1., 1.), num, row_begin=r0, row_count=rc)
+        part = eng.trace_pupil_grid(fld, g, 2, opts, nan_fill=True).to_host()
+        orc = oracle.trace_pupil_grid(fx.table, fld, g, 2, opts)
+        assert_same_as_oracle(part, orc, f'rows {r0}+{rc}')
+        sl = slice(r0 * num, (r0 + rc) * num)
+        bit_equal(part.seg, full.seg[:, :, sl], 'row block vs full grid')
+        bit_equal(part.pupil, full.pupil[:, sl], 'row block pupil')
+
+
+def test_sharded_spot_single_rank(engines):
+    """dist.trace_spot_sharded with world size 1 (no process group) on the GPU"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.dist import trace_spot_sharded
+    from rayoptics_amd.engine import TraceEngine
+    wl = workloads.load('rc_telescope_c4')
+    eng = TraceEngine(wl.table)
+    out = trace_spot_sharded(eng, wl.fields, wl.image_pts, 1, 24, wl.foc)
+    assert len(out) == 5
+    N = wl.n_ifcs
+    for (fi, wi), (xy, st) in out.items():
+        opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING,
+                                out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
+                                foc=wl.foc, image_pt=wl.image_pts[fi])
+        ref = oracle.trace_pupil_grid(wl.table, wl.fields[fi],
+                                      oracle.make_grid((-1., -1.), (1., 1.), 24), wi, opts)
+        np.testing.assert_array_equal(st, ref.status)
+        bit_equal(xy, ref.seg.T, f'field {fi}')
+    eng.close()
