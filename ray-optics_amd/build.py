@@ -33,14 +33,23 @@ def stale():
     return any(os.path.getmtime(p) > t for p in (SRC, HDR, __file__))
 
 
-def build(force=False, extra=()):
-    if not force and not stale():
+def build(force=False, extra=(), out=None):
+    """out != None builds an experiment variant (tools/ab_bench.py) next to the
+    product library without touching it"""
+    lib = out or LIB
+    if out is None and not force and not stale():
         return LIB
-    cmd = [hipcc(), *FLAGS, *extra, '-o', LIB, SRC]
+    cmd = [hipcc(), *FLAGS, *extra, '-o', lib, SRC]
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv,
-                extra=[a for a in sys.argv[1:] if a != '--force']))
+    argv = sys.argv[1:]
+    out = None
+    if '--out' in argv:
+        i = argv.index('--out')
+        out = argv[i + 1]
+        del argv[i:i + 2]
+    print(build(force='--force' in argv, out=out,
+                extra=[a for a in argv if a != '--force']))

@@ -39,6 +39,21 @@
 
 namespace {
 
+// ---- build-time knobs (defaults = the shipped configuration; the others are
+// kept for A/B measurement with tools/ab_bench.py) -------------
+#ifndef ROX_TABLE_SCALAR     // 1: read the surface table through the scalar cache
+#define ROX_TABLE_SCALAR 0   //    (s_load into SGPRs) instead of staging it in LDS
+#endif
+#ifndef ROX_MIN_WAVES        // __launch_bounds__ second argument (waves per SIMD)
+#define ROX_MIN_WAVES 1
+#endif
+#ifndef ROX_STORE_NT         // 1: non-temporal packet stores (measured: FULL 236 us vs 257 us)
+#define ROX_STORE_NT 1
+#endif
+#ifndef ROX_SHARED_RCP       // 1: the three divisions by one divisor share its reciprocal
+#define ROX_SHARED_RCP 0
+#endif
+
 constexpr int kBlock = 256;
 constexpr int kRowDoubles = sizeof(rox_surface) / sizeof(double);   // 49
 static_assert(sizeof(rox_surface) == 392, "rox_surface layout");
@@ -49,13 +64,24 @@ enum { AXIS_LIST = 0, AXIS_PRODUCT = 1 };
 
 struct v3 { double x, y, z; };
 
+#if ROX_TABLE_SCALAR
+// constant address space: uniform-address loads become s_load_dwordx{2,4,8}
+typedef const __attribute__((address_space(4))) double *tblp;
+typedef const __attribute__((address_space(4))) int32_t *tbli;
+#else
+typedef const double *tblp;     // LDS (generic pointer into __shared__)
+typedef const int32_t *tbli;
+#endif
+
 // ---------------------------------------------------------------- kernel args
 struct TraceArgs {
     const double *rows;        // [N][49] raw rox_surface rows
     const double *n_table;     // [W][N]
     const int32_t *slots;      // [2][N]: slot[s] (-1 = filtered phantom), nslots_before[s]
     int32_t n_ifcs, n_wvls;
-    int64_t n_rays;
+    int64_t n_rays;            // rays of this launch (<= 2^28: 32-bit lane byte offsets)
+    int64_t ray_base;          // index of this launch's first ray within the batch
+    int64_t in_ld;             // batch size = stride of the SoA inputs
     // explicit rays
     const double *pt0, *dir0;  // SoA [3][n_rays]
     const int32_t *wvl_idx;    // per ray or nullptr
@@ -81,7 +107,7 @@ __device__ __forceinline__ double dot3(const v3 &a, const v3 &b)
 }
 
 // Rt.dot(v): same chain per output row (dgemv on the F-ordered transpose view)
-__device__ __forceinline__ v3 rotate(const double *rt, const v3 &v)
+__device__ __forceinline__ v3 rotate(tblp rt, const v3 &v)
 {
     v3 r;
     r.x = fma(rt[2], v.z, fma(rt[1], v.y, fma(rt[0], v.x, 0.0)));
@@ -173,7 +199,7 @@ __device__ __forceinline__ bool quadric_hit(bool conic, double cv, double cc, do
 // powers, not Horner).  Returns false when the sag square root goes negative.
 template <bool WANT_F>
 __device__ __forceinline__ bool poly_eval(bool radial, double cv, double cc1, double ec,
-                                          int ncoef, const double *coefs,
+                                          int ncoef, tblp coefs,
                                           const v3 &p, double &f, v3 &df)
 {
     const double r2 = p.x * p.x + p.y * p.y;
@@ -230,7 +256,7 @@ __device__ __forceinline__ bool poly_eval(bool radial, double cv, double cc1, do
 // profiles.py:155-186 Spencer & Murty Newton iteration.  Returns the last
 // *evaluated* iterate as the hit point (p0 itself when |s1| <= eps at once).
 __device__ __forceinline__ bool newton_hit(bool radial, double cv, double cc1, double ec,
-                                           int ncoef, const double *coefs,
+                                           int ncoef, tblp coefs,
                                            const v3 &p0, const v3 &d, double eps,
                                            double &s, v3 &hit, v3 &df)
 {
@@ -256,13 +282,13 @@ __device__ __forceinline__ bool newton_hit(bool radial, double cv, double cc1, d
 }
 
 // surface.py:198-208 (+ interface.py:113-122, surface.py:416-419, 453-457)
-__device__ __forceinline__ bool inside_aperture(const double *row, int n_ap, double x,
+__device__ __forceinline__ bool inside_aperture(tblp row, int n_ap, double x,
                                                 double y, double fuzz)
 {
     if (n_ap > 0) {
-        const double *ap = row + (offsetof(rox_surface, ap) / sizeof(double));
+        tblp ap = row + (offsetof(rox_surface, ap) / sizeof(double));
         for (int k = 0; k < n_ap; ++k, ap += sizeof(rox_aperture) / sizeof(double)) {
-            const int2 ki = *reinterpret_cast<const int2 *>(ap);    // kind, is_obscuration
+            const int2 ki{((tbli)ap)[0], ((tbli)ap)[1]};            // kind, is_obscuration
             const double xx = x - ap[1];
             const double yy = y - ap[2];
             bool ans;
@@ -283,56 +309,88 @@ __device__ __forceinline__ bool inside_aperture(const double *row, int n_ap, dou
 }
 
 // ------------------------------------------------------------------ stores
-__device__ __forceinline__ void st(double *p, double v) { __builtin_nontemporal_store(v, p); }
+// One packet component of ray r lives at seg[(slot*10 + c)*ld + r].  The
+// (slot, c) part is wave-uniform, so it goes into an SGPR base; the ray part
+// is one 32-bit byte offset per lane computed once per ray: the store is
+// `global_store_dwordx2 v_off, v_data, s[base:base+1]` with no per-store
+// 64-bit VALU address arithmetic.  (The host splits batches longer than 2^28
+// rays into several launches so that the lane offset always fits 32 bits.)
+struct SegOut {
+    char *base;         // uniform: seg (already offset to this launch's first ray)
+    int64_t row_bytes;  // uniform: ld * 8
+    uint32_t voff;      // per lane: (r - first ray of the launch) * 8 < 2^32
+    __device__ __forceinline__ void put(int slot, int c, double v) const
+    {
+        char *b = base + ((int64_t)slot * ROX_SEG_DOUBLES + c) * row_bytes;
+        double *p = reinterpret_cast<double *>(b + (size_t)voff);
+#if ROX_STORE_NT
+        __builtin_nontemporal_store(v, p);
+#else
+        *p = v;
+#endif
+    }
+    __device__ __forceinline__ void pdn(int slot, const v3 &p, const v3 &d, const v3 &n) const
+    {
+        put(slot, 0, p.x); put(slot, 1, p.y); put(slot, 2, p.z);
+        put(slot, 3, d.x); put(slot, 4, d.y); put(slot, 5, d.z);
+        put(slot, 7, n.x); put(slot, 8, n.y); put(slot, 9, n.z);
+    }
+    __device__ __forceinline__ void dst(int slot, double v) const { put(slot, 6, v); }
+};
 
-__device__ __forceinline__ void store_pdn(double *seg, int64_t ld, int slot, int64_t r,
-                                          const v3 &p, const v3 &d, const v3 &n)
-{
-    double *b = seg + (int64_t)slot * ROX_SEG_DOUBLES * ld + r;
-    st(b + 0 * ld, p.x); st(b + 1 * ld, p.y); st(b + 2 * ld, p.z);
-    st(b + 3 * ld, d.x); st(b + 4 * ld, d.y); st(b + 5 * ld, d.z);
-    st(b + 7 * ld, n.x); st(b + 8 * ld, n.y); st(b + 9 * ld, n.z);
-}
-
-__device__ __forceinline__ void store_dst(double *seg, int64_t ld, int slot, int64_t r, double dst)
-{
-    st(seg + ((int64_t)slot * ROX_SEG_DOUBLES + 6) * ld + r, dst);
-}
+// system features a launch needs; the host picks the leanest instance
+enum { F_POLY = 1,      // some interface is an Even/RadialPolynomial (Newton code)
+       F_APLIST = 2,    // some interface carries clear_apertures
+       F_PHFILT = 4 };  // filter_out_phantoms with phantoms present
+constexpr int F_ALL = F_POLY | F_APLIST | F_PHFILT;
 
 // ------------------------------------------------------------------ the kernel
-template <int OUT_MODE, int GEN, bool PER_RAY_WVL>
-__global__ void __launch_bounds__(kBlock)
+template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT>
+__global__ void __launch_bounds__(kBlock, ROX_MIN_WAVES)
 trace_kernel(const TraceArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int N = a.n_ifcs;
-    double *tbl = lds;                               // [N][49]
-    double *ntab = tbl + (size_t)N * kRowDoubles;    // [W][N] (or [N] for one wavelength)
-    int32_t *slot = reinterpret_cast<int32_t *>(ntab + (PER_RAY_WVL ? (size_t)a.n_wvls * N : N));
-    int32_t *nslots_before = slot + N;
+#if ROX_TABLE_SCALAR
+    // wave-uniform table straight from the scalar cache: values land in SGPRs
+    tblp tbl = (tblp)a.rows;
+    tblp ntab = (tblp)a.n_table + (PER_RAY_WVL ? 0 : (size_t)a.wvl_idx_all * N);
+    tbli slot = (tbli)a.slots;
+    tbli nslots_before = slot + N;
+#else
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *tbl_w = lds;                               // [N][49]
+    double *ntab_w = tbl_w + (size_t)N * kRowDoubles;  // [W][N] (or [N] for one wavelength)
+    int32_t *slot_w = reinterpret_cast<int32_t *>(ntab_w + (PER_RAY_WVL ? (size_t)a.n_wvls * N : N));
 
     // stage the surface table once per workgroup
     for (int i = threadIdx.x; i < N * kRowDoubles; i += kBlock)
-        tbl[i] = a.rows[i];
+        tbl_w[i] = a.rows[i];
     if (PER_RAY_WVL) {
         for (int i = threadIdx.x; i < a.n_wvls * N; i += kBlock)
-            ntab[i] = a.n_table[i];
+            ntab_w[i] = a.n_table[i];
     } else {
         for (int i = threadIdx.x; i < N; i += kBlock)
-            ntab[i] = a.n_table[(size_t)a.wvl_idx_all * N + i];
+            ntab_w[i] = a.n_table[(size_t)a.wvl_idx_all * N + i];
     }
     for (int i = threadIdx.x; i < 2 * N; i += kBlock)
-        slot[i] = a.slots[i];
+        slot_w[i] = a.slots[i];
     __syncthreads();
+    tblp tbl = tbl_w;
+    tblp ntab = ntab_w;
+    tbli slot = slot_w;
+    tbli nslots_before = slot + N;
+#endif
+    // without phantom filtering segment k of a packet is interface k
+#define SLOT(s) ((FEAT & F_PHFILT) ? slot[s] : (s))
+#define NSLOTS_BEFORE(s) ((FEAT & F_PHFILT) ? nslots_before[s] : (s))
 
     const uint32_t flags = a.opts.flags;
     const bool check_ap = flags & ROX_CHECK_APERTURES;
     const bool intersect_obj = flags & ROX_INTERSECT_OBJ;
-    const bool filter_ph = flags & ROX_FILTER_PHANTOMS;
+    const bool filter_ph = (FEAT & F_PHFILT) && (flags & ROX_FILTER_PHANTOMS);
     const int first_surf = a.opts.first_surf, last_surf = a.opts.last_surf;
     const double eps = a.opts.eps, fuzz = a.opts.fuzz;
     const int64_t ld = a.out.ld;
-    double *const seg = a.out.seg;
 
     constexpr int O_CV = offsetof(rox_surface, cv) / 8, O_CC = offsetof(rox_surface, cc) / 8,
                   O_EC = offsetof(rox_surface, ec) / 8, O_COEF = offsetof(rox_surface, coefs) / 8,
@@ -341,16 +399,22 @@ trace_kernel(const TraceArgs a)
 
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < a.n_rays;
          r += (int64_t)gridDim.x * kBlock) {
+        SegOut so;
+        so.base = reinterpret_cast<char *>(a.out.seg);
+        so.row_bytes = ld * 8;
+        so.voff = (uint32_t)r * 8u;
+
         // ---- ray start -------------------------------------------------------
         v3 pt0, dir0;
         if (GEN == GEN_PUPIL) {
             double px, py;
+            const int64_t rg = a.ray_base + r;
             if (a.axis_kind == AXIS_PRODUCT) {
-                px = a.px[a.row_begin + r / a.axis_num];
-                py = a.py[r % a.axis_num];
+                px = a.px[a.row_begin + rg / a.axis_num];
+                py = a.py[rg % a.axis_num];
             } else {
-                px = a.px[r];
-                py = a.py[r];
+                px = a.px[rg];
+                py = a.py[rg];
             }
             if (flags & ROX_APPLY_VIGNETTING) {         // opticalspec.py:1339-1353
                 if (px < 0.0) { if (a.fld.vlx != 0.0) px *= (1.0 - a.fld.vlx); }
@@ -359,8 +423,8 @@ trace_kernel(const TraceArgs a)
                 else          { if (a.fld.vuy != 0.0) py *= (1.0 - a.fld.vuy); }
             }
             if (a.out.pupil) {
-                st(a.out.pupil + r, px);
-                st(a.out.pupil + ld + r, py);
+                a.out.pupil[r] = px;
+                a.out.pupil[ld + r] = py;
             }
             // opticalspec.py:358-366
             const v3 pt1{a.fld.eprad * px + a.fld.aim[0], a.fld.eprad * py + a.fld.aim[1],
@@ -370,36 +434,37 @@ trace_kernel(const TraceArgs a)
             if (dir0.z * a.fld.z_dir0 < 0)              // trace.py:307-308
                 dir0 = v3{-dir0.x, -dir0.y, -dir0.z};
         } else {
-            pt0 = v3{a.pt0[r], a.pt0[a.n_rays + r], a.pt0[2 * a.n_rays + r]};
-            dir0 = v3{a.dir0[r], a.dir0[a.n_rays + r], a.dir0[2 * a.n_rays + r]};
+            const int64_t rg = a.ray_base + r;
+            pt0 = v3{a.pt0[rg], a.pt0[a.in_ld + rg], a.pt0[2 * a.in_ld + rg]};
+            dir0 = v3{a.dir0[rg], a.dir0[a.in_ld + rg], a.dir0[2 * a.in_ld + rg]};
         }
-        const double *nw = ntab;
+        // per-ray wavelengths index the table per lane (a gather: plain pointer)
+        const double *nwl = nullptr;
         if (PER_RAY_WVL)
-            nw = ntab + (size_t)a.wvl_idx[r] * N;
+            nwl = (ROX_TABLE_SCALAR ? a.n_table : (const double *)ntab) +
+                  (size_t)a.wvl_idx[a.ray_base + r] * N;
+#define NW(i) (PER_RAY_WVL ? nwl[i] : ntab[i])
 
         // ---- object surface, raytrace.py:145-158 -----------------------------
         int status = ROX_OK, fail_surf = -1;
         v3 bp, bn, bd = dir0;               // before_pt, before_normal, before_dir
         int b4_mode = ROX_DUMMY;
         {
-            const double *row = tbl;
+            tblp row = tbl;
             if (intersect_obj) {
-                const int2 mp = *reinterpret_cast<const int2 *>(row);       // mode, profile
-                const int2 na = *reinterpret_cast<const int2 *>(row + 1);   // ncoef, n_ap
+                const int2 mp{((tbli)row)[0], ((tbli)row)[1]};      // mode, profile
                 b4_mode = mp.x;
                 double s_;
                 v3 df;
                 bool ok;
-                if (mp.y <= ROX_CONIC) {
+                if (!(FEAT & F_POLY) || mp.y <= ROX_CONIC) {
                     ok = quadric_hit(mp.y == ROX_CONIC, row[O_CV], row[O_CC], row[O_EC], pt0, dir0,
                                      row[O_ZDIR], s_, bp);
-                    if (ok) {
-                        const double k = (mp.y == ROX_CONIC) ? (row[O_CC] + 1.0) * row[O_CV] : row[O_CV];
-                        df = v3{-row[O_CV] * bp.x, -row[O_CV] * bp.y, 1.0 - k * bp.z};
-                    }
+                    const double k = (mp.y == ROX_CONIC) ? (row[O_CC] + 1.0) * row[O_CV] : row[O_CV];
+                    df = v3{-row[O_CV] * bp.x, -row[O_CV] * bp.y, 1.0 - k * bp.z};
                 } else {
                     ok = newton_hit(mp.y == ROX_RADIALPOLY, row[O_CV], row[O_CC] + 1.0, row[O_EC],
-                                    na.x, row + O_COEF, pt0, dir0, eps, s_, bp, df);
+                                    ((tbli)row)[2], row + O_COEF, pt0, dir0, eps, s_, bp, df);
                 }
                 if (!ok) {              // raised outside the try block: no packet
                     status = ROX_MISSED_SURFACE;
@@ -417,17 +482,14 @@ trace_kernel(const TraceArgs a)
         double acc_dst = 0.0;           // dst of the most recently appended segment
         int acc_slot = 0;
         v3 inc{0, 0, 0}, nrm{0, 0, 0}, ad = dir0;
-        bool alive = (status == ROX_OK);
-        if (OUT_MODE == ROX_OUT_FULL && alive)
-            store_pdn(seg, ld, 0, r, bp, bd, bn);
+        if (OUT_MODE == ROX_OUT_FULL && status == ROX_OK)
+            so.pdn(0, bp, bd, bn);
 
         // ---- remaining surfaces, raytrace.py:164-229 -------------------------
-        for (int surf = 1; surf < N && alive; ++surf) {
-            const double *prow = tbl + (size_t)(surf - 1) * kRowDoubles;    // `before`
-            const double *row = tbl + (size_t)surf * kRowDoubles;            // `after`
-            const int2 mp = *reinterpret_cast<const int2 *>(row);
-            const int2 na = *reinterpret_cast<const int2 *>(row + 1);
-            const int mode = mp.x, prof = mp.y;
+        for (int surf = 1; surf < N && status == ROX_OK; ++surf) {
+            tblp prow = tbl + (size_t)(surf - 1) * kRowDoubles;     // `before`
+            tblp row = tbl + (size_t)surf * kRowDoubles;             // `after`
+            const int mode = ((tbli)row)[0], prof = ((tbli)row)[1];
             const double cv = row[O_CV];
 
             // :170-174 transform to the new vertex frame, closest approach
@@ -441,23 +503,22 @@ trace_kernel(const TraceArgs a)
             double s;
             v3 df;
             bool ok;
-            if (prof <= ROX_CONIC) {
+            if (!(FEAT & F_POLY) || prof <= ROX_CONIC) {
                 ok = quadric_hit(prof == ROX_CONIC, cv, row[O_CC], row[O_EC], pp, b4d,
                                  z_dir_before, s, inc);
             } else {
-                ok = newton_hit(prof == ROX_RADIALPOLY, cv, row[O_CC] + 1.0, row[O_EC], na.x,
-                                row + O_COEF, pp, b4d, eps, s, inc, df);
+                ok = newton_hit(prof == ROX_RADIALPOLY, cv, row[O_CC] + 1.0, row[O_EC],
+                                ((tbli)row)[2], row + O_COEF, pp, b4d, eps, s, inc, df);
             }
-            const bool b4_filtered = (b4_mode == ROX_PHANTOM) && filter_ph;
+            const bool b4_filtered = filter_ph && (b4_mode == ROX_PHANTOM);
             if (!ok) {                                  // :231-237
                 status = ROX_MISSED_SURFACE;
                 fail_surf = surf;
-                alive = false;
                 if (OUT_MODE == ROX_OUT_FULL) {
-                    const int sl = b4_filtered ? nslots_before[surf - 1] : slot[surf - 1];
+                    const int sl = b4_filtered ? NSLOTS_BEFORE(surf - 1) : SLOT(surf - 1);
                     if (b4_filtered)
-                        store_pdn(seg, ld, sl, r, bp, bd, bn);
-                    store_dst(seg, ld, sl, r, pp_dst);
+                        so.pdn(sl, bp, bd, bn);
+                    so.dst(sl, pp_dst);
                 }
                 break;
             }
@@ -467,10 +528,10 @@ trace_kernel(const TraceArgs a)
                 acc_dst += dst_b4;
             } else {
                 acc_dst = dst_b4;
-                acc_slot = slot[surf - 1];
+                acc_slot = SLOT(surf - 1);
             }
             if (OUT_MODE == ROX_OUT_FULL)
-                store_dst(seg, ld, acc_slot, r, acc_dst);
+                so.dst(acc_slot, acc_dst);
 
             // :193-194 (in_gap_range, :123-132)
             {
@@ -478,84 +539,88 @@ trace_kernel(const TraceArgs a)
                 const bool in_gap = !(last_surf >= 0 && first_surf == last_surf) && g >= first_surf &&
                                     (last_surf < 0 || g < last_surf);
                 if (in_gap)
-                    opl += nw[surf - 1] * dst_b4;
+                    opl += NW(surf - 1) * dst_b4;
             }
 
             // :196 normal = normalize(df(inc_pt))
-            if (prof == ROX_SPHERICAL)
-                df = v3{-cv * inc.x, -cv * inc.y, 1.0 - cv * inc.z};
-            else if (prof == ROX_CONIC)
-                df = v3{-cv * inc.x, -cv * inc.y, 1.0 - (row[O_CC] + 1.0) * cv * inc.z};
+            if (!(FEAT & F_POLY) || prof <= ROX_CONIC) {
+                const double k = (prof == ROX_CONIC) ? (row[O_CC] + 1.0) * cv : cv;
+                df = v3{-cv * inc.x, -cv * inc.y, 1.0 - k * inc.z};
+            }
             nrm = unit(df);
 
             // :198-202 aperture test (in_surface_range, :134-142)
             if (check_ap && surf >= first_surf && (last_surf < 0 || surf <= last_surf) &&
                 mode != ROX_PHANTOM) {
-                if (!inside_aperture(row, na.y, inc.x, inc.y, fuzz)) {
+                const bool in = (FEAT & F_APLIST)
+                    ? inside_aperture(row, ((tbli)row)[3], inc.x, inc.y, fuzz)
+                    : sqrt(inc.x * inc.x + inc.y * inc.y) <=
+                          row[offsetof(rox_surface, max_aperture) / 8] + fuzz;
+                if (!in)
                     status = ROX_BLOCKED;               // :247-251
-                    fail_surf = surf;
-                    alive = false;
-                }
             }
 
             // :211-221 refract / reflect / pass through
-            if (alive) {
+            if (status == ROX_OK) {
                 if (mode == ROX_REFLECT) {
                     ad = mirror(b4d, nrm);
                 } else if (mode == ROX_TRANSMIT) {
-                    if (!refract(b4d, nrm, nw[surf - 1], nw[surf], ad)) {
+                    if (!refract(b4d, nrm, NW(surf - 1), NW(surf), ad))
                         status = ROX_TIR;               // :239-245
-                        fail_surf = surf;
-                        alive = false;
-                    }
                 } else {
                     ad = b4d;
                 }
             }
-            if (!alive) {
+            if (status != ROX_OK) {
                 // partial packet: [inc_pt, before_dir, 0.0, normal] in the next slot
+                fail_surf = surf;
                 if (OUT_MODE == ROX_OUT_FULL) {
-                    const int sl = nslots_before[surf];
-                    store_pdn(seg, ld, sl, r, inc, bd, nrm);
-                    store_dst(seg, ld, sl, r, 0.0);
+                    const int sl = NSLOTS_BEFORE(surf);
+                    so.pdn(sl, inc, bd, nrm);
+                    so.dst(sl, 0.0);
                 }
                 break;
             }
 
             // :223-229 roll
-            bp = inc; bn = nrm; bd = ad;
+            bp = inc; bd = ad;
+            if (FEAT & F_PHFILT)
+                bn = nrm;           // only a filtered phantom's late append needs it
             z_dir_before = row[O_ZDIR];
             b4_mode = mode;
             if (OUT_MODE == ROX_OUT_FULL) {
-                const bool cur_filtered = (mode == ROX_PHANTOM) && filter_ph && surf < N - 1;
+                const bool cur_filtered = filter_ph && (mode == ROX_PHANTOM) && surf < N - 1;
                 if (!cur_filtered)
-                    store_pdn(seg, ld, slot[surf], r, inc, ad, nrm);
+                    so.pdn(SLOT(surf), inc, ad, nrm);
             }
         }
 
         // ---- epilogue ---------------------------------------------------------
         if (status == ROX_OK) {                         // :259-262
             if (OUT_MODE == ROX_OUT_FULL) {
-                store_dst(seg, ld, slot[N - 1], r, 0.0);
+                so.dst(SLOT(N - 1), 0.0);
             } else if (OUT_MODE == ROX_OUT_LAST) {      // trace.py:214-217
-                store_pdn(seg, ld, 0, r, inc, ad, nrm);
-                store_dst(seg, ld, 0, r, 0.0);
+                so.pdn(0, inc, ad, nrm);
+                so.dst(0, 0.0);
             } else {                                    // axisarrayfigure.py:229-238
                 const double dist = a.opts.foc / ad.z;
                 const double dx = inc.x + dist * ad.x;
                 const double dy = inc.y + dist * ad.y;
-                st(seg + r, dx - a.opts.image_pt[0]);
-                st(seg + ld + r, dy - a.opts.image_pt[1]);
+                so.put(0, 0, dx - a.opts.image_pt[0]);
+                so.put(0, 1, dy - a.opts.image_pt[1]);
             }
         }
         if (a.out.op)
-            st(a.out.op + r, opl);      // op_delta = 0 + opl on success; opl on failure (:236)
+            a.out.op[r] = opl;          // op_delta = 0 + opl on success; opl on failure (:236)
         if (a.out.status)
             a.out.status[r] = (uint8_t)status;
         if (a.out.fail_surf)
             a.out.fail_surf[r] = (int16_t)fail_surf;
     }
 }
+#undef NW
+#undef SLOT
+#undef NSLOTS_BEFORE
 
 // trace.py:563-605 / 537-560: pupil coordinates by repeated `+=` of the step.
 // lane 0 walks the x axis, lane 1 the y axis (both are sequential by
@@ -603,9 +668,15 @@ struct rox_system {
     double *d_ntab = nullptr;
     int32_t *d_slots[2] = {nullptr, nullptr};   // [0]: no phantom filtering, [1]: filtered
     int32_t n_seg[2] = {0, 0};
-    double *d_axes = nullptr;           // scratch for pupil axes [2][axes_cap]
+    double *d_axes = nullptr;           // pupil axes [2][axes_cap]
     int32_t axes_cap = 0;
+    // the axes currently held in d_axes (spot diagrams reuse one grid definition
+    // for every field and wavelength): skip the serial accumulate when unchanged
+    double axes_key[4] = {0, 0, 0, 0};
+    int32_t axes_num = 0;
+    hipStream_t axes_stream = nullptr;
     int num_cus = 256;
+    int features = 0;                   // F_POLY | F_APLIST of the table
 };
 
 namespace {
@@ -650,20 +721,32 @@ int check_opts(const rox_system *sys, const rox_opts *o, const rox_out *out, int
     return 0;
 }
 
-template <int GEN, bool PRW>
+template <int GEN, bool PRW, int FEAT>
 void launch_mode(int out_mode, dim3 grid, size_t lds, hipStream_t st, const TraceArgs &a)
 {
     switch (out_mode) {
     case ROX_OUT_FULL:
-        hipLaunchKernelGGL((trace_kernel<ROX_OUT_FULL, GEN, PRW>), grid, dim3(kBlock), lds, st, a);
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_FULL, GEN, PRW, FEAT>), grid, dim3(kBlock), lds, st, a);
         break;
     case ROX_OUT_LAST:
-        hipLaunchKernelGGL((trace_kernel<ROX_OUT_LAST, GEN, PRW>), grid, dim3(kBlock), lds, st, a);
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_LAST, GEN, PRW, FEAT>), grid, dim3(kBlock), lds, st, a);
         break;
     default:
-        hipLaunchKernelGGL((trace_kernel<ROX_OUT_HITS, GEN, PRW>), grid, dim3(kBlock), lds, st, a);
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_HITS, GEN, PRW, FEAT>), grid, dim3(kBlock), lds, st, a);
         break;
     }
+}
+
+template <int FEAT>
+void launch_gen(int gen, bool prw, int out_mode, dim3 grid, size_t lds, hipStream_t st,
+                const TraceArgs &a)
+{
+    if (gen == GEN_PUPIL)
+        launch_mode<GEN_PUPIL, false, FEAT>(out_mode, grid, lds, st, a);
+    else if (prw)
+        launch_mode<GEN_RAYS, true, FEAT>(out_mode, grid, lds, st, a);
+    else
+        launch_mode<GEN_RAYS, false, FEAT>(out_mode, grid, lds, st, a);
 }
 
 int launch(const rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
@@ -676,21 +759,38 @@ int launch(const rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
     a.slots = sys->d_slots[(a.opts.flags & ROX_FILTER_PHANTOMS) ? 1 : 0];
     a.n_ifcs = sys->n_ifcs;
     a.n_wvls = sys->n_wvls;
-    const size_t lds = lds_bytes(sys, prw);
+    const size_t lds = ROX_TABLE_SCALAR ? 0 : lds_bytes(sys, prw);
     if (lds > 160 * 1024)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS (max 163840)", lds);
-    // enough workgroups to fill 256 CUs several times over, grid-stride the rest
-    int64_t blocks = (a.n_rays + kBlock - 1) / kBlock;
-    const int64_t cap = (int64_t)sys->num_cus * 8;
-    if (blocks > cap)
-        blocks = cap;
-    const dim3 grid((unsigned)blocks);
-    if (gen == GEN_PUPIL)
-        launch_mode<GEN_PUPIL, false>(a.opts.out_mode, grid, lds, st, a);
-    else if (prw)
-        launch_mode<GEN_RAYS, true>(a.opts.out_mode, grid, lds, st, a);
-    else
-        launch_mode<GEN_RAYS, false>(a.opts.out_mode, grid, lds, st, a);
+    // the leanest kernel instance that covers this system and these options
+    int feat = sys->features;
+    if ((a.opts.flags & ROX_FILTER_PHANTOMS) && sys->n_seg[1] != sys->n_seg[0])
+        feat |= F_PHFILT;
+    // lane byte offsets are 32-bit: at most 2^28 rays per launch
+    const int64_t total = a.n_rays, chunk_max = int64_t(1) << 28;
+    const rox_out out0 = a.out;
+    a.in_ld = total;
+    for (int64_t base = 0; base < total; base += chunk_max) {
+        a.ray_base = base;
+        a.n_rays = total - base < chunk_max ? total - base : chunk_max;
+        a.out.seg = out0.seg + base;
+        a.out.op = out0.op ? out0.op + base : nullptr;
+        a.out.status = out0.status ? out0.status + base : nullptr;
+        a.out.fail_surf = out0.fail_surf ? out0.fail_surf + base : nullptr;
+        a.out.pupil = out0.pupil ? out0.pupil + base : nullptr;
+        // enough workgroups to fill 256 CUs several times over, grid-stride the rest
+        int64_t blocks = (a.n_rays + kBlock - 1) / kBlock;
+        const int64_t cap = (int64_t)sys->num_cus * 8;
+        if (blocks > cap)
+            blocks = cap;
+        const dim3 grid((unsigned)blocks);
+        if (feat == 0)
+            launch_gen<0>(gen, prw, a.opts.out_mode, grid, lds, st, a);
+        else
+            launch_gen<F_ALL>(gen, prw, a.opts.out_mode, grid, lds, st, a);
+    }
+    a.n_rays = total;
+    a.out = out0;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -766,6 +866,7 @@ int ensure_axes(rox_system *sys, int32_t num)
         HIP_TRY(hipFree(sys->d_axes));
     sys->d_axes = nullptr;
     sys->axes_cap = 0;
+    sys->axes_num = 0;
     HIP_TRY(hipMalloc(&sys->d_axes, sizeof(double) * 2 * (size_t)num));
     sys->axes_cap = num;
     return 0;
@@ -798,9 +899,16 @@ int prepare_grid(rox_system *sys, const rox_field *fld, const rox_grid *grid, in
     const double sx = (grid->stop[0] - grid->start[0]) / (grid->num - 1);
     const double sy = (grid->stop[1] - grid->start[1]) / (grid->num - 1);
     double *px = sys->d_axes, *py = sys->d_axes + sys->axes_cap;
-    hipLaunchKernelGGL(pupil_axes_kernel, dim3(1), dim3(64), 0, st, grid->start[0], grid->start[1],
-                       sx, sy, grid->num, px, py);
-    HIP_TRY(hipGetLastError());
+    const double key[4] = {grid->start[0], grid->start[1], sx, sy};
+    if (sys->axes_num != grid->num || sys->axes_stream != st ||
+        memcmp(key, sys->axes_key, sizeof key) != 0) {
+        hipLaunchKernelGGL(pupil_axes_kernel, dim3(1), dim3(64), 0, st, grid->start[0],
+                           grid->start[1], sx, sy, grid->num, px, py);
+        HIP_TRY(hipGetLastError());
+        memcpy(sys->axes_key, key, sizeof key);
+        sys->axes_num = grid->num;
+        sys->axes_stream = st;
+    }
     a = TraceArgs{};
     a.n_rays = R;
     a.px = px;
@@ -861,6 +969,12 @@ int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_t
     sys->n_ifcs = n_ifcs;
     sys->n_wvls = n_wvls;
     sys->rows.assign(rows, rows + n_ifcs);
+    for (int i = 0; i < n_ifcs; ++i) {
+        if (rows[i].profile > ROX_CONIC)
+            sys->features |= F_POLY;
+        if (rows[i].n_ap > 0)
+            sys->features |= F_APLIST;
+    }
     hipError_t e = hipGetDevice(&sys->device);
     if (e != hipSuccess) {
         delete sys;

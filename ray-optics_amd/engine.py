@@ -12,7 +12,8 @@ from . import abi
 from .table import SurfaceTable
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libroxtrace.so')
+# ROX_LIB selects an experiment build of the same HIP source (tools/ab_bench.py)
+LIB_PATH = os.environ.get('ROX_LIB') or os.path.join(_HERE, 'libroxtrace.so')
 _lib = None
 
 

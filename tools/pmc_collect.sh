@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects rocprofv3 PMC counters for the trace kernels on the GPU box, one
+# counter group per pass (TCC slots: FETCH_SIZE and WRITE_SIZE cannot share a
+# pass; PMC is never combined with sys/hip/hsa tracing on this pool).
+#   usage: tools/pmc_collect.sh <tag>     (outputs under gpurun_out/pmc_<tag>/)
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+CMD="python $R/tools/ab_bench.py --reps 1 --launches 3"
+pass() {   # name counters...
+  local name=$1; shift
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o $name -- $CMD > $OUT/$name.log 2>&1
+  echo "pass $name rc=$?"
+}
+pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM
+pass sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+find $OUT -name "*.csv" | head -20
