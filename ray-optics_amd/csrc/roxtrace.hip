@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -721,6 +722,18 @@ int check_opts(const rox_system *sys, const rox_opts *o, const rox_out *out, int
     return 0;
 }
 
+// workgroups per CU of a launch (the rest of the batch is grid-strided).
+// ROX_BLOCKS_PER_CU overrides it for experiments (tools/ab_bench.py).
+int blocks_per_cu()
+{
+    static const int v = [] {
+        const char *e = getenv("ROX_BLOCKS_PER_CU");
+        const int n = e ? atoi(e) : 0;
+        return n > 0 ? n : 32;      // measured: FULL 238 us at 8/CU, 228 us at 32/CU
+    }();
+    return v;
+}
+
 template <int GEN, bool PRW, int FEAT>
 void launch_mode(int out_mode, dim3 grid, size_t lds, hipStream_t st, const TraceArgs &a)
 {
@@ -780,7 +793,7 @@ int launch(const rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
         a.out.pupil = out0.pupil ? out0.pupil + base : nullptr;
         // enough workgroups to fill 256 CUs several times over, grid-stride the rest
         int64_t blocks = (a.n_rays + kBlock - 1) / kBlock;
-        const int64_t cap = (int64_t)sys->num_cus * 8;
+        const int64_t cap = (int64_t)sys->num_cus * blocks_per_cu();
         if (blocks > cap)
             blocks = cap;
         const dim3 grid((unsigned)blocks);
