@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--check', action='store_true')
     ap.add_argument('--workload', default='dblgauss_c2')
     ap.add_argument('--field', type=int, default=0)
+    ap.add_argument('--ld-pad', type=int, default=-1, help='row pitch = R + pad doubles (-1: engine default)')
     args = ap.parse_args()
     import torch
     import rayoptics_amd  # noqa: F401
@@ -60,7 +61,8 @@ def main():
         o = make_opts(flags=flags, out_mode=mode, first_surf=1, last_surf=N - 2,
                       foc=wl.foc, image_pt=wl.image_pts[args.field])
         out = DeviceResult(torch, eng.device, eng.num_segments(flags), R, mode,
-                           want_pupil=(mode == abi.OUT_FULL), nan_fill=False)
+                           want_pupil=(mode == abi.OUT_FULL), nan_fill=False,
+                           ld=None if args.ld_pad < 0 else R + args.ld_pad)
         outs[name] = (o, out)
         eng.time_pupil_grid(fld, grid, wi, o, out, 3)       # warm
     times = {k: [] for k in outs}
