@@ -121,11 +121,13 @@ def trace_pupil_grid(table, fld, grid, wvl_idx, opts):
     return res
 
 
-def trace_pupil_list(table, fld, px, py, wvl_idx, opts):
+def trace_pupil_list(table, fld, px, py, wvl_idx, opts, res=None):
+    """res: reuse a HostResult (bench.py times the C call, not the 1 GB fill)"""
     px = np.ascontiguousarray(px, dtype=np.float64)
     py = np.ascontiguousarray(py, dtype=np.float64)
     R = px.shape[0]
-    res = HostResult(table.n_ifcs, R, opts.out_mode, want_pupil=True)
+    if res is None:
+        res = HostResult(table.n_ifcs, R, opts.out_mode, want_pupil=True)
     out = res.out_struct()
     rc = lib().rox_oracle_trace_pupil_list(table.rows, table.n_ifcs,
                                            table.n_table.ctypes.data,

@@ -1,0 +1,120 @@
+"""-m gpu: BASELINE.json's other configurations at (or near) full size.
+HIP vs oracle bit-exact where the oracle finishes in seconds; size-independent
+properties at the sizes it cannot reach."""
+import numpy as np
+import pytest
+
+from rayoptics_amd import abi, SurfaceTable, field_struct
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+SPOT = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+
+
+def same(dev, orc, what):
+    np.testing.assert_array_equal(dev.status, orc.status, err_msg=what)
+    np.testing.assert_array_equal(dev.fail_surf, orc.fail_surf, err_msg=what)
+    assert np.array_equal(dev.seg, orc.seg, equal_nan=True), what
+    assert np.array_equal(dev.op, orc.op, equal_nan=True), what
+
+
+def test_c3_even_asphere_zoom_3fields_3wvls_512():
+    """configs[2] stand-in: 29 interfaces, 4 EvenPolynomial aspheres (Newton
+    iterations diverge per lane), 3 fields x 3 wavelengths x 512x512"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    wl = workloads.load('nikkor_c3')
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    grid = make_grid((-1., -1.), (1., 1.), 512)
+    n_through = 0
+    for fi in range(3):
+        for wi in range(3):
+            opts = make_opts(flags=SPOT, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
+                             foc=wl.foc, image_pt=wl.image_pts[fi])
+            dev = eng.trace_pupil_grid(wl.fields[fi], grid, wi, opts, nan_fill=True).to_host()
+            orc = oracle.trace_pupil_grid(wl.table, wl.fields[fi], grid, wi, opts)
+            same(dev, orc, f'nikkor f{fi} w{wi}')
+            n_through += int((dev.status == 0).sum())
+    assert n_through > 9 * 512 * 512 * 0.3
+    # FULL packets for one (field, wavelength)
+    opts = make_opts(flags=SPOT, out_mode=abi.OUT_FULL, first_surf=1, last_surf=N - 2)
+    g = make_grid((-1., -1.), (1., 1.), 192)
+    dev = eng.trace_pupil_grid(wl.fields[2], g, 0, opts, nan_fill=True).to_host()
+    orc = oracle.trace_pupil_grid(wl.table, wl.fields[2], g, 0, opts)
+    same(dev, orc, 'nikkor FULL')
+    eng.close()
+
+
+def test_c4_ritchey_chretien_5fields_256_full_packets():
+    """configs[3]: two Conic mirrors (reflect path, z_dir = -1 gap) + field stop"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    wl = workloads.load('rc_telescope_c4')
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    grid = make_grid((-1., -1.), (1., 1.), 256)
+    opts = make_opts(flags=SPOT, out_mode=abi.OUT_FULL, first_surf=1, last_surf=N - 2)
+    blocked_at_stop = 0
+    for fi in range(5):
+        dev = eng.trace_pupil_grid(wl.fields[fi], grid, 0, opts, nan_fill=True).to_host()
+        orc = oracle.trace_pupil_grid(wl.table, wl.fields[fi], grid, 0, opts)
+        same(dev, orc, f'rc field {fi}')
+        blocked_at_stop += int(((dev.status == abi.BLOCKED) & (dev.fail_surf == N - 2)).sum())
+        ok = dev.status == 0
+        # after two reflections the rays travel in +z again
+        assert (dev.seg[N - 1, 5, ok] > 0).all() and (dev.seg[1, 5, ok] < 0).all()
+    assert blocked_at_stop > 0          # the hand-added field stop clips the outer fields
+    eng.close()
+
+
+def lens_chain(n_lenses=20):
+    """synthetic configs[4] stand-in: 42 interfaces, a stable periodic chain of
+    equi-convex singlets (f ~ 100, pitch 50), object at infinity"""
+    surfs = [dict(cv=0.0, thi=1.0e10, n=1.0, max_aperture=1e12)]
+    for _ in range(n_lenses):
+        surfs.append(dict(cv=1 / 103.0, thi=4.0, n=[1.5168, 1.5200, 1.5140], max_aperture=14.0))
+        surfs.append(dict(cv=-1 / 103.0, thi=46.0, n=1.0, max_aperture=14.0))
+    surfs.append(dict(cv=0.0, thi=0.0, n=1.0, max_aperture=50.0))
+    return SurfaceTable.from_prescription(surfs, wvls=(587.6, 486.1, 656.3), stop_idx=1)
+
+
+def test_c5_40_surface_chain_2048_grid():
+    """configs[4] shape: 42 interfaces, 2048x2048 pupil grid (4.2M rays) in
+    HITS mode; a 96-row block (196k rays) bit-exact vs the oracle, the rest
+    through properties: mirror symmetry in x, identical results when the grid
+    is traced as row blocks (the multi-GPU sharding unit)."""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    tbl = lens_chain()
+    N = tbl.n_ifcs
+    assert N == 42
+    eng = TraceEngine(tbl)
+    theta = np.deg2rad(1.5)
+    fld = field_struct([0.0, -1.0e10 * np.tan(theta), 0.0], (0., 0.), 10.0, 1.0e10)
+    opts = make_opts(flags=SPOT, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
+                     foc=0.0, image_pt=(0.0, 0.0))
+    num = 2048
+    full = eng.trace_pupil_grid(fld, make_grid((-1., -1.), (1., 1.), num), 1, opts, nan_fill=True)
+    st = full.status.cpu().numpy().reshape(num, num)
+    xy = full.seg.cpu().numpy().reshape(2, num, num)
+    assert 0.5 < (st == 0).mean() < 1.0
+    # bit-exact block vs oracle
+    r0, rc = 1000, 96
+    blk = oracle.make_grid((-1., -1.), (1., 1.), num, row_begin=r0, row_count=rc)
+    orc = oracle.trace_pupil_grid(tbl, fld, blk, 1, opts)
+    np.testing.assert_array_equal(st[r0:r0 + rc].ravel(), orc.status)
+    assert np.array_equal(xy[:, r0:r0 + rc].reshape(2, -1), orc.seg, equal_nan=True)
+    # row blocks reproduce the full grid
+    part = eng.trace_pupil_grid(fld, make_grid((-1., -1.), (1., 1.), num, row_begin=512, row_count=256),
+                                1, opts, nan_fill=True).to_host()
+    assert np.array_equal(part.seg, xy[:, 512:768].reshape(2, -1), equal_nan=True)
+    # the accumulate-by-step pupil axis is not exactly symmetric, so mirror
+    # symmetry of the y-field spot holds to rounding, not bitwise
+    ok = (st == 0) & (st[::-1] == 0)
+    assert np.abs(xy[0][ok] + xy[0][::-1][ok]).max() < 1e-9
+    assert np.abs(xy[1][ok] - xy[1][::-1][ok]).max() < 1e-9
+    eng.close()
