@@ -193,6 +193,13 @@ int rox_time_pupil_grid(rox_system *sys, const rox_field *fld,
                         const rox_opts *opts, const rox_out *out,
                         void *stream, int32_t launches, double *mean_ms);
 
+/* diagnostic: compares the kernels' exponent-band-guarded sqrt / division paths
+ * with the plain IEEE operators on n pseudo-random operand sets (whole exponent
+ * range, zeros, denormals, inf, nan).  counts[0] = sqrt mismatches, counts[1] =
+ * division mismatches (both must be 0), counts[2] = operand sets that took a
+ * guarded path. */
+int rox_selftest_fp64(uint64_t n, uint64_t seed, uint64_t counts[3]);
+
 #ifdef __cplusplus
 }
 #endif

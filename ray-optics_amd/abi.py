@@ -89,7 +89,7 @@ EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_last_error', 'rox_system_create', 'rox_system_destroy',
            'rox_system_num_segments', 'rox_trace_rays',
            'rox_trace_pupil_grid', 'rox_trace_pupil_list',
-           'rox_time_pupil_grid')
+           'rox_time_pupil_grid', 'rox_selftest_fp64')
 
 
 def declare(lib):
@@ -121,4 +121,6 @@ def declare(lib):
     lib.rox_time_pupil_grid.restype = C.c_int
     lib.rox_time_pupil_grid.argtypes = [vp, P(Field), P(Grid), i32, P(Opts),
                                         P(Out), vp, i32, P(dbl)]
+    lib.rox_selftest_fp64.restype = C.c_int
+    lib.rox_selftest_fp64.argtypes = [C.c_uint64, C.c_uint64, P(C.c_uint64)]
     return lib

@@ -51,8 +51,8 @@ namespace {
 #ifndef ROX_STORE_NT         // 1: non-temporal packet stores (measured: FULL 236 us vs 257 us)
 #define ROX_STORE_NT 1
 #endif
-#ifndef ROX_SHARED_RCP       // 1: the three divisions by one divisor share its reciprocal
-#define ROX_SHARED_RCP 0
+#ifndef ROX_SLIM_FP64        // 1: range-guarded slim sqrt / shared-reciprocal division triples
+#define ROX_SLIM_FP64 1       //    (bit-identical to sqrt() and `/`; see slim_* below)
 #endif
 
 constexpr int kBlock = 256;
@@ -117,37 +117,113 @@ __device__ __forceinline__ v3 rotate(tblp rt, const v3 &v)
     return r;
 }
 
+
+// ---------------------------------------------------------------- slim fp64
+// hipcc expands an f64 sqrt into v_rsq_f64 + 9 mul/fma (correctly rounded) wrapped
+// in input scaling (v_ldexp x2), a class test and selects; and every f64 `/` into
+// v_div_scale x2 + v_rcp_f64 + two Newton steps + q, residual, v_div_fmas,
+// v_div_fixup.  The scaling and fix-up only act on operands outside a band of
+// exponents (or zero / inf / nan).  Inside the band the functions below execute
+// the SAME instruction sequence minus those wrappers, so the results are
+// bit-identical; three quotients by one divisor share the refined reciprocal.
+// A wave takes the slim path only when every active lane passes the exponent
+// test (one wave-uniform branch); otherwise it falls back to the plain operators.
+//   band: biased exponent in [640, 1408)  <=>  2^-383 <= |x| < 2^385
+//   (v_div_scale scales when exponents differ by >= 768 or the numerator's
+//   exponent <= 53; the sqrt expansion scales below 2^-767)
+__device__ __forceinline__ bool in_band(double x)
+{
+    const uint32_t h = (uint32_t)__double2hiint(x) & 0x7fffffffu;
+    return (h - 0x28000000u) < 0x30000000u;
+}
+
+// numerators may also be exactly +-0 (the sign is restored below)
+__device__ __forceinline__ bool in_band_or_zero(double x) { return in_band(x) || x == 0.0; }
+
+// sqrt for x in the band: the expansion of llvm.sqrt.f64 without scaling/selects
+__device__ __forceinline__ double sqrt_band(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double s = x * y;
+    double h = y * 0.5;
+    const double r0 = fma(-h, s, 0.5);
+    s = fma(s, r0, s);
+    h = fma(h, r0, h);
+    const double d0 = fma(-s, s, x);
+    s = fma(d0, h, s);
+    const double d1 = fma(-s, s, x);
+    return fma(d1, h, s);
+}
+
+__device__ __forceinline__ double slim_sqrt(double x)
+{
+#if ROX_SLIM_FP64
+    if (__all(in_band(x)))
+        return sqrt_band(x);
+#endif
+    return sqrt(x);
+}
+
+// refined reciprocal exactly as the division expansion builds it (no scaling)
+__device__ __forceinline__ double rcp_band(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(r, fma(-b, r, 1.0), r);
+    r = fma(r, fma(-b, r, 1.0), r);
+    return r;
+}
+
+// a / b given r = rcp_band(b): quotient, exact residual, correction; v_div_fixup's
+// only effect inside the band is forcing the sign, which also covers a == +-0
+__device__ __forceinline__ double div_band(double a, double b, double r)
+{
+    const double q = a * r;
+    const double q1 = fma(fma(-b, q, a), r, q);
+    return copysign(q1, q);
+}
+
+// (a.x / b, a.y / b, a.z / b)
+__device__ __forceinline__ v3 slim_div3(const v3 &a, double b)
+{
+#if ROX_SLIM_FP64
+    if (__all(in_band(b) && in_band_or_zero(a.x) && in_band_or_zero(a.y) && in_band_or_zero(a.z))) {
+        const double r = rcp_band(b);
+        return v3{div_band(a.x, b, r), div_band(a.y, b, r), div_band(a.z, b, r)};
+    }
+#endif
+    return v3{a.x / b, a.y / b, a.z / b};
+}
+
 // misc_math.py:48-54 normalize
 __device__ __forceinline__ v3 unit(const v3 &v)
 {
-    const double len = sqrt(dot3(v, v));
+    const double len = slim_sqrt(dot3(v, v));
     if (len == 0.0)
         return v;
-    return v3{v.x / len, v.y / len, v.z / len};
+    return slim_div3(v, len);
 }
 
 // raytrace.py:19-30.  false = TIR (math.sqrt ValueError)
 __device__ __forceinline__ bool refract(const v3 &d, const v3 &nrm, double n_in,
                                         double n_out, v3 &out)
 {
-    const double nlen = sqrt(dot3(nrm, nrm));
+    const double nlen = slim_sqrt(dot3(nrm, nrm));
     const double cosI = dot3(d, nrm) / nlen;
     const double sin2 = 1.0 - cosI * cosI;
     const double rad = n_out * n_out - n_in * n_in * sin2;
     if (rad < 0.0)
         return false;
-    const double n_cosIp = copysign(sqrt(rad), cosI);
+    const double n_cosIp = copysign(slim_sqrt(rad), cosI);
     const double alpha = n_cosIp - n_in * cosI;
-    out.x = (n_in * d.x + alpha * nrm.x) / n_out;
-    out.y = (n_in * d.y + alpha * nrm.y) / n_out;
-    out.z = (n_in * d.z + alpha * nrm.z) / n_out;
+    out = slim_div3(v3{n_in * d.x + alpha * nrm.x, n_in * d.y + alpha * nrm.y,
+                       n_in * d.z + alpha * nrm.z}, n_out);
     return true;
 }
 
 // raytrace.py:33-38 (not renormalised)
 __device__ __forceinline__ v3 mirror(const v3 &d, const v3 &nrm)
 {
-    const double nlen = sqrt(dot3(nrm, nrm));
+    const double nlen = slim_sqrt(dot3(nrm, nrm));
     const double cosI = dot3(d, nrm) / nlen;
     const double k = 2.0 * cosI;
     return v3{d.x - k * nrm.x, d.y - k * nrm.y, d.z - k * nrm.z};
@@ -161,7 +237,7 @@ __device__ __forceinline__ bool quadric_root(double ax2, double cx2, double b,
         const double rad = b * b - ax2 * cx2;
         if (rad < 0.0)
             return false;                       // TraceMissedSurfaceError
-        const double den = z_dir * sqrt(rad) - b;
+        const double den = z_dir * slim_sqrt(rad) - b;
         // np.errstate(divide='raise') -> FloatingPointError -> s = 0 only for a
         // finite non-zero numerator; 0/0 and nan/0 stay NaN
         if (den == 0.0 && cx2 != 0.0 && isfinite(cx2))
@@ -555,7 +631,7 @@ trace_kernel(const TraceArgs a)
                 mode != ROX_PHANTOM) {
                 const bool in = (FEAT & F_APLIST)
                     ? inside_aperture(row, ((tbli)row)[3], inc.x, inc.y, fuzz)
-                    : sqrt(inc.x * inc.x + inc.y * inc.y) <=
+                    : slim_sqrt(inc.x * inc.x + inc.y * inc.y) <=
                           row[offsetof(rox_surface, max_aperture) / 8] + fuzz;
                 if (!in)
                     status = ROX_BLOCKED;               // :247-251
@@ -637,6 +713,59 @@ __global__ void pupil_axes_kernel(double x0, double y0, double sx, double sy, in
     for (int k = 0; k < num; ++k) {
         out[k] = v;
         v += step;
+    }
+}
+
+// Diagnostic: the slim fp64 paths against the plain operators on pseudo-random
+// operands spanning the whole exponent range (zeros, denormals, band edges,
+// inf and nan included).  counts[0] = sqrt mismatches, counts[1] = division
+// mismatches, counts[2] = lanes that took a slim path.
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ double test_operand(uint64_t bits, int kind)
+{
+    // kind 0: any bit pattern; 1: in/near the band (the common case); 2: specials
+    if (kind == 0)
+        return __longlong_as_double((long long)bits);
+    if (kind == 1) {
+        const uint64_t e = 1023 - 40 + (bits >> 52) % 80;           // 2^-40 .. 2^40
+        return __longlong_as_double((long long)((bits & 0x800fffffffffffffull) | (e << 52)));
+    }
+    const double sp[] = {0.0, -0.0, 1.0, -1.0, 4.9e-324, 2.2250738585072014e-308,
+                         0x1p-383, 0x1.fffffffffffffp-384, 0x1p385, 0x1.fffffffffffffp384,
+                         1.7976931348623157e308, __builtin_inf(), -__builtin_inf(),
+                         __builtin_nan(""), 0x1p-767, 3.0};
+    return sp[bits % 16];
+}
+
+__device__ __forceinline__ bool same_bits(double a, double b)
+{
+    return __double_as_longlong(a) == __double_as_longlong(b) || (a != a && b != b);
+}
+
+__global__ void __launch_bounds__(kBlock) selftest_kernel(uint64_t n, uint64_t seed,
+                                                           unsigned long long *counts)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * kBlock) {
+        // one operand class per wave so that the wave-uniform slim branch is taken
+        const int kind = (int)((i / 64) % 4 == 3 ? (i / 256) % 3 : 1);
+        const uint64_t k = i * 4 + seed * 0x9e3779b97f4a7c15ull;
+        const double a0 = test_operand(mix64(k), kind), a1 = test_operand(mix64(k + 1), kind);
+        const double a2 = test_operand(mix64(k + 2), kind), b = test_operand(mix64(k + 3), kind);
+        const double x = fabs(a0);
+        if (!same_bits(slim_sqrt(x), sqrt(x)))
+            atomicAdd(&counts[0], 1ull);
+        const v3 q = slim_div3(v3{a0, a1, a2}, b);
+        if (!same_bits(q.x, a0 / b) || !same_bits(q.y, a1 / b) || !same_bits(q.z, a2 / b))
+            atomicAdd(&counts[1], 1ull);
+        if (__all(in_band(b) && in_band_or_zero(a0) && in_band_or_zero(a1) && in_band_or_zero(a2)))
+            atomicAdd(&counts[2], 1ull);
     }
 }
 
@@ -1163,6 +1292,23 @@ int rox_trace_pupil_list(rox_system *sys, const rox_field *fld, int64_t n_rays, 
     }
     (void)hipFree(d_p);
     return rc;
+}
+
+int rox_selftest_fp64(uint64_t n, uint64_t seed, uint64_t counts[3])
+{
+    if (!counts)
+        return fail(ROX_E_ARG, "null argument");
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d, 0, 3 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(selftest_kernel, dim3(2048), dim3(kBlock), 0, nullptr, n, seed, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpy(counts, d, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess)
+        return fail(ROX_E_HIP, "selftest: %s", hipGetErrorString(e));
+    return 0;
 }
 
 int rox_time_pupil_grid(rox_system *sys, const rox_field *fld, const rox_grid *grid,

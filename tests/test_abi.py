@@ -27,7 +27,7 @@ def header_symbols():
     with open(os.path.join(ROOT, 'include', 'roxtrace.h')) as f:
         src = f.read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(rox_[a-z_]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(rox_[a-z0-9_]+)\s*\(', src)))
 
 
 def test_header_and_binding_agree():

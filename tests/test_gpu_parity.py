@@ -266,3 +266,20 @@ def test_sharded_spot_single_rank(engines):
         np.testing.assert_array_equal(st, ref.status)
         bit_equal(xy, ref.seg.T, f'field {fi}')
     eng.close()
+
+
+def test_slim_fp64_paths_equal_ieee_operators():
+    """the exponent-band-guarded sqrt and shared-reciprocal division used by
+    the kernels are bit-identical to sqrt() and `/` -- 2^27 operand sets over
+    the whole exponent range, zeros, denormals, band edges, inf, nan"""
+    from rayoptics_amd.engine import load_library
+    import torch
+    assert torch.cuda.is_available()
+    torch.zeros(1, device='cuda')
+    lib = load_library()
+    counts = (C.c_uint64 * 3)()
+    for seed in (1, 2):
+        rc = lib.rox_selftest_fp64(1 << 27, seed, counts)
+        assert rc == 0, lib.rox_last_error()
+        assert counts[0] == 0 and counts[1] == 0, list(counts)
+        assert counts[2] > (1 << 27) * 0.5          # the guarded paths were exercised
