@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define ROX_ABI_VERSION 1
+#define ROX_ABI_VERSION 2
 #define ROX_MAX_COEF 10   /* EvenPolynomial r^2..r^20 / RadialPolynomial r^1..r^10 */
 #define ROX_MAX_AP 4      /* clear apertures per surface carried in the table */
 #define ROX_SEG_DOUBLES 10 /* p[3], d[3], dst, nrml[3]  (model_constants.py:31) */
@@ -58,9 +58,13 @@ enum { ROX_OK = 0, ROX_MISSED_SURFACE = 1, ROX_TIR = 2, ROX_BLOCKED = 3,
 /* what rox_out.seg receives */
 enum { ROX_OUT_FULL = 0,  /* seg[n_seg][10][ld]: the whole RayPkg.ray          */
        ROX_OUT_LAST = 1,  /* seg[10][ld]: ray[-1] only (trace_safe 'last')      */
-       ROX_OUT_HITS = 2 };/* seg[2][ld]: SpotDiagramFigure's `spot` filter,
+       ROX_OUT_HITS = 2,  /* seg[2][ld]: SpotDiagramFigure's `spot` filter,
                              (ray[-1].p + (foc/ray[-1].d[2])*ray[-1].d - image_pt).xy
                              (rayoptics/mpl/axisarrayfigure.py:229-238)         */
+       ROX_OUT_OPD = 3 }; /* seg[1][ld]: wave_abr_full_calc_finite_pup, the OPD of
+                             the ray w.r.t. the chief ray on a finite reference
+                             sphere, system units (rayoptics/raytr/waveabr.py:256-307);
+                             constants in rox_opts.wf                           */
 /* rox_opts.flags */
 enum { ROX_CHECK_APERTURES = 1u,     /* raytrace.py:198-202                    */
        ROX_INTERSECT_OBJ = 2u,       /* raytrace.py:147-154                    */
@@ -102,6 +106,31 @@ typedef struct rox_surface {
     rox_aperture ap[ROX_MAX_AP];
 } rox_surface;               /* 392 bytes */
 
+/* Per (field, wavelength, focus) constants of the OPD calculation: the chief
+ * ray package and reference sphere that trace.setup_pupil_coords() leaves in
+ * fld.chief_ray / fld.ref_sphere (rayoptics/raytr/trace.py:608-624,
+ * rayoptics/raytr/waveabr.py:23-76).  Finite reference sphere only: callers keep
+ * is_kinda_big(ref_radius) cases on the host (waveabr.py:213-221). */
+typedef struct rox_wavefront {
+    double cr1_p[3];         /* cr_ray[1][mc.p]                                 */
+    double cr0_d[3];         /* cr_ray[0][mc.d]                                 */
+    double crk_p[3];         /* cr_ray[-2][mc.p]                                */
+    double crk_d[3];         /* cr_ray[-2][mc.d]                                */
+    double cr_op;            /* chief-ray optical path                          */
+    double cr_exp_pt[3];     /* cr_exp_seg[0]                                   */
+    double cr_exp_dist;      /* cr_exp_seg[2]                                   */
+    double ref_dir[3];       /* ref_sphere[1]                                   */
+    double ref_radius;       /* ref_sphere[2]                                   */
+    double n_obj, n_img;     /* abs(fod.n_obj), abs(fod.n_img)                  */
+    double sign_soln;        /* -1 if ref_dir[2]*cr.ray[-1].d[2] < 0 else +1    */
+    /* transform_after_surface(ifcs[-2], .) (rayoptics/elem/transform.py:234-258):
+     * 0 = identity, 1 = p - t, 2 = rt.dot(p - t), rt.dot(d) */
+    int32_t after_kind;
+    int32_t reserved;
+    double after_rt[9];
+    double after_t[3];
+} rox_wavefront;
+
 typedef struct rox_opts {
     uint32_t flags;          /* ROX_CHECK_APERTURES | ...                      */
     int32_t out_mode;        /* ROX_OUT_*                                      */
@@ -111,6 +140,7 @@ typedef struct rox_opts {
     double fuzz;             /* pt_inside_fuzz, surface.py:198 (1e-5)          */
     double foc;              /* HITS only: defocus                             */
     double image_pt[2];      /* HITS only: fld.ref_sphere[0][:2]               */
+    rox_wavefront wf;        /* OPD only                                       */
 } rox_opts;
 
 /* Per-field constants of the 'epd', non-wide-angle branch of

@@ -57,6 +57,8 @@ class HostResult:
             shape = (n_seg_rows, abi.SEG_DOUBLES, R)
         elif out_mode == abi.OUT_LAST:
             shape = (abi.SEG_DOUBLES, R)
+        elif out_mode == abi.OUT_OPD:
+            shape = (1, R)
         else:
             shape = (2, R)
         self.seg = np.full(shape, np.nan)
@@ -77,12 +79,14 @@ class HostResult:
 
 
 def make_opts(flags=abi.INTERSECT_OBJ, out_mode=abi.OUT_FULL, first_surf=0,
-              last_surf=-1, eps=1.0e-12, fuzz=1e-5, foc=0.0, image_pt=(0., 0.)):
+              last_surf=-1, eps=1.0e-12, fuzz=1e-5, foc=0.0, image_pt=(0., 0.), wf=None):
     o = abi.Opts()
     o.flags, o.out_mode = flags, out_mode
     o.first_surf, o.last_surf = first_surf, last_surf
     o.eps, o.fuzz, o.foc = eps, fuzz, foc
     o.image_pt[0], o.image_pt[1] = image_pt
+    if wf is not None:
+        o.wf = wf
     return o
 
 

@@ -5,7 +5,7 @@ by :mod:`rayoptics_amd.engine`, which fails loudly when it is missing.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_COEF = 10
 MAX_AP = 4
 SEG_DOUBLES = 10
@@ -23,7 +23,7 @@ AP_CIRCULAR, AP_RECTANGULAR, AP_ALWAYS_BLOCK = 0, 1, 2
 # per-ray status (rayoptics/raytr/traceerror.py)
 OK, MISSED_SURFACE, TIR, BLOCKED, EVANESCENT = 0, 1, 2, 3, 4
 # output modes
-OUT_FULL, OUT_LAST, OUT_HITS = 0, 1, 2
+OUT_FULL, OUT_LAST, OUT_HITS, OUT_OPD = 0, 1, 2, 3
 # flags
 CHECK_APERTURES = 1
 INTERSECT_OBJ = 2
@@ -50,11 +50,23 @@ class Surface(C.Structure):
                 ('ap', Aperture * MAX_AP)]
 
 
+class Wavefront(C.Structure):
+    _fields_ = [('cr1_p', C.c_double * 3), ('cr0_d', C.c_double * 3),
+                ('crk_p', C.c_double * 3), ('crk_d', C.c_double * 3),
+                ('cr_op', C.c_double), ('cr_exp_pt', C.c_double * 3),
+                ('cr_exp_dist', C.c_double), ('ref_dir', C.c_double * 3),
+                ('ref_radius', C.c_double), ('n_obj', C.c_double),
+                ('n_img', C.c_double), ('sign_soln', C.c_double),
+                ('after_kind', C.c_int32), ('reserved', C.c_int32),
+                ('after_rt', C.c_double * 9), ('after_t', C.c_double * 3)]
+
+
 class Opts(C.Structure):
     _fields_ = [('flags', C.c_uint32), ('out_mode', C.c_int32),
                 ('first_surf', C.c_int32), ('last_surf', C.c_int32),
                 ('eps', C.c_double), ('fuzz', C.c_double),
-                ('foc', C.c_double), ('image_pt', C.c_double * 2)]
+                ('foc', C.c_double), ('image_pt', C.c_double * 2),
+                ('wf', Wavefront)]
 
 
 class Field(C.Structure):
@@ -79,7 +91,8 @@ class Out(C.Structure):
 
 assert C.sizeof(Aperture) == 40
 assert C.sizeof(Surface) == 392
-assert C.sizeof(Opts) == 56
+assert C.sizeof(Wavefront) == 296
+assert C.sizeof(Opts) == 352
 assert C.sizeof(Field) == 96
 assert C.sizeof(Grid) == 48
 assert C.sizeof(Out) == 48

@@ -4,6 +4,7 @@
   trace_ray_list     <- rayoptics/raytr/analyses.py:437-455
   trace_ray_grid     <- rayoptics/raytr/analyses.py:666-696
   trace_ray_fan      <- rayoptics/raytr/analyses.py:212-230
+  eval_wavefront     <- rayoptics/raytr/analyses.py:699-732 (OPD fused on device)
 """
 import numpy as np
 
@@ -111,3 +112,50 @@ def trace_ray_fan(opt_model, fan_rng, fld, wvl, foc, output_filter=None,
         if pkg is not None:
             fan.append([pk.pupil[0, r], pk.pupil[1, r], pkg])
     return fan
+
+
+def eval_wavefront(opt_model, fld, wvl, foc, image_pt_2d=None, image_delta=None,
+                   num_rays=21, value_if_none=np.nan, **kwargs):
+    """rayoptics/raytr/analyses.py:699-732: OPD (in waves) over the vignetted
+    pupil bounding box.  Chief ray and reference sphere come from the
+    reference's own ``setup_pupil_coords``; the num_rays**2 traces *and* their
+    ``wave_abr_full_calc`` (rayoptics/raytr/waveabr.py:256-307) run in one
+    launch (ROX_OUT_OPD).  Packet filters or an infinite reference sphere take
+    the generic route: device trace, reference ``waveabr`` on the lazy views."""
+    from rayoptics.raytr import trace as ref_trace
+    from rayoptics.raytr import waveabr
+    from .table import wavefront_from_model, UnsupportedModelError
+    ref_sphere, cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc,
+                                                      image_pt=image_pt_2d,
+                                                      image_delta=image_delta)
+    fld.chief_ray = cr_pkg
+    fld.ref_sphere = ref_sphere
+    oversize = kwargs.get('oversize', 1.)
+    vig_bbox = fld.vignetting_bbox(opt_model['osp']['pupil'], oversize=oversize)
+    grid_def = [vig_bbox[0], vig_bbox[1], num_rays]
+    kwargs['check_apertures'] = kwargs.get('check_apertures', True)
+    convert_to_opd = 1 / opt_model.nm_to_sys_units(wvl)
+    fused = kwargs.get('output_filter') is None and kwargs.get('rayerr_filter') is None \
+        and not kwargs.get('filter_out_phantoms', False)
+    wf = None
+    if fused:
+        try:
+            wf = wavefront_from_model(opt_model, fld)
+        except UnsupportedModelError:
+            fused = False
+    if not fused:
+        fod = opt_model['analysis_results']['parax_data'].fod
+        grid = trace_ray_grid(opt_model, grid_def, fld, wvl, foc, **kwargs)
+        return np.array([[(px, py, convert_to_opd * waveabr.wave_abr_full_calc(
+            fod, fld, wvl, foc, pkg, cr_pkg, ref_sphere)) if pkg is not None
+            else (px, py, value_if_none) for px, py, pkg in row] for row in grid])
+    kwargs.pop('output_filter', None)
+    kwargs.pop('rayerr_filter', None)
+    kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', False)     # trace_ray_grid :674
+    pk = _trace_pupil(opt_model, fld, wvl, kwargs, None, None,
+                      grid=make_grid(grid_def[0], grid_def[1], num_rays),
+                      out_mode=abi.OUT_OPD, wf=wf)
+    ok = pk.status == abi.OK
+    opd = np.where(ok, convert_to_opd * pk.seg[0, 0], value_if_none)
+    out = np.stack([pk.pupil[0], pk.pupil[1], opd], axis=1)
+    return out.reshape(num_rays, num_rays, 3)

@@ -385,6 +385,50 @@ __device__ __forceinline__ bool inside_aperture(tblp row, int n_ap, double x,
     return sqrt(x * x + y * y) <= row[offsetof(rox_surface, max_aperture) / sizeof(double)] + fuzz;
 }
 
+// ------------------------------------------------------------------ OPD
+// waveabr.py:117-132 eic_distance
+__device__ __forceinline__ double eic_distance(const v3 &p, const v3 &d, const double *p0,
+                                               const double *d0)
+{
+    const v3 sd{d.x + d0[0], d.y + d0[1], d.z + d0[2]};
+    const v3 dp{p.x - p0[0], p.y - p0[1], p.z - p0[2]};
+    return dot3(sd, dp) / (1. + dot3(d, v3{d0[0], d0[1], d0[2]}));
+}
+
+// waveabr.py:256-307 wave_abr_full_calc_finite_pup (+ transform.py:234-258)
+__device__ __forceinline__ double wave_abr_finite_pup(const rox_wavefront &w, const v3 &ray1_p,
+                                                      const v3 &ray0_d, const v3 &rayk_p,
+                                                      const v3 &rayk_d, double ray_op)
+{
+    const double e1 = eic_distance(ray1_p, ray0_d, w.cr1_p, w.cr0_d);
+    const double ekp = eic_distance(rayk_p, rayk_d, w.crk_p, w.crk_d);
+    v3 b4p = rayk_p, b4d = rayk_d;
+    if (w.after_kind != 0) {
+        const v3 t{rayk_p.x - w.after_t[0], rayk_p.y - w.after_t[1], rayk_p.z - w.after_t[2]};
+        if (w.after_kind == 1) {
+            b4p = t;
+        } else {
+            const double *rt = w.after_rt;
+            b4p = v3{fma(rt[2], t.z, fma(rt[1], t.y, fma(rt[0], t.x, 0.0))),
+                     fma(rt[5], t.z, fma(rt[4], t.y, fma(rt[3], t.x, 0.0))),
+                     fma(rt[8], t.z, fma(rt[7], t.y, fma(rt[6], t.x, 0.0)))};
+            b4d = v3{fma(rt[2], rayk_d.z, fma(rt[1], rayk_d.y, fma(rt[0], rayk_d.x, 0.0))),
+                     fma(rt[5], rayk_d.z, fma(rt[4], rayk_d.y, fma(rt[3], rayk_d.x, 0.0))),
+                     fma(rt[8], rayk_d.z, fma(rt[7], rayk_d.y, fma(rt[6], rayk_d.x, 0.0)))};
+        }
+    }
+    const double dst = ekp - w.cr_exp_dist;
+    const v3 pc{(b4p.x - dst * b4d.x) - w.cr_exp_pt[0], (b4p.y - dst * b4d.y) - w.cr_exp_pt[1],
+                (b4p.z - dst * b4d.z) - w.cr_exp_pt[2]};
+    const v3 rd{w.ref_dir[0], w.ref_dir[1], w.ref_dir[2]};
+    const double R = w.ref_radius;
+    const double F = dot3(rd, b4d) - dot3(b4d, pc) / R;
+    const double J = dot3(pc, pc) / R - 2.0 * dot3(rd, pc);
+    const double denom = F + w.sign_soln * sqrt(F * F + J / R);
+    const double ep = (denom == 0) ? 0 : J / denom;
+    return -w.n_obj * e1 - ray_op + w.n_img * ekp + w.cr_op - w.n_img * ep;
+}
+
 // ------------------------------------------------------------------ stores
 // One packet component of ray r lives at seg[(slot*10 + c)*ld + r].  The
 // (slot, c) part is wave-uniform, so it goes into an SGPR base; the ray part
@@ -559,6 +603,7 @@ trace_kernel(const TraceArgs a)
         double acc_dst = 0.0;           // dst of the most recently appended segment
         int acc_slot = 0;
         v3 inc{0, 0, 0}, nrm{0, 0, 0}, ad = dir0;
+        v3 ray1_p{0, 0, 0}, rayk_p{0, 0, 0}, rayk_d{0, 0, 0};   // OPD mode: ray[1].p, ray[-2]
         if (OUT_MODE == ROX_OUT_FULL && status == ROX_OK)
             so.pdn(0, bp, bd, bn);
 
@@ -659,6 +704,14 @@ trace_kernel(const TraceArgs a)
                 break;
             }
 
+            if (OUT_MODE == ROX_OUT_OPD) {
+                if (surf == 1)
+                    ray1_p = inc;
+                if (surf == N - 2) {
+                    rayk_p = inc;
+                    rayk_d = ad;
+                }
+            }
             // :223-229 roll
             bp = inc; bd = ad;
             if (FEAT & F_PHFILT)
@@ -679,6 +732,8 @@ trace_kernel(const TraceArgs a)
             } else if (OUT_MODE == ROX_OUT_LAST) {      // trace.py:214-217
                 so.pdn(0, inc, ad, nrm);
                 so.dst(0, 0.0);
+            } else if (OUT_MODE == ROX_OUT_OPD) {
+                so.put(0, 0, wave_abr_finite_pup(a.opts.wf, ray1_p, dir0, rayk_p, rayk_d, opl));
             } else {                                    // axisarrayfigure.py:229-238
                 const double dist = a.opts.foc / ad.z;
                 const double dx = inc.x + dist * ad.x;
@@ -840,8 +895,16 @@ int check_opts(const rox_system *sys, const rox_opts *o, const rox_out *out, int
 {
     if (!sys || !o || !out)
         return fail(ROX_E_ARG, "null argument");
-    if (o->out_mode < ROX_OUT_FULL || o->out_mode > ROX_OUT_HITS)
+    if (o->out_mode < ROX_OUT_FULL || o->out_mode > ROX_OUT_OPD)
         return fail(ROX_E_ARG, "bad out_mode %d", o->out_mode);
+    if (o->out_mode == ROX_OUT_OPD) {
+        if (sys->n_ifcs < 3)
+            return fail(ROX_E_ARG, "OPD output needs at least 3 interfaces");
+        if ((o->flags & ROX_FILTER_PHANTOMS) && sys->n_seg[1] != sys->n_seg[0])
+            return fail(ROX_E_UNSUPPORTED, "OPD output with filter_out_phantoms");
+        if (!(o->wf.ref_radius != 0.0))
+            return fail(ROX_E_ARG, "OPD output needs rox_opts.wf (ref_radius is 0)");
+    }
     if (out->ld < n_rays)
         return fail(ROX_E_ARG, "out.ld (%lld) < n_rays (%lld)", (long long)out->ld, (long long)n_rays);
     if (!out->seg && n_rays > 0)
@@ -872,6 +935,9 @@ void launch_mode(int out_mode, dim3 grid, size_t lds, hipStream_t st, const Trac
         break;
     case ROX_OUT_LAST:
         hipLaunchKernelGGL((trace_kernel<ROX_OUT_LAST, GEN, PRW, FEAT>), grid, dim3(kBlock), lds, st, a);
+        break;
+    case ROX_OUT_OPD:
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_OPD, GEN, PRW, FEAT>), grid, dim3(kBlock), lds, st, a);
         break;
     default:
         hipLaunchKernelGGL((trace_kernel<ROX_OUT_HITS, GEN, PRW, FEAT>), grid, dim3(kBlock), lds, st, a);
@@ -941,6 +1007,8 @@ int64_t seg_rows(const rox_system *sys, const rox_opts *o)
 {
     if (o->out_mode == ROX_OUT_FULL)
         return (int64_t)sys->n_seg[(o->flags & ROX_FILTER_PHANTOMS) ? 1 : 0] * ROX_SEG_DOUBLES;
+    if (o->out_mode == ROX_OUT_OPD)
+        return 1;
     return o->out_mode == ROX_OUT_LAST ? ROX_SEG_DOUBLES : 2;
 }
 

@@ -47,8 +47,10 @@ def _check(rc, what):
 
 
 def make_opts(flags=abi.INTERSECT_OBJ, out_mode=abi.OUT_FULL, first_surf=0,
-              last_surf=-1, eps=1.0e-12, fuzz=1e-5, foc=0.0, image_pt=(0., 0.)):
+              last_surf=-1, eps=1.0e-12, fuzz=1e-5, foc=0.0, image_pt=(0., 0.), wf=None):
     o = abi.Opts()
+    if wf is not None:
+        o.wf = wf
     o.flags, o.out_mode = int(flags), int(out_mode)
     o.first_surf, o.last_surf = int(first_surf), int(last_surf)
     o.eps, o.fuzz, o.foc = float(eps), float(fuzz), float(foc)
@@ -97,6 +99,8 @@ class DeviceResult:
             shape = (n_seg, abi.SEG_DOUBLES, self.ld)
         elif out_mode == abi.OUT_LAST:
             shape = (abi.SEG_DOUBLES, self.ld)
+        elif out_mode == abi.OUT_OPD:
+            shape = (1, self.ld)
         else:
             shape = (2, self.ld)
         new = (lambda s: torch.full(s, float('nan'), dtype=torch.float64, device=device)) \

@@ -67,6 +67,7 @@ class HostPackets:
     needed to serve reference-shaped results for ray ``r``"""
 
     def __init__(self, host, table, flags, out_mode, wvl_of_ray):
+        # [K, 10, R] (FULL), or one pseudo-segment [1, rows, R] for LAST/HITS/OPD
         self.seg = host.seg if host.seg.ndim == 3 else host.seg[None]
         self.op = host.op
         self.status = host.status

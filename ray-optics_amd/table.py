@@ -286,3 +286,57 @@ def field_from_model(opt_model, fld):
     return field_struct(pt0, aim_pt, pupil_value / 2, fod.obj_dist + z_enp,
                         (fld.vlx, fld.vux, fld.vly, fld.vuy),
                         opt_model['seq_model'].z_dir[0])
+
+
+def wavefront_from_model(opt_model, fld, chief_ray_pkg=None, ref_sphere=None):
+    """``rox_wavefront``: the chief-ray package and reference sphere that
+    ``trace.setup_pupil_coords`` leaves in ``fld.chief_ray`` / ``fld.ref_sphere``
+    (rayoptics/raytr/trace.py:608-624), as ``wave_abr_full_calc_finite_pup``
+    reads them (rayoptics/raytr/waveabr.py:256-307).  Infinite reference
+    spheres (``is_kinda_big``, waveabr.py:213-216) stay on the host."""
+    fod = opt_model['analysis_results']['parax_data'].fod
+    cr_pkg = fld.chief_ray if chief_ray_pkg is None else chief_ray_pkg
+    rs = fld.ref_sphere if ref_sphere is None else ref_sphere
+    cr, cr_exp_seg = cr_pkg
+    cr_ray, cr_op, _wvl = cr
+    cr_exp_pt, _cr_exp_dir, cr_exp_dist, ifc, _b4_pt, _b4_dir = cr_exp_seg
+    _image_pt, ref_dir, ref_radius, _lcl_tfrm_last = rs
+    if np.isinf(ref_radius) or abs(ref_radius) > 1e8:
+        raise UnsupportedModelError('infinite reference sphere: OPD stays on the host')
+    w = abi.Wavefront()
+    for i in range(3):
+        w.cr1_p[i] = float(cr_ray[1][0][i])
+        w.cr0_d[i] = float(cr_ray[0][1][i])
+        w.crk_p[i] = float(cr_ray[-2][0][i])
+        w.crk_d[i] = float(cr_ray[-2][1][i])
+        w.cr_exp_pt[i] = float(cr_exp_pt[i])
+        w.ref_dir[i] = float(ref_dir[i])
+    w.cr_op = float(cr_op)
+    w.cr_exp_dist = float(cr_exp_dist)
+    w.ref_radius = float(ref_radius)
+    w.n_obj, w.n_img = abs(float(fod.n_obj)), abs(float(fod.n_img))
+    w.sign_soln = -1.0 if ref_dir[2] * cr_ray[-1][1][2] < 0 else 1.0
+    # transform_after_surface(ifc, .), rayoptics/elem/transform.py:234-258
+    w.after_kind = 0
+    dec = getattr(ifc, 'decenter', None)
+    if dec:
+        r, t = dec.tform_after_surf()
+        for i in range(3):
+            w.after_t[i] = float(t[i])
+        if r is None:
+            w.after_kind = 1
+        else:
+            w.after_kind = 2
+            rt = r.transpose()
+            for a in range(3):
+                for b in range(3):
+                    w.after_rt[3 * a + b] = float(rt[a][b])
+    return w
+
+
+def wavefront_to_array(w):
+    return np.frombuffer(bytes(w), dtype=np.uint8).copy()
+
+
+def wavefront_from_array(a):
+    return abi.Wavefront.from_buffer_copy(np.asarray(a, dtype=np.uint8).tobytes())

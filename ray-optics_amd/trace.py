@@ -15,7 +15,7 @@ from .raypkg import HostPackets, RayPkg, RaySeg
 from .table import field_from_model, UnsupportedModelError
 
 
-def opts_from_kwargs(n_ifcs, kwargs, out_mode, foc=0.0, image_pt=(0., 0.)):
+def opts_from_kwargs(n_ifcs, kwargs, out_mode, foc=0.0, image_pt=(0., 0.), wf=None):
     """kwargs threaded through the reference's layers (trace.py:116-146,
     raytrace.py:83-99) -> the C ABI's flags word + scalars.  first/last_surf
     default as in raytrace.trace (raytrace.py:77-79)."""
@@ -34,7 +34,7 @@ def opts_from_kwargs(n_ifcs, kwargs, out_mode, foc=0.0, image_pt=(0., 0.)):
                      first_surf=kwargs.get('first_surf', 1),
                      last_surf=-1 if last is None else last,
                      eps=kwargs.get('eps', 1.0e-12),
-                     fuzz=1e-5 if fuzz is None else fuzz, foc=foc, image_pt=image_pt)
+                     fuzz=1e-5 if fuzz is None else fuzz, foc=foc, image_pt=image_pt, wf=wf)
 
 
 def emit(pk, r, output_filter, rayerr_filter, named, ifcs):
@@ -57,7 +57,7 @@ def emit(pk, r, output_filter, rayerr_filter, named, ifcs):
 
 def _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter, grid=None,
                  pupil_list=None,
-                 out_mode=None, foc=0.0, image_pt=(0., 0.)):
+                 out_mode=None, foc=0.0, image_pt=(0., 0.), wf=None):
     pupil_type = kwargs.get('pupil_type', 'rel pupil')
     if pupil_type != 'rel pupil':
         raise UnsupportedModelError(f'pupil_type {pupil_type!r} is generated on the host')
@@ -68,7 +68,7 @@ def _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter, grid
         # partial packets (rayerr_filter='full') need the FULL layout
         out_mode = (abi.OUT_LAST if output_filter == 'last' and rayerr_filter != 'full'
                     else abi.OUT_FULL)
-    opts = opts_from_kwargs(tbl.n_ifcs, kwargs, out_mode, foc, image_pt)
+    opts = opts_from_kwargs(tbl.n_ifcs, kwargs, out_mode, foc, image_pt, wf)
     wi = tbl.wvl_index(wvl)
     if grid is not None:
         res = eng.trace_pupil_grid(f, grid, wi, opts)

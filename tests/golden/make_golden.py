@@ -235,6 +235,26 @@ def case_list_of_rays(opm, R, rng):
                 last=last, op=op, status=status)
 
 
+def case_opd(opm, fi, wvl, num):
+    """analyses.eval_wavefront (analyses.py:699-732): OPD in waves over the
+    vignetted pupil bounding box, every ray through wave_abr_full_calc"""
+    from rayoptics_amd.table import wavefront_from_model, wavefront_to_array
+    sm, osp = opm['seq_model'], opm['optical_spec']
+    fld = osp['fov'].fields[fi]
+    foc = osp['focus'].focus_shift
+    N = len(sm.ifcs)
+    grid = analyses.eval_wavefront(opm, fld, wvl, foc, num_rays=num)
+    vig_bbox = fld.vignetting_bbox(osp['pupil'], oversize=1.)
+    return dict(field=field_arr(field_from_model(opm, fld)),
+                wvl_idx=np.int64(list(osp['wvls'].wavelengths).index(wvl)),
+                start=np.array(vig_bbox[0]), stop=np.array(vig_bbox[1]), num=np.int64(num),
+                flags=np.int64(abi.INTERSECT_OBJ | abi.CHECK_APERTURES),
+                first_surf=np.int64(1), last_surf=np.int64(N - 2),
+                wavefront=wavefront_to_array(wavefront_from_model(opm, fld)),
+                convert_to_opd=np.float64(1 / opm.nm_to_sys_units(wvl)),
+                opd_grid=np.array(grid, dtype=float))
+
+
 def save(name, table, cases):
     flat = {'table_json': np.array(json.dumps(table.to_dict()))}
     for cname, d in cases.items():
@@ -342,6 +362,8 @@ def main():
         'fan_f1': case_grid(opm, 1, 656.3, 21, kind='fan', start=(0., -1.), stop=(0., 1.)),
         'spot': case_spot(opm, 16),
         'list_last': case_list_of_rays(opm, 64, rng),
+        'opd_f0': case_opd(opm, 0, 587.6, 15),
+        'opd_f2': case_opd(opm, 2, 486.1, 16),
     })
     # finite-conjugate variant separates kernel bugs from the 1e10 cancellation
     opm = rm.dblgauss(obj_thi=1.0e3)
@@ -365,6 +387,7 @@ def main():
         'grid_f0': case_grid(opm, 0, 550.0, 10),
         'grid_f4': case_grid(opm, 4, 550.0, 10),
         'spot': case_spot(opm, 10),
+        'opd_f3': case_opd(opm, 3, 550.0, 12),
     })
 
     # C3 stand-in: 29 interfaces, 4 even aspheres
@@ -373,6 +396,7 @@ def main():
         'rays_ap': case_rays(opm, 192, rng, True),
         'grid_f1': case_grid(opm, 1, 587.5618, 8),
         'spot': case_spot(opm, 8),
+        'opd_f1': case_opd(opm, 1, 587.5618, 12),
     })
 
     # RadialPolynomial aspheres (the reference's timed asphere model)
@@ -387,6 +411,7 @@ def main():
     save('tilted_singlet', ra.SurfaceTable.from_seq_model(opm['seq_model']), {
         'rays_ap': case_rays(opm, 256, rng, True, pupil_scale=1.6),
         'grid_f1': case_grid(opm, 1, 650.0, 10),
+        'opd_f1': case_opd(opm, 1, 550.0, 11),
     })
 
 

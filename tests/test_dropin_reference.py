@@ -243,3 +243,24 @@ def test_unsupported_model_policy(ref, installed):
     installed.install('reference')
     g = trace.trace_grid(*args, img_filter=lambda p, pkg: 0.0)
     assert g.shape == (3, 3)
+
+
+def test_eval_wavefront_and_raygrid_opd(ref, installed):
+    """OPD maps: the fused device path (ROX_OUT_OPD) and the RayGrid container
+    (trace_wavefront -> wave_abr_pre_calc/_calc on lazy views) vs the reference"""
+    import rayoptics.raytr.analyses as analyses
+    opm = ref.dblgauss()
+    fld = opm['osp']['fov'].fields[2]
+
+    def ew():
+        return analyses.eval_wavefront(opm, fld, 587.6, 0.0, num_rays=13)
+    go, gt = both(installed, ew)
+    assert go.shape == gt.shape == (13, 13, 3)
+    np.testing.assert_array_equal(go, gt)
+    assert np.isfinite(go[:, :, 2]).sum() > 40
+
+    def rg():
+        g = analyses.RayGrid(opm, f=1, wl=656.3, num_rays=10)
+        return np.array(g.grid)
+    go, gt = both(installed, rg)
+    np.testing.assert_array_equal(go, gt)

@@ -283,3 +283,38 @@ def test_slim_fp64_paths_equal_ieee_operators():
         assert rc == 0, lib.rox_last_error()
         assert counts[0] == 0 and counts[1] == 0, list(counts)
         assert counts[2] > (1 << 27) * 0.5          # the guarded paths were exercised
+
+
+from test_oracle_golden import OPD_CASES, opd_opts, check_opd_grid  # noqa: E402
+
+
+@pytest.mark.parametrize('name,case', OPD_CASES)
+def test_opd_mode(engines, name, case):
+    """ROX_OUT_OPD: wave_abr_full_calc_finite_pup fused into the trace epilogue"""
+    from oracle import oracle
+    fx = H.fixture(name)
+    c = fx[case]
+    fld = H.field_from_arr(c['field'])
+    grid = oracle.make_grid(c['start'], c['stop'], int(c['num']))
+    opts = opd_opts(c)
+    dev = engines(name).trace_pupil_grid(fld, grid, int(c['wvl_idx']), opts, nan_fill=True).to_host()
+    orc = oracle.trace_pupil_grid(fx.table, fld, grid, int(c['wvl_idx']), opts)
+    assert_same_as_oracle(dev, orc, f'{name}/{case}')
+    check_opd_grid(c, dev, exact=(name != 'tilted_singlet'))
+
+
+def test_opd_full_size_wavefront(engines):
+    """1024x1024 OPD map of the double Gauss edge field: every ray vs the oracle"""
+    from oracle import oracle
+    fx = H.fixture('dblgauss')
+    c = fx['opd_f2']
+    fld = H.field_from_arr(c['field'])
+    grid = oracle.make_grid(c['start'], c['stop'], 1024)
+    opts = opd_opts(c)
+    dev = engines('dblgauss').trace_pupil_grid(fld, grid, int(c['wvl_idx']), opts, nan_fill=True).to_host()
+    orc = oracle.trace_pupil_grid(fx.table, fld, grid, int(c['wvl_idx']), opts)
+    assert_same_as_oracle(dev, orc, 'OPD 1024x1024')
+    ok = dev.status == 0
+    assert ok.mean() > 0.3
+    waves = float(c['convert_to_opd']) * dev.seg[0][ok]
+    assert np.abs(waves).max() < 200           # a real wavefront, not garbage

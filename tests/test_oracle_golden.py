@@ -143,3 +143,44 @@ def test_list_of_rays_last_segment():
     np.testing.assert_array_equal(res.status, c['status'])
     H.assert_soa_close(c['last'], res.seg, 'last', require_exact=True)
     H.assert_soa_close(c['op'], np.where(res.status == 0, res.op, np.nan), 'op', require_exact=True)
+
+
+OPD_CASES = [('dblgauss', 'opd_f0'), ('dblgauss', 'opd_f2'), ('rc_telescope', 'opd_f3'),
+             ('nikkor', 'opd_f1'), ('tilted_singlet', 'opd_f1')]
+
+
+def opd_opts(c):
+    from rayoptics_amd.table import wavefront_from_array
+    return oracle.make_opts(flags=int(c['flags']), out_mode=abi.OUT_OPD,
+                            first_surf=int(c['first_surf']), last_surf=int(c['last_surf']),
+                            wf=wavefront_from_array(c['wavefront']))
+
+
+def check_opd_grid(c, res, exact):
+    """res: HostResult-like (seg[1][R], status, pupil) vs analyses.eval_wavefront"""
+    num = int(c['num'])
+    exp = c['opd_grid']                  # [num][num][3] = px, py, opd in waves (nan if no ray)
+    got = np.where(res.status == 0, float(c['convert_to_opd']) * res.seg[0], np.nan).reshape(num, num)
+    np.testing.assert_array_equal(res.pupil[0].reshape(num, num), exp[:, :, 0])
+    np.testing.assert_array_equal(res.pupil[1].reshape(num, num), exp[:, :, 1])
+    assert np.array_equal(np.isnan(got), np.isnan(exp[:, :, 2]))
+    m = ~np.isnan(got)
+    assert m.sum() > num
+    # OPD is a difference of optical paths of O(100) system units: 1e-10
+    # absolute on the path lengths is ~2e-7 waves
+    assert np.abs(got[m] - exp[:, :, 2][m]).max() <= 1e-10 * float(c['convert_to_opd'])
+    frac = float(np.mean(got[m] == exp[:, :, 2][m]))
+    if exact:
+        assert frac == 1.0, frac
+    return frac
+
+
+@pytest.mark.parametrize('name,case', OPD_CASES)
+def test_opd_vs_reference_eval_wavefront(name, case):
+    """OUT_OPD == analyses.eval_wavefront -> waveabr.wave_abr_full_calc"""
+    fx = H.fixture(name)
+    c = fx[case]
+    fld = H.field_from_arr(c['field'])
+    grid = oracle.make_grid(c['start'], c['stop'], int(c['num']))
+    res = oracle.trace_pupil_grid(fx.table, fld, grid, int(c['wvl_idx']), opd_opts(c))
+    check_opd_grid(c, res, exact=(name != 'tilted_singlet'))
