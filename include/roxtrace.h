@@ -72,6 +72,14 @@ enum { ROX_CHECK_APERTURES = 1u,     /* raytrace.py:198-202                    *
        ROX_APPLY_VIGNETTING = 8u,    /* trace.py:298-300 (pupil entries only)  */
        ROX_HOST_POINTERS = 16u };    /* buffers are host memory: the library
                                         stages them through HBM itself        */
+/* rox_surface.rt_order: NumPy hands `rt.dot(v)` to OpenBLAS dgemv, whose FMA
+ * chain runs over the columns in a different order for an F-ordered rt (the
+ * transpose view compute_local_transforms makes, rayoptics/elem/transform.py:86)
+ * and a C-ordered one (np.identity, or the transpose of a transpose that
+ * 'dec and return' decenters produce).  Probed on OpenBLAS 0.3.29/Haswell:
+ *   F: y_i = fma(a_i2,x2, fma(a_i1,x1, fma(a_i0,x0, 0)))
+ *   C: y_i = fma(a_i2,x2, fma(a_i0,x0, fma(a_i1,x1, 0)))                       */
+enum { ROX_RT_F_ORDER = 0, ROX_RT_C_ORDER = 1 };
 /* rox_grid.kind */
 enum { ROX_GRID_PRODUCT = 0, /* trace_grid: ray r=(i*num+j), x_i outer, y_j inner */
        ROX_GRID_FAN = 1 };   /* trace_fan: ray r at (x_r, y_r), num rays          */
@@ -95,6 +103,8 @@ typedef struct rox_surface {
     int32_t profile;         /* ROX_SPHERICAL...                               */
     int32_t ncoef;           /* max_nonzero_coef (profiles.py:827-832)         */
     int32_t n_ap;            /* len(clear_apertures); 0 -> max_aperture test   */
+    int32_t rt_order;        /* summation order of rt.dot(v), see ROX_RT_*      */
+    int32_t reserved;
     double cv;               /* vertex curvature                               */
     double cc;               /* conic constant                                 */
     double ec;               /* cc + 1.0 as the reference evaluates it         */
@@ -104,7 +114,7 @@ typedef struct rox_surface {
     double z_dir;            /* z_dir[i] of the gap after this interface       */
     double max_aperture;     /* interface.py:113-122                           */
     rox_aperture ap[ROX_MAX_AP];
-} rox_surface;               /* 392 bytes */
+} rox_surface;               /* 400 bytes */
 
 /* Per (field, wavelength, focus) constants of the OPD calculation: the chief
  * ray package and reference sphere that trace.setup_pupil_coords() leaves in
@@ -126,7 +136,7 @@ typedef struct rox_wavefront {
     /* transform_after_surface(ifcs[-2], .) (rayoptics/elem/transform.py:234-258):
      * 0 = identity, 1 = p - t, 2 = rt.dot(p - t), rt.dot(d) */
     int32_t after_kind;
-    int32_t reserved;
+    int32_t after_order;     /* ROX_RT_* of after_rt                            */
     double after_rt[9];
     double after_t[3];
 } rox_wavefront;

@@ -30,6 +30,8 @@ INTERSECT_OBJ = 2
 FILTER_PHANTOMS = 4
 APPLY_VIGNETTING = 8
 HOST_POINTERS = 16
+# summation order of rt.dot(v) (see include/roxtrace.h)
+RT_F_ORDER, RT_C_ORDER = 0, 1
 # grid kinds
 GRID_PRODUCT, GRID_FAN = 0, 1
 
@@ -43,6 +45,7 @@ class Aperture(C.Structure):
 class Surface(C.Structure):
     _fields_ = [('mode', C.c_int32), ('profile', C.c_int32),
                 ('ncoef', C.c_int32), ('n_ap', C.c_int32),
+                ('rt_order', C.c_int32), ('reserved', C.c_int32),
                 ('cv', C.c_double), ('cc', C.c_double), ('ec', C.c_double),
                 ('coefs', C.c_double * MAX_COEF),
                 ('rt', C.c_double * 9), ('t', C.c_double * 3),
@@ -57,7 +60,7 @@ class Wavefront(C.Structure):
                 ('cr_exp_dist', C.c_double), ('ref_dir', C.c_double * 3),
                 ('ref_radius', C.c_double), ('n_obj', C.c_double),
                 ('n_img', C.c_double), ('sign_soln', C.c_double),
-                ('after_kind', C.c_int32), ('reserved', C.c_int32),
+                ('after_kind', C.c_int32), ('after_order', C.c_int32),
                 ('after_rt', C.c_double * 9), ('after_t', C.c_double * 3)]
 
 
@@ -90,7 +93,7 @@ class Out(C.Structure):
 
 
 assert C.sizeof(Aperture) == 40
-assert C.sizeof(Surface) == 392
+assert C.sizeof(Surface) == 400
 assert C.sizeof(Wavefront) == 296
 assert C.sizeof(Opts) == 352
 assert C.sizeof(Field) == 96

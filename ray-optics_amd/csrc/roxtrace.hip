@@ -56,8 +56,8 @@ namespace {
 #endif
 
 constexpr int kBlock = 256;
-constexpr int kRowDoubles = sizeof(rox_surface) / sizeof(double);   // 49
-static_assert(sizeof(rox_surface) == 392, "rox_surface layout");
+constexpr int kRowDoubles = sizeof(rox_surface) / sizeof(double);   // 50
+static_assert(sizeof(rox_surface) == 400, "rox_surface layout");
 static_assert(sizeof(rox_aperture) == 40, "rox_aperture layout");
 
 enum { GEN_RAYS = 0, GEN_PUPIL = 1 };
@@ -107,13 +107,22 @@ __device__ __forceinline__ double dot3(const v3 &a, const v3 &b)
     return fma(a.z, b.z, acc);
 }
 
-// Rt.dot(v): same chain per output row (dgemv on the F-ordered transpose view)
-__device__ __forceinline__ v3 rotate(tblp rt, const v3 &v)
+// Rt.dot(v) = OpenBLAS dgemv: an fma chain per output row; the column order is
+// 0,1,2 for the F-ordered transpose view and 1,0,2 for a C-ordered array
+// (include/roxtrace.h ROX_RT_*).  `order` is wave-uniform.
+template <class P>
+__device__ __forceinline__ v3 rotate(P rt, int order, const v3 &v)
 {
     v3 r;
-    r.x = fma(rt[2], v.z, fma(rt[1], v.y, fma(rt[0], v.x, 0.0)));
-    r.y = fma(rt[5], v.z, fma(rt[4], v.y, fma(rt[3], v.x, 0.0)));
-    r.z = fma(rt[8], v.z, fma(rt[7], v.y, fma(rt[6], v.x, 0.0)));
+    if (order == ROX_RT_C_ORDER) {
+        r.x = fma(rt[2], v.z, fma(rt[0], v.x, fma(rt[1], v.y, 0.0)));
+        r.y = fma(rt[5], v.z, fma(rt[3], v.x, fma(rt[4], v.y, 0.0)));
+        r.z = fma(rt[8], v.z, fma(rt[6], v.x, fma(rt[7], v.y, 0.0)));
+    } else {
+        r.x = fma(rt[2], v.z, fma(rt[1], v.y, fma(rt[0], v.x, 0.0)));
+        r.y = fma(rt[5], v.z, fma(rt[4], v.y, fma(rt[3], v.x, 0.0)));
+        r.z = fma(rt[8], v.z, fma(rt[7], v.y, fma(rt[6], v.x, 0.0)));
+    }
     return r;
 }
 
@@ -408,13 +417,8 @@ __device__ __forceinline__ double wave_abr_finite_pup(const rox_wavefront &w, co
         if (w.after_kind == 1) {
             b4p = t;
         } else {
-            const double *rt = w.after_rt;
-            b4p = v3{fma(rt[2], t.z, fma(rt[1], t.y, fma(rt[0], t.x, 0.0))),
-                     fma(rt[5], t.z, fma(rt[4], t.y, fma(rt[3], t.x, 0.0))),
-                     fma(rt[8], t.z, fma(rt[7], t.y, fma(rt[6], t.x, 0.0)))};
-            b4d = v3{fma(rt[2], rayk_d.z, fma(rt[1], rayk_d.y, fma(rt[0], rayk_d.x, 0.0))),
-                     fma(rt[5], rayk_d.z, fma(rt[4], rayk_d.y, fma(rt[3], rayk_d.x, 0.0))),
-                     fma(rt[8], rayk_d.z, fma(rt[7], rayk_d.y, fma(rt[6], rayk_d.x, 0.0)))};
+            b4p = rotate(w.after_rt, w.after_order, t);
+            b4d = rotate(w.after_rt, w.after_order, rayk_d);
         }
     }
     const double dst = ekp - w.cr_exp_dist;
@@ -615,9 +619,10 @@ trace_kernel(const TraceArgs a)
             const double cv = row[O_CV];
 
             // :170-174 transform to the new vertex frame, closest approach
-            const v3 b4p = rotate(prow + O_RT, v3{bp.x - prow[O_T], bp.y - prow[O_T + 1],
-                                                  bp.z - prow[O_T + 2]});
-            const v3 b4d = rotate(prow + O_RT, bd);
+            const int rt_order = ((tbli)prow)[4];
+            const v3 b4p = rotate(prow + O_RT, rt_order, v3{bp.x - prow[O_T], bp.y - prow[O_T + 1],
+                                                            bp.z - prow[O_T + 2]});
+            const v3 b4d = rotate(prow + O_RT, rt_order, bd);
             const double pp_dst = -dot3(b4p, b4d);
             const v3 pp{b4p.x + pp_dst * b4d.x, b4p.y + pp_dst * b4d.y, b4p.z + pp_dst * b4d.z};
 

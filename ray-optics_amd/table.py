@@ -79,6 +79,15 @@ def _aperture_rows(row, ifc):
             raise UnsupportedModelError(f'aperture {kind} is not supported')
 
 
+def rt_order_of(rt):
+    """which dgemv kernel NumPy's ``rt.dot(v)`` reaches: the F-ordered transpose
+    view (``r.transpose()``) or a C-ordered array (include/roxtrace.h ROX_RT_*)"""
+    flags = getattr(rt, 'flags', None)
+    if flags is not None and flags['F_CONTIGUOUS'] and not flags['C_CONTIGUOUS']:
+        return abi.RT_F_ORDER
+    return abi.RT_C_ORDER
+
+
 class SurfaceTable:
     """rows[N] of ``rox_surface`` + n_table[W][N] + the wavelengths (nm)."""
 
@@ -125,6 +134,7 @@ class SurfaceTable:
                 rt, t = np.identity(3), np.zeros(3)
             else:
                 rt, t = tfrm
+            row.rt_order = rt_order_of(rt)
             for a in range(3):
                 for b in range(3):
                     row.rt[3 * a + b] = float(rt[a][b])
@@ -188,6 +198,7 @@ class SurfaceTable:
                 row.coefs[k] = float(coefs[k])
             for a in range(3):
                 row.rt[4 * a] = 1.0
+            row.rt_order = abi.RT_C_ORDER       # np.identity(3)
             row.t[2] = float(s.get('thi', 0.0)) if i < N - 1 else 0.0
             if mode == 'reflect':
                 zdir = -zdir
@@ -204,6 +215,7 @@ class SurfaceTable:
         for r in self.rows:
             rows.append(dict(
                 mode=r.mode, profile=r.profile, ncoef=r.ncoef, n_ap=r.n_ap,
+                rt_order=r.rt_order,
                 cv=r.cv, cc=r.cc, ec=r.ec, coefs=list(r.coefs),
                 rt=list(r.rt), t=list(r.t), z_dir=r.z_dir,
                 max_aperture=r.max_aperture,
@@ -220,6 +232,7 @@ class SurfaceTable:
         for row, s in zip(rows, d['rows']):
             row.mode, row.profile = s['mode'], s['profile']
             row.ncoef, row.n_ap = s['ncoef'], s['n_ap']
+            row.rt_order = s.get('rt_order', abi.RT_F_ORDER)
             row.cv, row.cc, row.ec = s['cv'], s['cc'], s['ec']
             for k, c in enumerate(s['coefs']):
                 row.coefs[k] = c
@@ -328,6 +341,7 @@ def wavefront_from_model(opt_model, fld, chief_ray_pkg=None, ref_sphere=None):
         else:
             w.after_kind = 2
             rt = r.transpose()
+            w.after_order = rt_order_of(rt)
             for a in range(3):
                 for b in range(3):
                     w.after_rt[3 * a + b] = float(rt[a][b])

@@ -300,7 +300,7 @@ def test_opd_mode(engines, name, case):
     dev = engines(name).trace_pupil_grid(fld, grid, int(c['wvl_idx']), opts, nan_fill=True).to_host()
     orc = oracle.trace_pupil_grid(fx.table, fld, grid, int(c['wvl_idx']), opts)
     assert_same_as_oracle(dev, orc, f'{name}/{case}')
-    check_opd_grid(c, dev, exact=(name != 'tilted_singlet'))
+    check_opd_grid(c, dev, exact=True)
 
 
 def test_opd_full_size_wavefront(engines):
