@@ -42,6 +42,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--num', type=int, default=1024, help='pupil grid is num x num')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='take the multi-rank code path (process group, collectives, sharded '
+                         'spot) even with one rank: a 1-GPU rehearsal of the N>1 run')
     ap.add_argument('--cpu-sample-rows', type=int, default=0,
                     help='pupil rows traced by the CPU baseline (0 = auto, ~10 s)')
     return ap.parse_args()
@@ -62,8 +65,10 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with '
                          f'{args.gpus} ranks (WORLD_SIZE={world})')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=torch.device('cuda', local_rank))
 
@@ -88,7 +93,7 @@ def main():
         eng.trace_pupil_grid(fld, grid, wi, opts, out=out)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -100,7 +105,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -113,7 +118,7 @@ def main():
     nseg = np.where(ok, N, np.where(status == abi.MISSED_SURFACE, fail, fail + 1))
     alg_bytes = int(nseg.sum()) * 80 + R * (8 + 1 + 2 + 16)
     tot = torch.tensor([inters, R], dtype=torch.float64, device=eng.device)
-    if world > 1:
+    if multi:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     inters_all, rays_all = tot[0].item(), tot[1].item()
 
@@ -141,7 +146,7 @@ def main():
     # N > 1: the path's one exchange step -- every (field, wavelength) spot
     # diagram sharded by pupil-row blocks, hits gathered to rank 0 over RCCL
     sharded = None
-    if world > 1:
+    if multi:
         try:
             from rayoptics_amd.dist import trace_spot_sharded
             trace_spot_sharded(eng, wl.fields, wl.image_pts, nw, num, wl.foc)      # warm-up
@@ -200,7 +205,7 @@ def main():
             'sharded_spot': sharded,
         }
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -10,35 +10,33 @@ try:
     from rayoptics.raytr.traceerror import (TraceError, TraceMissedSurfaceError,  # noqa: F401
                                             TraceTIRError, TraceRayBlockedError,
                                             TraceEvanescentRayError)
-except Exception:      # reference not installed: same names, same attributes
+except Exception:      # reference not installed: equivalent classes, built here
     class TraceError(Exception):
-        def __init__(self, surf=None, ray_pkg=None):
-            self.surf = surf
-            self.ray_pkg = ray_pkg
+        """per-ray trace failure; carries .surf and .ray_pkg like the reference's"""
 
-    class TraceMissedSurfaceError(TraceError):
-        def __init__(self, ifc=None, prev_seg=None):
-            self.ifc = ifc
-            self.prev_seg = prev_seg
+        def __init__(self, *args, **kw):
+            super().__init__()
+            self.surf = kw.get('surf')
+            self.ray_pkg = kw.get('ray_pkg')
+            for name, val in zip(self._fields, args):
+                setattr(self, name, val)
 
-    class TraceTIRError(TraceError):
-        def __init__(self, inc_dir, normal, prev_indx, follow_indx):
-            self.ifc = None
-            self.int_pt = None
-            self.inc_dir = inc_dir
-            self.normal = normal
-            self.prev_indx = prev_indx
-            self.follow_indx = follow_indx
+        _fields = ()
 
-    class TraceEvanescentRayError(TraceError):
-        def __init__(self, ifc, int_pt, inc_dir, normal, prev_indx, follow_indx):
-            self.ifc = ifc
-            self.int_pt = int_pt
+    def _kind(name, fields, doc):
+        return type(name, (TraceError,), {'_fields': fields, '__doc__': doc,
+                                          **{f: None for f in fields}})
 
-    class TraceRayBlockedError(TraceError):
-        def __init__(self, ifc, int_pt):
-            self.ifc = ifc
-            self.int_pt = int_pt
+    TraceMissedSurfaceError = _kind('TraceMissedSurfaceError', ('ifc', 'prev_seg'),
+                                    'the ray misses an interface')
+    TraceTIRError = _kind('TraceTIRError', ('inc_dir', 'normal', 'prev_indx', 'follow_indx'),
+                          'total internal reflection at an interface')
+    TraceTIRError.ifc = TraceTIRError.int_pt = None
+    TraceRayBlockedError = _kind('TraceRayBlockedError', ('ifc', 'int_pt'),
+                                 'the ray is blocked by an aperture')
+    TraceEvanescentRayError = _kind('TraceEvanescentRayError',
+                                    ('ifc', 'int_pt', 'inc_dir', 'normal', 'prev_indx',
+                                     'follow_indx'), 'evanescent diffracted ray')
 
 
 def make_error(status, surf, ifc=None, ray_pkg=None, int_pt=None, inc_dir=None,
