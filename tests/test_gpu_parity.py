@@ -318,3 +318,83 @@ def test_opd_full_size_wavefront(engines):
     assert ok.mean() > 0.3
     waves = float(c['convert_to_opd']) * dev.seg[0][ok]
     assert np.abs(waves).max() < 200           # a real wavefront, not garbage
+
+
+def test_edge_grids_and_pitches(engines):
+    """num = 1 and 2 grids (step = x/0 is never used for a ray), explicit row
+    pitches (ld > R, odd), and per-ray wavelengths over a ragged batch"""
+    from oracle import oracle
+    from rayoptics_amd.engine import DeviceResult
+    import torch
+    fx = H.fixture('dblgauss')
+    c = fx['grid_f2']
+    eng = engines('dblgauss')
+    fld = H.field_from_arr(c['field'])
+    opts = H.make_opts(c)
+    for num, start, stop in [(1, (0.25, -0.5), (1., 1.)), (2, (-0.3, -0.3), (0.3, 0.3)), (3, (0., 0.), (0., 0.))]:
+        grid = oracle.make_grid(start, stop, num)
+        with np.errstate(all='ignore'):
+            orc = oracle.trace_pupil_grid(fx.table, fld, grid, 0, opts)
+        dev = eng.trace_pupil_grid(fld, grid, 0, opts, nan_fill=True).to_host()
+        assert_same_as_oracle(dev, orc, f'num={num}')
+    # explicit pitches
+    grid = oracle.make_grid((-1., -1.), (1., 1.), 23)
+    orc = oracle.trace_pupil_grid(fx.table, fld, grid, 1, opts)
+    for ld in (529, 530, 1001, 4096):
+        out = DeviceResult(torch, eng.device, eng.num_segments(opts.flags), 529, abi.OUT_FULL,
+                           want_pupil=True, nan_fill=True, ld=ld)
+        dev = eng.trace_pupil_grid(fld, grid, 1, opts, out=out).to_host()
+        assert_same_as_oracle(dev, orc, f'ld={ld}')
+    # per-ray wavelengths, ragged
+    cr = fx['rays_ap']
+    R = 333
+    wi = (np.arange(R) % 3).astype(np.int32)
+    o2 = H.make_opts(cr)
+    dev = eng.trace_rays(cr['pt0'][:, :R], cr['dir0'][:, :R], wi, o2, nan_fill=True).to_host()
+    orc = oracle.trace_rays(fx.table, cr['pt0'][:, :R], cr['dir0'][:, :R], wi, o2)
+    assert_same_as_oracle(dev, orc, 'per-ray wavelengths')
+
+
+def test_argument_errors_are_reported_not_crashes(engines):
+    from rayoptics_amd.engine import EngineError, make_opts, make_grid
+    fx = H.fixture('dblgauss')
+    eng = engines('dblgauss')
+    fld = H.field_from_arr(fx['grid_f2']['field'])
+    with pytest.raises(EngineError, match='wvl_idx'):
+        eng.trace_pupil_grid(fld, make_grid((-1, -1), (1, 1), 4), 7, make_opts())
+    with pytest.raises(EngineError, match='row block'):
+        eng.trace_pupil_grid(fld, make_grid((-1, -1), (1, 1), 4, row_begin=3, row_count=2), 0, make_opts())
+    with pytest.raises(EngineError, match='OPD'):
+        eng.trace_pupil_grid(fld, make_grid((-1, -1), (1, 1), 4), 0, make_opts(out_mode=abi.OUT_OPD))
+    with pytest.raises(EngineError, match='out_mode'):
+        eng.trace_pupil_grid(fld, make_grid((-1, -1), (1, 1), 4), 0, make_opts(out_mode=9))
+
+
+def test_large_table_many_wavelengths():
+    """44 interfaces x 5 wavelengths staged in LDS (the largest prescription
+    shape in the reference tree), per-ray wavelength gather"""
+    from oracle import oracle
+    from rayoptics_amd import SurfaceTable
+    from rayoptics_amd.engine import TraceEngine
+    surfs = [dict(cv=0.0, thi=500.0, n=1.0, max_aperture=1e9)]
+    rng = np.random.default_rng(11)
+    for k in range(21):
+        n = [1.5 + 0.01 * k + 0.002 * w for w in range(5)]
+        surfs.append(dict(cv=0.004 * (1 + k % 3), thi=3.0, n=n, max_aperture=20.0,
+                          profile='Conic' if k % 4 == 1 else 'Spherical', cc=-0.4))
+        surfs.append(dict(cv=-0.003 * (1 + k % 2), thi=8.0, n=1.0, max_aperture=20.0))
+    surfs.append(dict(cv=0.0, thi=0.0, n=1.0, max_aperture=100.0))
+    tbl = SurfaceTable.from_prescription(surfs, wvls=(450., 500., 550., 600., 650.))
+    assert tbl.n_ifcs == 44
+    eng = TraceEngine(tbl)
+    R = 5000
+    pt0 = np.stack([rng.uniform(-5, 5, R), rng.uniform(-5, 5, R), np.zeros(R)])
+    d = np.stack([rng.uniform(-.02, .02, R), rng.uniform(-.02, .02, R), np.ones(R)])
+    d /= np.linalg.norm(d, axis=0)
+    wi = rng.integers(0, 5, R).astype(np.int32)
+    opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES, first_surf=1, last_surf=42)
+    dev = eng.trace_rays(pt0, d, wi, opts, nan_fill=True).to_host()
+    orc = oracle.trace_rays(tbl, pt0, d, wi, opts)
+    assert_same_as_oracle(dev, orc, '44 interfaces x 5 wvls')
+    assert (dev.status == 0).mean() > 0.2
+    eng.close()
