@@ -353,15 +353,31 @@ __device__ __forceinline__ bool newton_hit(bool radial, double cv, double cc1, d
     double s1 = -f / dot3(d, df);
     double delta = fabs(s1);
     int iter = 0;
-    while (delta > eps && iter < 1000) {
+    bool ok = true;
+    // one Spencer-Murty step for the lanes that have not converged
+    auto step = [&]() {
         p = v3{p0.x + s1 * d.x, p0.y + s1 * d.y, p0.z + s1 * d.z};
-        if (!poly_eval<true>(radial, cv, cc1, ec, ncoef, coefs, p, f, df))
-            return false;
+        if (!poly_eval<true>(radial, cv, cc1, ec, ncoef, coefs, p, f, df)) {
+            ok = false;
+            delta = 0.0;            // leave the iteration; the caller reports the miss
+            return;
+        }
         const double s2 = s1 - f / dot3(d, df);
         delta = fabs(s2 - s1);
         s1 = s2;
         ++iter;
-    }
+    };
+    // measured on the reference's even-asphere zoom: 2 steps 20 %, 3 steps 73 %,
+    // 4 steps 6 %, more < 1 % -- four steps straight-line and
+    // predicated per lane, then the residual loop (cap 1000 as in the reference)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (delta > eps)
+            step();
+    while (delta > eps && iter < 1000)
+        step();
+    if (!ok)
+        return false;
     s = s1;
     hit = p;        // df already holds df(hit): normal() re-evaluates the same expression
     return true;
