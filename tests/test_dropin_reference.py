@@ -264,3 +264,25 @@ def test_eval_wavefront_and_raygrid_opd(ref, installed):
         return np.array(g.grid)
     go, gt = both(installed, rg)
     np.testing.assert_array_equal(go, gt)
+
+
+def test_host_generated_ray_starts(ref, installed):
+    """pupil specs outside the device's 'epd' branch (object-space NA here):
+    ray starts from the reference's ray_start_from_osp, trace on the device"""
+    import rayoptics.raytr.trace as trace
+    from rayoptics.raytr.opticalspec import PupilSpec
+    opm = ref.singlet()
+    osp = opm['optical_spec']
+    osp['pupil'] = PupilSpec(osp, key=['object', 'NA'], value=0.04)
+    ref.finish(opm)             # (the element/part-tree update is bypassed, SURVEY 8c)
+    fld = osp['fov'].fields[1]
+
+    def run():
+        return trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 7], fld, 650.0, 0.0,
+                                img_filter=lambda p, pkg: np.full(4, np.nan) if pkg is None else
+                                np.array([p[0], p[1], pkg[0][-1][0][0], pkg[0][-1][0][1]]),
+                                form='grid', append_if_none=True)
+    go, gt = both(installed, run)
+    assert go.shape == gt.shape == (7, 7, 4)
+    np.testing.assert_array_equal(go, gt)
+    assert np.isfinite(go[:, :, 2]).sum() > 10
