@@ -241,12 +241,48 @@ def cpu_baseline(wl, fld, wi, opts, num, rows):
     ok = res.status == abi.OK
     inters = int(ok.sum()) * (N - 1) + int(res.fail_surf[~ok].astype(np.int64).sum())
     inters *= passes
+    allc = cpu_all_cores(wl, fld, wi, opts, num, xs, ys)
     return {'value': inters / dt, 'unit': 'ray-surface intersections/s', 'cores': 1,
             'kind': 'port',
             'sample': f'{passes} passes over {rows} pupil rows x {num} = {rows * num} rays of the '
                       f'same grid, FULL packets, oracle/rox_oracle.c -O2 single thread, {dt:.1f} s',
             'rays_per_s': passes * rows * num / dt,
-            'host_cpu_count': os.cpu_count()}
+            'host_cpu_count': os.cpu_count(), 'all_cores': allc}
+
+
+def cpu_all_cores(wl, fld, wi, opts, num, xs, ys):
+    """context only: the same oracle fanned over threads (ctypes releases the
+    GIL), one pass over the whole grid split into row blocks"""
+    import threading
+    from oracle import oracle
+    from rayoptics_amd import abi
+    nthr = max(1, min(os.cpu_count() or 1, 64, num))
+    N = wl.n_ifcs
+    bounds = [(num * k) // nthr for k in range(nthr + 1)]
+    jobs = []
+    for k in range(nthr):
+        rows = bounds[k + 1] - bounds[k]
+        if rows == 0:
+            continue
+        px = np.repeat(xs[bounds[k]:bounds[k + 1]], num)
+        py = np.tile(ys, rows)
+        jobs.append((px, py, oracle.HostResult(N, rows * num, opts.out_mode, want_pupil=True)))
+    oracle.lib()
+    thr = [threading.Thread(target=oracle.trace_pupil_list,
+                            args=(wl.table, fld, px, py, wi, opts), kwargs={'res': res})
+           for px, py, res in jobs]
+    t0 = time.perf_counter()
+    for t in thr:
+        t.start()
+    for t in thr:
+        t.join()
+    dt = time.perf_counter() - t0
+    inters = 0
+    for _px, _py, res in jobs:
+        ok = res.status == abi.OK
+        inters += int(ok.sum()) * (N - 1) + int(res.fail_surf[~ok].astype(np.int64).sum())
+    return {'value': inters / dt, 'unit': 'ray-surface intersections/s', 'threads': len(jobs),
+            'sample': f'one pass over the {num}x{num} grid, {dt:.2f} s'}
 
 
 if __name__ == '__main__':
