@@ -48,6 +48,32 @@ def partition(n_fields, n_wvls, num, world):
     return out
 
 
+class _HitsWindow:
+    """a DeviceResult-shaped window [off, off+n) of the exchange buffers, so
+    the HITS kernel writes where the collective will read"""
+
+    def __init__(self, xy, st, off, n, cap):
+        import torch
+        self.R, self.out_mode, self.ld = n, abi.OUT_HITS, cap
+        self._xy, self._off = xy, off
+        self.seg = xy[:, off:off + n]
+        self.status = st[off:off + n]
+        self.op = None
+        self.fail_surf = None
+        self.pupil = None
+        self._torch = torch
+
+    def out_struct(self):
+        o = abi.Out()
+        o.seg = self._xy.data_ptr() + 8 * self._off
+        o.op = None
+        o.status = self.status.data_ptr()
+        o.fail_surf = None
+        o.pupil = None
+        o.ld = self.ld
+        return o
+
+
 def trace_spot_sharded(engine, fields, image_pts, n_wvls, num, foc, flags=None,
                        group=None, all_ranks=False, first_surf=1, last_surf=None):
     """spot diagrams for every (field, wavelength), sharded over the process
@@ -68,45 +94,53 @@ def trace_spot_sharded(engine, fields, image_pts, n_wvls, num, foc, flags=None,
     sizes = [sum(b.row_count for b in blocks) * num for blocks in plan]
     cap = max(max(sizes), 1)
 
-    # local trace: packed [3, cap] = x, y, status (as f64) so that one
-    # collective moves everything
-    packed = None
+    # local trace straight into the exchange buffers: xy [2, cap] f64 and
+    # status [cap] u8 (17 B per ray on the wire), no intermediate copies
+    dev = getattr(engine, 'device', 'cpu')
+    xy_loc = torch.full((2, cap), float('nan'), dtype=torch.float64, device=dev)
+    st_loc = torch.full((cap,), 255, dtype=torch.uint8, device=dev)
     off = 0
     for b in plan[rank]:
         opts = make_opts(flags=flags, out_mode=abi.OUT_HITS, first_surf=first_surf,
                          last_surf=last, foc=foc, image_pt=image_pts[b.fi])
         grid = make_grid((-1., -1.), (1., 1.), num, row_begin=b.row_begin,
                          row_count=b.row_count)
-        res = engine.trace_pupil_grid(fields[b.fi], grid, b.wi, opts, want_pupil=False,
-                                      nan_fill=True)
-        seg, status = res.seg, res.status
-        if packed is None:
-            packed = torch.full((3, cap), float('nan'), dtype=torch.float64,
-                                device=seg.device)
         n = b.row_count * num
-        packed[0:2, off:off + n] = seg
-        packed[2, off:off + n] = status.to(torch.float64)
+        out = _HitsWindow(xy_loc, st_loc, off, n, cap)
+        res = engine.trace_pupil_grid(fields[b.fi], grid, b.wi, opts, want_pupil=False, out=out)
+        if res is not out:          # engines without out= support (test doubles)
+            xy_loc[:, off:off + n] = res.seg
+            st_loc[off:off + n] = res.status
         off += n
-    if packed is None:
-        dev = getattr(engine, 'device', 'cpu')
-        packed = torch.full((3, cap), float('nan'), dtype=torch.float64, device=dev)
 
     # the exchange step
     if world == 1:
-        parts = [packed]
+        xy_parts, st_parts = [xy_loc], [st_loc]
     elif all_ranks:
-        parts = [torch.empty_like(packed) for _ in range(world)]
-        dist.all_gather(parts, packed, group=group)
+        xy_parts = [torch.empty_like(xy_loc) for _ in range(world)]
+        st_parts = [torch.empty_like(st_loc) for _ in range(world)]
+        dist.all_gather(xy_parts, xy_loc, group=group)
+        dist.all_gather(st_parts, st_loc, group=group)
     else:
-        parts = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
-        dist.gather(packed, parts, dst=0, group=group)
+        xy_parts = [torch.empty_like(xy_loc) for _ in range(world)] if rank == 0 else None
+        st_parts = [torch.empty_like(st_loc) for _ in range(world)] if rank == 0 else None
+        dist.gather(xy_loc, xy_parts, dst=0, group=group)
+        dist.gather(st_loc, st_parts, dst=0, group=group)
         if rank != 0:
             return None
+
+    def to_numpy(t):
+        if t.device.type == 'cpu':
+            return t.numpy()
+        h = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        h.copy_(t, non_blocking=True)
+        torch.cuda.synchronize(t.device)
+        return h.numpy()
 
     # reassemble per (field, wavelength) in row order
     out = {}
     for k, blocks in enumerate(plan):
-        buf = parts[k].cpu().numpy()
+        buf, stb = to_numpy(xy_parts[k]), to_numpy(st_parts[k])
         off = 0
         for b in blocks:
             xy, st = out.setdefault((b.fi, b.wi), (np.full((num * num, 2), np.nan),
@@ -115,6 +149,6 @@ def trace_spot_sharded(engine, fields, image_pts, n_wvls, num, foc, flags=None,
             r0 = b.row_begin * num
             xy[r0:r0 + n, 0] = buf[0, off:off + n]
             xy[r0:r0 + n, 1] = buf[1, off:off + n]
-            st[r0:r0 + n] = buf[2, off:off + n].astype(np.uint8)
+            st[r0:r0 + n] = stb[off:off + n]
             off += n
     return out

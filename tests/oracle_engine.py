@@ -53,7 +53,7 @@ class OracleEngine:
         return self._trim(oracle.trace_rays(self.table, np.asarray(pt0), np.asarray(dir0),
                                             wvl_idx, opts), opts)
 
-    def trace_pupil_grid(self, fld, grid, wvl_idx=0, opts=None, **kw):
+    def trace_pupil_grid(self, fld, grid, wvl_idx=0, opts=None, **kw):      # (out= ignored)
         return self._trim(oracle.trace_pupil_grid(self.table, fld, grid, wvl_idx, opts), opts)
 
     def trace_pupil_list(self, fld, px, py, wvl_idx=0, opts=None, **kw):
