@@ -398,3 +398,22 @@ def test_large_table_many_wavelengths():
     assert_same_as_oracle(dev, orc, '44 interfaces x 5 wvls')
     assert (dev.status == 0).mean() > 0.2
     eng.close()
+
+
+def test_cell_phone_doc_table_kat_on_device(engines):
+    """the HIP Newton path against the ray table printed in the reference's
+    documentation (Cell_Phone_lens.rst:311-328)"""
+    from test_oracle_golden import CELL_PHONE_DOC_MARGINAL as doc
+    fx = H.fixture('cell_phone')
+    N = fx.table.n_ifcs
+    from oracle import oracle
+    opts = oracle.make_opts(flags=abi.INTERSECT_OBJ, first_surf=1, last_surf=N - 2)
+    dev = engines('cell_phone').trace_rays(np.array([[0.], [1.], [0.]]), np.array([[0.], [0.], [1.]]),
+                                           1, opts, nan_fill=True).to_host()
+    assert dev.status[0] == abi.OK
+    seg = dev.seg[:, :, 0]
+    np.testing.assert_allclose(seg[:, 1], doc[:, 0], atol=6e-6)
+    np.testing.assert_allclose(seg[:, 2], doc[:, 1], atol=6e-6, rtol=6e-5)
+    np.testing.assert_allclose(seg[:, 4], doc[:, 2], atol=6e-7)
+    np.testing.assert_allclose(seg[:, 5], doc[:, 3], atol=6e-7)
+    np.testing.assert_allclose(seg[1:, 6], doc[1:, 4], rtol=6e-5, atol=6e-6)

@@ -184,3 +184,45 @@ def test_opd_vs_reference_eval_wavefront(name, case):
     grid = oracle.make_grid(c['start'], c['stop'], int(c['num']))
     res = oracle.trace_pupil_grid(fx.table, fld, grid, int(c['wvl_idx']), opd_opts(c))
     check_opd_grid(c, res, exact=True)
+
+
+# docs/source/examples/Cell_Phone_lens/Cell_Phone_lens.rst:311-328 -- list_ray of
+# rt.trace(sm, [0,1,0], [0,0,1], central wvl) through the 8-asphere
+# RadialPolynomial phone lens (rayoptics/optical/tests/cell_phone_camera.roa):
+# rows = Y, Z, M, N, Len as printed (X = L = 0)
+CELL_PHONE_DOC_MARGINAL = np.array([
+    [1.00000, 0.0, 0.000000, 1.000000, 1e10],
+    [1.00000, 0.0, 0.000000, 1.000000, 0.26119],
+    [1.00000, 0.26119, -0.163284, 0.986579, 0.93632],
+    [0.84711, -0.0050525, -0.272278, 0.962219, 0.86687],
+    [0.61108, -0.10094, -0.024063, 0.999710, 0.79796],
+    [0.59188, -0.053212, -0.171810, 0.985130, 0.16841],
+    [0.56295, 0.012694, -0.122925, 0.992416, 0.89598],
+    [0.45281, 0.01188, -0.158261, 0.987397, 0.2017],
+    [0.42089, 0.051033, -0.178956, 0.983857, 0.83614],
+    [0.27126, 0.023675, -0.185004, 0.982738, 0.6882],
+    [0.14394, 0.0, -0.122034, 0.992526, 0.40301],
+    [0.09476, 0.0, -0.185004, 0.982738, 0.65124],
+    [-0.02573, 0.0, -0.185004, 0.982738, 0.0]])
+
+
+def test_cell_phone_doc_table_kat():
+    """the reference's documentation prints this ray to 5-6 digits: a known
+    answer for the Newton (Spencer-Murty) path on RadialPolynomial aspheres"""
+    fx = H.fixture('cell_phone')
+    N = fx.table.n_ifcs
+    assert N == 13
+    wi = fx.table.wvls.index(587.5618) if 587.5618 in fx.table.wvls else 1
+    pt0 = np.array([[0.], [1.], [0.]])
+    dir0 = np.array([[0.], [0.], [1.]])
+    res = oracle.trace_rays(fx.table, pt0, dir0, wi,
+                            oracle.make_opts(flags=abi.INTERSECT_OBJ, first_surf=1, last_surf=N - 2))
+    assert res.status[0] == abi.OK
+    seg = res.seg[:, :, 0]
+    doc = CELL_PHONE_DOC_MARGINAL
+    np.testing.assert_allclose(seg[:, 0], 0.0, atol=1e-15)
+    np.testing.assert_allclose(seg[:, 1], doc[:, 0], atol=6e-6)
+    np.testing.assert_allclose(seg[:, 2], doc[:, 1], atol=6e-6, rtol=6e-5)
+    np.testing.assert_allclose(seg[:, 4], doc[:, 2], atol=6e-7)
+    np.testing.assert_allclose(seg[:, 5], doc[:, 3], atol=6e-7)
+    np.testing.assert_allclose(seg[1:, 6], doc[1:, 4], rtol=6e-5, atol=6e-6)
