@@ -47,7 +47,8 @@ extern "C" {
 /* interface interact_mode (raytrace.py:211-221) */
 enum { ROX_TRANSMIT = 0, ROX_REFLECT = 1, ROX_DUMMY = 2, ROX_PHANTOM = 3 };
 /* surface profile kinds (rayoptics/elem/profiles.py) */
-enum { ROX_SPHERICAL = 0, ROX_CONIC = 1, ROX_EVENPOLY = 2, ROX_RADIALPOLY = 3 };
+enum { ROX_SPHERICAL = 0, ROX_CONIC = 1, ROX_EVENPOLY = 2, ROX_RADIALPOLY = 3,
+       ROX_YTOROID = 4, ROX_XTOROID = 5 };
 /* clear-aperture kinds (rayoptics/elem/surface.py:398-494).  Elliptical has
  * no point_inside() in the reference, so it returns None and the ray is
  * always blocked; ROX_AP_ALWAYS_BLOCK reproduces that. */
@@ -108,13 +109,14 @@ typedef struct rox_surface {
     double cv;               /* vertex curvature                               */
     double cc;               /* conic constant                                 */
     double ec;               /* cc + 1.0 as the reference evaluates it         */
+    double cR;               /* Y/XToroid sweep curvature (profiles.py:1317-1437) */
     double coefs[ROX_MAX_COEF];
     double rt[9];            /* lcl_tfrms[i][0], row-major (already R^T)       */
     double t[3];             /* lcl_tfrms[i][1]                                */
     double z_dir;            /* z_dir[i] of the gap after this interface       */
     double max_aperture;     /* interface.py:113-122                           */
     rox_aperture ap[ROX_MAX_AP];
-} rox_surface;               /* 400 bytes */
+} rox_surface;               /* 408 bytes */
 
 /* Per (field, wavelength, focus) constants of the OPD calculation: the chief
  * ray package and reference sphere that trace.setup_pupil_coords() leaves in

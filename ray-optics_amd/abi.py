@@ -15,9 +15,10 @@ TRANSMIT, REFLECT, DUMMY, PHANTOM = 0, 1, 2, 3
 MODE_NAMES = {'transmit': TRANSMIT, 'reflect': REFLECT, 'dummy': DUMMY,
               'phantom': PHANTOM}
 # profile kinds  (rayoptics/elem/profiles.py)
-SPHERICAL, CONIC, EVENPOLY, RADIALPOLY = 0, 1, 2, 3
+SPHERICAL, CONIC, EVENPOLY, RADIALPOLY, YTOROID, XTOROID = 0, 1, 2, 3, 4, 5
 PROFILE_NAMES = {'Spherical': SPHERICAL, 'Conic': CONIC,
-                 'EvenPolynomial': EVENPOLY, 'RadialPolynomial': RADIALPOLY}
+                 'EvenPolynomial': EVENPOLY, 'RadialPolynomial': RADIALPOLY,
+                 'YToroid': YTOROID, 'XToroid': XTOROID}
 # aperture kinds (rayoptics/elem/surface.py:398-494)
 AP_CIRCULAR, AP_RECTANGULAR, AP_ALWAYS_BLOCK = 0, 1, 2
 # per-ray status (rayoptics/raytr/traceerror.py)
@@ -47,6 +48,7 @@ class Surface(C.Structure):
                 ('ncoef', C.c_int32), ('n_ap', C.c_int32),
                 ('rt_order', C.c_int32), ('reserved', C.c_int32),
                 ('cv', C.c_double), ('cc', C.c_double), ('ec', C.c_double),
+                ('cR', C.c_double),
                 ('coefs', C.c_double * MAX_COEF),
                 ('rt', C.c_double * 9), ('t', C.c_double * 3),
                 ('z_dir', C.c_double), ('max_aperture', C.c_double),
@@ -93,7 +95,7 @@ class Out(C.Structure):
 
 
 assert C.sizeof(Aperture) == 40
-assert C.sizeof(Surface) == 400
+assert C.sizeof(Surface) == 408
 assert C.sizeof(Wavefront) == 296
 assert C.sizeof(Opts) == 352
 assert C.sizeof(Field) == 96

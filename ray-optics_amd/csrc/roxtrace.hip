@@ -56,8 +56,8 @@ namespace {
 #endif
 
 constexpr int kBlock = 256;
-constexpr int kRowDoubles = sizeof(rox_surface) / sizeof(double);   // 50
-static_assert(sizeof(rox_surface) == 400, "rox_surface layout");
+constexpr int kRowDoubles = sizeof(rox_surface) / sizeof(double);   // 51
+static_assert(sizeof(rox_surface) == 408, "rox_surface layout");
 static_assert(sizeof(rox_aperture) == 40, "rox_aperture layout");
 
 enum { GEN_RAYS = 0, GEN_PUPIL = 1 };
@@ -283,11 +283,40 @@ __device__ __forceinline__ bool quadric_hit(bool conic, double cv, double cc, do
 // One evaluation of f(p) and df(p) for the polynomial aspheres
 // (profiles.py:849-885 even, 1070-1113 radial; forward accumulation of the
 // powers, not Horner).  Returns false when the sag square root goes negative.
+// kind = ROX_EVENPOLY | ROX_RADIALPOLY | ROX_YTOROID | ROX_XTOROID (wave-uniform).
 template <bool WANT_F>
-__device__ __forceinline__ bool poly_eval(bool radial, double cv, double cc1, double ec,
+__device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, double ec, double cR,
                                           int ncoef, tblp coefs,
                                           const v3 &p, double &f, v3 &df)
 {
+    if (kind >= ROX_YTOROID) {
+        // profiles.py:1337-1377 YToroid.fY/f/df; XToroid swaps x and y (:1429-1434)
+        const bool xt = (kind == ROX_XTOROID);
+        const double px = xt ? p.y : p.x, py = xt ? p.x : p.y;
+        const double y2 = py * py;
+        const double rad = 1. - cc1 * cv * cv * y2;
+        if (rad < 0.0)
+            return false;
+        const double srad = sqrt(rad);
+        double z_asp = 0.0, y_pow = y2;
+        double e_asp = 0.0, c_coef = 2.0, d_pow = 1;
+        for (int i = 0; i < ncoef; ++i) {
+            z_asp += coefs[i] * y_pow;
+            y_pow *= y2;
+            e_asp += c_coef * coefs[i] * d_pow;
+            c_coef += 2.0;
+            d_pow *= y2;
+        }
+        const double fY = cv * y2 / (1. + srad) + z_asp;
+        if (WANT_F)
+            f = p.z - fY - cR * (px * px + p.z * p.z - fY * fY) / 2;
+        const double dfdY = cv / srad + e_asp;
+        const double Fx = -cR * px;
+        const double Fy = (cR * fY - 1) * (dfdY) * py;
+        df = xt ? v3{Fy, Fx, 1 - cR * p.z} : v3{Fx, Fy, 1 - cR * p.z};
+        return true;
+    }
+    const bool radial = (kind == ROX_RADIALPOLY);
     const double r2 = p.x * p.x + p.y * p.y;
     double e_tot;
     if (!radial) {
@@ -341,14 +370,14 @@ __device__ __forceinline__ bool poly_eval(bool radial, double cv, double cc1, do
 
 // profiles.py:155-186 Spencer & Murty Newton iteration.  Returns the last
 // *evaluated* iterate as the hit point (p0 itself when |s1| <= eps at once).
-__device__ __forceinline__ bool newton_hit(bool radial, double cv, double cc1, double ec,
+__device__ __forceinline__ bool newton_hit(int kind, double cv, double cc1, double ec, double cR,
                                            int ncoef, tblp coefs,
                                            const v3 &p0, const v3 &d, double eps,
                                            double &s, v3 &hit, v3 &df)
 {
     v3 p = p0;
     double f;
-    if (!poly_eval<true>(radial, cv, cc1, ec, ncoef, coefs, p, f, df))
+    if (!poly_eval<true>(kind, cv, cc1, ec, cR, ncoef, coefs, p, f, df))
         return false;
     double s1 = -f / dot3(d, df);
     double delta = fabs(s1);
@@ -357,7 +386,7 @@ __device__ __forceinline__ bool newton_hit(bool radial, double cv, double cc1, d
     // one Spencer-Murty step for the lanes that have not converged
     auto step = [&]() {
         p = v3{p0.x + s1 * d.x, p0.y + s1 * d.y, p0.z + s1 * d.z};
-        if (!poly_eval<true>(radial, cv, cc1, ec, ncoef, coefs, p, f, df)) {
+        if (!poly_eval<true>(kind, cv, cc1, ec, cR, ncoef, coefs, p, f, df)) {
             ok = false;
             delta = 0.0;            // leave the iteration; the caller reports the miss
             return;
@@ -534,7 +563,8 @@ trace_kernel(const TraceArgs a)
     const int64_t ld = a.out.ld;
 
     constexpr int O_CV = offsetof(rox_surface, cv) / 8, O_CC = offsetof(rox_surface, cc) / 8,
-                  O_EC = offsetof(rox_surface, ec) / 8, O_COEF = offsetof(rox_surface, coefs) / 8,
+                  O_EC = offsetof(rox_surface, ec) / 8, O_CR = offsetof(rox_surface, cR) / 8,
+                  O_COEF = offsetof(rox_surface, coefs) / 8,
                   O_RT = offsetof(rox_surface, rt) / 8, O_T = offsetof(rox_surface, t) / 8,
                   O_ZDIR = offsetof(rox_surface, z_dir) / 8;
 
@@ -604,7 +634,7 @@ trace_kernel(const TraceArgs a)
                     const double k = (mp.y == ROX_CONIC) ? (row[O_CC] + 1.0) * row[O_CV] : row[O_CV];
                     df = v3{-row[O_CV] * bp.x, -row[O_CV] * bp.y, 1.0 - k * bp.z};
                 } else {
-                    ok = newton_hit(mp.y == ROX_RADIALPOLY, row[O_CV], row[O_CC] + 1.0, row[O_EC],
+                    ok = newton_hit(mp.y, row[O_CV], row[O_CC] + 1.0, row[O_EC], row[O_CR],
                                     ((tbli)row)[2], row + O_COEF, pt0, dir0, eps, s_, bp, df);
                 }
                 if (!ok) {              // raised outside the try block: no packet
@@ -650,7 +680,7 @@ trace_kernel(const TraceArgs a)
                 ok = quadric_hit(prof == ROX_CONIC, cv, row[O_CC], row[O_EC], pp, b4d,
                                  z_dir_before, s, inc);
             } else {
-                ok = newton_hit(prof == ROX_RADIALPOLY, cv, row[O_CC] + 1.0, row[O_EC],
+                ok = newton_hit(prof, cv, row[O_CC] + 1.0, row[O_EC], row[O_CR],
                                 ((tbli)row)[2], row + O_COEF, pp, b4d, eps, s, inc, df);
             }
             const bool b4_filtered = filter_ph && (b4_mode == ROX_PHANTOM);
@@ -1190,7 +1220,7 @@ int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_t
     for (int i = 0; i < n_ifcs; ++i) {
         const rox_surface &s = rows[i];
         if (s.mode < ROX_TRANSMIT || s.mode > ROX_PHANTOM || s.profile < ROX_SPHERICAL ||
-            s.profile > ROX_RADIALPOLY || s.ncoef < 0 || s.ncoef > ROX_MAX_COEF || s.n_ap < 0 ||
+            s.profile > ROX_XTOROID || s.ncoef < 0 || s.ncoef > ROX_MAX_COEF || s.n_ap < 0 ||
             s.n_ap > ROX_MAX_AP)
             return fail(ROX_E_ARG, "rox_system_create: row %d is malformed", i);
     }

@@ -8,7 +8,7 @@ of refractive indices, by *reading* a live reference ``SequentialModel`` --
 nothing is re-derived: transforms come from ``seq_model.lcl_tfrms``, indices
 from ``seq_model.rndx``, ``max_nonzero_coef`` from the profile.
 
-Interfaces the kernels do not implement (phase elements, thin lenses, toroids,
+Interfaces the kernels do not implement (phase elements, thin lenses,
 unknown aperture classes) raise :class:`UnsupportedModelError` so that callers
 keep such models on the reference's own CPU path.
 """
@@ -37,7 +37,9 @@ def _profile_row(row, prof):
     else:
         row.cc = float(prof.cc)
         row.ec = float(prof.ec)         # property: cc + 1.0 (profiles.py:515-517)
-    if kind in ('EvenPolynomial', 'RadialPolynomial'):
+    if kind in ('YToroid', 'XToroid'):
+        row.cR = float(prof.cR)
+    if kind in ('EvenPolynomial', 'RadialPolynomial', 'YToroid', 'XToroid'):
         coefs = [float(c) for c in prof.coefs]
         # profiles.py:827-832 calc_max_nonzero_coef (refreshed by update())
         mnc = getattr(prof, 'max_nonzero_coef', None)
@@ -216,7 +218,7 @@ class SurfaceTable:
             rows.append(dict(
                 mode=r.mode, profile=r.profile, ncoef=r.ncoef, n_ap=r.n_ap,
                 rt_order=r.rt_order,
-                cv=r.cv, cc=r.cc, ec=r.ec, coefs=list(r.coefs),
+                cv=r.cv, cc=r.cc, ec=r.ec, cR=r.cR, coefs=list(r.coefs),
                 rt=list(r.rt), t=list(r.t), z_dir=r.z_dir,
                 max_aperture=r.max_aperture,
                 ap=[dict(kind=a.kind, is_obscuration=a.is_obscuration,
@@ -234,6 +236,7 @@ class SurfaceTable:
             row.ncoef, row.n_ap = s['ncoef'], s['n_ap']
             row.rt_order = s.get('rt_order', abi.RT_F_ORDER)
             row.cv, row.cc, row.ec = s['cv'], s['cc'], s['ec']
+            row.cR = s.get('cR', 0.0)
             for k, c in enumerate(s['coefs']):
                 row.coefs[k] = c
             for k, v in enumerate(s['rt']):

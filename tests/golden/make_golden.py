@@ -414,6 +414,14 @@ def main():
         'opd_f1': case_opd(opm, 1, 550.0, 11),
     })
 
+    # aspheric toroids (Newton path, anamorphic)
+    opm = rm.toroid_lens()
+    save('toroid_lens', ra.SurfaceTable.from_seq_model(opm['seq_model']), {
+        'rays_ap': case_rays(opm, 256, rng, True, pupil_scale=1.5),
+        'grid_f1': case_grid(opm, 1, 450.0, 11),
+        'opd_f1': case_opd(opm, 1, 550.0, 9),
+    })
+
 
 if __name__ == '__main__':
     main()

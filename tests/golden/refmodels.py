@@ -232,3 +232,25 @@ def tilted_singlet():
                                   surface.Circular(radius=0.8, y_offset=0.5,
                                                    is_obscuration=True)]
     return opm
+
+
+def toroid_lens():
+    """synthetic anamorphic pair: a YToroid and an XToroid surface (aspheric
+    toroids on a conic base, rayoptics/elem/profiles.py:1117-1437), both
+    intersected by the Spencer-Murty Newton iteration"""
+    opm = new_model(('object', 'epd'), 6.0, ('object', 'angle'), 3.0,
+                    [0., 1.0], [(550.0, 1.0), (450.0, 1.0)], 0, obj_thi=150.0)
+    sm = opm['seq_model']
+    sm.add_surface([0.02, 4.0, 1.58, 41.0])
+    sm.set_stop()
+    sm.ifcs[sm.cur_surface].profile = profiles.YToroid(
+        c=0.025, cR=0.012, cc=-0.3, coefs=[0., 2.0e-5, -3.0e-7, 0., 0., 0., 0., 0., 0., 0.])
+    sm.add_surface([-0.01, 6.0])
+    sm.add_surface([0.015, 3.0, 1.49, 70.0])
+    sm.ifcs[sm.cur_surface].profile = profiles.XToroid(
+        c=0.018, cR=-0.006, cc=0.4, coefs=[1.0e-4, -1.5e-5, 0., 0., 0., 0., 0., 0., 0., 0.])
+    sm.add_surface([-0.02, 55.0])
+    finish(opm, do_apertures=False)
+    for ifc in sm.ifcs:
+        ifc.max_aperture = 9.0
+    return opm

@@ -62,6 +62,6 @@ def test_engine_fails_loudly_without_gpu():
 
 def test_struct_sizes_match_header():
     # sizes asserted in abi.py against the C header's static layout
-    assert C.sizeof(abi.Surface) == 400 and C.sizeof(abi.Aperture) == 40
+    assert C.sizeof(abi.Surface) == 408 and C.sizeof(abi.Aperture) == 40
     assert C.sizeof(abi.Opts) == 352 and C.sizeof(abi.Field) == 96
     assert C.sizeof(abi.Grid) == 48 and C.sizeof(abi.Out) == 48

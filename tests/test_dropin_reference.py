@@ -235,7 +235,9 @@ def test_unsupported_model_policy(ref, installed):
     from rayoptics.elem import profiles
     opm = ref.singlet()
     sm = opm['seq_model']
-    sm.ifcs[1].profile = profiles.YToroid(c=0.01)
+    class BiconicLike(profiles.Spherical):      # a profile class the kernels do not know
+        pass
+    sm.ifcs[1].profile = BiconicLike(c=0.01)
     fld = opm['osp']['fov'].fields[0]
     args = (opm, [np.array([-1., -1.]), np.array([1., 1.]), 3], fld, 650.0, 0.0)
     with pytest.raises(UnsupportedModelError):

@@ -67,7 +67,8 @@ def test_profiles_kat():
 RAY_CASES = [('dblgauss_seq', 'bundle'), ('dblgauss', 'rays_ap'),
              ('dblgauss', 'rays_noap'), ('dblgauss_finite', 'rays_ap'),
              ('rc_telescope', 'rays_ap'), ('nikkor', 'rays_ap'),
-             ('cell_phone', 'rays_ap'), ('tilted_singlet', 'rays_ap')]
+             ('cell_phone', 'rays_ap'), ('tilted_singlet', 'rays_ap'),
+             ('toroid_lens', 'rays_ap')]
 
 
 @pytest.mark.parametrize('name,case', RAY_CASES)
@@ -88,7 +89,8 @@ GRID_CASES = [('dblgauss', 'grid_f0'), ('dblgauss', 'grid_f2'), ('dblgauss', 'fa
               ('dblgauss_finite', 'grid_f2'), ('singlet', 'grid64'),
               ('singlet', 'grid_f1'), ('rc_telescope', 'grid_f0'),
               ('rc_telescope', 'grid_f4'), ('nikkor', 'grid_f1'),
-              ('cell_phone', 'grid_f2'), ('tilted_singlet', 'grid_f1')]
+              ('cell_phone', 'grid_f2'), ('tilted_singlet', 'grid_f1'),
+              ('toroid_lens', 'grid_f1')]
 
 
 @pytest.mark.parametrize('name,case', GRID_CASES)
@@ -146,7 +148,7 @@ def test_list_of_rays_last_segment():
 
 
 OPD_CASES = [('dblgauss', 'opd_f0'), ('dblgauss', 'opd_f2'), ('rc_telescope', 'opd_f3'),
-             ('nikkor', 'opd_f1'), ('tilted_singlet', 'opd_f1')]
+             ('nikkor', 'opd_f1'), ('tilted_singlet', 'opd_f1'), ('toroid_lens', 'opd_f1')]
 
 
 def opd_opts(c):
