@@ -288,3 +288,28 @@ def test_host_generated_ray_starts(ref, installed):
     assert go.shape == gt.shape == (7, 7, 4)
     np.testing.assert_array_equal(go, gt)
     assert np.isfinite(go[:, :, 2]).sum() > 10
+
+
+def test_eval_wavefront_infinite_reference_sphere(ref, installed):
+    """image-space telecentric system, axial field: the reference sphere is
+    'kinda big' (waveabr.py:213-216), so the OPD is evaluated by the reference's
+    wave_abr_full_calc_inf_ref on lazy views of device-traced packets"""
+    import rayoptics.raytr.analyses as analyses
+    import rayoptics.raytr.trace as trace
+    opm = ref.new_model(('object', 'epd'), 6.0, ('object', 'angle'), 3.0, [0., 1.0],
+                        [(550.0, 1.0)], 0, obj_thi=1e10)
+    sm = opm['seq_model']
+    sm.add_surface([0.0, 32.38806981225028])       # stop at the front focal plane
+    sm.set_stop()
+    sm.add_surface([1 / 40.0, 5.0, 1.6, 50.0])
+    sm.add_surface([-1 / 40.0, 30.0])
+    ref.finish(opm)
+    fld = opm['osp']['fov'].fields[0]
+    rs, _cr = trace.setup_pupil_coords(opm, fld, 550.0, 0.0)
+    assert rs[2] > 1e8
+
+    def ew():
+        return analyses.eval_wavefront(opm, fld, 550.0, 0.0, num_rays=9)
+    go, gt = both(installed, ew)
+    np.testing.assert_array_equal(go, gt)
+    assert np.isfinite(go[:, :, 2]).sum() > 20
