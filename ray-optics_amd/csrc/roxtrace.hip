@@ -493,8 +493,10 @@ struct SegOut {
     {
         char *b = base + ((int64_t)slot * ROX_SEG_DOUBLES + c) * row_bytes;
         double *p = reinterpret_cast<double *>(b + (size_t)voff);
-#if ROX_STORE_NT
+#if ROX_STORE_NT == 1
         __builtin_nontemporal_store(v, p);
+#elif ROX_STORE_NT == 2       // write-through (sc1), experiment
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
         *p = v;
 #endif

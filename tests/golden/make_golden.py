@@ -347,6 +347,13 @@ def main():
     workload_file(rm.rc_telescope(), 'rc_telescope_c4',
                   'BASELINE.json configs[3]: Ritchey-Chretien mirror pair + field '
                   'stop, 5 fields (rayoptics/models/Ritchey_Chretien.roa)')
+    workload_file(rm.singlet(), 'singlet_c1',
+                  'BASELINE.json configs[0]: singlet, 4 interfaces (the shape of '
+                  'rayoptics/models/singlet_f5.roa)')
+    workload_file(rm.cell_phone(), 'cell_phone',
+                  '13-interface phone lens, 8 RadialPolynomial aspheres '
+                  '(rayoptics/optical/tests/cell_phone_camera.roa): the asphere model of '
+                  'the reference timing table (rayoptics/raytr/tests/trace_results.txt:10)')
     workload_file(rm.nikkor(), 'nikkor_c3',
                   'BASELINE.json configs[2] stand-in: 29-interface zoom with 4 '
                   'even aspheres (rayoptics/optical/tests/Nikon Nikkor Z 14-30mm f-4 S.roa)')
