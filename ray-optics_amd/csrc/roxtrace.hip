@@ -56,8 +56,17 @@ namespace {
 #endif
 
 constexpr int kBlock = 256;
-constexpr int kRowDoubles = sizeof(rox_surface) / sizeof(double);   // 51
 static_assert(sizeof(rox_surface) == 408, "rox_surface layout");
+// Device-side row = the public rox_surface + per-surface values that are the
+// same for every ray and are therefore computed once at rox_system_create:
+// dcoefs[i] = c_coef_i * coefs[i], the product the df() loops of the polynomial
+// profiles form per evaluation (c_coef_i = 2(i+1), or i+1 for RadialPolynomial;
+// exact small integers, so the host product has the reference's rounding).
+struct dev_surface {
+    rox_surface pub;
+    double dcoefs[ROX_MAX_COEF];
+};
+constexpr int kRowDoubles = sizeof(dev_surface) / sizeof(double);   // 61
 static_assert(sizeof(rox_aperture) == 40, "rox_aperture layout");
 
 enum { GEN_RAYS = 0, GEN_PUPIL = 1 };
@@ -289,6 +298,7 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
                                           int ncoef, tblp coefs,
                                           const v3 &p, double &f, v3 &df)
 {
+    tblp dcoefs = coefs + (offsetof(dev_surface, dcoefs) - offsetof(rox_surface, coefs)) / 8;
     if (kind >= ROX_YTOROID) {
         // profiles.py:1337-1377 YToroid.fY/f/df; XToroid swaps x and y (:1429-1434)
         const bool xt = (kind == ROX_XTOROID);
@@ -299,12 +309,11 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
             return false;
         const double srad = sqrt(rad);
         double z_asp = 0.0, y_pow = y2;
-        double e_asp = 0.0, c_coef = 2.0, d_pow = 1;
+        double e_asp = 0.0, d_pow = 1;
         for (int i = 0; i < ncoef; ++i) {
             z_asp += coefs[i] * y_pow;
             y_pow *= y2;
-            e_asp += c_coef * coefs[i] * d_pow;
-            c_coef += 2.0;
+            e_asp += dcoefs[i] * d_pow;         // (c_coef*coefs[i])*y_pow
             d_pow *= y2;
         }
         const double fY = cv * y2 / (1. + srad) + z_asp;
@@ -319,34 +328,43 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
     const bool radial = (kind == ROX_RADIALPOLY);
     const double r2 = p.x * p.x + p.y * p.y;
     double e_tot;
+    // sag() and df() take the square root of the same radicand when
+    // (cc + 1.0) and ec are the same number (they are, unless a caller fills the
+    // table otherwise): evaluate it once.  `same` is wave-uniform.
+    const bool same = (cc1 == ec) || radial;
+    const double rad_e = 1. - ec * cv * cv * r2;
     if (!radial) {
+        double srad_e;
         if (WANT_F) {
             const double rad = 1. - cc1 * cv * cv * r2;     // (cc + 1.0)*cv*cv*r2
             if (rad < 0.0)
                 return false;
-            const double z = cv * r2 / (1. + sqrt(rad));
+            const double srad = sqrt(rad);
+            srad_e = same ? srad : sqrt(rad_e);
+            const double z = cv * r2 / (1. + srad);
             double z_asp = 0.0, r_pow = r2;
             for (int i = 0; i < ncoef; ++i) {
                 z_asp += coefs[i] * r_pow;
                 r_pow *= r2;
             }
             f = p.z - (z + z_asp);
+        } else {
+            srad_e = sqrt(rad_e);
         }
-        const double e = cv / sqrt(1. - ec * cv * cv * r2);
-        double r_pow = 1, e_asp = 0.0, c_coef = 2.0;
+        const double e = cv / srad_e;
+        double r_pow = 1, e_asp = 0.0;
         for (int i = 0; i < ncoef; ++i) {
-            e_asp += c_coef * coefs[i] * r_pow;
-            c_coef += 2.0;
+            e_asp += dcoefs[i] * r_pow;         // (c_coef*coefs[i])*r_pow
             r_pow *= r2;
         }
         e_tot = e + e_asp;
     } else {
         const double r = sqrt(r2);
+        const double srad_e = sqrt(rad_e);      // NaN when negative: caught below
         if (WANT_F) {
-            const double rad = 1. - ec * cv * cv * r2;
-            if (rad < 0.0)
+            if (rad_e < 0.0)
                 return false;
-            const double z = cv * r2 / (1. + sqrt(rad));
+            const double z = cv * r2 / (1. + srad_e);
             double z_asp = 0.0, r_pow = r;
             for (int i = 0; i < ncoef; ++i) {
                 z_asp += coefs[i] * r_pow;
@@ -354,12 +372,11 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
             }
             f = p.z - (z + z_asp);
         }
-        const double e = cv / sqrt(1. - ec * cv * cv * r2);
-        double e_asp = 0.0, c_coef = 1.0;
+        const double e = cv / srad_e;
+        double e_asp = 0.0;
         double r_pow = (r == 0.0) ? 1.0 : 1 / r;
         for (int i = 0; i < ncoef; ++i) {
-            e_asp += c_coef * coefs[i] * r_pow;
-            c_coef += 1.0;
+            e_asp += dcoefs[i] * r_pow;         // (c_coef*coef)*r_pow
             r_pow *= r;
         }
         e_tot = e + e_asp;
@@ -939,7 +956,7 @@ void slot_map(const rox_system *s, bool filter, std::vector<int32_t> &m, int32_t
 size_t lds_bytes(const rox_system *s, bool per_ray_wvl)
 {
     const size_t N = s->n_ifcs;
-    size_t b = N * sizeof(rox_surface) + (per_ray_wvl ? (size_t)s->n_wvls * N : N) * sizeof(double) +
+    size_t b = N * sizeof(dev_surface) + (per_ray_wvl ? (size_t)s->n_wvls * N : N) * sizeof(double) +
                2 * N * sizeof(int32_t);
     return (b + 15) & ~size_t(15);
 }
@@ -1248,12 +1265,22 @@ int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_t
         sys->num_cus = prop.multiProcessorCount;
     int rc = 0;
     do {
-        const size_t rb = sizeof(rox_surface) * n_ifcs, nb = sizeof(double) * n_wvls * n_ifcs;
+        std::vector<dev_surface> drows(n_ifcs);
+        for (int i = 0; i < n_ifcs; ++i) {
+            drows[i].pub = rows[i];
+            const double c0 = rows[i].profile == ROX_RADIALPOLY ? 1.0 : 2.0;
+            double c_coef = c0;                 // profiles.py:877-882, 1104-1109, 1364-1369
+            for (int k = 0; k < ROX_MAX_COEF; ++k) {
+                drows[i].dcoefs[k] = c_coef * rows[i].coefs[k];
+                c_coef += c0;
+            }
+        }
+        const size_t rb = sizeof(dev_surface) * n_ifcs, nb = sizeof(double) * n_wvls * n_ifcs;
         if (hipMalloc(&sys->d_rows, rb) != hipSuccess || hipMalloc(&sys->d_ntab, nb) != hipSuccess) {
             rc = fail(ROX_E_HIP, "hipMalloc failed for the surface table");
             break;
         }
-        if (hipMemcpy(sys->d_rows, rows, rb, hipMemcpyHostToDevice) != hipSuccess ||
+        if (hipMemcpy(sys->d_rows, drows.data(), rb, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(sys->d_ntab, n_table, nb, hipMemcpyHostToDevice) != hipSuccess) {
             rc = fail(ROX_E_HIP, "hipMemcpy failed for the surface table");
             break;
