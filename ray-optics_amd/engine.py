@@ -29,10 +29,22 @@ def load_library():
         # process *before* libroxtrace.so (linked against the same SONAME)
         # is dlopen'ed, or the two sides would not share device pointers
         import torch  # noqa: F401
+        if not os.path.exists(LIB_PATH) and not os.environ.get('ROX_LIB'):
+            # not built yet (fresh checkout): compile the HIP source in-tree now
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location(
+                    'rox_build', os.path.join(_HERE, 'build.py'))
+                b = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(b)
+                b.build()
+            except Exception as e:
+                raise EngineError(
+                    f'{LIB_PATH} is missing and could not be built ({e!r}): run '
+                    '`python ray-optics_amd/build.py` (hipcc --offload-arch=gfx950).  '
+                    'There is no CPU fallback.')
         if not os.path.exists(LIB_PATH):
-            raise EngineError(
-                f'{LIB_PATH} is missing: build it with `python ray-optics_amd/build.py` '
-                '(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+            raise EngineError(f'{LIB_PATH} is missing.  There is no CPU fallback.')
         lib = abi.declare(C.CDLL(LIB_PATH))
         if lib.rox_abi_version() != abi.ABI_VERSION:
             raise EngineError('libroxtrace.so ABI version mismatch')
