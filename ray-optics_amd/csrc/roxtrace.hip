@@ -55,7 +55,10 @@ namespace {
 #define ROX_SLIM_FP64 1       //    (bit-identical to sqrt() and `/`; see slim_* below)
 #endif
 
-constexpr int kBlock = 256;
+#ifndef ROX_BLOCK            // workgroup size (FULL: 128 -> 222, 256 -> 214, 512 -> 208, 1024 -> 212 us)
+#define ROX_BLOCK 512
+#endif
+constexpr int kBlock = ROX_BLOCK;
 static_assert(sizeof(rox_surface) == 408, "rox_surface layout");
 // Device-side row = the public rox_surface + per-surface values that are the
 // same for every ray and are therefore computed once at rox_system_create:
@@ -991,7 +994,7 @@ int blocks_per_cu()
     static const int v = [] {
         const char *e = getenv("ROX_BLOCKS_PER_CU");
         const int n = e ? atoi(e) : 0;
-        return n > 0 ? n : 32;      // measured: FULL 238 us at 8/CU, 228 us at 32/CU
+        return n > 0 ? n : 32 * 256 / kBlock;      // measured: FULL 238 us at 8/CU, 228 us at 32/CU
     }();
     return v;
 }
