@@ -55,6 +55,9 @@ namespace {
 #define ROX_SLIM_FP64 1       //    (bit-identical to sqrt() and `/`; see slim_* below)
 #endif
 
+#ifndef ROX_XCD_SWIZZLE      // 1: workgroups of one XCD (blockIdx % 8) take consecutive ray tiles
+#define ROX_XCD_SWIZZLE 0
+#endif
 #ifndef ROX_BLOCK            // workgroup size (FULL: 128 -> 222, 256 -> 214, 512 -> 208, 1024 -> 212 us)
 #define ROX_BLOCK 512
 #endif
@@ -590,7 +593,13 @@ trace_kernel(const TraceArgs a)
                   O_RT = offsetof(rox_surface, rt) / 8, O_T = offsetof(rox_surface, t) / 8,
                   O_ZDIR = offsetof(rox_surface, z_dir) / 8;
 
-    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < a.n_rays;
+#if ROX_XCD_SWIZZLE
+    const unsigned per_xcd = (gridDim.x + 7u) / 8u;
+    const unsigned vblock = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+#else
+    const unsigned vblock = blockIdx.x;
+#endif
+    for (int64_t r = (int64_t)vblock * kBlock + threadIdx.x; r < a.n_rays;
          r += (int64_t)gridDim.x * kBlock) {
         SegOut so;
         so.base = reinterpret_cast<char *>(a.out.seg);
