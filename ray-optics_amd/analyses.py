@@ -1,6 +1,6 @@
 """Drop-ins for the list / grid / fan drivers of ``rayoptics.raytr.analyses``.
 
-  trace_list_of_rays <- rayoptics/raytr/analyses.py:458-510
+  trace_list_of_rays <- rayoptics/raytr/analyses.py:458-510   (+ trace_rays_soa, its array form)
   trace_ray_list     <- rayoptics/raytr/analyses.py:437-455
   trace_ray_grid     <- rayoptics/raytr/analyses.py:666-696
   trace_ray_fan      <- rayoptics/raytr/analyses.py:212-230
@@ -53,6 +53,27 @@ def trace_list_of_rays(opt_model, rays, output_filter=None, rayerr_filter=None,
         else:
             ray_list.append(output_filter(pkg))
     return ray_list
+
+
+def trace_rays_soa(opt_model, pt0, dir0, wvl, out_mode=abi.OUT_FULL, on_device=False, **kwargs):
+    """array form of :func:`trace_list_of_rays` for large batches: ``pt0``,
+    ``dir0`` are ``[3, R]`` arrays (numpy or torch), ``wvl`` one wavelength or
+    ``R`` of them (nm, members of the spectral region).  No per-ray Python
+    objects are created: returns the engine's ``DeviceResult`` (``on_device``)
+    or a :class:`~.raypkg.HostPackets`, whose ``pkg(r)`` / ``error(r)`` give the
+    reference-shaped view of any single ray on demand."""
+    eng = session.engine_for(opt_model)
+    tbl = eng.table
+    if np.ndim(wvl) == 0:
+        wi = tbl.wvl_index(wvl)
+    else:
+        lut = {w: i for i, w in enumerate(tbl.wvls)}
+        wi = np.fromiter((lut[float(w)] for w in wvl), dtype=np.int32, count=len(wvl))
+    opts = opts_from_kwargs(tbl.n_ifcs, kwargs, out_mode)
+    res = eng.trace_rays(pt0, dir0, wi, opts)
+    if on_device:
+        return res
+    return HostPackets(res.to_host(), tbl, opts.flags, out_mode, wvl)
 
 
 def trace_ray_list(opt_model, pupil_coords, fld, wvl, foc, append_if_none=False,

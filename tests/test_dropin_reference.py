@@ -313,3 +313,26 @@ def test_eval_wavefront_infinite_reference_sphere(ref, installed):
     go, gt = both(installed, ew)
     np.testing.assert_array_equal(go, gt)
     assert np.isfinite(go[:, :, 2]).sum() > 20
+
+
+def test_trace_rays_soa_matches_list_form(ref, installed):
+    import rayoptics.raytr.analyses as analyses
+    from rayoptics_amd.analyses import trace_rays_soa
+    opm = ref.rc_telescope()
+    osp = opm['osp']
+    rng = np.random.default_rng(9)
+    rays = []
+    for r in range(50):
+        p, d = osp.ray_start_from_osp(rng.uniform(-1.3, 1.3, 2), osp['fov'].fields[r % 5], 'rel pupil')
+        rays.append((p, d, 550.0))
+    lst = analyses.trace_list_of_rays(opm, rays, rayerr_filter='summary', check_apertures=True)
+    pk = trace_rays_soa(opm, np.array([r[0] for r in rays]).T, np.array([r[1] for r in rays]).T,
+                        550.0, check_apertures=True)
+    n_err = 0
+    for r, item in enumerate(lst):
+        if pk.status[r] == 0:
+            same_pkg(pk.pkg(r), item)
+        else:
+            assert type(pk.error(r)) is type(item[1]) and pk.error(r).surf == item[1].surf
+            n_err += 1
+    assert 0 < n_err < 50
