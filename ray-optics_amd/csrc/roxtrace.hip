@@ -1008,6 +1008,18 @@ int blocks_per_cu()
     return v;
 }
 
+// rays per kernel launch (lane byte offsets are 32-bit: at most 2^28).
+// ROX_RAYS_PER_LAUNCH overrides it for experiments.
+int64_t rays_per_launch()
+{
+    static const int64_t v = [] {
+        const char *e = getenv("ROX_RAYS_PER_LAUNCH");
+        const long long n = e ? atoll(e) : 0;
+        return (n > 0 && n <= (1LL << 28)) ? (int64_t)n : (int64_t(1) << 28);
+    }();
+    return v;
+}
+
 template <int GEN, bool PRW, int FEAT>
 void launch_mode(int out_mode, dim3 grid, size_t lds, hipStream_t st, const TraceArgs &a)
 {
@@ -1057,7 +1069,7 @@ int launch(const rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
     if ((a.opts.flags & ROX_FILTER_PHANTOMS) && sys->n_seg[1] != sys->n_seg[0])
         feat |= F_PHFILT;
     // lane byte offsets are 32-bit: at most 2^28 rays per launch
-    const int64_t total = a.n_rays, chunk_max = int64_t(1) << 28;
+    const int64_t total = a.n_rays, chunk_max = rays_per_launch();
     const rox_out out0 = a.out;
     a.in_ld = total;
     for (int64_t base = 0; base < total; base += chunk_max) {
