@@ -417,3 +417,46 @@ def test_cell_phone_doc_table_kat_on_device(engines):
     np.testing.assert_allclose(seg[:, 4], doc[:, 2], atol=6e-7)
     np.testing.assert_allclose(seg[:, 5], doc[:, 3], atol=6e-7)
     np.testing.assert_allclose(seg[1:, 6], doc[1:, 4], rtol=6e-5, atol=6e-6)
+
+
+def test_pupil_list_entry(engines):
+    """rox_trace_pupil_list (analyses.trace_ray_list): explicit pupil
+    coordinates, device and host-pointer forms, vs the oracle"""
+    from oracle import oracle
+    from rayoptics_amd.engine import load_library
+    fx = H.fixture('dblgauss')
+    c = fx['grid_f2']
+    eng = engines('dblgauss')
+    fld = H.field_from_arr(c['field'])
+    rng = np.random.default_rng(4)
+    R = 1500
+    px, py = rng.uniform(-1.1, 1.1, R), rng.uniform(-1.1, 1.1, R)
+    for mode in (abi.OUT_FULL, abi.OUT_LAST, abi.OUT_HITS):
+        opts = H.make_opts(c, out_mode=mode, foc=0.02, image_pt=(0.3, 18.0))
+        orc = oracle.trace_pupil_list(fx.table, fld, px, py, 2, opts)
+        dev = eng.trace_pupil_list(fld, px, py, 2, opts, nan_fill=True).to_host()
+        assert_same_as_oracle(dev, orc, f'pupil list mode {mode}')
+    # host pointers straight through the C ABI
+    opts = H.make_opts(c)
+    orc = oracle.trace_pupil_list(fx.table, fld, px, py, 0, opts)
+    opts.flags |= abi.HOST_POINTERS
+    res = oracle.HostResult(fx.table.n_ifcs, R, abi.OUT_FULL, want_pupil=True)
+    out = res.out_struct()
+    rc = load_library().rox_trace_pupil_list(eng._handle, C.byref(fld), R, px.ctypes.data,
+                                             py.ctypes.data, 0, C.byref(opts), C.byref(out), None)
+    assert rc == 0, load_library().rox_last_error()
+    assert_same_as_oracle(res, orc, 'pupil list, host pointers')
+    # explicit rays, host pointers
+    cr = fx['rays_ap']
+    o2 = H.make_opts(cr)
+    orc = oracle.trace_rays(fx.table, cr['pt0'], cr['dir0'], cr['wvl_idx'], o2)
+    o2.flags |= abi.HOST_POINTERS
+    Rr = cr['pt0'].shape[1]
+    res = oracle.HostResult(fx.table.n_ifcs, Rr, abi.OUT_FULL)
+    out = res.out_struct()
+    p0 = np.ascontiguousarray(cr['pt0']); d0 = np.ascontiguousarray(cr['dir0'])
+    wi = np.ascontiguousarray(cr['wvl_idx'], dtype=np.int32)
+    rc = load_library().rox_trace_rays(eng._handle, Rr, p0.ctypes.data, d0.ctypes.data, wi.ctypes.data, 0,
+                                       C.byref(o2), C.byref(out), None)
+    assert rc == 0, load_library().rox_last_error()
+    assert_same_as_oracle(res, orc, 'explicit rays, host pointers')
