@@ -5,6 +5,7 @@
   trace_ray_grid     <- rayoptics/raytr/analyses.py:666-696
   trace_ray_fan      <- rayoptics/raytr/analyses.py:212-230
   eval_wavefront     <- rayoptics/raytr/analyses.py:699-732 (OPD fused on device)
+  trace_wavefront / focus_wavefront <- rayoptics/raytr/analyses.py:735-791 (RayGrid, PSF)
 """
 import numpy as np
 
@@ -180,3 +181,90 @@ def eval_wavefront(opt_model, fld, wvl, foc, image_pt_2d=None, image_delta=None,
     opd = np.where(ok, convert_to_opd * pk.seg[0, 0], value_if_none)
     out = np.stack([pk.pupil[0], pk.pupil[1], opd], axis=1)
     return out.reshape(num_rays, num_rays, 3)
+
+
+class _DeferredWavefront:
+    """what the fused :func:`trace_wavefront` hands to :func:`focus_wavefront`
+    in place of a grid of ray packets: the grid definition and trace options.
+    The trace does not depend on the focus, so re-evaluating trace + OPD on the
+    device for every refocus gives what the reference's pre-calc / refocus split
+    gives (same formulas, same operation order, waveabr.py:309-353)."""
+
+    def __init__(self, grid_def, kwargs):
+        self.grid_def = grid_def
+        self.kwargs = kwargs
+
+
+def _opd_fusable(kwargs):
+    return (kwargs.get('output_filter') is None and kwargs.get('rayerr_filter') is None
+            and not kwargs.get('filter_out_phantoms', False))
+
+
+def _opd_grid(opt_model, fld, wvl, grid_def, kwargs, wf, value_if_none):
+    kw = dict(kwargs)
+    for k in ('output_filter', 'rayerr_filter', 'oversize'):
+        kw.pop(k, None)
+    kw['apply_vignetting'] = kw.get('apply_vignetting', False)      # trace_ray_grid :674
+    num = grid_def[2]
+    pk = _trace_pupil(opt_model, fld, wvl, kw, None, None,
+                      grid=make_grid(grid_def[0], grid_def[1], num),
+                      out_mode=abi.OUT_OPD, wf=wf)
+    convert_to_opd = 1 / opt_model.nm_to_sys_units(wvl)
+    ok = pk.status == abi.OK
+    opd = np.where(ok, convert_to_opd * pk.seg[0, 0], value_if_none)
+    return np.stack([pk.pupil[0], pk.pupil[1], opd], axis=1).reshape(num, num, 3)
+
+
+def trace_wavefront(opt_model, fld, wvl, foc, image_pt_2d=None, image_delta=None,
+                    num_rays=21, **kwargs):
+    """rayoptics/raytr/analyses.py:735-766"""
+    from rayoptics.raytr import trace as ref_trace
+    from rayoptics.raytr import waveabr
+    from .table import wavefront_from_model, UnsupportedModelError
+    ref_sphere, cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc,
+                                                      image_pt=image_pt_2d,
+                                                      image_delta=image_delta)
+    fld.chief_ray = cr_pkg
+    fld.ref_sphere = ref_sphere
+    oversize = kwargs.get('oversize', 1.)
+    vig_bbox = fld.vignetting_bbox(opt_model['osp']['pupil'], oversize=oversize)
+    grid_def = [vig_bbox[0], vig_bbox[1], num_rays]
+    kwargs['check_apertures'] = kwargs.get('check_apertures', True)
+    if _opd_fusable(kwargs):
+        try:
+            wavefront_from_model(opt_model, fld)         # finite reference sphere?
+            return _DeferredWavefront(grid_def, dict(kwargs)), None
+        except UnsupportedModelError:
+            pass
+    fod = opt_model['analysis_results']['parax_data'].fod
+    grid = trace_ray_grid(opt_model, grid_def, fld, wvl, foc, **kwargs)
+    upd_grid = [[waveabr.wave_abr_pre_calc(fod, fld, wvl, foc, pkg, cr_pkg, ref_sphere)
+                 if pkg is not None else None for _px, _py, pkg in row] for row in grid]
+    return grid, upd_grid
+
+
+def focus_wavefront(opt_model, grid_pkg, fld, wvl, foc, image_pt_2d=None,
+                    image_delta=None, value_if_none=np.nan, **kwargs):
+    """rayoptics/raytr/analyses.py:769-791"""
+    from rayoptics.raytr import trace as ref_trace
+    from rayoptics.raytr import waveabr
+    from .table import wavefront_from_model, UnsupportedModelError
+    grid, upd_grid = grid_pkg
+    ref_sphere, cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc,
+                                                      image_pt=image_pt_2d,
+                                                      image_delta=image_delta)
+    fod = opt_model['analysis_results']['parax_data'].fod
+    if isinstance(grid, _DeferredWavefront):
+        try:
+            wf = wavefront_from_model(opt_model, fld, cr_pkg, ref_sphere)
+            return _opd_grid(opt_model, fld, wvl, grid.grid_def, grid.kwargs, wf, value_if_none)
+        except UnsupportedModelError:       # the sphere went infinite at this focus
+            g = trace_ray_grid(opt_model, grid.grid_def, fld, wvl, foc, **dict(grid.kwargs))
+            return np.array([[(px, py, waveabr.wave_abr_full_calc(fod, fld, wvl, foc, pkg, cr_pkg,
+                                                                  ref_sphere)
+                               / opt_model.nm_to_sys_units(wvl)) if pkg is not None
+                              else (px, py, value_if_none) for px, py, pkg in row] for row in g])
+    convert_to_opd = 1 / opt_model.nm_to_sys_units(wvl)
+    return np.array([[(g[0], g[1], convert_to_opd * waveabr.wave_abr_calc(
+        fod, fld, wvl, foc, g[2], cr_pkg, u, ref_sphere)) if g[2] is not None
+        else (g[0], g[1], value_if_none) for g, u in zip(ig, iu)] for ig, iu in zip(grid, upd_grid)])

@@ -44,6 +44,8 @@ def install(fallback='raise'):
              (ranalyses, 'trace_ray_grid', _a.trace_ray_grid),
              (ranalyses, 'trace_ray_fan', _a.trace_ray_fan),
              (ranalyses, 'eval_wavefront', _a.eval_wavefront),
+             (ranalyses, 'trace_wavefront', _a.trace_wavefront),
+             (ranalyses, 'focus_wavefront', _a.focus_wavefront),
              (SequentialModel, 'trace_grid', _t.seq_trace_grid)]
     for owner, name, ours in seams:
         theirs = getattr(owner, name)

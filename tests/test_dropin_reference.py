@@ -336,3 +336,27 @@ def test_trace_rays_soa_matches_list_form(ref, installed):
             assert type(pk.error(r)) is type(item[1]) and pk.error(r).surf == item[1].surf
             n_err += 1
     assert 0 < n_err < 50
+
+
+def test_raygrid_refocus_fused(ref, installed):
+    """RayGrid (Wavefront figure, PSF): rebuild, then refocus without retrace
+    (build='update') -- the fused device OPD must equal the reference's
+    pre-calc/refocus split at every focus"""
+    import rayoptics.raytr.analyses as analyses
+    opm = ref.dblgauss()
+
+    def run():
+        g = analyses.RayGrid(opm, f=2, wl=587.6, num_rays=11)
+        a = np.array(g.grid)
+        g.foc = 0.05
+        g.update_data(build='update')
+        b = np.array(g.grid)
+        g.foc = -0.02
+        g.image_delta = np.array([0.001, -0.002])
+        g.update_data(build='update')
+        return a, b, np.array(g.grid)
+    ours, theirs = both(installed, run)
+    for a, b in zip(ours, theirs):
+        assert a.shape == b.shape == (3, 11, 11)
+        np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(ours[0], ours[1], equal_nan=True)
