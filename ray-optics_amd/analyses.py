@@ -6,6 +6,7 @@
   trace_ray_fan      <- rayoptics/raytr/analyses.py:212-230
   eval_wavefront     <- rayoptics/raytr/analyses.py:699-732 (OPD fused on device)
   trace_wavefront / focus_wavefront <- rayoptics/raytr/analyses.py:735-791 (RayGrid, PSF)
+  trace_pupil_coords / focus_pupil_coords <- rayoptics/raytr/analyses.py:545-580 (RayList, RayGeoPSF)
 """
 import numpy as np
 
@@ -268,3 +269,78 @@ def focus_wavefront(opt_model, grid_pkg, fld, wvl, foc, image_pt_2d=None,
     return np.array([[(g[0], g[1], convert_to_opd * waveabr.wave_abr_calc(
         fod, fld, wvl, foc, g[2], cr_pkg, u, ref_sphere)) if g[2] is not None
         else (g[0], g[1], value_if_none) for g, u in zip(ig, iu)] for ig, iu in zip(grid, upd_grid)])
+
+
+class _DeferredRayList:
+    """what the fused :func:`trace_pupil_coords` hands to
+    :func:`focus_pupil_coords`: the pupil coordinates and trace options.  It
+    still behaves as the reference's list of ``[px, py, ray_pkg]`` entries for
+    any other consumer (materialised by a FULL device trace on first use)."""
+
+    def __init__(self, opt_model, pupil_coords, fld, wvl, foc, kwargs):
+        self.opt_model, self.fld, self.wvl, self.foc = opt_model, fld, wvl, foc
+        self.pupil = np.array([[p[0], p[1]] for p in pupil_coords], dtype=float).reshape(-1, 2)
+        self.kwargs = kwargs
+        self._list = None
+
+    def _materialise(self):
+        if self._list is None:
+            self._list = trace_ray_list(self.opt_model, [p.copy() for p in self.pupil],
+                                        self.fld, self.wvl, self.foc, **dict(self.kwargs))
+        return self._list
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __len__(self):
+        return len(self._materialise())
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+
+def trace_pupil_coords(opt_model, pupil_coords, fld, wvl, foc,
+                       image_pt_2d=None, image_delta=None, **kwargs):
+    """rayoptics/raytr/analyses.py:545-558"""
+    from rayoptics.raytr import trace as ref_trace
+    ref_sphere, cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc,
+                                                      image_pt=image_pt_2d,
+                                                      image_delta=image_delta)
+    fld.chief_ray = cr_pkg
+    fld.ref_sphere = ref_sphere
+    kwargs['check_apertures'] = kwargs.get('check_apertures', True)
+    if _opd_fusable(kwargs) and not kwargs.get('append_if_none', False):
+        return _DeferredRayList(opt_model, pupil_coords, fld, wvl, foc, dict(kwargs))
+    return trace_ray_list(opt_model, pupil_coords, fld, wvl, foc, **kwargs)
+
+
+def focus_pupil_coords(opt_model, ray_list, fld, wvl, foc,
+                       image_pt_2d=None, image_delta=None, **kwargs):
+    """rayoptics/raytr/analyses.py:561-580: transverse aberrations of
+    pre-traced rays at a (new) focus.  For the deferred list this is one HITS
+    launch over the pupil coordinates (the trace does not depend on focus)."""
+    from rayoptics.raytr import trace as ref_trace
+    ref_sphere, _cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc,
+                                                       image_pt=image_pt_2d,
+                                                       image_delta=image_delta)
+    image_pt = ref_sphere[0]
+    if isinstance(ray_list, _DeferredRayList):
+        kw = dict(ray_list.kwargs)
+        for k in ('output_filter', 'rayerr_filter', 'append_if_none'):
+            kw.pop(k, None)
+        kw['apply_vignetting'] = kw.get('apply_vignetting', True)
+        pk = _trace_pupil(opt_model, fld, wvl, kw, None, None,
+                          pupil_list=(ray_list.pupil[:, 0].copy(), ray_list.pupil[:, 1].copy()),
+                          out_mode=abi.OUT_HITS, foc=foc, image_pt=image_pt[:2])
+        ok = pk.status == abi.OK
+        return np.ascontiguousarray(pk.seg[0][:, ok].T)
+    data = []
+    for _px, _py, pkg in ray_list:
+        if pkg is not None:
+            seg = pkg[0][-1]
+            dist = foc / seg[1][2]
+            t_abr = (seg[0] + dist * seg[1]) - image_pt
+            data.append((t_abr[0], t_abr[1]))
+        else:
+            data.append(np.nan)
+    return np.array(data)

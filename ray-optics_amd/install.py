@@ -46,6 +46,8 @@ def install(fallback='raise'):
              (ranalyses, 'eval_wavefront', _a.eval_wavefront),
              (ranalyses, 'trace_wavefront', _a.trace_wavefront),
              (ranalyses, 'focus_wavefront', _a.focus_wavefront),
+             (ranalyses, 'trace_pupil_coords', _a.trace_pupil_coords),
+             (ranalyses, 'focus_pupil_coords', _a.focus_pupil_coords),
              (SequentialModel, 'trace_grid', _t.seq_trace_grid)]
     for owner, name, ours in seams:
         theirs = getattr(owner, name)

@@ -360,3 +360,23 @@ def test_raygrid_refocus_fused(ref, installed):
         assert a.shape == b.shape == (3, 11, 11)
         np.testing.assert_array_equal(a, b)
     assert not np.array_equal(ours[0], ours[1], equal_nan=True)
+
+
+def test_raylist_refocus_fused(ref, installed):
+    """RayList (RayGeoPSF's data): rebuild, refocus, and the list view"""
+    import rayoptics.raytr.analyses as analyses
+    opm = ref.dblgauss()
+
+    def run():
+        rl = analyses.RayList(opm, num_rays=9, f=2, wl=486.1)
+        a = np.array(rl.ray_abr)
+        rl.foc = 0.08
+        rl.update_data(build='update')
+        b = np.array(rl.ray_abr)
+        first = rl.ray_list[0]
+        return a, b, np.array([first[0], first[1], first[2][1]]), len(rl.ray_list)
+    ours, theirs = both(installed, run)
+    for a, b in zip(ours[:3], theirs[:3]):
+        np.testing.assert_array_equal(a, b)
+    assert ours[3] == theirs[3] > 10
+    assert not np.array_equal(ours[0], ours[1])
