@@ -16,13 +16,17 @@
  *                             trace_safe -> trace.py:253-310 trace_base ->
  *                             opticalspec.py:289-400 ray_start_from_osp,
  *                             opticalspec.py:1339-1353 apply_vignetting)
+ *   rox_aim_chief_rays     <- rayoptics/raytr/trace.py:313-415    iterate_ray() (1-D branch)
+ *                             rayoptics/raytr/trace.py:627-640    aim_chief_ray()
  *   rox_system_create      <- rayoptics/seq/sequential.py:149-202 path()/path_sequence()
  *                             (the per-wavelength (Intfc, Gap, Tfrm, Indx, Zdir)
  *                             list flattened into one POD table)
  *
  * All arithmetic is IEEE binary64.  Plain pointers and sizes only; no torch or
  * numpy types appear in any signature.  The Python binding a ray-optics
- * maintainer would add is a ctypes stub: see INTEGRATION.md.
+ * maintainer would add is a ctypes stub: see INTEGRATION.md.  Timing and
+ * self-test helpers used by bench.py and tests/ are declared separately in
+ * roxtrace_diag.h: they are not part of the drop-in boundary.
  *
  * Ownership: the caller owns every input/output buffer; the library owns only
  * the rox_system handle.  Every entry point returns 0 on success and a
@@ -39,16 +43,25 @@
 extern "C" {
 #endif
 
-#define ROX_ABI_VERSION 2
+#define ROX_ABI_VERSION 3
 #define ROX_MAX_COEF 10   /* EvenPolynomial r^2..r^20 / RadialPolynomial r^1..r^10 */
 #define ROX_MAX_AP 4      /* clear apertures per surface carried in the table */
 #define ROX_SEG_DOUBLES 10 /* p[3], d[3], dst, nrml[3]  (model_constants.py:31) */
 
 /* interface interact_mode (raytrace.py:211-221) */
 enum { ROX_TRANSMIT = 0, ROX_REFLECT = 1, ROX_DUMMY = 2, ROX_PHANTOM = 3 };
-/* surface profile kinds (rayoptics/elem/profiles.py) */
+/* surface profile kinds (rayoptics/elem/profiles.py).  ROX_THINLENS is not a
+ * profile in the reference but the ThinLens interface's own intersect/normal
+ * (rayoptics/oprops/thinlens.py:128-136): s = -p.z/d.z, normal (0,0,1). */
 enum { ROX_SPHERICAL = 0, ROX_CONIC = 1, ROX_EVENPOLY = 2, ROX_RADIALPOLY = 3,
-       ROX_YTOROID = 4, ROX_XTOROID = 5 };
+       ROX_YTOROID = 4, ROX_XTOROID = 5, ROX_THINLENS = 6 };
+/* phase elements (raytrace.py:41-48, 205-210; rayoptics/oprops/doe.py) */
+enum { ROX_PH_NONE = 0,
+       ROX_PH_GRATING = 1,   /* DiffractionGrating.phase_ludwig, doe.py:124-175 */
+       ROX_PH_DOE_RADIAL = 2,/* DiffractiveElement.phase with radial_phase_fct,
+                                doe.py:28-54, 272-323                           */
+       ROX_PH_HOLOGRAM = 3 };/* HolographicElement.phase, doe.py:375-397 (the
+                                phase element of every ThinLens)               */
 /* clear-aperture kinds (rayoptics/elem/surface.py:398-494).  Elliptical has
  * no point_inside() in the reference, so it returns None and the ray is
  * always blocked; ROX_AP_ALWAYS_BLOCK reproduces that. */
@@ -62,10 +75,22 @@ enum { ROX_OUT_FULL = 0,  /* seg[n_seg][10][ld]: the whole RayPkg.ray          *
        ROX_OUT_HITS = 2,  /* seg[2][ld]: SpotDiagramFigure's `spot` filter,
                              (ray[-1].p + (foc/ray[-1].d[2])*ray[-1].d - image_pt).xy
                              (rayoptics/mpl/axisarrayfigure.py:229-238)         */
-       ROX_OUT_OPD = 3 }; /* seg[1][ld]: wave_abr_full_calc_finite_pup, the OPD of
+       ROX_OUT_OPD = 3,   /* seg[1][ld]: wave_abr_full_calc_finite_pup, the OPD of
                              the ray w.r.t. the chief ray on a finite reference
                              sphere, system units (rayoptics/raytr/waveabr.py:256-307);
                              constants in rox_opts.wf                           */
+       ROX_OUT_HITS_COMPACT = 4 };
+                          /* seg[n_hits][2]: the HITS pair (x, y) of the rays that
+                             reach the image only, interleaved, packed in ray order
+                             -- the (R_ok, 2) array SequentialModel.trace_grid(...,
+                             form='list', append_if_none=False) hands to
+                             SpotDiagramFigure (rayoptics/seq/sequential.py:1058-1085,
+                             rayoptics/mpl/axisarrayfigure.py:229-263).  The count goes
+                             to rox_out.n_hits.  seg / n_hits may be device memory or
+                             device-mapped pinned host memory (hipHostMalloc): the
+                             kernel then writes the spot straight into host memory.
+                             op / fail_surf / pupil are not written in this mode;
+                             status is optional.                                */
 /* rox_opts.flags */
 enum { ROX_CHECK_APERTURES = 1u,     /* raytrace.py:198-202                    */
        ROX_INTERSECT_OBJ = 2u,       /* raytrace.py:147-154                    */
@@ -99,6 +124,25 @@ typedef struct rox_aperture {
 /* One row per interface, object and image included.  Row i carries the
  * transform and gap data *from* interface i *to* interface i+1, exactly as
  * the reference's path tuple does (sequential.py:167-202). */
+/* Phase element attached to an interface (ifc.phase_element).  Which fields
+ * are read depends on kind:
+ *   GRATING    a = grating_normal, order, spacing_nm = _grating_spacing_nm
+ *   DOE_RADIAL coefs[ncoef] = coefficients (r^2, r^4, ...), order, ref_wl
+ *   HOLOGRAM   a = ref_pt, b = obj_pt, flags bit0 ref_virtual, bit1 obj_virtual,
+ *              ref_wl                                                          */
+typedef struct rox_phase {
+    int32_t kind;            /* ROX_PH_*                                       */
+    int32_t ncoef;
+    int32_t flags;
+    int32_t reserved;
+    double order;
+    double ref_wl;           /* nm                                             */
+    double spacing_nm;
+    double a[3];
+    double b[3];
+    double coefs[ROX_MAX_COEF];
+} rox_phase;                 /* 168 bytes */
+
 typedef struct rox_surface {
     int32_t mode;            /* ROX_TRANSMIT...                                */
     int32_t profile;         /* ROX_SPHERICAL...                               */
@@ -116,7 +160,8 @@ typedef struct rox_surface {
     double z_dir;            /* z_dir[i] of the gap after this interface       */
     double max_aperture;     /* interface.py:113-122                           */
     rox_aperture ap[ROX_MAX_AP];
-} rox_surface;               /* 408 bytes */
+    rox_phase ph;            /* kind == ROX_PH_NONE: refract / reflect as usual */
+} rox_surface;               /* 576 bytes */
 
 /* Per (field, wavelength, focus) constants of the OPD calculation: the chief
  * ray package and reference sphere that trace.setup_pupil_coords() leaves in
@@ -155,16 +200,37 @@ typedef struct rox_opts {
     rox_wavefront wf;        /* OPD only                                       */
 } rox_opts;
 
-/* Per-field constants of the 'epd', non-wide-angle branch of
- * ray_start_from_osp (opticalspec.py:358-366) and of apply_vignetting. */
+/* Per-field constants of ray_start_from_osp (opticalspec.py:289-400), one
+ * kind per branch of that function, and of apply_vignetting
+ * (opticalspec.py:1339-1353).  With pupil = (px, py) after vignetting:
+ *   EPD       :358-366  pt1 = (eprad*px + aim[0], eprad*py + aim[1], z_enp);
+ *                       dir0 = normalize(pt1 - pt0)
+ *   EPD_WIDE  :340-356  pt1 = rot.(eprad*px, eprad*py, 0), pt1.z -= z_enp
+ *                       (z_enp carries obj2enp_dist); dir0 = normalize(pt1 - pt0);
+ *                       callers clear ROX_INTERSECT_OBJ (trace.py:302-303) and
+ *                       the sign flip of trace.py:304-308 is skipped
+ *   AIM_PT    :334-337  pupil_type 'aim pt': pt1 = (px, py, z_enp)
+ *   NA        :372-376  pupil_dir = eprad*(px, py)  (eprad carries na/n)
+ *   FNO       :377-384  slope = eprad (= -1/(2 fno)); hypt = sqrt(1 + (px*slope)^2
+ *                       + (py*slope)^2); pupil_dir = slope*(px, py)/hypt
+ *   AIM_DIR   :369-371  pupil_type 'aim dir': dir_tot = (px, py)
+ *   the angular kinds (NA, FNO, AIM_DIR) finish with dir_tot = pupil_dir + cr_dir,
+ *   dir0 = (dir_tot, sqrt(1 - dir_tot.dir_tot))  (:386-398)                      */
+enum { ROX_FLD_EPD = 0, ROX_FLD_EPD_WIDE = 1, ROX_FLD_AIM_PT = 2, ROX_FLD_NA = 3,
+       ROX_FLD_FNO = 4, ROX_FLD_AIM_DIR = 5 };
+
 typedef struct rox_field {
-    double pt0[3];           /* obj2enp_dist*[d0x/d0z, d0y/d0z, 0]             */
+    double pt0[3];           /* EPD: obj2enp_dist*[d0x/d0z, d0y/d0z, 0]; else p0 */
     double aim[2];           /* fld.aim_info or (0,0)                          */
-    double eprad;            /* pupil_value/2                                  */
+    double eprad;            /* pupil_value/2 (see the kinds above)            */
     double z_enp;            /* fod.obj_dist + fod.enp_dist (pt1[2])           */
     double vlx, vux, vly, vuy;   /* opticalspec.py:1339-1353                   */
     double z_dir0;           /* seq_model.z_dir[0] (trace.py:307)              */
-} rox_field;
+    int32_t kind;            /* ROX_FLD_*                                      */
+    int32_t rot_order;       /* ROX_RT_* of rot (np.matmul -> dgemv)           */
+    double rot[9];           /* EPD_WIDE: rot_v1_into_v2(d0, z), row-major     */
+    double cr_dir[2];        /* angular kinds: chief-ray direction (:386-392)  */
+} rox_field;                 /* 192 bytes */
 
 typedef struct rox_grid {
     double start[2];         /* grid_rng[0]                                    */
@@ -182,6 +248,8 @@ typedef struct rox_out {
     int16_t *fail_surf;      /* [ld] surface index at which the ray failed, -1 if ok; or NULL */
     double *pupil;           /* [2][ld] pupil coords after vignetting (pupil entries) or NULL */
     int64_t ld;              /* ray-axis leading dimension, >= number of rays  */
+    int64_t *n_hits;         /* HITS_COMPACT only: receives the number of (x, y)
+                                pairs written to seg                          */
 } rox_out;
 
 typedef struct rox_system rox_system;
@@ -195,10 +263,17 @@ const char *rox_last_error(void);
 /* system table ----------------------------------------------------------- */
 /* rows[n_ifcs]; n_table[n_wvls][n_ifcs], n_table[w][i] = refractive index of
  * the gap after interface i at wavelength w (unsigned, sequential.py:649-655;
- * the last column is unused).  The handle is immutable: a model edit means a
- * new handle (mirrors path_sequence.cache_clear(), sequential.py:666-668). */
+ * the last column is unused); wvls[n_wvls] = the wavelengths in nm (read by
+ * phase elements only; may be NULL when no row carries one).  The handle's
+ * table is immutable: a model edit means a new handle (mirrors
+ * path_sequence.cache_clear(), sequential.py:666-668).
+ *
+ * Threading: launches on different HIP streams and from different host threads
+ * may share one handle -- per-launch scratch (cached pupil axes, compaction
+ * state) is kept per stream behind a mutex.  Launches on one stream run in
+ * stream order as usual. */
 int rox_system_create(const rox_surface *rows, int32_t n_ifcs,
-                      const double *n_table, int32_t n_wvls,
+                      const double *n_table, const double *wvls, int32_t n_wvls,
                       rox_system **out_sys);
 int rox_system_destroy(rox_system *sys);
 /* number of segments a FULL packet holds (n_ifcs minus filtered phantoms) */
@@ -227,20 +302,32 @@ int rox_trace_pupil_list(rox_system *sys, const rox_field *fld,
                          int32_t wvl_idx, const rox_opts *opts,
                          const rox_out *out, void *stream);
 
-/* timing helper for bench.py: runs `launches` back-to-back launches of the
- * pupil-grid kernel on `stream`, bracketed by HIP events recorded on that
- * same stream, and returns the mean kernel duration in milliseconds. */
-int rox_time_pupil_grid(rox_system *sys, const rox_field *fld,
-                        const rox_grid *grid, int32_t wvl_idx,
-                        const rox_opts *opts, const rox_out *out,
-                        void *stream, int32_t launches, double *mean_ms);
-
-/* diagnostic: compares the kernels' exponent-band-guarded sqrt / division paths
- * with the plain IEEE operators on n pseudo-random operand sets (whole exponent
- * range, zeros, denormals, inf, nan).  counts[0] = sqrt mismatches, counts[1] =
- * division mismatches (both must be 0), counts[2] = operand sets that took a
- * guarded path. */
-int rox_selftest_fp64(uint64_t n, uint64_t seed, uint64_t counts[3]);
+/* chief-ray aiming ------------------------------------------------------- */
+/* One problem per (field, wavelength): the 1-D branch of trace.iterate_ray
+ * (rayoptics/raytr/trace.py:313-415) as trace.aim_chief_ray calls it
+ * (trace.py:627-640, from OpticalSpecs.update_optical_properties,
+ * opticalspec.py:263-281): find y1 such that the ray from pt0 towards
+ * (0, y1, z_enp) meets interface `surf` at y_target, by the secant iteration
+ * of scipy.optimize.newton (x0 = 0, tol 1.48e-8, maxiter 50), every trial ray
+ * traced through the whole system (raytrace.trace defaults).  All problems run
+ * in one launch, one lane each.  Fields or targets off the y axis take
+ * iterate_ray's 2-D (MINPACK) branch, which stays on the host:
+ * ROX_E_UNSUPPORTED.  probs / aim_y / result are host memory; synchronous. */
+enum { ROX_AIM_CONVERGED = 0,   /* aim_y = root                                 */
+       ROX_AIM_NOT_CONVERGED = 1,/* aim_y = results.root as iterate_ray keeps it */
+       ROX_AIM_TRACE_ERROR = 2 };/* a trial ray failed before `surf`: aim_y = 0  */
+typedef struct rox_aim {
+    double pt0[3];           /* osp.obj_coords(fld)[0]                         */
+    double z_enp;            /* fod.obj_dist + fod.enp_dist                    */
+    double y_target;         /* xy_target[1]                                   */
+    double z_dir0;           /* seq_model.z_dir[0]                             */
+    int32_t wvl_idx;
+    int32_t surf;            /* ifcx (the stop surface)                        */
+    int32_t flip;            /* not wide angle: dir0 = -dir0 if dir0.z*z_dir0 < 0 */
+    int32_t reserved;
+} rox_aim;                   /* 64 bytes */
+int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs,
+                       double eps, double *aim_y, int32_t *result, void *stream);
 
 #ifdef __cplusplus
 }

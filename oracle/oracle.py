@@ -29,21 +29,32 @@ def lib():
         vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
         P = C.POINTER
         L.rox_oracle_trace_rays.restype = C.c_int
-        L.rox_oracle_trace_rays.argtypes = [P(abi.Surface), i32, vp, i32, i64,
+        L.rox_oracle_trace_rays.argtypes = [P(abi.Surface), i32, vp, vp, i32, i64,
                                             vp, vp, vp, i32, P(abi.Opts), P(abi.Out)]
         L.rox_oracle_trace_pupil_grid.restype = C.c_int
-        L.rox_oracle_trace_pupil_grid.argtypes = [P(abi.Surface), i32, vp, i32,
+        L.rox_oracle_trace_pupil_grid.argtypes = [P(abi.Surface), i32, vp, vp, i32,
                                                   P(abi.Field), P(abi.Grid), i32,
                                                   P(abi.Opts), P(abi.Out)]
         L.rox_oracle_trace_pupil_list.restype = C.c_int
-        L.rox_oracle_trace_pupil_list.argtypes = [P(abi.Surface), i32, vp, i32,
+        L.rox_oracle_trace_pupil_list.argtypes = [P(abi.Surface), i32, vp, vp, i32,
                                                   P(abi.Field), i64, vp, vp, i32,
                                                   P(abi.Opts), P(abi.Out)]
         L.rox_oracle_intersect.restype = C.c_int
         L.rox_oracle_intersect.argtypes = [P(abi.Surface), vp, vp, C.c_double,
                                            C.c_double, P(C.c_double), vp, vp]
+        L.rox_oracle_aim_chief_rays.restype = C.c_int
+        L.rox_oracle_aim_chief_rays.argtypes = [P(abi.Surface), i32, vp, vp, i32, i32,
+                                                P(abi.Aim), C.c_double, vp, vp]
         _LIB = L
     return _LIB
+
+
+def _wvls(table):
+    """wavelengths (nm) as a float64 array kept alive on the table"""
+    w = getattr(table, '_wvls_arr', None)
+    if w is None:
+        w = table._wvls_arr = np.ascontiguousarray(table.wvls, dtype=np.float64)
+    return w
 
 
 class HostResult:
@@ -59,8 +70,11 @@ class HostResult:
             shape = (abi.SEG_DOUBLES, R)
         elif out_mode == abi.OUT_OPD:
             shape = (1, R)
+        elif out_mode == abi.OUT_HITS_COMPACT:
+            shape = (R, 2)              # packed (x, y) pairs; n_hits of them are valid
         else:
             shape = (2, R)
+        self.n_hits = np.zeros(1, dtype=np.int64)
         self.seg = np.full(shape, np.nan)
         self.op = np.full(R, np.nan)
         self.status = np.full(R, 255, dtype=np.uint8)
@@ -75,7 +89,13 @@ class HostResult:
         o.fail_surf = self.fail_surf.ctypes.data
         o.pupil = self.pupil.ctypes.data if self.pupil is not None else None
         o.ld = self.R
+        o.n_hits = self.n_hits.ctypes.data
         return o
+
+    @property
+    def hits(self):
+        """HITS_COMPACT: the (n_hits, 2) array"""
+        return self.seg[:int(self.n_hits[0])]
 
 
 def make_opts(flags=abi.INTERSECT_OBJ, out_mode=abi.OUT_FULL, first_surf=0,
@@ -103,7 +123,8 @@ def trace_rays(table, pt0, dir0, wvl_idx, opts):
         wi = np.ascontiguousarray(wvl_idx, dtype=np.int32)
         wi_ptr, wi_all = wi.ctypes.data, 0
     rc = lib().rox_oracle_trace_rays(table.rows, table.n_ifcs,
-                                     table.n_table.ctypes.data, len(table.wvls),
+                                     table.n_table.ctypes.data, _wvls(table).ctypes.data,
+                                     len(table.wvls),
                                      R, pt0.ctypes.data, dir0.ctypes.data,
                                      wi_ptr, wi_all, C.byref(opts), C.byref(out))
     if rc:
@@ -117,6 +138,7 @@ def trace_pupil_grid(table, fld, grid, wvl_idx, opts):
     out = res.out_struct()
     rc = lib().rox_oracle_trace_pupil_grid(table.rows, table.n_ifcs,
                                            table.n_table.ctypes.data,
+                                           _wvls(table).ctypes.data,
                                            len(table.wvls), C.byref(fld),
                                            C.byref(grid), wvl_idx,
                                            C.byref(opts), C.byref(out))
@@ -135,6 +157,7 @@ def trace_pupil_list(table, fld, px, py, wvl_idx, opts, res=None):
     out = res.out_struct()
     rc = lib().rox_oracle_trace_pupil_list(table.rows, table.n_ifcs,
                                            table.n_table.ctypes.data,
+                                           _wvls(table).ctypes.data,
                                            len(table.wvls), C.byref(fld), R,
                                            px.ctypes.data, py.ctypes.data,
                                            wvl_idx, C.byref(opts), C.byref(out))
@@ -150,3 +173,17 @@ def make_grid(start, stop, num, kind=abi.GRID_PRODUCT, row_begin=0, row_count=0)
     g.num, g.kind = num, kind
     g.row_begin, g.row_count = row_begin, row_count
     return g
+
+
+def aim_chief_rays(table, probs, eps=1.0e-12):
+    """probs: sequence of abi.Aim -> (aim_y float64[n], result int32[n])"""
+    n = len(probs)
+    arr = (abi.Aim * n)(*probs)
+    aim_y = np.zeros(n)
+    result = np.zeros(n, dtype=np.int32)
+    rc = lib().rox_oracle_aim_chief_rays(table.rows, table.n_ifcs, table.n_table.ctypes.data,
+                                         _wvls(table).ctypes.data, len(table.wvls), n, arr,
+                                         eps, aim_y.ctypes.data, result.ctypes.data)
+    if rc:
+        raise RuntimeError(f'oracle error {rc}')
+    return aim_y, result

@@ -5,7 +5,7 @@ by :mod:`rayoptics_amd.engine`, which fails loudly when it is missing.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_COEF = 10
 MAX_AP = 4
 SEG_DOUBLES = 10
@@ -15,16 +15,18 @@ TRANSMIT, REFLECT, DUMMY, PHANTOM = 0, 1, 2, 3
 MODE_NAMES = {'transmit': TRANSMIT, 'reflect': REFLECT, 'dummy': DUMMY,
               'phantom': PHANTOM}
 # profile kinds  (rayoptics/elem/profiles.py)
-SPHERICAL, CONIC, EVENPOLY, RADIALPOLY, YTOROID, XTOROID = 0, 1, 2, 3, 4, 5
+SPHERICAL, CONIC, EVENPOLY, RADIALPOLY, YTOROID, XTOROID, THINLENS = 0, 1, 2, 3, 4, 5, 6
 PROFILE_NAMES = {'Spherical': SPHERICAL, 'Conic': CONIC,
                  'EvenPolynomial': EVENPOLY, 'RadialPolynomial': RADIALPOLY,
                  'YToroid': YTOROID, 'XToroid': XTOROID}
+# phase elements (rayoptics/oprops/doe.py)
+PH_NONE, PH_GRATING, PH_DOE_RADIAL, PH_HOLOGRAM = 0, 1, 2, 3
 # aperture kinds (rayoptics/elem/surface.py:398-494)
 AP_CIRCULAR, AP_RECTANGULAR, AP_ALWAYS_BLOCK = 0, 1, 2
 # per-ray status (rayoptics/raytr/traceerror.py)
 OK, MISSED_SURFACE, TIR, BLOCKED, EVANESCENT = 0, 1, 2, 3, 4
 # output modes
-OUT_FULL, OUT_LAST, OUT_HITS, OUT_OPD = 0, 1, 2, 3
+OUT_FULL, OUT_LAST, OUT_HITS, OUT_OPD, OUT_HITS_COMPACT = 0, 1, 2, 3, 4
 # flags
 CHECK_APERTURES = 1
 INTERSECT_OBJ = 2
@@ -35,12 +37,25 @@ HOST_POINTERS = 16
 RT_F_ORDER, RT_C_ORDER = 0, 1
 # grid kinds
 GRID_PRODUCT, GRID_FAN = 0, 1
+# rox_field.kind: the branches of ray_start_from_osp (opticalspec.py:289-400)
+FLD_EPD, FLD_EPD_WIDE, FLD_AIM_PT, FLD_NA, FLD_FNO, FLD_AIM_DIR = 0, 1, 2, 3, 4, 5
+# rox_aim_chief_rays result codes
+AIM_CONVERGED, AIM_NOT_CONVERGED, AIM_TRACE_ERROR = 0, 1, 2
 
 
 class Aperture(C.Structure):
     _fields_ = [('kind', C.c_int32), ('is_obscuration', C.c_int32),
                 ('x_offset', C.c_double), ('y_offset', C.c_double),
                 ('a', C.c_double), ('b', C.c_double)]
+
+
+class Phase(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('ncoef', C.c_int32),
+                ('flags', C.c_int32), ('reserved', C.c_int32),
+                ('order', C.c_double), ('ref_wl', C.c_double),
+                ('spacing_nm', C.c_double),
+                ('a', C.c_double * 3), ('b', C.c_double * 3),
+                ('coefs', C.c_double * MAX_COEF)]
 
 
 class Surface(C.Structure):
@@ -52,7 +67,7 @@ class Surface(C.Structure):
                 ('coefs', C.c_double * MAX_COEF),
                 ('rt', C.c_double * 9), ('t', C.c_double * 3),
                 ('z_dir', C.c_double), ('max_aperture', C.c_double),
-                ('ap', Aperture * MAX_AP)]
+                ('ap', Aperture * MAX_AP), ('ph', Phase)]
 
 
 class Wavefront(C.Structure):
@@ -79,7 +94,9 @@ class Field(C.Structure):
                 ('eprad', C.c_double), ('z_enp', C.c_double),
                 ('vlx', C.c_double), ('vux', C.c_double),
                 ('vly', C.c_double), ('vuy', C.c_double),
-                ('z_dir0', C.c_double)]
+                ('z_dir0', C.c_double),
+                ('kind', C.c_int32), ('rot_order', C.c_int32),
+                ('rot', C.c_double * 9), ('cr_dir', C.c_double * 2)]
 
 
 class Grid(C.Structure):
@@ -91,23 +108,35 @@ class Grid(C.Structure):
 class Out(C.Structure):
     _fields_ = [('seg', C.c_void_p), ('op', C.c_void_p),
                 ('status', C.c_void_p), ('fail_surf', C.c_void_p),
-                ('pupil', C.c_void_p), ('ld', C.c_int64)]
+                ('pupil', C.c_void_p), ('ld', C.c_int64),
+                ('n_hits', C.c_void_p)]
+
+
+class Aim(C.Structure):
+    _fields_ = [('pt0', C.c_double * 3), ('z_enp', C.c_double),
+                ('y_target', C.c_double), ('z_dir0', C.c_double),
+                ('wvl_idx', C.c_int32), ('surf', C.c_int32),
+                ('flip', C.c_int32), ('reserved', C.c_int32)]
 
 
 assert C.sizeof(Aperture) == 40
-assert C.sizeof(Surface) == 408
+assert C.sizeof(Phase) == 168
+assert C.sizeof(Surface) == 576
 assert C.sizeof(Wavefront) == 296
 assert C.sizeof(Opts) == 352
-assert C.sizeof(Field) == 96
+assert C.sizeof(Field) == 192
 assert C.sizeof(Grid) == 48
-assert C.sizeof(Out) == 48
+assert C.sizeof(Out) == 56
+assert C.sizeof(Aim) == 64
 
-# every symbol include/roxtrace.h declares (checked by tests/test_abi.py)
+# every symbol include/roxtrace.h declares (checked by tests/test_abi.py) ...
 EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_last_error', 'rox_system_create', 'rox_system_destroy',
            'rox_system_num_segments', 'rox_trace_rays',
            'rox_trace_pupil_grid', 'rox_trace_pupil_list',
-           'rox_time_pupil_grid', 'rox_selftest_fp64')
+           'rox_aim_chief_rays')
+# ... and the measurement / self-test helpers of include/roxtrace_diag.h
+DIAG_EXPORTS = ('rox_time_pupil_grid', 'rox_selftest_fp64')
 
 
 def declare(lib):
@@ -123,7 +152,7 @@ def declare(lib):
     lib.rox_last_error.restype = C.c_char_p
     lib.rox_last_error.argtypes = []
     lib.rox_system_create.restype = C.c_int
-    lib.rox_system_create.argtypes = [P(Surface), i32, vp, i32, P(vp)]
+    lib.rox_system_create.argtypes = [P(Surface), i32, vp, vp, i32, P(vp)]
     lib.rox_system_destroy.restype = C.c_int
     lib.rox_system_destroy.argtypes = [vp]
     lib.rox_system_num_segments.restype = C.c_int
@@ -136,6 +165,8 @@ def declare(lib):
     lib.rox_trace_pupil_list.restype = C.c_int
     lib.rox_trace_pupil_list.argtypes = [vp, P(Field), i64, vp, vp, i32,
                                          P(Opts), P(Out), vp]
+    lib.rox_aim_chief_rays.restype = C.c_int
+    lib.rox_aim_chief_rays.argtypes = [vp, i32, P(Aim), dbl, vp, vp, vp]
     lib.rox_time_pupil_grid.restype = C.c_int
     lib.rox_time_pupil_grid.argtypes = [vp, P(Field), P(Grid), i32, P(Opts),
                                         P(Out), vp, i32, P(dbl)]

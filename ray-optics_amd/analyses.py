@@ -13,7 +13,7 @@ import numpy as np
 from . import abi, session
 from .engine import make_grid
 from .raypkg import HostPackets
-from .trace import opts_from_kwargs, emit, _trace_pupil
+from .trace import opts_from_kwargs, emit, _trace_pupil, _launch_setup
 
 
 def trace_list_of_rays(opt_model, rays, output_filter=None, rayerr_filter=None,
@@ -329,11 +329,10 @@ def focus_pupil_coords(opt_model, ray_list, fld, wvl, foc,
         for k in ('output_filter', 'rayerr_filter', 'append_if_none'):
             kw.pop(k, None)
         kw['apply_vignetting'] = kw.get('apply_vignetting', True)
-        pk = _trace_pupil(opt_model, fld, wvl, kw, None, None,
-                          pupil_list=(ray_list.pupil[:, 0].copy(), ray_list.pupil[:, 1].copy()),
-                          out_mode=abi.OUT_HITS, foc=foc, image_pt=image_pt[:2])
-        ok = pk.status == abi.OK
-        return np.ascontiguousarray(pk.seg[0][:, ok].T)
+        eng, f, wi, opts = _launch_setup(opt_model, fld, wvl, kw, abi.OUT_HITS_COMPACT,
+                                         foc, image_pt[:2])
+        return eng.trace_pupil_list_hits(f, ray_list.pupil[:, 0].copy(),
+                                         ray_list.pupil[:, 1].copy(), wi, opts)
     data = []
     for _px, _py, pkg in ray_list:
         if pkg is not None:

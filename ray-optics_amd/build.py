@@ -1,21 +1,30 @@
 """builds libroxtrace.so (HIP kernels + C ABI) in-tree for gfx950.
 
-    python ray-optics_amd/build.py [--force]
+    python ray-optics_amd/build.py [--force] [--out lib.so] [extra hipcc flags]
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off is load-bearing: the
 kernels restate NumPy's unfused elementwise arithmetic and spell the BLAS dot
-sites as explicit fma() (see csrc/roxtrace.hip header)."""
+sites as explicit fma() (see csrc/rox_device.hpp header).
+
+The trace kernel is compiled once per feature instance (csrc/inst_*.hip), each
+in its own translation unit so that the instances build in parallel; objects
+are cached under build/obj and rebuilt when a source, a header or the flags
+change."""
+import concurrent.futures
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, 'csrc', 'roxtrace.hip')
-HDR = os.path.join(HERE, '..', 'include', 'roxtrace.h')
+CSRC = os.path.join(HERE, 'csrc')
+INC = os.path.join(HERE, '..', 'include')
 LIB = os.path.join(HERE, 'libroxtrace.so')
+OBJ_ROOT = os.path.join(HERE, '..', 'build', 'obj')
 
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-ffp-contract=off', '-fno-fast-math', '-Wall', '-Wno-unused-function']
 
 
@@ -26,21 +35,63 @@ def hipcc():
     raise RuntimeError('hipcc not found')
 
 
-def stale():
-    if not os.path.exists(LIB):
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hpp')) + glob.glob(os.path.join(INC, '*.h')))
+
+
+def source_hash(extra=()):
+    """digest of every input of the build: sources, headers, flags, this file"""
+    h = hashlib.sha256()
+    for p in sources() + headers() + [os.path.abspath(__file__)]:
+        with open(p, 'rb') as f:
+            h.update(os.path.basename(p).encode() + b'\0' + f.read())
+    h.update(' '.join(FLAGS + list(extra)).encode())
+    return h.hexdigest()
+
+
+def _stamp(lib):
+    return lib + '.srchash'
+
+
+def stale(lib=None, extra=()):
+    lib = lib or LIB
+    if not os.path.exists(lib) or not os.path.exists(_stamp(lib)):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in (SRC, HDR, __file__))
+    with open(_stamp(lib)) as f:
+        return f.read().strip() != source_hash(extra)
 
 
 def build(force=False, extra=(), out=None):
     """out != None builds an experiment variant (tools/ab_bench.py) next to the
     product library without touching it"""
     lib = out or LIB
-    if out is None and not force and not stale():
-        return LIB
-    cmd = [hipcc(), *FLAGS, *extra, '-o', lib, SRC]
-    subprocess.check_call(cmd)
+    extra = list(extra)
+    if not force and not stale(lib, extra):
+        return lib
+    digest = source_hash(extra)
+    objdir = os.path.join(OBJ_ROOT, digest[:16])
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
+        if not os.path.exists(obj):
+            tmp = obj + f'.tmp{os.getpid()}'
+            subprocess.check_call([cc, *FLAGS, *extra, '-c', src, '-o', tmp])
+            os.replace(tmp, obj)
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    tmp = lib + f'.tmp{os.getpid()}'
+    subprocess.check_call([cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp, *objs])
+    os.replace(tmp, lib)
+    with open(_stamp(lib), 'w') as f:
+        f.write(digest + '\n')
     return lib
 
 

@@ -1,0 +1,118 @@
+// inst_aim.hip -- batched chief-ray aiming: the 1-D branch of trace.iterate_ray
+// (rayoptics/raytr/trace.py:313-415) with scipy.optimize.newton's secant
+// iteration (scipy/optimize/_zeros_py.py, `fprime is None` branch; x0 = 0,
+// tol = 1.48e-8, rtol = 0, maxiter = 50, disp = False) restated per lane: one
+// lane = one (field, wavelength) problem, every trial ray traced through the
+// whole system with raytrace.trace's defaults (raytrace.py:51-80).
+#include "rox_device.hpp"
+
+namespace rox {
+namespace {
+
+__global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
+{
+    const int N = a.n_ifcs, W = a.n_wvls;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *tbl_w = lds;
+    double *ntab_w = tbl_w + (size_t)N * kRowDoubles;
+    double *phc_w = ntab_w + (size_t)W * N;
+    double *wvls_w = phc_w + (size_t)W * N * kPhaseConsts;
+    int32_t *slot_w = reinterpret_cast<int32_t *>(wvls_w + W);
+    for (int i = threadIdx.x; i < N * kRowDoubles; i += 64)
+        tbl_w[i] = a.rows[i];
+    for (int i = threadIdx.x; i < W * N; i += 64)
+        ntab_w[i] = a.n_table[i];
+    for (int i = threadIdx.x; i < W * N * kPhaseConsts; i += 64)
+        phc_w[i] = a.ph_consts[i];
+    for (int i = threadIdx.x; i < W; i += 64)
+        wvls_w[i] = a.wvls[i];
+    for (int i = threadIdx.x; i < 2 * N; i += 64)
+        slot_w[i] = a.slots[i];
+    __syncthreads();
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n)
+        return;
+    const rox_aim pb = a.probs[i];
+
+    Ctx c;
+    c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
+    c.slot = slot_w; c.nslots_before = slot_w + N;
+    c.N = N;
+    c.check_ap = false; c.intersect_obj = true; c.filter_ph = false;    // raytrace.py:51-80, 83-99
+    c.first_surf = 1; c.last_surf = N - 2;
+    c.eps = a.eps; c.fuzz = 1e-5;
+    c.probe_surf = pb.surf;
+    SegOut so{nullptr, 0, 0};
+    const v3 pt0{pb.pt0[0], pb.pt0[1], pb.pt0[2]};
+
+    // trace.py:322-349 y_stop_coordinate; `raised`: a trial ray failed before surf
+    bool raised = false;
+    auto f = [&](double y1) -> double {
+        const v3 pt1{0., y1, pb.z_enp};
+        v3 dir0 = unit(v3{pt1.x - pt0.x, pt1.y - pt0.y, pt1.z - pt0.z});
+        if (pb.flip && dir0.z * pb.z_dir0 < 0)
+            dir0 = v3{-dir0.x, -dir0.y, -dir0.z};
+        RayEnd e;
+        trace_ray<MODE_PROBE, true, F_ALL>(c, so, pt0, dir0, pb.wvl_idx, true, e);
+        double y_ray;
+        if (e.status != ROX_OK) {
+            y_ray = 0.;                         // final_coord = [0, 0, 0]
+            if (e.fail_surf < pb.surf)
+                raised = true;
+        } else {
+            y_ray = e.probe_p.y;
+        }
+        return y_ray - pb.y_target;
+    };
+
+    const double tol = 1.48e-8;
+    double p0 = 0.0, p = 0.0;
+    int result = ROX_AIM_NOT_CONVERGED;
+    const double eps = 1e-4;
+    double p1 = p0 * (1 + eps);
+    p1 += (p1 >= 0 ? eps : -eps);
+    double q0 = f(p0);
+    double q1 = raised ? 0.0 : f(p1);
+    if (!raised) {
+        if (fabs(q1) < fabs(q0)) {
+            double t = p0; p0 = p1; p1 = t;
+            t = q0; q0 = q1; q1 = t;
+        }
+        for (int itr = 0; itr < 50; ++itr) {
+            if (q1 == q0) {
+                p = (p1 + p0) / 2.0;
+                break;                          // _ECONVERR, but the root is still used
+            }
+            if (fabs(q1) > fabs(q0))
+                p = (-q0 / q1 * p1 + p0) / (1 - q0 / q1);
+            else
+                p = (-q1 / q0 * p0 + p1) / (1 - q1 / q0);
+            // np.isclose(p, p1, rtol=0, atol=tol)
+            const bool close = (isfinite(p) && isfinite(p1)) ? (fabs(p - p1) <= tol) : (p == p1);
+            if (close) {
+                result = ROX_AIM_CONVERGED;
+                break;
+            }
+            p0 = p1; q0 = q1;
+            p1 = p;
+            q1 = f(p1);
+            if (raised)
+                break;
+        }
+    }
+    if (raised) {                               // trace.py:395-396: start_y = 0.0
+        p = 0.0;
+        result = ROX_AIM_TRACE_ERROR;
+    }
+    a.aim_y[i] = p;
+    a.result[i] = result;
+}
+
+}  // namespace
+
+void launch_aim(const AimArgs &a, size_t lds, hipStream_t st)
+{
+    hipLaunchKernelGGL(aim_kernel, dim3((a.n + 63) / 64), dim3(64), lds, st, a);
+}
+
+}  // namespace rox

@@ -1,0 +1,7 @@
+// inst_radial.hip -- the trace kernels of feature instance F_RADIAL (rox_device.hpp):
+// one translation unit per instance so that the instances compile in parallel.
+#include "rox_device.hpp"
+
+namespace rox {
+void launch_radial(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_RADIAL>(k, a); }
+}  // namespace rox

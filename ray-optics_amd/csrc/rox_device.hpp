@@ -1,0 +1,1327 @@
+// rox_device.hpp -- device code of the sequential real-ray trace for gfx950
+// (MI355X, CDNA4): arithmetic, surface intersection, phase elements, packet
+// stores and the trace kernel template.  Included by every kernel-instance
+// translation unit (inst_*.hip) and by the host side (roxtrace.hip).
+//
+// Hot path of mjhoptics/ray-optics restated as hand-written HIP (reference
+// paths relative to /root/reference/src/):
+//   rayoptics/raytr/raytrace.py:83-264   trace_raw   -> trace_ray() (the loop)
+//   rayoptics/raytr/raytrace.py:19-38    bend/reflect -> refract(), mirror()
+//   rayoptics/raytr/raytrace.py:41-48, 205-210 phase  -> apply_phase()
+//   rayoptics/oprops/doe.py:124-175      DiffractionGrating.phase_ludwig
+//   rayoptics/oprops/doe.py:28-54, 272-323 DiffractiveElement.phase + radial_phase_fct
+//   rayoptics/oprops/doe.py:375-397      HolographicElement.phase (every ThinLens)
+//   rayoptics/oprops/thinlens.py:128-136 ThinLens.normal/intersect
+//   rayoptics/elem/profiles.py:310-336   Spherical.intersect  \  quadric_hit()
+//   rayoptics/elem/profiles.py:569-593   Conic.intersect      /
+//   rayoptics/elem/profiles.py:155-186   intersect_spencer    -> newton_hit()
+//   rayoptics/elem/profiles.py:849-885   EvenPolynomial.sag/df \ poly_eval()
+//   rayoptics/elem/profiles.py:1070-1113 RadialPolynomial.sag/df/
+//   rayoptics/elem/profiles.py:1317-1437 Y/XToroid            /
+//   rayoptics/elem/surface.py:198-208, 416-457 point_inside    -> inside_aperture()
+//   rayoptics/raytr/opticalspec.py:289-400, 1339-1353; trace.py:298-308
+//                                         pupil -> (pt0, dir0) -> ray_start()
+//
+// Execution model: one wavefront lane = one ray; 512-thread workgroups take
+// tiles of 512 consecutive rays.  Every per-surface parameter is wave-uniform:
+// the surface table is staged once per workgroup in LDS and read with
+// same-address (broadcast, conflict-free) ds_reads.  Ray packets are SoA
+// [segment][component][ray]: each store is 64 lanes x 8 B = 512 B contiguous.
+// All arithmetic is IEEE binary64 with the reference's operation order: this
+// code is compiled with -ffp-contract=off, NumPy's BLAS dot sites are spelled
+// as explicit fma chains (dot3), division and sqrt are the correctly rounded
+// ones.  No MFMA: this is 3-vector arithmetic, not a contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/roxtrace.h"
+
+#pragma clang fp contract(off)
+
+// ---- build-time knobs (defaults = the shipped configuration; the others are
+// kept for A/B measurement with tools/ab_bench.py) -------------
+#ifndef ROX_MIN_WAVES        // __launch_bounds__ second argument (waves per SIMD)
+#define ROX_MIN_WAVES 4       // 128 VGPRs
+#endif
+#ifndef ROX_STORE_NT         // 1: non-temporal packet stores (measured: FULL 236 us vs 257 us)
+#define ROX_STORE_NT 1
+#endif
+#ifndef ROX_SLIM_FP64        // 1: range-guarded slim sqrt / shared-reciprocal division triples
+#define ROX_SLIM_FP64 1       //    (bit-identical to sqrt() and `/`; see slim_* below)
+#endif
+#ifndef ROX_BLOCK            // workgroup size (FULL: 128 -> 222, 256 -> 214, 512 -> 208, 1024 -> 212 us)
+#define ROX_BLOCK 512
+#endif
+#ifndef ROX_WG_SYNC          // 1: a workgroup barrier per surface (keeps the waves of a
+#define ROX_WG_SYNC 0         //    workgroup on one packet row; experiment)
+#endif
+
+namespace rox {
+
+constexpr int kBlock = ROX_BLOCK;
+constexpr int kWaves = kBlock / 64;
+static_assert(sizeof(rox_aperture) == 40, "rox_aperture layout");
+static_assert(sizeof(rox_phase) == 168, "rox_phase layout");
+static_assert(sizeof(rox_surface) == 576, "rox_surface layout");
+static_assert(sizeof(rox_field) == 192, "rox_field layout");
+
+// Device-side row = the public rox_surface + per-surface values that are the
+// same for every ray and are therefore computed once at rox_system_create:
+// dcoefs[i] = c_coef_i * coefs[i], the product the df() loops of the polynomial
+// profiles form per evaluation (c_coef_i = 2(i+1), or i+1 for RadialPolynomial;
+// exact small integers, so the host product has the reference's rounding).
+struct dev_surface {
+    rox_surface pub;
+    double dcoefs[ROX_MAX_COEF];
+};
+constexpr int kRowDoubles = sizeof(dev_surface) / sizeof(double);   // 82
+// Per (wavelength, interface) constants of a DiffractionGrating, formed on the
+// host with libm pow() exactly as the reference's `mu**2` / `T**2` are:
+//   [0] mu = n_in/n_out  [1] mu**2  [2] T  [3] T**2          (doe.py:138-143)
+constexpr int kPhaseConsts = 4;
+
+enum { GEN_RAYS = 0, GEN_PUPIL = 1 };
+enum { AXIS_LIST = 0, AXIS_PRODUCT = 1 };
+// internal output mode of the aiming kernel: no packet stores, the intercept
+// at TraceArgs.probe_surf is kept
+constexpr int MODE_PROBE = 100;
+
+// system features a launch needs; the host picks the leanest instance
+enum { F_EVEN = 1,      // some interface is an EvenPolynomial (Newton code)
+       F_RADIAL = 2,    // ... a RadialPolynomial
+       F_TOROID = 4,    // ... a Y/XToroid
+       F_APLIST = 8,    // some interface carries clear_apertures
+       F_PHFILT = 16,   // filter_out_phantoms with phantoms present
+       F_PHASE = 32 };  // phase elements / thin lenses
+constexpr int F_POLY = F_EVEN | F_RADIAL | F_TOROID;
+constexpr int F_ALL = F_POLY | F_APLIST | F_PHFILT | F_PHASE;
+
+struct v3 { double x, y, z; };
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+typedef const double *tblp;     // LDS (generic pointer into __shared__)
+typedef const int32_t *tbli;
+
+// ---------------------------------------------------------------- kernel args
+struct TraceArgs {
+    const double *rows;        // [N][kRowDoubles] dev_surface rows
+    const double *n_table;     // [W][N]
+    const double *ph_consts;   // [W][N][kPhaseConsts] or nullptr
+    const double *wvls;        // [W] nm
+    const int32_t *slots;      // [2][N]: slot[s] (-1 = filtered phantom), nslots_before[s]
+    int32_t n_ifcs, n_wvls;
+    int64_t n_rays;            // rays of this launch (<= 2^28: 32-bit lane byte offsets)
+    int64_t ray_base;          // index of this launch's first ray within the batch
+    int64_t in_ld;             // batch size = stride of the SoA inputs
+    // explicit rays
+    const double *pt0, *dir0;  // SoA [3][n_rays]
+    const int32_t *wvl_idx;    // per ray or nullptr
+    int32_t wvl_idx_all;
+    // pupil rays
+    const double *px, *py;     // axis / list coordinates
+    int32_t axis_kind;         // AXIS_LIST: px[r],py[r]; AXIS_PRODUCT: px[r/num], py[r%num]
+    int32_t axis_num;
+    int32_t row_begin;         // AXIS_PRODUCT: first pupil row of this launch
+    // HITS_COMPACT: decoupled look-back state of this launch
+    uint64_t *tile_state;      // [tiles] (epoch << 32 | flag << 30 | count)
+    uint32_t *ticket;          // [0] next tile, [1] workgroups done
+    int64_t *hits_base;        // hits of the earlier launches of this call (device)
+    uint32_t epoch;
+    int32_t first_chunk, last_chunk;
+    rox_field fld;
+    rox_opts opts;
+    rox_out out;
+};
+
+// ---------------------------------------------------------------- arithmetic
+// np.dot / ndarray.dot / np.linalg.norm on float64[3] = OpenBLAS ddot:
+// acc = 0; acc = fma(a_i, b_i, acc), i = 0, 1, 2.
+__device__ __forceinline__ double dot3(const v3 &a, const v3 &b)
+{
+    double acc = fma(a.x, b.x, 0.0);
+    acc = fma(a.y, b.y, acc);
+    return fma(a.z, b.z, acc);
+}
+
+// Rt.dot(v) = OpenBLAS dgemv: an fma chain per output row; the column order is
+// 0,1,2 for the F-ordered transpose view and 1,0,2 for a C-ordered array
+// (include/roxtrace.h ROX_RT_*).  `order` is wave-uniform.
+template <class P>
+__device__ __forceinline__ v3 rotate(P rt, int order, const v3 &v)
+{
+    v3 r;
+    if (order == ROX_RT_C_ORDER) {
+        r.x = fma(rt[2], v.z, fma(rt[0], v.x, fma(rt[1], v.y, 0.0)));
+        r.y = fma(rt[5], v.z, fma(rt[3], v.x, fma(rt[4], v.y, 0.0)));
+        r.z = fma(rt[8], v.z, fma(rt[6], v.x, fma(rt[7], v.y, 0.0)));
+    } else {
+        r.x = fma(rt[2], v.z, fma(rt[1], v.y, fma(rt[0], v.x, 0.0)));
+        r.y = fma(rt[5], v.z, fma(rt[4], v.y, fma(rt[3], v.x, 0.0)));
+        r.z = fma(rt[8], v.z, fma(rt[7], v.y, fma(rt[6], v.x, 0.0)));
+    }
+    return r;
+}
+
+// np.cross on float64[3]: each component is multiply, multiply, subtract
+__device__ __forceinline__ v3 cross3(const v3 &a, const v3 &b)
+{
+    return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// ---------------------------------------------------------------- slim fp64
+// hipcc expands an f64 sqrt into v_rsq_f64 + 9 mul/fma (correctly rounded) wrapped
+// in input scaling (v_ldexp x2), a class test and selects; and every f64 `/` into
+// v_div_scale x2 + v_rcp_f64 + two Newton steps + q, residual, v_div_fmas,
+// v_div_fixup.  The scaling and fix-up only act on operands outside a band of
+// exponents (or zero / inf / nan).  Inside the band the functions below execute
+// the SAME instruction sequence minus those wrappers, so the results are
+// bit-identical; three quotients by one divisor share the refined reciprocal.
+// A wave takes the slim path only when every active lane passes the exponent
+// test (one wave-uniform branch); otherwise it falls back to the plain operators.
+//   band: biased exponent in [640, 1408)  <=>  2^-383 <= |x| < 2^385
+//   (v_div_scale scales when exponents differ by >= 768 or the numerator's
+//   exponent <= 53; the sqrt expansion scales below 2^-767)
+__device__ __forceinline__ bool in_band(double x)
+{
+    const uint32_t h = (uint32_t)__double2hiint(x) & 0x7fffffffu;
+    return (h - 0x28000000u) < 0x30000000u;
+}
+
+// numerators may also be exactly +-0 (the sign is restored below)
+__device__ __forceinline__ bool in_band_or_zero(double x) { return in_band(x) || x == 0.0; }
+
+// sqrt for x in the band: the expansion of llvm.sqrt.f64 without scaling/selects
+__device__ __forceinline__ double sqrt_band(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double s = x * y;
+    double h = y * 0.5;
+    const double r0 = fma(-h, s, 0.5);
+    s = fma(s, r0, s);
+    h = fma(h, r0, h);
+    const double d0 = fma(-s, s, x);
+    s = fma(d0, h, s);
+    const double d1 = fma(-s, s, x);
+    return fma(d1, h, s);
+}
+
+__device__ __forceinline__ double slim_sqrt(double x)
+{
+#if ROX_SLIM_FP64
+    if (__all(in_band(x)))
+        return sqrt_band(x);
+#endif
+    return sqrt(x);
+}
+
+// refined reciprocal exactly as the division expansion builds it (no scaling)
+__device__ __forceinline__ double rcp_band(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(r, fma(-b, r, 1.0), r);
+    r = fma(r, fma(-b, r, 1.0), r);
+    return r;
+}
+
+// a / b given r = rcp_band(b): quotient, exact residual, correction; v_div_fixup's
+// only effect inside the band is forcing the sign, which also covers a == +-0
+__device__ __forceinline__ double div_band(double a, double b, double r)
+{
+    const double q = a * r;
+    const double q1 = fma(fma(-b, q, a), r, q);
+    return copysign(q1, q);
+}
+
+// a / b
+__device__ __forceinline__ double slim_div(double a, double b)
+{
+#if ROX_SLIM_FP64
+    if (__all(in_band(b) && in_band_or_zero(a)))
+        return div_band(a, b, rcp_band(b));
+#endif
+    return a / b;
+}
+
+// (a.x / b, a.y / b, a.z / b)
+__device__ __forceinline__ v3 slim_div3(const v3 &a, double b)
+{
+#if ROX_SLIM_FP64
+    if (__all(in_band(b) && in_band_or_zero(a.x) && in_band_or_zero(a.y) && in_band_or_zero(a.z))) {
+        const double r = rcp_band(b);
+        return v3{div_band(a.x, b, r), div_band(a.y, b, r), div_band(a.z, b, r)};
+    }
+#endif
+    return v3{a.x / b, a.y / b, a.z / b};
+}
+
+// misc_math.py:48-54 normalize
+__device__ __forceinline__ v3 unit(const v3 &v)
+{
+    const double len = slim_sqrt(dot3(v, v));
+    if (len == 0.0)
+        return v;
+    return slim_div3(v, len);
+}
+
+// raytrace.py:19-30.  false = TIR (math.sqrt ValueError)
+__device__ __forceinline__ bool refract(const v3 &d, const v3 &nrm, double n_in,
+                                        double n_out, v3 &out)
+{
+    const double nlen = slim_sqrt(dot3(nrm, nrm));
+    const double cosI = dot3(d, nrm) / nlen;
+    const double sin2 = 1.0 - cosI * cosI;
+    const double rad = n_out * n_out - n_in * n_in * sin2;
+    if (rad < 0.0)
+        return false;
+    const double n_cosIp = copysign(slim_sqrt(rad), cosI);
+    const double alpha = n_cosIp - n_in * cosI;
+    out = slim_div3(v3{n_in * d.x + alpha * nrm.x, n_in * d.y + alpha * nrm.y,
+                       n_in * d.z + alpha * nrm.z}, n_out);
+    return true;
+}
+
+// raytrace.py:33-38 (not renormalised)
+__device__ __forceinline__ v3 mirror(const v3 &d, const v3 &nrm)
+{
+    const double nlen = slim_sqrt(dot3(nrm, nrm));
+    const double cosI = dot3(d, nrm) / nlen;
+    const double k = 2.0 * cosI;
+    return v3{d.x - k * nrm.x, d.y - k * nrm.y, d.z - k * nrm.z};
+}
+
+// profiles.py:321-336 / 580-593: s = cx2 / (z_dir*sqrt(b*b - ax2*cx2) - b)
+__device__ __forceinline__ bool quadric_root(double ax2, double cx2, double b,
+                                             double z_dir, double &s)
+{
+    if ((b != 0) || (cx2 != 0) || (ax2 != 0)) {
+        const double rad = b * b - ax2 * cx2;
+        if (rad < 0.0)
+            return false;                       // TraceMissedSurfaceError
+        const double den = z_dir * slim_sqrt(rad) - b;
+        // np.errstate(divide='raise') -> FloatingPointError -> s = 0 only for a
+        // finite non-zero numerator; 0/0 and nan/0 stay NaN
+        if (den == 0.0 && cx2 != 0.0 && isfinite(cx2))
+            s = 0.0;
+        else
+            s = cx2 / den;
+    } else {
+        s = 0.0;
+    }
+    return true;
+}
+
+// Spherical (conic == false) / Conic closed-form intersection
+__device__ __forceinline__ bool quadric_hit(bool conic, double cv, double cc, double ec,
+                                            const v3 &p, const v3 &d, double z_dir,
+                                            double &s, v3 &hit)
+{
+    double ax2, cx2, b;
+    if (!conic) {
+        ax2 = cv;
+        cx2 = cv * dot3(p, p) - 2 * p.z;
+        b = cv * dot3(d, p) - d.z;
+    } else {
+        ax2 = cv * (1. + cc * d.z * d.z);
+        cx2 = cv * (p.x * p.x + p.y * p.y + ec * p.z * p.z) - 2.0 * p.z;
+        b = cv * (d.x * p.x + d.y * p.y + ec * d.z * p.z) - d.z;
+    }
+    if (!quadric_root(ax2, cx2, b, z_dir, s))
+        return false;
+    hit = v3{p.x + s * d.x, p.y + s * d.y, p.z + s * d.z};
+    return true;
+}
+
+// One evaluation of f(p) and df(p) for the polynomial aspheres
+// (profiles.py:849-885 even, 1070-1113 radial; forward accumulation of the
+// powers, not Horner).  Returns false when the sag square root goes negative.
+// kind = ROX_EVENPOLY | ROX_RADIALPOLY | ROX_YTOROID | ROX_XTOROID (wave-uniform);
+// FEAT says which of the three families this kernel instance carries code for.
+template <int FEAT, bool WANT_F>
+__device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, double ec, double cR,
+                                          int ncoef, tblp coefs,
+                                          const v3 &p, double &f, v3 &df)
+{
+    tblp dcoefs = coefs + (offsetof(dev_surface, dcoefs) - offsetof(rox_surface, coefs)) / 8;
+    if ((FEAT & F_TOROID) && (!(FEAT & (F_EVEN | F_RADIAL)) || kind >= ROX_YTOROID)) {
+        // profiles.py:1337-1377 YToroid.fY/f/df; XToroid swaps x and y (:1429-1434)
+        const bool xt = (kind == ROX_XTOROID);
+        const double px = xt ? p.y : p.x, py = xt ? p.x : p.y;
+        const double y2 = py * py;
+        const double rad = 1. - cc1 * cv * cv * y2;
+        if (rad < 0.0)
+            return false;
+        const double srad = slim_sqrt(rad);
+        double z_asp = 0.0, y_pow = y2;
+        double e_asp = 0.0, d_pow = 1;
+        for (int i = 0; i < ncoef; ++i) {
+            z_asp += coefs[i] * y_pow;
+            y_pow *= y2;
+            e_asp += dcoefs[i] * d_pow;         // (c_coef*coefs[i])*y_pow
+            d_pow *= y2;
+        }
+        const double fY = slim_div(cv * y2, 1. + srad) + z_asp;
+        if (WANT_F)
+            f = p.z - fY - cR * (px * px + p.z * p.z - fY * fY) / 2;
+        const double dfdY = slim_div(cv, srad) + e_asp;
+        const double Fx = -cR * px;
+        const double Fy = (cR * fY - 1) * (dfdY) * py;
+        df = xt ? v3{Fy, Fx, 1 - cR * p.z} : v3{Fx, Fy, 1 - cR * p.z};
+        return true;
+    }
+    const bool radial = (FEAT & F_RADIAL) && (!(FEAT & F_EVEN) || kind == ROX_RADIALPOLY);
+    const double r2 = p.x * p.x + p.y * p.y;
+    double e_tot;
+    // sag() and df() take the square root of the same radicand when
+    // (cc + 1.0) and ec are the same number (they are, unless a caller fills the
+    // table otherwise): evaluate it once.  `same` is wave-uniform.
+    const bool same = (cc1 == ec) || radial;
+    const double rad_e = 1. - ec * cv * cv * r2;
+    if (!radial) {
+        double srad_e;
+        if (WANT_F) {
+            const double rad = 1. - cc1 * cv * cv * r2;     // (cc + 1.0)*cv*cv*r2
+            if (rad < 0.0)
+                return false;
+            const double srad = slim_sqrt(rad);
+            srad_e = same ? srad : sqrt(rad_e);
+            const double z = slim_div(cv * r2, 1. + srad);
+            double z_asp = 0.0, r_pow = r2;
+            for (int i = 0; i < ncoef; ++i) {
+                z_asp += coefs[i] * r_pow;
+                r_pow *= r2;
+            }
+            f = p.z - (z + z_asp);
+        } else {
+            srad_e = sqrt(rad_e);
+        }
+        const double e = slim_div(cv, srad_e);
+        double r_pow = 1, e_asp = 0.0;
+        for (int i = 0; i < ncoef; ++i) {
+            e_asp += dcoefs[i] * r_pow;         // (c_coef*coefs[i])*r_pow
+            r_pow *= r2;
+        }
+        e_tot = e + e_asp;
+    } else {
+        const double r = slim_sqrt(r2);
+        if (WANT_F && rad_e < 0.0)
+            return false;
+        const double srad_e = WANT_F ? slim_sqrt(rad_e) : sqrt(rad_e);   // NaN when negative
+        if (WANT_F) {
+            const double z = slim_div(cv * r2, 1. + srad_e);
+            double z_asp = 0.0, r_pow = r;
+            for (int i = 0; i < ncoef; ++i) {
+                z_asp += coefs[i] * r_pow;
+                r_pow *= r;
+            }
+            f = p.z - (z + z_asp);
+        }
+        const double e = slim_div(cv, srad_e);
+        double e_asp = 0.0;
+        double r_pow = (r == 0.0) ? 1.0 : 1 / r;
+        for (int i = 0; i < ncoef; ++i) {
+            e_asp += dcoefs[i] * r_pow;         // (c_coef*coef)*r_pow
+            r_pow *= r;
+        }
+        e_tot = e + e_asp;
+    }
+    df = v3{-e_tot * p.x, -e_tot * p.y, 1.0};
+    return true;
+}
+
+// profiles.py:155-186 Spencer & Murty Newton iteration.  Returns the last
+// *evaluated* iterate as the hit point (p0 itself when |s1| <= eps at once).
+template <int FEAT>
+__device__ __forceinline__ bool newton_hit(int kind, double cv, double cc1, double ec, double cR,
+                                           int ncoef, tblp coefs,
+                                           const v3 &p0, const v3 &d, double eps,
+                                           double &s, v3 &hit, v3 &df)
+{
+    v3 p = p0;
+    double f;
+    if (!poly_eval<FEAT, true>(kind, cv, cc1, ec, cR, ncoef, coefs, p, f, df))
+        return false;
+    double s1 = -f / dot3(d, df);
+    double delta = fabs(s1);
+    int iter = 0;
+    bool ok = true;
+    // one Spencer-Murty step for the lanes that have not converged
+    auto step = [&]() {
+        p = v3{p0.x + s1 * d.x, p0.y + s1 * d.y, p0.z + s1 * d.z};
+        if (!poly_eval<FEAT, true>(kind, cv, cc1, ec, cR, ncoef, coefs, p, f, df)) {
+            ok = false;
+            delta = 0.0;            // leave the iteration; the caller reports the miss
+            return;
+        }
+        const double s2 = s1 - f / dot3(d, df);
+        delta = fabs(s2 - s1);
+        s1 = s2;
+        ++iter;
+    };
+    // measured on the reference's even-asphere zoom: 2 steps 20 %, 3 steps 73 %,
+    // 4 steps 6 %, more < 1 % -- four steps straight-line and
+    // predicated per lane, then the residual loop (cap 1000 as in the reference)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (delta > eps)
+            step();
+    while (delta > eps && iter < 1000)
+        step();
+    if (!ok)
+        return false;
+    s = s1;
+    hit = p;        // df already holds df(hit): normal() re-evaluates the same expression
+    return true;
+}
+
+// surface.py:198-208 (+ interface.py:113-122, surface.py:416-419, 453-457)
+__device__ __forceinline__ bool inside_aperture(tblp row, int n_ap, double x,
+                                                double y, double fuzz)
+{
+    if (n_ap > 0) {
+        tblp ap = row + (offsetof(rox_surface, ap) / sizeof(double));
+        for (int k = 0; k < n_ap; ++k, ap += sizeof(rox_aperture) / sizeof(double)) {
+            const int2 ki{((tbli)ap)[0], ((tbli)ap)[1]};            // kind, is_obscuration
+            const double xx = x - ap[1];
+            const double yy = y - ap[2];
+            bool ans;
+            if (ki.x == ROX_AP_CIRCULAR)
+                ans = sqrt(xx * xx + yy * yy) <= ap[3] + fuzz;
+            else if (ki.x == ROX_AP_RECTANGULAR)
+                ans = (fabs(xx) <= ap[3] + fuzz) && (fabs(yy) <= ap[4] + fuzz);
+            else
+                return false;               // Elliptical: point_inside() returns None
+            if (ki.y)
+                ans = !ans;
+            if (!ans)
+                return false;
+        }
+        return true;
+    }
+    return sqrt(x * x + y * y) <= row[offsetof(rox_surface, max_aperture) / sizeof(double)] + fuzz;
+}
+
+// ------------------------------------------------------------------ phase
+// x**n as the reference's `r_sqr**(i+1)` evaluates it: libm pow(), which is
+// correctly rounded except for ~1e-3 of its arguments.  Here: the product in
+// double-double (error ~2^-100), rounded once -- the correctly rounded power.
+__device__ __forceinline__ double pow_int(double x, int n)
+{
+    if (n == 0)
+        return 1.0;
+    double hi = x, lo = 0.0;
+    for (int k = 1; k < n; ++k) {
+        const double ph = hi * x;
+        const double pl = fma(hi, x, -ph);
+        const double t = fma(lo, x, pl);
+        hi = ph + t;
+        lo = t - (hi - ph);
+    }
+    return hi;
+}
+
+enum { PHASE_OK = 0, PHASE_EVANESCENT = 1, PHASE_TIR = 2 };
+
+// raytrace.py:41-48 phase() over the phase element of the row.  ph points at
+// rox_surface.ph of the row; pc at the (wavelength, interface) grating
+// constants.  Returns PHASE_*; `out` = after_dir, `dW` = phs.
+__device__ __forceinline__ int apply_phase(tblp ph, tblp pc, const v3 &pt, const v3 &in_dir,
+                                           const v3 &srf_nrml, double z_dir, double wvl,
+                                           double n_in, double n_out, int mode, v3 &out,
+                                           double &dW)
+{
+    constexpr int O_ORDER = offsetof(rox_phase, order) / 8, O_REFWL = offsetof(rox_phase, ref_wl) / 8,
+                  O_SPACING = offsetof(rox_phase, spacing_nm) / 8, O_A = offsetof(rox_phase, a) / 8,
+                  O_B = offsetof(rox_phase, b) / 8, O_COEF = offsetof(rox_phase, coefs) / 8;
+    const int kind = ((tbli)ph)[0];
+    if (kind == ROX_PH_GRATING) {               // doe.py:124-175 phase_ludwig
+        const double refl = (mode == ROX_REFLECT) ? -1.0 : 1.0;
+        const v3 un = unit(srf_nrml);
+        const v3 normal{z_dir * un.x, z_dir * un.y, z_dir * un.z};
+        const v3 G{ph[O_A], ph[O_A + 1], ph[O_A + 2]};
+        const v3 P = cross3(G, normal);
+        const v3 D = unit(cross3(normal, P));
+        const double mu = pc[0], mu2 = pc[1], T = pc[2], T2 = pc[3];
+        const double in_cosI = dot3(in_dir, normal);
+        const double V = mu * in_cosI;
+        const double W = mu2 - 1 + T2 - 2 * mu * T * dot3(D, in_dir);
+        const double result = sqrt(V * V - W);  // np.sqrt: NaN, not an exception
+        const double Q1 = result - V;
+        const double Q2 = -result - V;
+        // Python's max(a, b) = b if b > a else a; min(a, b) = b if b < a else a
+        double Q = Q1;
+        if (mode == ROX_TRANSMIT)
+            Q = (Q2 > Q1) ? Q2 : Q1;
+        else if (mode == ROX_REFLECT)
+            Q = (Q2 < Q1) ? Q2 : Q1;
+        v3 o{mu * in_dir.x - T * D.x + Q * normal.x, mu * in_dir.y - T * D.y + Q * normal.y,
+             mu * in_dir.z - T * D.z + Q * normal.z};
+        const double rz = 1 - o.x * o.x - o.y * o.y;
+        if (rz < 0.0)
+            return PHASE_EVANESCENT;            // math.sqrt ValueError
+        o.z = copysign(sqrt(rz), o.z);
+        const double si = 1 - in_cosI * in_cosI;
+        if (si < 0.0)
+            return PHASE_EVANESCENT;
+        const double in_sinI = sqrt(si);
+        const double out_cosI = dot3(o, normal);
+        const double so = 1 - out_cosI * out_cosI;
+        if (so < 0.0)
+            return PHASE_EVANESCENT;
+        const double out_sinI = sqrt(so);
+        dW = (ph[O_SPACING] / wvl) * (n_in * in_sinI + refl * n_out * out_sinI);
+        out = o;
+        return PHASE_OK;
+    }
+    if (kind == ROX_PH_DOE_RADIAL) {            // doe.py:272-323 + radial_phase_fct :28-54
+        const double order = ph[O_ORDER];
+        const v3 normal = unit(srf_nrml);
+        v3 inc = in_dir;
+        if (n_in != 1.0) {
+            if (!refract(in_dir, srf_nrml, n_in, 1.0, inc))
+                return PHASE_TIR;
+        }
+        const double in_cosI = dot3(inc, normal);
+        const double mu = wvl / ph[O_REFWL];
+        const double r_sqr = pt.x * pt.x + pt.y * pt.y;
+        double w = 0, dWdX = 0, dWdY = 0;
+        const int nc = ((tbli)ph)[1];
+        for (int i = 0; i < nc; ++i) {
+            const double c = ph[O_COEF + i];
+            w += c * pow_int(r_sqr, i + 1);
+            const double r_exp = pow_int(r_sqr, i);
+            const double fc = (double)(2 * (i + 1)) * c;
+            dWdX += fc * pt.x * r_exp;
+            dWdY += fc * pt.y * r_exp;
+        }
+        const double om = order * mu;
+        const double b = in_cosI + om * (normal.x * dWdX + normal.y * dWdY);
+        const double c = mu * (mu * (dWdX * dWdX + dWdY * dWdY) / 2 +
+                               order * (inc.x * dWdX + inc.y * dWdY));
+        const double rad = b * b - 2 * c;
+        if (rad < 0.0)
+            return PHASE_EVANESCENT;
+        const double Q = -b + z_dir * sqrt(rad);
+        v3 o{inc.x + om * dWdX + Q * normal.x, inc.y + om * dWdY + Q * normal.y,
+             inc.z + om * 0.0 + Q * normal.z};
+        dW = w * mu;
+        if (n_in != 1.0) {
+            v3 o2;
+            if (!refract(o, srf_nrml, 1.0, n_out, o2))
+                return PHASE_TIR;
+            o = o2;
+        }
+        out = o;
+        return PHASE_OK;
+    }
+    // ROX_PH_HOLOGRAM, doe.py:375-397
+    const int flags = ((tbli)ph)[2];
+    const v3 normal = unit(srf_nrml);
+    v3 ref_dir = unit(v3{pt.x - ph[O_A], pt.y - ph[O_A + 1], pt.z - ph[O_A + 2]});
+    if (flags & 1)
+        ref_dir = v3{-ref_dir.x, -ref_dir.y, -ref_dir.z};
+    const double ref_cosI = dot3(ref_dir, normal);
+    v3 obj_dir = unit(v3{pt.x - ph[O_B], pt.y - ph[O_B + 1], pt.z - ph[O_B + 2]});
+    if (flags & 2)
+        obj_dir = v3{-obj_dir.x, -obj_dir.y, -obj_dir.z};
+    const double obj_cosI = dot3(obj_dir, normal);
+    const double in_cosI = dot3(in_dir, normal);
+    const double mu = wvl / ph[O_REFWL];
+    const double b = in_cosI + mu * (obj_cosI - ref_cosI);
+    const double refp_cosI = dot3(ref_dir, in_dir);
+    const double objp_cosI = dot3(obj_dir, in_dir);
+    const double ro_cosI = dot3(ref_dir, obj_dir);
+    const double c = mu * (mu * (1.0 - ro_cosI) + (objp_cosI - refp_cosI));
+    const double rad = b * b - 2 * c;
+    if (rad < 0.0)
+        return PHASE_EVANESCENT;
+    const double Q = -b + z_dir * sqrt(rad);
+    out = v3{in_dir.x + mu * (obj_dir.x - ref_dir.x) + Q * normal.x,
+             in_dir.y + mu * (obj_dir.y - ref_dir.y) + Q * normal.y,
+             in_dir.z + mu * (obj_dir.z - ref_dir.z) + Q * normal.z};
+    dW = 0.;
+    return PHASE_OK;
+}
+
+// ------------------------------------------------------------------ OPD
+// waveabr.py:117-132 eic_distance
+__device__ __forceinline__ double eic_distance(const v3 &p, const v3 &d, const double *p0,
+                                               const double *d0)
+{
+    const v3 sd{d.x + d0[0], d.y + d0[1], d.z + d0[2]};
+    const v3 dp{p.x - p0[0], p.y - p0[1], p.z - p0[2]};
+    return dot3(sd, dp) / (1. + dot3(d, v3{d0[0], d0[1], d0[2]}));
+}
+
+// waveabr.py:256-307 wave_abr_full_calc_finite_pup (+ transform.py:234-258)
+__device__ __forceinline__ double wave_abr_finite_pup(const rox_wavefront &w, const v3 &ray1_p,
+                                                      const v3 &ray0_d, const v3 &rayk_p,
+                                                      const v3 &rayk_d, double ray_op)
+{
+    const double e1 = eic_distance(ray1_p, ray0_d, w.cr1_p, w.cr0_d);
+    const double ekp = eic_distance(rayk_p, rayk_d, w.crk_p, w.crk_d);
+    v3 b4p = rayk_p, b4d = rayk_d;
+    if (w.after_kind != 0) {
+        const v3 t{rayk_p.x - w.after_t[0], rayk_p.y - w.after_t[1], rayk_p.z - w.after_t[2]};
+        if (w.after_kind == 1) {
+            b4p = t;
+        } else {
+            b4p = rotate(w.after_rt, w.after_order, t);
+            b4d = rotate(w.after_rt, w.after_order, rayk_d);
+        }
+    }
+    const double dst = ekp - w.cr_exp_dist;
+    const v3 pc{(b4p.x - dst * b4d.x) - w.cr_exp_pt[0], (b4p.y - dst * b4d.y) - w.cr_exp_pt[1],
+                (b4p.z - dst * b4d.z) - w.cr_exp_pt[2]};
+    const v3 rd{w.ref_dir[0], w.ref_dir[1], w.ref_dir[2]};
+    const double R = w.ref_radius;
+    const double F = dot3(rd, b4d) - dot3(b4d, pc) / R;
+    const double J = dot3(pc, pc) / R - 2.0 * dot3(rd, pc);
+    const double denom = F + w.sign_soln * sqrt(F * F + J / R);
+    const double ep = (denom == 0) ? 0 : J / denom;
+    return -w.n_obj * e1 - ray_op + w.n_img * ekp + w.cr_op - w.n_img * ep;
+}
+
+// ------------------------------------------------------------------ stores
+// One packet component of ray r lives at seg[(slot*10 + c)*ld + r].  The
+// (slot, c) part is wave-uniform, so it goes into an SGPR base; the ray part
+// is one 32-bit byte offset per lane computed once per ray: the store is
+// `global_store_dwordx2 v_off, v_data, s[base:base+1]` with no per-store
+// 64-bit VALU address arithmetic.  (The host splits batches longer than 2^28
+// rays into several launches so that the lane offset always fits 32 bits.)
+struct SegOut {
+    char *base;         // uniform: seg (already offset to this launch's first ray)
+    int64_t row_bytes;  // uniform: ld * 8
+    uint32_t voff;      // per lane: (r - first ray of the launch) * 8 < 2^32
+    __device__ __forceinline__ void put(int slot, int c, double v) const
+    {
+        char *b = base + ((int64_t)slot * ROX_SEG_DOUBLES + c) * row_bytes;
+        double *p = reinterpret_cast<double *>(b + (size_t)voff);
+#if ROX_STORE_NT == 1
+        __builtin_nontemporal_store(v, p);
+#else
+        *p = v;
+#endif
+    }
+    __device__ __forceinline__ void pdn(int slot, const v3 &p, const v3 &d, const v3 &n) const
+    {
+        put(slot, 0, p.x); put(slot, 1, p.y); put(slot, 2, p.z);
+        put(slot, 3, d.x); put(slot, 4, d.y); put(slot, 5, d.z);
+        put(slot, 7, n.x); put(slot, 8, n.y); put(slot, 9, n.z);
+    }
+    __device__ __forceinline__ void dst(int slot, double v) const { put(slot, 6, v); }
+};
+
+// the workgroup's view of the surface table (LDS) + the launch options
+struct Ctx {
+    tblp tbl;               // [N][kRowDoubles]
+    tblp ntab;              // [N] (one wavelength) or [W][N] (per-ray wavelengths)
+    tblp phc;               // [N][kPhaseConsts] or [W][N][kPhaseConsts]; FEAT & F_PHASE only
+    tblp wvls;              // [W]
+    tbli slot, nslots_before;
+    int N;
+    bool check_ap, intersect_obj, filter_ph;
+    int first_surf, last_surf;
+    double eps, fuzz;
+    int probe_surf;         // MODE_PROBE
+};
+
+// what a traced ray leaves in registers for the epilogues
+struct RayEnd {
+    int status, fail_surf;
+    double opl, phs;        // op_delta = phs + opl on success (raytrace.py:208, 261)
+    v3 inc, ad, nrm;        // ray[-1]
+    v3 ray1_p, rayk_p, rayk_d;   // OPD mode: ray[1].p, ray[-2].{p, d}
+    v3 probe_p;             // MODE_PROBE: ray[probe_surf].p
+};
+
+// ------------------------------------------------------------------ one ray
+// raytrace.py:83-264 trace_raw for one lane.  wi = wavelength index of the ray
+// (wave-uniform unless PER_RAY_WVL).
+// `live` = false for the lanes past the end of the batch: they trace nothing.
+#if ROX_WG_SYNC     // every wave must reach every barrier: lanes idle instead of leaving
+#define ROX_LEAVE continue
+#else
+#define ROX_LEAVE break
+#endif
+template <int OUT_MODE, bool PER_RAY_WVL, int FEAT>
+__device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const v3 &pt0,
+                                          const v3 &dir0, int wi, bool live, RayEnd &e)
+{
+    constexpr int O_CV = offsetof(rox_surface, cv) / 8, O_CC = offsetof(rox_surface, cc) / 8,
+                  O_EC = offsetof(rox_surface, ec) / 8, O_CR = offsetof(rox_surface, cR) / 8,
+                  O_COEF = offsetof(rox_surface, coefs) / 8,
+                  O_RT = offsetof(rox_surface, rt) / 8, O_T = offsetof(rox_surface, t) / 8,
+                  O_ZDIR = offsetof(rox_surface, z_dir) / 8,
+                  O_PH = offsetof(rox_surface, ph) / 8;
+    constexpr bool kPoly = (FEAT & F_POLY) != 0;
+    const int N = c.N;
+    tblp tbl = c.tbl;
+    tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
+#define SLOT(s) ((FEAT & F_PHFILT) ? c.slot[s] : (s))
+#define NSLOTS_BEFORE(s) ((FEAT & F_PHFILT) ? c.nslots_before[s] : (s))
+    // without phantom filtering segment k of a packet is interface k
+
+    // ---- object surface, raytrace.py:145-158 -----------------------------
+    int status = live ? ROX_OK : 255, fail_surf = -1;
+    v3 bp, bn, bd = dir0;               // before_pt, before_normal, before_dir
+    int b4_mode = ROX_DUMMY;
+    if (live) {
+        tblp row = tbl;
+        if (c.intersect_obj) {
+            const int2 mp{((tbli)row)[0], ((tbli)row)[1]};      // mode, profile
+            b4_mode = mp.x;
+            double s_;
+            v3 df;
+            bool ok;
+            if ((FEAT & F_PHASE) && mp.y == ROX_THINLENS) {     // thinlens.py:131-134
+                s_ = -pt0.z / dir0.z;
+                bp = v3{pt0.x + s_ * dir0.x, pt0.y + s_ * dir0.y, pt0.z + s_ * dir0.z};
+                ok = true;
+            } else if (!kPoly || mp.y <= ROX_CONIC) {
+                ok = quadric_hit(mp.y == ROX_CONIC, row[O_CV], row[O_CC], row[O_EC], pt0, dir0,
+                                 row[O_ZDIR], s_, bp);
+                const double k = (mp.y == ROX_CONIC) ? (row[O_CC] + 1.0) * row[O_CV] : row[O_CV];
+                df = v3{-row[O_CV] * bp.x, -row[O_CV] * bp.y, 1.0 - k * bp.z};
+            } else {
+                ok = newton_hit<FEAT>(mp.y, row[O_CV], row[O_CC] + 1.0, row[O_EC], row[O_CR],
+                                      ((tbli)row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
+            }
+            if (!ok) {              // raised outside the try block: no packet
+                status = ROX_MISSED_SURFACE;
+                fail_surf = 0;
+            } else if ((FEAT & F_PHASE) && mp.y == ROX_THINLENS) {
+                bn = v3{0., 0., 1.};
+            } else {
+                bn = unit(df);
+            }
+        } else {
+            bp = pt0;
+            bn = v3{0., 0., 1.};
+        }
+    }
+    double z_dir_before = tbl[O_ZDIR];
+    double opl = 0.0, phs = 0.0;
+    double acc_dst = 0.0;           // dst of the most recently appended segment
+    int acc_slot = 0;
+    v3 inc{0, 0, 0}, nrm{0, 0, 0}, ad = dir0;
+    e.ray1_p = e.rayk_p = e.rayk_d = e.probe_p = v3{0, 0, 0};
+    if (OUT_MODE == MODE_PROBE && c.probe_surf == 0)
+        e.probe_p = bp;
+    if (OUT_MODE == ROX_OUT_FULL && status == ROX_OK)
+        so.pdn(0, bp, bd, bn);
+
+    // ---- remaining surfaces, raytrace.py:164-229 -------------------------
+#if ROX_WG_SYNC
+    for (int surf = 1; surf < N; ++surf) {
+        __builtin_amdgcn_s_barrier();
+        if (status != ROX_OK)
+            continue;
+#else
+    for (int surf = 1; surf < N && status == ROX_OK; ++surf) {
+#endif
+        tblp prow = tbl + (size_t)(surf - 1) * kRowDoubles;     // `before`
+        tblp row = tbl + (size_t)surf * kRowDoubles;             // `after`
+        const int mode = ((tbli)row)[0], prof = ((tbli)row)[1];
+        const double cv = row[O_CV];
+        const bool thin = (FEAT & F_PHASE) && prof == ROX_THINLENS;
+
+        // :170-174 transform to the new vertex frame, closest approach
+        const int rt_order = ((tbli)prow)[4];
+        const v3 b4p = rotate(prow + O_RT, rt_order, v3{bp.x - prow[O_T], bp.y - prow[O_T + 1],
+                                                        bp.z - prow[O_T + 2]});
+        const v3 b4d = rotate(prow + O_RT, rt_order, bd);
+        const double pp_dst = -dot3(b4p, b4d);
+        const v3 pp{b4p.x + pp_dst * b4d.x, b4p.y + pp_dst * b4d.y, b4p.z + pp_dst * b4d.z};
+
+        // :181-183 intersect
+        double s;
+        v3 df;
+        bool ok;
+        if (thin) {
+            s = -pp.z / b4d.z;
+            inc = v3{pp.x + s * b4d.x, pp.y + s * b4d.y, pp.z + s * b4d.z};
+            ok = true;
+        } else if (!kPoly || prof <= ROX_CONIC) {
+            ok = quadric_hit(prof == ROX_CONIC, cv, row[O_CC], row[O_EC], pp, b4d,
+                             z_dir_before, s, inc);
+        } else {
+            ok = newton_hit<FEAT>(prof, cv, row[O_CC] + 1.0, row[O_EC], row[O_CR],
+                                  ((tbli)row)[2], row + O_COEF, pp, b4d, c.eps, s, inc, df);
+        }
+        const bool b4_filtered = c.filter_ph && (b4_mode == ROX_PHANTOM);
+        if (!ok) {                                  // :231-237
+            status = ROX_MISSED_SURFACE;
+            fail_surf = surf;
+            if (OUT_MODE == ROX_OUT_FULL) {
+                const int sl = b4_filtered ? NSLOTS_BEFORE(surf - 1) : SLOT(surf - 1);
+                if (b4_filtered)
+                    so.pdn(sl, bp, bd, bn);
+                so.dst(sl, pp_dst);
+            }
+            ROX_LEAVE;
+        }
+        const double dst_b4 = pp_dst + s;
+        // :185-191 the *previous* segment is completed only now
+        if (b4_filtered) {
+            acc_dst += dst_b4;
+        } else {
+            acc_dst = dst_b4;
+            acc_slot = SLOT(surf - 1);
+        }
+        if (OUT_MODE == ROX_OUT_FULL)
+            so.dst(acc_slot, acc_dst);
+
+        // :193-194 (in_gap_range, :123-132)
+        {
+            const int g = surf - 1;
+            const bool in_gap = !(c.last_surf >= 0 && c.first_surf == c.last_surf) &&
+                                g >= c.first_surf && (c.last_surf < 0 || g < c.last_surf);
+            if (in_gap)
+                opl += nwl[surf - 1] * dst_b4;
+        }
+
+        // :196 normal = normalize(df(inc_pt))
+        if (thin) {
+            nrm = v3{0., 0., 1.};
+        } else {
+            if (!kPoly || prof <= ROX_CONIC) {
+                const double k = (prof == ROX_CONIC) ? (row[O_CC] + 1.0) * cv : cv;
+                df = v3{-cv * inc.x, -cv * inc.y, 1.0 - k * inc.z};
+            }
+            nrm = unit(df);
+        }
+
+        // :198-202 aperture test (in_surface_range, :134-142)
+        if (c.check_ap && surf >= c.first_surf && (c.last_surf < 0 || surf <= c.last_surf) &&
+            mode != ROX_PHANTOM) {
+            const bool in = (FEAT & F_APLIST)
+                ? inside_aperture(row, ((tbli)row)[3], inc.x, inc.y, c.fuzz)
+                : slim_sqrt(inc.x * inc.x + inc.y * inc.y) <=
+                      row[offsetof(rox_surface, max_aperture) / 8] + c.fuzz;
+            if (!in)
+                status = ROX_BLOCKED;               // :247-251
+        }
+
+        // :205-221 phase element, or refract / reflect / pass through
+        if (status == ROX_OK) {
+            if ((FEAT & F_PHASE) && ((tbli)(row + O_PH))[0] != ROX_PH_NONE) {
+                double dW = 0.0;
+                tblp pc = c.phc + ((PER_RAY_WVL ? (size_t)wi * N : 0) + surf) * kPhaseConsts;
+                const int rc = apply_phase(row + O_PH, pc, inc, b4d, nrm, z_dir_before,
+                                           c.wvls[wi], nwl[surf - 1], nwl[surf], mode, ad, dW);
+                if (rc == PHASE_OK)
+                    phs += dW;
+                else
+                    status = (rc == PHASE_TIR) ? ROX_TIR : ROX_EVANESCENT;    // :253-257
+            } else if (mode == ROX_REFLECT) {
+                ad = mirror(b4d, nrm);
+            } else if (mode == ROX_TRANSMIT) {
+                if (!refract(b4d, nrm, nwl[surf - 1], nwl[surf], ad))
+                    status = ROX_TIR;               // :239-245
+            } else {
+                ad = b4d;
+            }
+        }
+        if (status != ROX_OK) {
+            // partial packet: [inc_pt, before_dir, 0.0, normal] in the next slot
+            fail_surf = surf;
+            if (OUT_MODE == ROX_OUT_FULL) {
+                const int sl = NSLOTS_BEFORE(surf);
+                so.pdn(sl, inc, bd, nrm);
+                so.dst(sl, 0.0);
+            }
+            ROX_LEAVE;
+        }
+
+        if (OUT_MODE == ROX_OUT_OPD) {
+            if (surf == 1)
+                e.ray1_p = inc;
+            if (surf == N - 2) {
+                e.rayk_p = inc;
+                e.rayk_d = ad;
+            }
+        }
+        if (OUT_MODE == MODE_PROBE && surf == c.probe_surf)
+            e.probe_p = inc;
+        // :223-229 roll
+        bp = inc; bd = ad;
+        if (FEAT & F_PHFILT)
+            bn = nrm;           // only a filtered phantom's late append needs it
+        z_dir_before = row[O_ZDIR];
+        b4_mode = mode;
+        if (OUT_MODE == ROX_OUT_FULL) {
+            const bool cur_filtered = c.filter_ph && (mode == ROX_PHANTOM) && surf < N - 1;
+            if (!cur_filtered)
+                so.pdn(SLOT(surf), inc, ad, nrm);
+        }
+    }
+    if (OUT_MODE == ROX_OUT_FULL && status == ROX_OK)   // :259-262
+        so.dst(SLOT(N - 1), 0.0);
+#undef SLOT
+#undef NSLOTS_BEFORE
+#undef ROX_LEAVE
+    e.status = status;
+    e.fail_surf = fail_surf;
+    e.opl = opl;
+    e.phs = phs;
+    e.inc = inc; e.ad = ad; e.nrm = nrm;
+}
+
+// ------------------------------------------------------------------ ray start
+// opticalspec.py:1339-1353 apply_vignetting + :289-400 ray_start_from_osp +
+// trace.py:302-308.  pupil (px, py) is updated in place (the reference's quirk).
+__device__ __forceinline__ void ray_start(const rox_field &f, uint32_t flags, double &px,
+                                          double &py, v3 &pt0, v3 &dir0)
+{
+    if (flags & ROX_APPLY_VIGNETTING) {         // opticalspec.py:1339-1353
+        if (px < 0.0) { if (f.vlx != 0.0) px *= (1.0 - f.vlx); }
+        else          { if (f.vux != 0.0) px *= (1.0 - f.vux); }
+        if (py < 0.0) { if (f.vly != 0.0) py *= (1.0 - f.vly); }
+        else          { if (f.vuy != 0.0) py *= (1.0 - f.vuy); }
+    }
+    pt0 = v3{f.pt0[0], f.pt0[1], f.pt0[2]};
+    const int kind = f.kind;                    // wave-uniform
+    if (kind <= ROX_FLD_AIM_PT) {
+        v3 pt1;
+        if (kind == ROX_FLD_EPD) {              // :358-366
+            pt1 = v3{f.eprad * px + f.aim[0], f.eprad * py + f.aim[1], f.z_enp};
+        } else if (kind == ROX_FLD_AIM_PT) {    // :334-337
+            pt1 = v3{px, py, f.z_enp};
+        } else {                                // :340-356 wide angle
+            pt1 = rotate(f.rot, f.rot_order, v3{f.eprad * px, f.eprad * py, f.eprad * 0.});
+            pt1.z -= f.z_enp;
+        }
+        dir0 = unit(v3{pt1.x - pt0.x, pt1.y - pt0.y, pt1.z - pt0.z});
+    } else {                                    // :368-398 angular measures
+        double dx, dy;
+        if (kind == ROX_FLD_NA) {
+            dx = f.eprad * px;
+            dy = f.eprad * py;
+        } else if (kind == ROX_FLD_FNO) {
+            const double slope = f.eprad;
+            const double ax = px * slope, ay = py * slope;
+            const double hypt = sqrt(1 + ax * ax + ay * ay);
+            dx = slope * px / hypt;
+            dy = slope * py / hypt;
+        } else {
+            dx = px;
+            dy = py;
+        }
+        if (kind != ROX_FLD_AIM_DIR) {
+            dx += f.cr_dir[0];
+            dy += f.cr_dir[1];
+        }
+        const double dd = fma(dy, dy, fma(dx, dx, 0.0));    // np.dot of 2-vectors
+        dir0 = v3{dx, dy, sqrt(1 - dd)};
+    }
+    if (kind != ROX_FLD_EPD_WIDE && dir0.z * f.z_dir0 < 0)   // trace.py:304-308
+        dir0 = v3{-dir0.x, -dir0.y, -dir0.z};
+}
+
+// ------------------------------------------------------------------ compaction
+// tile_state word: epoch << 32 | flag << 30 | count  (count < 2^30)
+enum : uint64_t { TS_AGG = 1, TS_PREFIX = 2 };
+__device__ __forceinline__ uint64_t ts_pack(uint32_t epoch, uint64_t flag, uint32_t count)
+{
+    return ((uint64_t)epoch << 32) | (flag << 30) | count;
+}
+
+// ------------------------------------------------------------------ the kernel
+template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT>
+__global__ void __launch_bounds__(kBlock, ROX_MIN_WAVES)
+trace_kernel(const TraceArgs a)
+{
+    constexpr bool kCompact = (OUT_MODE == ROX_OUT_HITS_COMPACT);
+    const int N = a.n_ifcs;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *tbl_w = lds;                               // [N][kRowDoubles]
+    const int nw_rows = PER_RAY_WVL ? a.n_wvls : 1;
+    double *ntab_w = tbl_w + (size_t)N * kRowDoubles;  // [W][N] (or [N] for one wavelength)
+    double *phc_w = ntab_w + (size_t)nw_rows * N;      // [W][N][4] (F_PHASE only)
+    double *wvls_w = phc_w + ((FEAT & F_PHASE) ? (size_t)nw_rows * N * kPhaseConsts : 0);
+    int32_t *slot_w = reinterpret_cast<int32_t *>(wvls_w + a.n_wvls);
+
+    // stage the surface table once per workgroup
+    for (int i = threadIdx.x; i < N * kRowDoubles; i += kBlock)
+        tbl_w[i] = a.rows[i];
+    {
+        const size_t w0 = PER_RAY_WVL ? 0 : (size_t)a.wvl_idx_all * N;
+        for (int i = threadIdx.x; i < nw_rows * N; i += kBlock)
+            ntab_w[i] = a.n_table[w0 + i];
+        if (FEAT & F_PHASE)
+            for (int i = threadIdx.x; i < nw_rows * N * kPhaseConsts; i += kBlock)
+                phc_w[i] = a.ph_consts[w0 * kPhaseConsts + i];
+    }
+    for (int i = threadIdx.x; i < a.n_wvls; i += kBlock)
+        wvls_w[i] = a.wvls[i];
+    for (int i = threadIdx.x; i < 2 * N; i += kBlock)
+        slot_w[i] = a.slots[i];
+    __syncthreads();
+
+    Ctx c;
+    c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
+    c.slot = slot_w; c.nslots_before = slot_w + N;
+    c.N = N;
+    const uint32_t flags = a.opts.flags;
+    c.check_ap = flags & ROX_CHECK_APERTURES;
+    c.intersect_obj = flags & ROX_INTERSECT_OBJ;
+    c.filter_ph = (FEAT & F_PHFILT) && (flags & ROX_FILTER_PHANTOMS);
+    c.first_surf = a.opts.first_surf; c.last_surf = a.opts.last_surf;
+    c.eps = a.opts.eps; c.fuzz = a.opts.fuzz;
+    c.probe_surf = -1;
+    const int64_t ld = a.out.ld;
+    const int64_t n_tiles = (a.n_rays + kBlock - 1) / kBlock;
+
+    // HITS_COMPACT: tiles are handed out by ticket, so that the tile a workgroup
+    // waits for in the look-back is always held by a running workgroup
+    __shared__ int64_t s_tile;
+    __shared__ int32_t s_wcnt[kWaves];
+    __shared__ uint32_t s_excl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    for (int64_t it = 0;; ++it) {
+        int64_t tile;
+        if (kCompact) {
+            if (threadIdx.x == 0)
+                s_tile = (int64_t)atomicAdd(&a.ticket[0], 1u);
+            __syncthreads();
+            tile = s_tile;
+        } else {
+            tile = (int64_t)blockIdx.x + it * gridDim.x;
+        }
+        if (tile >= n_tiles)
+            break;
+        const int64_t r = tile * kBlock + threadIdx.x;
+        const bool active = r < a.n_rays;
+        RayEnd e;
+        SegOut so;
+        so.base = reinterpret_cast<char *>(a.out.seg);
+        so.row_bytes = ld * 8;
+        so.voff = (uint32_t)r * 8u;
+        v3 pt0{0, 0, 0}, dir0{0, 0, 1};
+        int wi = a.wvl_idx_all;
+        bool wi_ok = true;
+        if (active) {
+            // ---- ray start ---------------------------------------------------
+            const int64_t rg = a.ray_base + r;
+            if (GEN == GEN_PUPIL) {
+                double px, py;
+                if (a.axis_kind == AXIS_PRODUCT) {
+                    px = a.px[a.row_begin + rg / a.axis_num];
+                    py = a.py[rg % a.axis_num];
+                } else {
+                    px = a.px[rg];
+                    py = a.py[rg];
+                }
+                ray_start(a.fld, flags, px, py, pt0, dir0);
+                if (!kCompact && a.out.pupil) {
+                    a.out.pupil[r] = px;
+                    a.out.pupil[ld + r] = py;
+                }
+            } else {
+                pt0 = v3{a.pt0[rg], a.pt0[a.in_ld + rg], a.pt0[2 * a.in_ld + rg]};
+                dir0 = v3{a.dir0[rg], a.dir0[a.in_ld + rg], a.dir0[2 * a.in_ld + rg]};
+            }
+            if (PER_RAY_WVL) {
+                wi = a.wvl_idx[rg];
+                wi_ok = (wi >= 0 && wi < a.n_wvls);     // a bad index never reaches the table
+                if (!wi_ok)
+                    wi = 0;
+            }
+        }
+        trace_ray<OUT_MODE, PER_RAY_WVL, FEAT>(c, so, pt0, dir0, wi, active, e);
+        if (active) {
+            if (PER_RAY_WVL && !wi_ok) {
+                // reported as a miss at the object surface; no packet
+                e.status = ROX_MISSED_SURFACE;
+                e.fail_surf = 0;
+                e.opl = __builtin_nan("");
+            }
+
+            // ---- per-ray outputs ---------------------------------------------
+            if (e.status == ROX_OK) {
+                if (OUT_MODE == ROX_OUT_LAST) {             // trace.py:214-217
+                    so.pdn(0, e.inc, e.ad, e.nrm);
+                    so.dst(0, 0.0);
+                } else if (OUT_MODE == ROX_OUT_OPD) {
+                    so.put(0, 0, wave_abr_finite_pup(a.opts.wf, e.ray1_p, dir0, e.rayk_p,
+                                                     e.rayk_d, e.phs + e.opl));
+                } else if (OUT_MODE == ROX_OUT_HITS) {      // axisarrayfigure.py:229-238
+                    const double dist = a.opts.foc / e.ad.z;
+                    so.put(0, 0, (e.inc.x + dist * e.ad.x) - a.opts.image_pt[0]);
+                    so.put(0, 1, (e.inc.y + dist * e.ad.y) - a.opts.image_pt[1]);
+                }
+            }
+            if (!kCompact) {
+                if (a.out.op)       // op_delta = phs + opl on success; opl on failure (:236)
+                    a.out.op[r] = (e.status == ROX_OK) ? e.phs + e.opl : e.opl;
+                if (a.out.fail_surf)
+                    a.out.fail_surf[r] = (int16_t)e.fail_surf;
+            }
+            if (a.out.status)
+                a.out.status[r] = (uint8_t)e.status;
+        }
+
+        if (kCompact) {
+            // ---- stable compaction of the hits: ballot ranks within the wave,
+            // wave counts through LDS, tile prefix by decoupled look-back ---------
+            const bool ok = active && e.status == ROX_OK;
+            const uint64_t mask = __ballot(ok);
+            const int lrank = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0)
+                s_wcnt[wave] = __popcll(mask);
+            __syncthreads();
+            int woff = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                const int cnt = s_wcnt[w];
+                if (w < wave)
+                    woff += cnt;
+                total += cnt;
+            }
+            if (wave == 0) {
+                uint32_t excl = 0;
+                uint64_t *st = a.tile_state;
+                if (tile == 0) {
+                    if (lane == 0)
+                        __hip_atomic_store(&st[0], ts_pack(a.epoch, TS_PREFIX, (uint32_t)total),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    if (lane == 0)
+                        __hip_atomic_store(&st[tile], ts_pack(a.epoch, TS_AGG, (uint32_t)total),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int64_t look = tile - 1;
+                    for (;;) {
+                        const int64_t idx = look - lane;
+                        uint64_t w = ts_pack(a.epoch, TS_PREFIX, 0);    // before tile 0
+                        if (idx >= 0)
+                            w = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const bool ready = (uint32_t)(w >> 32) == a.epoch && ((w >> 30) & 3u) != 0;
+                        const bool is_pref = ready && ((w >> 30) & 3u) == TS_PREFIX;
+                        const uint64_t rmask = __ballot(ready), pmask = __ballot(is_pref);
+                        const int first_not = (~rmask) ? __builtin_ctzll(~rmask) : 64;
+                        const int first_pref = pmask ? __builtin_ctzll(pmask) : 64;
+                        if (first_pref < first_not) {
+                            uint32_t v = (lane <= first_pref) ? (uint32_t)(w & 0x3fffffffu) : 0u;
+                            for (int o = 32; o > 0; o >>= 1)
+                                v += __shfl_xor(v, o);
+                            excl += v;
+                            break;
+                        }
+                        if (first_not == 64) {      // 64 aggregates: take them, look further back
+                            uint32_t v = (uint32_t)(w & 0x3fffffffu);
+                            for (int o = 32; o > 0; o >>= 1)
+                                v += __shfl_xor(v, o);
+                            excl += v;
+                            look -= 64;
+                        } else {
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                    if (lane == 0)
+                        __hip_atomic_store(&st[tile], ts_pack(a.epoch, TS_PREFIX, excl + (uint32_t)total),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (lane == 0)
+                    s_excl = excl;
+            }
+            __syncthreads();
+            const int64_t base = a.first_chunk ? 0 : *a.hits_base;
+            const int64_t at = base + (int64_t)s_excl + woff + lrank;
+            if (ok) {
+                const double dist = a.opts.foc / e.ad.z;
+                d2 xy;
+                xy.x = (e.inc.x + dist * e.ad.x) - a.opts.image_pt[0];
+                xy.y = (e.inc.y + dist * e.ad.y) - a.opts.image_pt[1];
+                __builtin_nontemporal_store(xy, reinterpret_cast<d2 *>(a.out.seg) + at);
+            }
+            if (tile == n_tiles - 1 && threadIdx.x == 0) {
+                const int64_t all = base + (int64_t)s_excl + total;
+                if (a.last_chunk)
+                    *a.out.n_hits = all;
+                else
+                    *a.hits_base = all;         // read by the next launch of this call
+            }
+        }
+    }
+    if (kCompact && threadIdx.x == 0) {
+        // the last workgroup out re-arms the ticket for the next launch of this
+        // stream context (every workgroup leaves exactly once, after its last draw)
+        if (atomicAdd(&a.ticket[1], 1u) == gridDim.x - 1) {
+            __hip_atomic_store(&a.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ launching
+struct LaunchCfg {
+    int gen;            // GEN_*
+    bool per_ray_wvl;
+    int out_mode;       // ROX_OUT_*
+    dim3 grid;
+    size_t lds;
+    hipStream_t stream;
+};
+
+template <int GEN, bool PRW, int FEAT>
+inline void launch_mode(const LaunchCfg &k, const TraceArgs &a)
+{
+    const dim3 block(kBlock);
+    switch (k.out_mode) {
+    case ROX_OUT_FULL:
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_FULL, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        break;
+    case ROX_OUT_LAST:
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_LAST, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        break;
+    case ROX_OUT_OPD:
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_OPD, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        break;
+    case ROX_OUT_HITS_COMPACT:
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_HITS_COMPACT, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        break;
+    default:
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_HITS, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        break;
+    }
+}
+
+// all (output mode, ray source) variants of one feature instance
+template <int FEAT>
+inline void launch_instance(const LaunchCfg &k, const TraceArgs &a)
+{
+    if (k.gen == GEN_PUPIL)
+        launch_mode<GEN_PUPIL, false, FEAT>(k, a);
+    else if (k.per_ray_wvl)
+        launch_mode<GEN_RAYS, true, FEAT>(k, a);
+    else
+        launch_mode<GEN_RAYS, false, FEAT>(k, a);
+}
+
+// the feature instances that are compiled (one translation unit each,
+// csrc/inst_*.hip); the host launches the first one that covers the need
+constexpr int kInstances[] = {0, F_EVEN, F_RADIAL, F_POLY, F_APLIST, F_ALL};
+void launch_lean(const LaunchCfg &, const TraceArgs &);
+void launch_even(const LaunchCfg &, const TraceArgs &);
+void launch_radial(const LaunchCfg &, const TraceArgs &);
+void launch_poly(const LaunchCfg &, const TraceArgs &);
+void launch_aplist(const LaunchCfg &, const TraceArgs &);
+void launch_general(const LaunchCfg &, const TraceArgs &);
+
+// chief-ray aiming (csrc/inst_aim.hip)
+struct AimArgs {
+    const double *rows, *n_table, *ph_consts, *wvls;
+    const int32_t *slots;
+    int32_t n_ifcs, n_wvls, n;
+    const rox_aim *probs;      // device
+    double eps;
+    double *aim_y;             // device [n]
+    int32_t *result;           // device [n]
+};
+void launch_aim(const AimArgs &, size_t lds, hipStream_t);
+
+}  // namespace rox

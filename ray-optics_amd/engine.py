@@ -29,8 +29,10 @@ def load_library():
         # process *before* libroxtrace.so (linked against the same SONAME)
         # is dlopen'ed, or the two sides would not share device pointers
         import torch  # noqa: F401
-        if not os.path.exists(LIB_PATH) and not os.environ.get('ROX_LIB'):
-            # not built yet (fresh checkout): compile the HIP source in-tree now
+        if not os.environ.get('ROX_LIB'):
+            # missing (fresh checkout) or stale (a source, header or flag changed
+            # since it was built -- build.py compares a digest of its inputs):
+            # compile the HIP sources in-tree now.  A stale library is never loaded.
             try:
                 import importlib.util
                 spec = importlib.util.spec_from_file_location(
@@ -40,7 +42,7 @@ def load_library():
                 b.build()
             except Exception as e:
                 raise EngineError(
-                    f'{LIB_PATH} is missing and could not be built ({e!r}): run '
+                    f'{LIB_PATH} is missing or stale and could not be built ({e!r}): run '
                     '`python ray-optics_amd/build.py` (hipcc --offload-arch=gfx950).  '
                     'There is no CPU fallback.')
         if not os.path.exists(LIB_PATH):
@@ -86,6 +88,16 @@ def grid_rays(grid):
     return (grid.row_count or grid.num) * grid.num
 
 
+_NP_DTYPES = {}
+
+
+def _np_dtypes(torch):
+    if not _NP_DTYPES:
+        _NP_DTYPES.update({torch.float64: np.float64, torch.uint8: np.uint8,
+                           torch.int16: np.int16, torch.int32: np.int32,
+                           torch.int64: np.int64})
+
+
 def padded_ld(R):
     """row pitch (in doubles) of the SoA packet buffer.  Rows exactly 2^k bytes
     apart put one ray's 130 packet components on the same HBM channel; a pitch
@@ -94,6 +106,63 @@ def padded_ld(R):
     if R <= 0:
         return 1
     return (R + 511) // 512 * 512 + 256
+
+
+class PinnedPool:
+    """page-locked host buffers that outlive one call: handing the caller a
+    NumPy array that *is* the pinned buffer saves a second pass over the data
+    (a 13 MB spot diagram is ~1.5 ms of memcpy, five times the trace).  A block
+    goes back to the pool when the last array viewing it is garbage-collected."""
+
+    def __init__(self):
+        self._free = {}         # nbytes (rounded) -> [uint8 pinned tensors]
+
+    @staticmethod
+    def _round(nbytes):
+        if nbytes > (64 << 20):                 # big blocks: 16 MiB granules
+            return (nbytes + (16 << 20) - 1) // (16 << 20) * (16 << 20)
+        n = 4096
+        while n < nbytes:
+            n *= 2
+        return n
+
+    def take(self, torch, nbytes):
+        n = self._round(max(int(nbytes), 1))
+        lst = self._free.get(n)
+        t = lst.pop() if lst else torch.empty(n, dtype=torch.uint8).pin_memory()
+        return _Lease(self, n, t)
+
+    def give_back(self, n, t):
+        self._free.setdefault(n, []).append(t)
+
+
+class _Lease:
+    """one pinned block on loan; NumPy arrays made by :meth:`array` keep it
+    alive (they hold it as their base object)"""
+
+    def __init__(self, pool, n, tensor):
+        self._pool, self._n, self.tensor = pool, n, tensor
+        self.ptr = tensor.data_ptr()
+
+    def array(self, shape, dtype, offset=0):
+        a = np.asarray(_View(self, shape, np.dtype(dtype).str, self.ptr + offset))
+        return a
+
+    def __del__(self):
+        try:
+            self._pool.give_back(self._n, self.tensor)
+        except Exception:
+            pass
+
+
+class _View:
+    def __init__(self, lease, shape, typestr, ptr):
+        self._lease = lease
+        self.__array_interface__ = {'shape': tuple(shape), 'typestr': typestr,
+                                    'data': (ptr, False), 'version': 3}
+
+
+_pool = PinnedPool()
 
 
 class DeviceResult:
@@ -119,6 +188,7 @@ class DeviceResult:
             if nan_fill else (lambda s: torch.empty(s, dtype=torch.float64, device=device))
         self.R = R
         self.out_mode = out_mode
+        self._torch = torch
         self._seg = new(shape)                  # pitched storage
         self.seg = self._seg[..., :R]           # [.., R] view the callers index
         self.op = new((R,))
@@ -137,17 +207,27 @@ class DeviceResult:
         o.ld = self.ld
         return o
 
-    def to_host(self):
-        """numpy copies (synchronises)"""
+    def to_host(self, want=('seg', 'op', 'status', 'fail_surf', 'pupil')):
+        """NumPy copies of the arrays named in ``want`` (others None), through
+        pooled pinned memory, one synchronisation"""
         class _H:
             pass
         h = _H()
         h.R, h.out_mode = self.R, self.out_mode
-        h.seg = self.seg.cpu().numpy()
-        h.op = self.op.cpu().numpy()
-        h.status = self.status.cpu().numpy()
-        h.fail_surf = self.fail_surf.cpu().numpy()
-        h.pupil = self.pupil.cpu().numpy() if self.pupil is not None else None
+        torch = self._torch
+        pend = []
+        for name in ('seg', 'op', 'status', 'fail_surf', 'pupil'):
+            t = getattr(self, name) if name in want else None
+            if t is None:
+                setattr(h, name, None)
+                continue
+            lease = _pool.take(torch, t.numel() * t.element_size())
+            dst = lease.tensor[:t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+            dst.copy_(t, non_blocking=True)
+            pend.append((name, lease, t))
+        torch.cuda.current_stream(self.seg.device).synchronize()
+        for name, lease, t in pend:
+            setattr(h, name, lease.array(t.shape, _NP_DTYPES[t.dtype]))
         return h
 
 
@@ -162,6 +242,7 @@ class TraceEngine:
         if not torch.cuda.is_available():
             raise EngineError('no GPU visible: the trace engine has no CPU fallback')
         self.torch = torch
+        _np_dtypes(torch)
         self.lib = load_library()
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None
                                    else torch.device(device).index or 0)
@@ -171,6 +252,7 @@ class TraceEngine:
             _check(self.lib.rox_set_device(self.device.index), 'rox_set_device')
             _check(self.lib.rox_system_create(table.rows, table.n_ifcs,
                                               table.n_table.ctypes.data,
+                                              table.wvls_arr.ctypes.data,
                                               len(table.wvls), C.byref(self._handle)),
                    'rox_system_create')
 
@@ -257,6 +339,80 @@ class TraceEngine:
                    'rox_trace_pupil_list')
         res._keep = (px, py)
         return res
+
+    # -- spot diagram: hits compacted on the device, written to pinned memory ----
+    def _hits_out(self, R, want_status=False):
+        """a pinned block for up to R (x, y) pairs + the count, and its rox_out"""
+        lease = _pool.take(self.torch, 16 * R + 64)
+        o = abi.Out()
+        o.seg = lease.ptr
+        o.n_hits = lease.ptr + 16 * R           # 8-byte count behind the pairs
+        o.ld = R
+        st = None
+        if want_status:
+            st = self.torch.empty((R,), dtype=self.torch.uint8, device=self.device)
+            o.status = st.data_ptr()
+        return lease, o, st
+
+    def _hits_finish(self, lease, R):
+        self.torch.cuda.current_stream(self.device).synchronize()
+        n = int(lease.array((1,), np.int64, offset=16 * R)[0])
+        return lease.array((n, 2), np.float64)
+
+    def trace_pupil_grid_hits(self, fld, grid, wvl_idx, opts):
+        """ROX_OUT_HITS_COMPACT over a pupil grid: the (R_ok, 2) array of
+        transverse aberrations, in ray order, as a NumPy array that views the
+        pinned buffer the kernel wrote (no device->host copy, no host copy)."""
+        R = grid_rays(grid)
+        lease, o, _st = self._hits_out(R)
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_trace_pupil_grid(self._handle, C.byref(fld), C.byref(grid),
+                                                 int(wvl_idx), C.byref(opts), C.byref(o),
+                                                 self._stream()), 'rox_trace_pupil_grid')
+        return self._hits_finish(lease, R)
+
+    def trace_pupil_list_hits(self, fld, px, py, wvl_idx, opts):
+        t = self.torch
+        px = self._dev(px, t.float64)
+        py = self._dev(py, t.float64)
+        R = px.shape[0]
+        lease, o, _st = self._hits_out(R)
+        with t.cuda.device(self.device):
+            _check(self.lib.rox_trace_pupil_list(self._handle, C.byref(fld), R, px.data_ptr(),
+                                                 py.data_ptr(), int(wvl_idx), C.byref(opts),
+                                                 C.byref(o), self._stream()),
+                   'rox_trace_pupil_list')
+        return self._hits_finish(lease, R)
+
+    def trace_rays_hits(self, pt0, dir0, wvl_idx, opts):
+        t = self.torch
+        pt0 = self._dev(pt0, t.float64)
+        dir0 = self._dev(dir0, t.float64)
+        R = pt0.shape[1]
+        if np.ndim(wvl_idx) == 0 and not isinstance(wvl_idx, t.Tensor):
+            wi, wi_ptr, wi_all = None, None, int(wvl_idx)
+        else:
+            wi = self._dev(wvl_idx, t.int32)
+            wi_ptr, wi_all = wi.data_ptr(), 0
+        lease, o, _st = self._hits_out(R)
+        with t.cuda.device(self.device):
+            _check(self.lib.rox_trace_rays(self._handle, R, pt0.data_ptr(), dir0.data_ptr(),
+                                           wi_ptr, wi_all, C.byref(opts), C.byref(o),
+                                           self._stream()), 'rox_trace_rays')
+        return self._hits_finish(lease, R)
+
+    # -- chief-ray aiming ---------------------------------------------------------
+    def aim_chief_rays(self, probs, eps=1.0e-12):
+        """probs: sequence of abi.Aim -> (aim_y float64[n], result int32[n])"""
+        n = len(probs)
+        arr = (abi.Aim * n)(*probs)
+        aim_y = np.zeros(n)
+        result = np.zeros(n, dtype=np.int32)
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_aim_chief_rays(self._handle, n, arr, float(eps),
+                                               aim_y.ctypes.data, result.ctypes.data,
+                                               self._stream()), 'rox_aim_chief_rays')
+        return aim_y, result
 
     def time_pupil_grid(self, fld, grid, wvl_idx, opts, out, launches):
         """mean duration (ms) of the trace kernel over `launches` launches,

@@ -1,20 +1,37 @@
 """engine cache + policy for models the kernels do not cover.
 
-``engine_for(opt_model)`` re-reads the surface table on every call (a walk
-over N interfaces) and reuses the device handle while the table bytes are
-unchanged, so a model edit can never be traced with a stale table.
+``engine_for(opt_model)`` returns the device engine of the model's current
+surface table.  Validity is checked on every call, cheaply:
 
-FALLBACK decides what happens for *models* outside the kernels' scope (phase
-elements, toroids, wide-angle ray starts ...):
+* the snapshots the reference itself traces from -- ``seq_model.lcl_tfrms`` and
+  ``seq_model.rndx`` are rebuilt as new lists by ``SequentialModel.update_model``
+  (rayoptics/seq/sequential.py:600-668, where the reference clears its own
+  ``path_sequence`` cache) -- are compared by identity, and
+* everything ``path()`` reads *through* the live interface objects (profile
+  parameters, apertures, phase elements, interact modes) is compared by value
+  (:func:`_fingerprint`), because the reference sees such edits without an
+  ``update_model()``.
+
+Only when either differs is the table re-extracted (``SurfaceTable.from_seq_model``)
+and, if its bytes changed, a new device handle created: a stale table is never
+traced.  Models that carry a prebuilt table (``seq_model.surface_table``:
+:class:`~.workloads.TableModel`, tables parsed from prescription files) use it
+as is.
+
+FALLBACK decides what happens for *models* outside the kernels' scope (unknown
+interface, profile or phase classes):
   'raise'      (default) UnsupportedModelError
   'reference'  the call is handed to the reference's own, unmodified function
 A missing library or GPU is never a fallback case: that always raises.
 """
+import weakref
+
 from .table import SurfaceTable
 
 ENGINE_FACTORY = None       # None -> engine.TraceEngine (the HIP path)
 FALLBACK = 'raise'
-_cache = {}
+MAX_ENGINES = 16            # device handles kept alive (least recently used out first)
+_cache = {}                 # id(seq_model) -> _Entry, in LRU order
 
 
 def _factory():
@@ -24,21 +41,97 @@ def _factory():
     return TraceEngine
 
 
+def _prof_key(p):
+    if p is None:
+        return None
+    c = getattr(p, 'coefs', None)
+    return (type(p), p.cv, getattr(p, 'cc', None), getattr(p, 'ec', None),
+            getattr(p, 'cR', None), tuple(c) if c is not None else None)
+
+
+def _ap_key(ca):
+    return (type(ca), getattr(ca, 'radius', None), getattr(ca, 'x_half_width', None),
+            getattr(ca, 'y_half_width', None), getattr(ca, 'x_offset', 0.0),
+            getattr(ca, 'y_offset', 0.0), getattr(ca, 'is_obscuration', False))
+
+
+def _phase_key(pe):
+    if pe is None:
+        return None
+    d = getattr(pe, '__dict__', {})
+    return (type(pe),) + tuple((k, tuple(v) if hasattr(v, '__len__') and not isinstance(v, str)
+                                else v) for k, v in sorted(d.items()) if k != 'debug_output')
+
+
+def _fingerprint(sm):
+    """what path() reads through the live interface objects, by value"""
+    out = []
+    for ifc in sm.ifcs:
+        cas = getattr(ifc, 'clear_apertures', None)
+        out.append((type(ifc), ifc.interact_mode, ifc.max_aperture,
+                    _prof_key(getattr(ifc, 'profile', None)),
+                    tuple(_ap_key(ca) for ca in cas) if cas else None,
+                    _phase_key(getattr(ifc, 'phase_element', None))
+                    if hasattr(ifc, 'phase_element') else None))
+    return out
+
+
+class _Entry:
+    __slots__ = ('ref', 'lcl_tfrms', 'rndx', 'wvls', 'finger', 'sig', 'engine')
+
+
+def _evict():
+    while len(_cache) > MAX_ENGINES:
+        key = next(iter(_cache))
+        _cache.pop(key).engine.close()
+
+
 def engine_for(opt_model):
     sm = opt_model['seq_model']
-    table = SurfaceTable.from_seq_model(sm)
-    sig = bytes(table.rows) + table.n_table.tobytes() + repr(table.wvls).encode()
-    hit = _cache.get(id(sm))
-    if hit is not None and hit[0] == sig:
-        return hit[1]
-    if hit is not None:
-        hit[1].close()
-    eng = _factory()(table)
-    _cache[id(sm)] = (sig, eng)
-    return eng
+    key = id(sm)
+    ent = _cache.get(key)
+    if ent is not None and ent.ref() is not sm:        # id reused by another object
+        _cache.pop(key).engine.close()
+        ent = None
+    prebuilt = getattr(sm, 'surface_table', None)
+    if prebuilt is not None:
+        if ent is not None and ent.sig is prebuilt:
+            return ent.engine
+        table, sig, finger, wvls = prebuilt, prebuilt, None, None
+    else:
+        wvls = tuple(opt_model['osp']['wvls'].wavelengths)
+        finger = _fingerprint(sm)
+        if (ent is not None and ent.lcl_tfrms is sm.lcl_tfrms and ent.rndx is sm.rndx
+                and ent.wvls == wvls and ent.finger == finger):
+            _cache[key] = _cache.pop(key)              # most recently used
+            return ent.engine
+        table = SurfaceTable.from_seq_model(sm)
+        sig = bytes(table.rows) + table.n_table.tobytes() + repr(table.wvls).encode()
+        if ent is not None and ent.sig == sig:         # re-validated: same table bytes
+            ent.lcl_tfrms, ent.rndx, ent.wvls, ent.finger = sm.lcl_tfrms, sm.rndx, wvls, finger
+            return ent.engine
+    if ent is not None:
+        _cache.pop(key).engine.close()
+    new = _Entry()
+    new.ref = weakref.ref(sm) if _weakrefable(sm) else (lambda sm=sm: sm)
+    new.lcl_tfrms = getattr(sm, 'lcl_tfrms', None)
+    new.rndx = getattr(sm, 'rndx', None)
+    new.wvls, new.finger, new.sig = wvls, finger, sig
+    new.engine = _factory()(table)
+    _cache[key] = new
+    _evict()
+    return new.engine
+
+
+def _weakrefable(obj):
+    try:
+        weakref.ref(obj)
+        return True
+    except TypeError:
+        return False
 
 
 def clear():
-    for _sig, eng in _cache.values():
-        eng.close()
+    for ent in _cache.values():
+        ent.engine.close()
     _cache.clear()

@@ -8,9 +8,10 @@ of refractive indices, by *reading* a live reference ``SequentialModel`` --
 nothing is re-derived: transforms come from ``seq_model.lcl_tfrms``, indices
 from ``seq_model.rndx``, ``max_nonzero_coef`` from the profile.
 
-Interfaces the kernels do not implement (phase elements, thin lenses,
-unknown aperture classes) raise :class:`UnsupportedModelError` so that callers
-keep such models on the reference's own CPU path.
+Interfaces the kernels do not implement (unknown profile, aperture or phase
+element classes; DiffractiveElements with a phase function other than
+``radial_phase_fct``) raise :class:`UnsupportedModelError` so that callers keep
+such models on the reference's own CPU path.
 """
 import json
 import numpy as np
@@ -81,6 +82,45 @@ def _aperture_rows(row, ifc):
             raise UnsupportedModelError(f'aperture {kind} is not supported')
 
 
+def _vec3(v):
+    return [float(v[0]), float(v[1]), float(v[2])]
+
+
+def _phase_row(row, pe):
+    """rox_phase from ``ifc.phase_element`` (rayoptics/oprops/doe.py)"""
+    ph = row.ph
+    kind = type(pe).__name__
+    if kind == 'DiffractionGrating':            # doe.py:57-175 (phase_ludwig)
+        ph.kind = abi.PH_GRATING
+        ph.order = float(pe.order)
+        ph.spacing_nm = float(pe._grating_spacing_nm)
+        for i, v in enumerate(_vec3(pe.grating_normal)):
+            ph.a[i] = v
+    elif kind == 'DiffractiveElement':          # doe.py:225-323
+        fct = getattr(pe.phase_fct, '__name__', None)
+        if fct != 'radial_phase_fct':
+            raise UnsupportedModelError(f'DiffractiveElement phase function {fct!r}')
+        coefs = [float(c) for c in pe.coefficients]
+        if len(coefs) > abi.MAX_COEF:
+            raise UnsupportedModelError(f'DiffractiveElement with {len(coefs)} coefficients')
+        ph.kind = abi.PH_DOE_RADIAL
+        ph.ncoef = len(coefs)
+        for i, c in enumerate(coefs):
+            ph.coefs[i] = c
+        ph.order = float(pe.order)
+        ph.ref_wl = float(pe.ref_wl)
+    elif kind == 'HolographicElement':          # doe.py:326-397
+        ph.kind = abi.PH_HOLOGRAM
+        ph.ref_wl = float(pe.ref_wl)
+        ph.flags = (1 if pe.ref_virtual else 0) | (2 if pe.obj_virtual else 0)
+        for i, v in enumerate(_vec3(pe.ref_pt)):
+            ph.a[i] = v
+        for i, v in enumerate(_vec3(pe.obj_pt)):
+            ph.b[i] = v
+    else:
+        raise UnsupportedModelError(f'phase element {kind} is not supported')
+
+
 def rt_order_of(rt):
     """which dgemv kernel NumPy's ``rt.dot(v)`` reaches: the F-ordered transpose
     view (``r.transpose()``) or a C-ordered array (include/roxtrace.h ROX_RT_*)"""
@@ -97,6 +137,7 @@ class SurfaceTable:
         self.rows = rows
         self.n_table = np.ascontiguousarray(n_table, dtype=np.float64)
         self.wvls = [float(w) for w in wvls]
+        self.wvls_arr = np.ascontiguousarray(self.wvls, dtype=np.float64)   # nm, for the C ABI
         self.stop_idx = stop_idx
         assert self.n_table.shape == (len(self.wvls), len(rows))
 
@@ -123,13 +164,22 @@ class SurfaceTable:
         for i, seg in enumerate(paths[0]):
             ifc, _gap, tfrm, _n, zdir = seg
             row = rows[i]
-            if hasattr(ifc, 'phase_element'):
-                raise UnsupportedModelError('phase elements stay on the CPU path')
-            if not hasattr(ifc, 'profile'):
+            row.mode = abi.MODE_NAMES.get(ifc.interact_mode, abi.DUMMY)
+            if type(ifc).__name__ == 'ThinLens':
+                # its own planar intersect / constant normal (thinlens.py:128-136)
+                row.profile = abi.THINLENS
+                row.ec = 1.0
+            elif hasattr(ifc, 'profile'):
+                _profile_row(row, ifc.profile)
+            else:
                 raise UnsupportedModelError(
                     f'interface {type(ifc).__name__} has no surface profile')
-            row.mode = abi.MODE_NAMES.get(ifc.interact_mode, abi.DUMMY)
-            _profile_row(row, ifc.profile)
+            # raytrace.py:205 tests hasattr only: a None phase_element would fail
+            # in the reference, so it is refused here
+            if hasattr(ifc, 'phase_element'):
+                if ifc.phase_element is None:
+                    raise UnsupportedModelError('phase_element is None')
+                _phase_row(row, ifc.phase_element)
             _aperture_rows(row, ifc)
             row.max_aperture = float(ifc.max_aperture)
             if tfrm is None:
@@ -224,6 +274,12 @@ class SurfaceTable:
                 ap=[dict(kind=a.kind, is_obscuration=a.is_obscuration,
                          x_offset=a.x_offset, y_offset=a.y_offset, a=a.a, b=a.b)
                     for a in r.ap[:r.n_ap]]))
+            if r.ph.kind != abi.PH_NONE:
+                ph = r.ph
+                rows[-1]['ph'] = dict(kind=ph.kind, ncoef=ph.ncoef, flags=ph.flags,
+                                      order=ph.order, ref_wl=ph.ref_wl,
+                                      spacing_nm=ph.spacing_nm, a=list(ph.a), b=list(ph.b),
+                                      coefs=list(ph.coefs))
         return dict(wvls=self.wvls, stop_idx=self.stop_idx,
                     n_table=self.n_table.tolist(), rows=rows)
 
@@ -249,6 +305,14 @@ class SurfaceTable:
                 ap.kind, ap.is_obscuration = a['kind'], a['is_obscuration']
                 ap.x_offset, ap.y_offset = a['x_offset'], a['y_offset']
                 ap.a, ap.b = a['a'], a['b']
+            if 'ph' in s:
+                p, ph = s['ph'], row.ph
+                ph.kind, ph.ncoef, ph.flags = p['kind'], p['ncoef'], p['flags']
+                ph.order, ph.ref_wl, ph.spacing_nm = p['order'], p['ref_wl'], p['spacing_nm']
+                for k in range(3):
+                    ph.a[k], ph.b[k] = p['a'][k], p['b'][k]
+                for k, c in enumerate(p['coefs']):
+                    ph.coefs[k] = c
         return cls(rows, np.array(d['n_table'], dtype=np.float64), d['wvls'],
                    d.get('stop_idx'))
 
@@ -262,8 +326,10 @@ class SurfaceTable:
             return cls.from_dict(json.load(f))
 
 
-def field_struct(pt0, aim, eprad, z_enp, vig=(0., 0., 0., 0.), z_dir0=1.0):
-    """fill a ``rox_field`` (vig = (vlx, vux, vly, vuy))."""
+def field_struct(pt0, aim, eprad, z_enp, vig=(0., 0., 0., 0.), z_dir0=1.0,
+                 kind=abi.FLD_EPD, rot=None, cr_dir=(0., 0.)):
+    """fill a ``rox_field`` (vig = (vlx, vux, vly, vuy)); see include/roxtrace.h
+    for what ``eprad`` / ``z_enp`` carry in each kind."""
     f = abi.Field()
     for i in range(3):
         f.pt0[i] = float(pt0[i])
@@ -271,37 +337,86 @@ def field_struct(pt0, aim, eprad, z_enp, vig=(0., 0., 0., 0.), z_dir0=1.0):
     f.eprad, f.z_enp = float(eprad), float(z_enp)
     f.vlx, f.vux, f.vly, f.vuy = (float(v) for v in vig)
     f.z_dir0 = float(z_dir0)
+    f.kind = int(kind)
+    if rot is not None:
+        f.rot_order = rt_order_of(rot)
+        for a in range(3):
+            for b in range(3):
+                f.rot[3 * a + b] = float(rot[a][b])
+    f.cr_dir[0], f.cr_dir[1] = float(cr_dir[0]), float(cr_dir[1])
     return f
 
 
-def field_from_model(opt_model, fld):
-    """per-field constants of the 'epd', non-wide-angle branch of
-    ``OpticalSpecs.ray_start_from_osp`` (rayoptics/raytr/opticalspec.py:289-366).
-
-    Raises :class:`UnsupportedModelError` for the branches that stay on the
-    host (angular pupil keys, wide-angle fields, telecentric pupils)."""
+def field_from_model(opt_model, fld, pupil_type='rel pupil'):
+    """per-field constants of ``OpticalSpecs.ray_start_from_osp``
+    (rayoptics/raytr/opticalspec.py:289-400), every branch: 'epd' pupils
+    (plain, wide-angle, 'aim pt'), angular pupils ('NA', 'f/#', 'aim dir').
+    The per-ray part of each branch runs on the device (``rox_field.kind``).
+    Fields that carry prebuilt constants (``fld.rox_field``: table-backed
+    models, :mod:`~.workloads`) use them as is."""
+    pre = getattr(fld, 'rox_field', None)
+    if pre is not None and pupil_type == 'rel pupil':
+        return pre
     osp = opt_model['optical_spec']
     fod = opt_model['analysis_results']['parax_data'].fod
-    if osp['fov'].is_wide_angle:
-        raise UnsupportedModelError('wide-angle fields are generated on the host')
     pupil_oi_key, pupil_value_key = osp['pupil'].key
     pupil_value = osp['pupil'].value
-    if pupil_oi_key == 'image':                      # :311-325
-        if abs(fod.m) < 1e-10 or not abs(fod.enp_dist) > 1e10:
+    n_obj, n_img = osp.obj_img_rindex()
+    p0, d0 = osp.obj_coords(fld)                       # :306
+    if pupil_oi_key == 'image':                        # :311-325
+        if abs(fod.m) < 1e-10:
             pupil_value_key, pupil_value = 'epd', 2 * fod.enp_radius
+        elif abs(fod.enp_dist) > 1e10:                 # telecentric entrance pupil
+            from rayoptics.parax import etendue
+            pupil_value_key = 'NA'
+            slp0 = etendue.na2slp_parax(fod.obj_na, n=n_obj)
+            pupil_value = etendue.slp2na(slp0, n=n_obj)
         else:
-            raise UnsupportedModelError('telecentric entrance pupil')
-    if pupil_value_key != 'epd':
-        raise UnsupportedModelError(f"pupil key {pupil_value_key!r} is generated on the host")
-    _p0, d0 = osp['fov'].obj_coords(fld)              # :308
+            pupil_value_key, pupil_value = 'epd', 2 * fod.enp_radius
     aim_info = getattr(fld, 'aim_info', None)
-    aim_pt = [0., 0.] if aim_info is None else aim_info          # :359
     z_enp = fod.enp_dist
-    obj2enp_dist = -(fod.obj_dist + z_enp)                       # :360
-    pt0 = obj2enp_dist * np.array([d0[0] / d0[2], d0[1] / d0[2], 0.])   # :364
-    return field_struct(pt0, aim_pt, pupil_value / 2, fod.obj_dist + z_enp,
-                        (fld.vlx, fld.vux, fld.vly, fld.vuy),
-                        opt_model['seq_model'].z_dir[0])
+    vig = (fld.vlx, fld.vux, fld.vly, fld.vuy)
+    z_dir0 = opt_model['seq_model'].z_dir[0]
+    if pupil_value_key == 'epd':
+        if pupil_type == 'aim pt':                     # :334-337
+            return field_struct(p0, (0., 0.), 0.0, fod.obj_dist + z_enp, vig, z_dir0,
+                                kind=abi.FLD_AIM_PT)
+        eprad = pupil_value / 2
+        if osp['fov'].is_wide_angle:                   # :340-356
+            from rayoptics.util.misc_math import rot_v1_into_v2
+            rot_mat_d2s = rot_v1_into_v2(d0, np.array([0., 0., 1.]))
+            if aim_info is not None:
+                z_enp = aim_info
+            obj2enp_dist = -(fod.obj_dist + z_enp)
+            if osp.conjugate_type('object') == 'infinite':
+                enp_pt = np.array([0., 0., obj2enp_dist])
+                rot_mat_s2d = rot_v1_into_v2(np.array([0., 0., 1.]), d0)
+                pt0 = np.matmul(rot_mat_s2d, enp_pt) - enp_pt
+            else:
+                pt0 = p0
+            return field_struct(pt0, (0., 0.), eprad, obj2enp_dist, vig, z_dir0,
+                                kind=abi.FLD_EPD_WIDE, rot=rot_mat_d2s)
+        aim_pt = [0., 0.] if aim_info is None else aim_info          # :358-366
+        obj2enp_dist = -(fod.obj_dist + z_enp)
+        pt0 = obj2enp_dist * np.array([d0[0] / d0[2], d0[1] / d0[2], 0.])
+        return field_struct(pt0, aim_pt, eprad, fod.obj_dist + z_enp, vig, z_dir0)
+    # an angular based measure, :368-398
+    if pupil_type == 'aim dir':
+        return field_struct(p0, (0., 0.), 0.0, 0.0, vig, z_dir0, kind=abi.FLD_AIM_DIR)
+    if 'NA' in pupil_value_key:
+        n = n_obj if pupil_oi_key == 'object' else n_img
+        kind, scale = abi.FLD_NA, pupil_value / n
+    elif 'f/#' in pupil_value_key:
+        kind, scale = abi.FLD_FNO, -1 / (2 * pupil_value)
+    else:
+        raise UnsupportedModelError(f'pupil key {pupil_value_key!r}')
+    if d0 is not None:
+        cr_dir = d0[:2]
+    else:
+        from rayoptics.util.misc_math import normalize
+        pt1 = np.array([aim_info[0], aim_info[1], fod.obj_dist + fod.enp_dist])
+        cr_dir = normalize(pt1 - p0)[:2]
+    return field_struct(p0, (0., 0.), scale, 0.0, vig, z_dir0, kind=kind, cr_dir=cr_dir)
 
 
 def wavefront_from_model(opt_model, fld, chief_ray_pkg=None, ref_sphere=None):

@@ -12,7 +12,7 @@ import numpy as np
 from . import abi, session
 from .engine import make_opts, make_grid
 from .raypkg import HostPackets, RayPkg, RaySeg
-from .table import field_from_model, UnsupportedModelError
+from .table import field_from_model
 
 
 def opts_from_kwargs(n_ifcs, kwargs, out_mode, foc=0.0, image_pt=(0., 0.), wf=None):
@@ -55,89 +55,35 @@ def emit(pk, r, output_filter, rayerr_filter, named, ifcs):
     return output_filter(pkg), None
 
 
-def _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter, grid=None,
-                 pupil_list=None,
-                 out_mode=None, foc=0.0, image_pt=(0., 0.), wf=None):
+def _launch_setup(opt_model, fld, wvl, kwargs, out_mode, foc=0.0, image_pt=(0., 0.), wf=None):
+    """engine, field constants, wavelength index and options of one pupil launch:
+    trace_base's preamble (rayoptics/raytr/trace.py:253-310).  Every branch of
+    ray_start_from_osp runs on the device (``rox_field.kind``)."""
     pupil_type = kwargs.get('pupil_type', 'rel pupil')
     eng = session.engine_for(opt_model)
     tbl = eng.table
+    opts = opts_from_kwargs(tbl.n_ifcs, kwargs, out_mode, foc, image_pt, wf)
+    f = field_from_model(opt_model, fld, pupil_type)
+    if pupil_type != 'rel pupil':
+        opts.flags &= ~abi.APPLY_VIGNETTING             # trace.py:291-295
+    if f.kind == abi.FLD_EPD_WIDE:
+        opts.flags &= ~abi.INTERSECT_OBJ                # trace.py:302-303
+    return eng, f, tbl.wvl_index(wvl), opts
+
+
+def _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter, grid=None,
+                 pupil_list=None,
+                 out_mode=None, foc=0.0, image_pt=(0., 0.), wf=None):
     if out_mode is None:
         # partial packets (rayerr_filter='full') need the FULL layout
         out_mode = (abi.OUT_LAST if output_filter == 'last' and rayerr_filter != 'full'
                     else abi.OUT_FULL)
-    opts = opts_from_kwargs(tbl.n_ifcs, kwargs, out_mode, foc, image_pt, wf)
-    wi = tbl.wvl_index(wvl)
-    try:
-        if pupil_type != 'rel pupil':
-            raise UnsupportedModelError(pupil_type)
-        f = field_from_model(opt_model, fld)
-    except UnsupportedModelError:
-        # angular pupil keys, wide-angle fields, 'aim pt' / 'aim dir' pupils: the
-        # ray *starts* come from the reference's own ray_start_from_osp on the
-        # host; the trace still runs on the device (explicit-ray entry)
-        return _trace_host_generated(opt_model, eng, fld, wvl, wi, opts, out_mode,
-                                     pupil_type, grid, pupil_list)
+    eng, f, wi, opts = _launch_setup(opt_model, fld, wvl, kwargs, out_mode, foc, image_pt, wf)
     if grid is not None:
         res = eng.trace_pupil_grid(f, grid, wi, opts)
     else:
         res = eng.trace_pupil_list(f, pupil_list[0], pupil_list[1], wi, opts)
-    return HostPackets(res.to_host(), tbl, opts.flags, out_mode, wvl)
-
-
-def _pupil_points(grid, pupil_list):
-    """pupil coordinates in the reference's order, by repeated `+=` of the step
-    (rayoptics/raytr/trace.py:566-604, 541-559)"""
-    if grid is None:
-        return np.stack([np.asarray(pupil_list[0], float), np.asarray(pupil_list[1], float)], 1)
-    num = grid.num
-    start = np.array([grid.start[0], grid.start[1]])
-    with np.errstate(all='ignore'):
-        step = (np.array([grid.stop[0], grid.stop[1]]) - start) / (num - 1)
-    pts = []
-    if grid.kind == abi.GRID_FAN:
-        for _ in range(num):
-            pts.append(start.copy())
-            start += step
-    else:
-        y0 = grid.start[1]
-        for _i in range(num):
-            for _j in range(num):
-                pts.append(start.copy())
-                start[1] += step[1]
-            start[0] += step[0]
-            start[1] = y0
-        pts = pts[(grid.row_begin * num):((grid.row_begin + (grid.row_count or num)) * num)]
-    return np.array(pts).reshape(-1, 2)
-
-
-def _trace_host_generated(opt_model, eng, fld, wvl, wi, opts, out_mode, pupil_type,
-                          grid, pupil_list):
-    """trace_base (rayoptics/raytr/trace.py:253-310) with the ray start left to
-    the reference: apply_vignetting + OpticalSpecs.ray_start_from_osp per pupil
-    point, then one device launch over the explicit rays."""
-    osp = opt_model['optical_spec']
-    sm = opt_model['seq_model']
-    pts = _pupil_points(grid, pupil_list)
-    R = pts.shape[0]
-    pt0 = np.empty((3, R))
-    dir0 = np.empty((3, R))
-    wide = osp['fov'].is_wide_angle
-    vig = bool(opts.flags & abi.APPLY_VIGNETTING) and pupil_type == 'rel pupil'
-    for r in range(R):
-        pupil = pts[r]
-        if vig:
-            pupil = fld.apply_vignetting(pupil)         # in place, as in the reference
-        p, d = osp.ray_start_from_osp(pupil, fld, pupil_type)
-        if not wide and d[2] * sm.z_dir[0] < 0:            # trace.py:304-308
-            d = -d
-        pt0[:, r], dir0[:, r] = p, d
-    if wide:
-        opts.flags &= ~abi.INTERSECT_OBJ                    # trace.py:302-303
-    opts.flags &= ~abi.APPLY_VIGNETTING
-    res = eng.trace_rays(pt0, dir0, wi, opts)
-    host = res.to_host()
-    host.pupil = np.ascontiguousarray(pts.T)
-    return HostPackets(host, eng.table, opts.flags, out_mode, wvl)
+    return HostPackets(res.to_host(), eng.table, opts.flags, out_mode, wvl)
 
 
 def trace_grid(opt_model, grid_rng, fld, wvl, foc, img_filter=None,
@@ -200,14 +146,18 @@ def trace_fan(opt_model, fan_rng, fld, wvl, foc, img_filter=None, **kwargs):
 def trace_grid_spot(opt_model, grid_rng, fld, wvl, foc, image_pt, **kwargs):
     """fused spot diagram: the transverse aberrations SpotDiagramFigure's
     ``spot`` filter computes (rayoptics/mpl/axisarrayfigure.py:229-238), for the
-    rays that get through, as one (R_ok, 2) array; HITS output mode."""
+    rays that get through, as one (R_ok, 2) array -- what
+    ``seq_model.trace_grid(spot, fi, wl, num_rays, form='list',
+    append_if_none=False)`` returns per wavelength (sequential.py:1058-1085);
+    ROX_OUT_HITS_COMPACT output mode."""
     kwargs['check_apertures'] = True
     kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', True)
-    pk = _trace_pupil(opt_model, fld, wvl, kwargs, None, None,
-                      grid=make_grid(grid_rng[0], grid_rng[1], grid_rng[2]),
-                      out_mode=abi.OUT_HITS, foc=foc, image_pt=image_pt[:2])
-    ok = pk.status == abi.OK
-    return np.ascontiguousarray(pk.seg[0][:, ok].T)
+    eng, f, wi, opts = _launch_setup(opt_model, fld, wvl, kwargs, abi.OUT_HITS_COMPACT,
+                                     foc, image_pt[:2])
+    # survivors are packed in ray order on the device and written straight into
+    # pinned host memory: the array returned *is* that buffer
+    return eng.trace_pupil_grid_hits(f, make_grid(grid_rng[0], grid_rng[1], grid_rng[2]),
+                                     wi, opts)
 
 
 def _is_spot_filter(fct):

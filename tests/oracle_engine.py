@@ -16,7 +16,7 @@ class _Res:
     def __init__(self, host):
         self._h = host
 
-    def to_host(self):
+    def to_host(self, want=None):
         return self._h
 
     @property
@@ -58,3 +58,17 @@ class OracleEngine:
 
     def trace_pupil_list(self, fld, px, py, wvl_idx=0, opts=None, **kw):
         return self._trim(oracle.trace_pupil_list(self.table, fld, px, py, wvl_idx, opts), opts)
+
+    # ROX_OUT_HITS_COMPACT entries: the (R_ok, 2) array
+    def trace_pupil_grid_hits(self, fld, grid, wvl_idx, opts):
+        return oracle.trace_pupil_grid(self.table, fld, grid, wvl_idx, opts).hits.copy()
+
+    def trace_pupil_list_hits(self, fld, px, py, wvl_idx, opts):
+        return oracle.trace_pupil_list(self.table, fld, px, py, wvl_idx, opts).hits.copy()
+
+    def trace_rays_hits(self, pt0, dir0, wvl_idx, opts):
+        return oracle.trace_rays(self.table, np.asarray(pt0), np.asarray(dir0), wvl_idx,
+                                 opts).hits.copy()
+
+    def aim_chief_rays(self, probs, eps=1.0e-12):
+        return oracle.aim_chief_rays(self.table, probs, eps)

@@ -23,8 +23,8 @@ def lib():
     return C.CDLL(path)
 
 
-def header_symbols():
-    with open(os.path.join(ROOT, 'include', 'roxtrace.h')) as f:
+def header_symbols(header='roxtrace.h'):
+    with open(os.path.join(ROOT, 'include', header)) as f:
         src = f.read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(rox_[a-z0-9_]+)\s*\(', src)))
@@ -32,10 +32,11 @@ def header_symbols():
 
 def test_header_and_binding_agree():
     assert header_symbols() == sorted(abi.EXPORTS)
+    assert header_symbols('roxtrace_diag.h') == sorted(abi.DIAG_EXPORTS)
 
 
 def test_library_exports_every_declared_symbol(lib):
-    for name in header_symbols():
+    for name in header_symbols() + header_symbols('roxtrace_diag.h'):
         assert hasattr(lib, name), f'{name} not exported'
 
 
@@ -43,7 +44,7 @@ def test_abi_version_and_error_string(lib):
     abi.declare(lib)
     assert lib.rox_abi_version() == abi.ABI_VERSION
     # argument errors are reported without touching a device
-    rc = lib.rox_system_create(None, 0, None, 0, None)
+    rc = lib.rox_system_create(None, 0, None, None, 0, None)
     assert rc == -1
     assert b'rox_system_create' in lib.rox_last_error()
 
@@ -60,8 +61,26 @@ def test_engine_fails_loudly_without_gpu():
         TraceEngine(tbl)
 
 
-def test_struct_sizes_match_header():
-    # sizes asserted in abi.py against the C header's static layout
-    assert C.sizeof(abi.Surface) == 408 and C.sizeof(abi.Aperture) == 40
-    assert C.sizeof(abi.Opts) == 352 and C.sizeof(abi.Field) == 96
-    assert C.sizeof(abi.Grid) == 48 and C.sizeof(abi.Out) == 48
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof / offsetof of every struct as a C compiler sees include/roxtrace.h
+    against the ctypes mirror in abi.py"""
+    import subprocess
+    structs = {'rox_aperture': abi.Aperture, 'rox_phase': abi.Phase, 'rox_surface': abi.Surface,
+               'rox_wavefront': abi.Wavefront, 'rox_opts': abi.Opts, 'rox_field': abi.Field,
+               'rox_grid': abi.Grid, 'rox_out': abi.Out, 'rox_aim': abi.Aim}
+    lines = ['#include <stdio.h>', '#include <stddef.h>',
+             f'#include "{ROOT}/include/roxtrace.h"', 'int main(void) {']
+    for cname, st in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _t in st._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['return 0; }']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-o', str(exe), str(src)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, st in structs.items():
+        assert int(got[cname]) == C.sizeof(st), cname
+        for fname, _t in st._fields_:
+            assert int(got[f'{cname}.{fname}']) == getattr(st, fname).offset, f'{cname}.{fname}'
