@@ -55,8 +55,8 @@
 #ifndef ROX_BLOCK            // workgroup size (FULL: 128 -> 222, 256 -> 214, 512 -> 208, 1024 -> 212 us)
 #define ROX_BLOCK 512
 #endif
-#ifndef ROX_WG_SYNC          // 1: a workgroup barrier per surface (keeps the waves of a
-#define ROX_WG_SYNC 0         //    workgroup on one packet row; experiment)
+#ifndef ROX_WG_SYNC          // 1: FULL mode: a workgroup barrier per surface keeps the waves of a
+#define ROX_WG_SYNC 1         //    workgroup on the same packet rows (218 -> 202 us)
 #endif
 
 namespace rox {
@@ -741,11 +741,10 @@ struct RayEnd {
 // raytrace.py:83-264 trace_raw for one lane.  wi = wavelength index of the ray
 // (wave-uniform unless PER_RAY_WVL).
 // `live` = false for the lanes past the end of the batch: they trace nothing.
-#if ROX_WG_SYNC     // every wave must reach every barrier: lanes idle instead of leaving
-#define ROX_LEAVE continue
-#else
-#define ROX_LEAVE break
-#endif
+// kSync (FULL packets only): the waves of a workgroup meet at a barrier before
+// every surface, so that the workgroup writes whole [segment] rows together;
+// every wave must then reach every barrier: failed lanes idle instead of leaving.
+#define ROX_LEAVE if (kSync) continue; else break
 template <int OUT_MODE, bool PER_RAY_WVL, int FEAT>
 __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const v3 &pt0,
                                           const v3 &dir0, int wi, bool live, RayEnd &e)
@@ -757,6 +756,7 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
                   O_ZDIR = offsetof(rox_surface, z_dir) / 8,
                   O_PH = offsetof(rox_surface, ph) / 8;
     constexpr bool kPoly = (FEAT & F_POLY) != 0;
+    constexpr bool kSync = ROX_WG_SYNC && OUT_MODE == ROX_OUT_FULL;
     const int N = c.N;
     tblp tbl = c.tbl;
     tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
@@ -814,14 +814,12 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         so.pdn(0, bp, bd, bn);
 
     // ---- remaining surfaces, raytrace.py:164-229 -------------------------
-#if ROX_WG_SYNC
-    for (int surf = 1; surf < N; ++surf) {
-        __builtin_amdgcn_s_barrier();
-        if (status != ROX_OK)
-            continue;
-#else
-    for (int surf = 1; surf < N && status == ROX_OK; ++surf) {
-#endif
+    for (int surf = 1; surf < N && (kSync || status == ROX_OK); ++surf) {
+        if (kSync) {
+            __builtin_amdgcn_s_barrier();
+            if (status != ROX_OK)
+                continue;
+        }
         tblp prow = tbl + (size_t)(surf - 1) * kRowDoubles;     // `before`
         tblp row = tbl + (size_t)surf * kRowDoubles;             // `after`
         const int mode = ((tbli)row)[0], prof = ((tbli)row)[1];
@@ -1193,33 +1191,46 @@ trace_kernel(const TraceArgs a)
                     if (lane == 0)
                         __hip_atomic_store(&st[tile], ts_pack(a.epoch, TS_AGG, (uint32_t)total),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // Look back over the predecessors, nearest first, 512 states per
+                    // round trip (8 independent loads per lane): sum aggregates until a
+                    // tile that already knows its inclusive prefix is met; a tile that
+                    // has published nothing yet is waited for, keeping the partial sum.
                     int64_t look = tile - 1;
-                    for (;;) {
-                        const int64_t idx = look - lane;
-                        uint64_t w = ts_pack(a.epoch, TS_PREFIX, 0);    // before tile 0
-                        if (idx >= 0)
-                            w = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const bool ready = (uint32_t)(w >> 32) == a.epoch && ((w >> 30) & 3u) != 0;
-                        const bool is_pref = ready && ((w >> 30) & 3u) == TS_PREFIX;
-                        const uint64_t rmask = __ballot(ready), pmask = __ballot(is_pref);
-                        const int first_not = (~rmask) ? __builtin_ctzll(~rmask) : 64;
-                        const int first_pref = pmask ? __builtin_ctzll(pmask) : 64;
-                        if (first_pref < first_not) {
-                            uint32_t v = (lane <= first_pref) ? (uint32_t)(w & 0x3fffffffu) : 0u;
+                    for (bool done = false; !done;) {
+                        uint64_t w[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int64_t idx = look - (k * 64 + lane);
+                            w[k] = ts_pack(a.epoch, TS_PREFIX, 0);      // before tile 0
+                            if (idx >= 0)
+                                w[k] = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        int consumed = 512;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const uint32_t flag = (uint32_t)(w[k] >> 30) & 3u;
+                            const bool ready = (uint32_t)(w[k] >> 32) == a.epoch && flag != 0;
+                            const uint64_t rmask = __ballot(ready);
+                            const uint64_t pmask = __ballot(ready && flag == TS_PREFIX);
+                            const int first_not = (~rmask) ? __builtin_ctzll(~rmask) : 64;
+                            const int first_pref = pmask ? __builtin_ctzll(pmask) : 64;
+                            const int take = first_pref < first_not ? first_pref + 1 : first_not;
+                            uint32_t v = lane < take ? (uint32_t)(w[k] & 0x3fffffffu) : 0u;
                             for (int o = 32; o > 0; o >>= 1)
                                 v += __shfl_xor(v, o);
                             excl += v;
-                            break;
+                            if (first_pref < first_not) {
+                                done = true;
+                                break;
+                            }
+                            if (first_not < 64) {       // wait for that tile, resume from it
+                                consumed = k * 64 + first_not;
+                                __builtin_amdgcn_s_sleep(1);
+                                break;
+                            }
                         }
-                        if (first_not == 64) {      // 64 aggregates: take them, look further back
-                            uint32_t v = (uint32_t)(w & 0x3fffffffu);
-                            for (int o = 32; o > 0; o >>= 1)
-                                v += __shfl_xor(v, o);
-                            excl += v;
-                            look -= 64;
-                        } else {
-                            __builtin_amdgcn_s_sleep(2);
-                        }
+                        look -= consumed;
                     }
                     if (lane == 0)
                         __hip_atomic_store(&st[tile], ts_pack(a.epoch, TS_PREFIX, excl + (uint32_t)total),

@@ -34,6 +34,7 @@ def _guard(ours, theirs):
 def install(fallback='raise'):
     import rayoptics.raytr.trace as rtrace
     import rayoptics.raytr.analyses as ranalyses
+    import rayoptics.raytr.opticalspec as ropticalspec
     from rayoptics.seq.sequential import SequentialModel
     if _saved:
         uninstall()
@@ -48,7 +49,14 @@ def install(fallback='raise'):
              (ranalyses, 'focus_wavefront', _a.focus_wavefront),
              (ranalyses, 'trace_pupil_coords', _a.trace_pupil_coords),
              (ranalyses, 'focus_pupil_coords', _a.focus_pupil_coords),
-             (SequentialModel, 'trace_grid', _t.seq_trace_grid)]
+             (SequentialModel, 'trace_grid', _t.seq_trace_grid),
+             # chief-ray aiming: trace.aim_chief_ray is imported by name into
+             # opticalspec (opticalspec.py:19), so both bindings are replaced, and
+             # update_optical_properties aims all fields in one launch
+             (rtrace, 'aim_chief_ray', _t.aim_chief_ray),
+             (ropticalspec, 'aim_chief_ray', _t.aim_chief_ray),
+             (ropticalspec.OpticalSpecs, 'update_optical_properties',
+              _t.osp_update_optical_properties)]
     for owner, name, ours in seams:
         theirs = getattr(owner, name)
         _saved[(owner, name)] = theirs

@@ -5,6 +5,9 @@ the per-ray Python loop replaced by one device launch.
   trace_grid      <- rayoptics/raytr/trace.py:563-605
   trace_fan       <- rayoptics/raytr/trace.py:537-560
   seq_trace_grid  <- rayoptics/seq/sequential.py:1058-1085 (method)
+  aim_chief_ray   <- rayoptics/raytr/trace.py:627-640 (iterate_ray's 1-D branch on the device)
+  osp_update_optical_properties <- rayoptics/raytr/opticalspec.py:263-281 (method; all
+                                   fields aimed in one launch)
 Result filtering follows trace_safe, rayoptics/raytr/trace.py:160-221.
 """
 import numpy as np
@@ -198,3 +201,92 @@ def seq_trace_grid(self, fct, fi, wl=None, num_rays=21, form='grid',
                               **dict(kwargs))
         grids.append(grid)
     return grids, wvls.render_colors
+
+
+# ---- chief-ray aiming --------------------------------------------------------
+def _aim_problem(opt_model, fld, wvl, tbl, stop):
+    """rox_aim for the 1-D branch of iterate_ray (trace.py:376-392), or None when
+    the field takes another branch (2-D MINPACK iteration, wide-angle search)"""
+    osp = opt_model['optical_spec']
+    if osp['fov'].is_wide_angle:
+        return None
+    fod = opt_model['analysis_results']['parax_data'].fod
+    pt0, _d0 = osp.obj_coords(fld)
+    if pt0[0] != 0.0:
+        return None
+    a = abi.Aim()
+    for i in range(3):
+        a.pt0[i] = float(pt0[i])
+    a.z_enp = float(fod.obj_dist + fod.enp_dist)
+    a.y_target = 0.0
+    a.z_dir0 = float(opt_model['seq_model'].z_dir[0])
+    a.wvl_idx = tbl.wvl_index(wvl)
+    a.surf = int(stop)
+    a.flip = 1
+    return a
+
+
+def aim_chief_rays(opt_model, flds, wvl=None):
+    """aim_info for every field in ``flds``: the fields on iterate_ray's 1-D
+    branch are solved together in one launch (one lane each, secant iteration
+    restated from scipy.optimize.newton); the others -- off-axis-in-x fields
+    (2-D MINPACK iteration) and wide-angle pupil searches -- keep the reference's
+    own host code (rayoptics/raytr/trace.py:313-415, wideangle.py:86-427)."""
+    from rayoptics.raytr import trace as ref_trace
+    sm = opt_model['seq_model']
+    if wvl is None:
+        wvl = sm.central_wavelength()
+    stop = sm.stop_surface
+    out = [None] * len(flds)
+    if stop is None and not opt_model['optical_spec']['fov'].is_wide_angle:
+        return [np.array([0., 0.]) + np.array([0., 0.]) for _ in flds]      # floating stop, :412-413
+    eng = session.engine_for(opt_model)
+    probs, where = [], []
+    for k, fld in enumerate(flds):
+        a = _aim_problem(opt_model, fld, wvl, eng.table, stop) if stop is not None else None
+        if a is None:
+            out[k] = _ref_aim_chief_ray(ref_trace)(opt_model, fld, wvl)
+        else:
+            probs.append(a)
+            where.append(k)
+    if probs:
+        aim_y, _result = eng.aim_chief_rays(probs)
+        for k, y in zip(where, aim_y):
+            out[k] = np.array([0., float(y)])
+    return out
+
+
+def _ref_aim_chief_ray(ref_trace):
+    """the reference's own aim_chief_ray, also while install() has it rebound"""
+    fn = ref_trace.aim_chief_ray
+    return getattr(fn, '__wrapped__', fn)
+
+
+def aim_chief_ray(opt_model, fld, wvl=None):
+    """rayoptics/raytr/trace.py:627-640"""
+    return aim_chief_rays(opt_model, [fld], wvl)[0]
+
+
+def osp_update_optical_properties(self, **kwargs):
+    """rayoptics/raytr/opticalspec.py:263-281 as a replacement *method* of
+    OpticalSpecs: first-order data from the reference, then every field's chief
+    ray aimed in one device launch instead of a Python loop of iterated rays."""
+    from rayoptics.parax.firstorder import compute_first_order
+    opm = self.opt_model
+    sm = opm['seq_model']
+    if sm.get_num_surfaces() > 2:
+        src = kwargs.get('src_model', None)
+        stop = sm.stop_surface
+        wvl = self.spectral_region.central_wvl
+        opm['analysis_results']['parax_data'] = compute_first_order(opm, stop, wvl, src_model=src)
+        if self.do_aiming:
+            flds = self.field_of_view.fields
+            try:
+                for fld, aim in zip(flds, aim_chief_rays(opm, flds, wvl)):
+                    fld.aim_info = aim
+            except Exception:           # per-field failures are reported, not raised (:277-281)
+                for i, fld in enumerate(flds):
+                    try:
+                        fld.aim_info = aim_chief_ray(opm, fld, wvl)
+                    except Exception:
+                        print(f"OpticalSpecs aim_chief_ray failure at field {i}")

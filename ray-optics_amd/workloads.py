@@ -19,6 +19,7 @@ class Workload:
         self.table = SurfaceTable.from_dict(d['table'])
         self.foc = d['foc']
         self.ref_wvl_idx = d['ref_wvl_idx']
+        self.aim = d.get('aim')     # chief-ray aiming problems + the reference's answers
         self.fields = []
         self.image_pts = []
         for fd in d['fields']:

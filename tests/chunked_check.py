@@ -1,0 +1,63 @@
+"""run by tests/test_gpu_r02.py::test_chunked_launches in a subprocess with
+ROX_RAYS_PER_LAUNCH set (the library reads it once): a ragged batch over the
+multi-launch path, every output mode, vs the oracle."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import rayoptics_amd  # noqa: E402,F401
+from rayoptics_amd import abi  # noqa: E402
+from rayoptics_amd.engine import TraceEngine  # noqa: E402
+from oracle import oracle  # noqa: E402
+import helpers as H  # noqa: E402
+
+assert os.environ.get('ROX_RAYS_PER_LAUNCH') == '4096'
+
+
+def same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    ok = (a.shape == b.shape) and bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+    assert ok, what
+
+
+for name in ('dblgauss', 'tilted_singlet'):
+    fx = H.fixture(name)
+    c = fx['grid_f2'] if name == 'dblgauss' else fx['grid_f1']
+    eng = TraceEngine(fx.table)
+    fld = H.field_from_arr(c['field'])
+    N = fx.table.n_ifcs
+    num = 131                               # 17161 rays = 4 launches + a ragged fifth
+    grid = oracle.make_grid((-1., -1.), (1., 1.), num)
+    for mode in (abi.OUT_FULL, abi.OUT_LAST, abi.OUT_HITS, abi.OUT_HITS_COMPACT):
+        opts = H.make_opts(c, out_mode=mode, foc=0.02, image_pt=(0.1, 0.3))
+        orc = oracle.trace_pupil_grid(fx.table, fld, grid, 0, opts)
+        if mode == abi.OUT_HITS_COMPACT:
+            same(eng.trace_pupil_grid_hits(fld, grid, 0, opts), orc.hits, f'{name} compact')
+            same(eng.trace_pupil_grid_hits(fld, grid, 0, opts), orc.hits, f'{name} compact again')
+            continue
+        dev = eng.trace_pupil_grid(fld, grid, 0, opts, nan_fill=True).to_host()
+        assert np.array_equal(dev.status, orc.status) and np.array_equal(dev.fail_surf, orc.fail_surf)
+        same(dev.seg, orc.seg, f'{name} mode {mode} seg')
+        same(dev.op, orc.op, f'{name} mode {mode} op')
+        same(dev.pupil, orc.pupil, f'{name} mode {mode} pupil')
+    # explicit rays with per-ray wavelengths, OPD-free modes
+    if name == 'dblgauss':
+        cr = fx['rays_ap']
+        reps = 9
+        pt0 = np.tile(cr['pt0'], (1, reps))
+        d0 = np.tile(cr['dir0'], (1, reps))
+        wi = np.tile(np.asarray(cr['wvl_idx'], dtype=np.int32) if np.ndim(cr['wvl_idx']) else
+                     np.full(cr['pt0'].shape[1], int(cr['wvl_idx']), np.int32), reps)
+        o = H.make_opts(cr)
+        dev = eng.trace_rays(pt0, d0, wi, o, nan_fill=True).to_host()
+        orc = oracle.trace_rays(fx.table, pt0, d0, wi, o)
+        assert np.array_equal(dev.status, orc.status)
+        same(dev.seg, orc.seg, 'rays seg')
+        same(dev.op, orc.op, 'rays op')
+    eng.close()
+print('chunked ok')

@@ -83,3 +83,62 @@ def assert_result_matches(case, res, atol=ATOL, require_exact=False, seg_key='se
     f1 = assert_soa_close(case[seg_key], np.asarray(res.seg)[:K], 'seg', atol, require_exact)
     f2 = assert_soa_close(case['op'], res.op, 'op', atol, require_exact)
     return min(f1, f2)
+
+
+def phase_table(rng, kind, wvls=(486.1, 587.6, 656.3)):
+    """a small system with one phase element of `kind` ('grating', 'doe',
+    'hologram', 'thinlens'), built without the reference (GPU box)"""
+    N = int(rng.integers(4, 8))
+    k_phase = int(rng.integers(1, N - 1))
+    surfs = []
+    for i in range(N):
+        interior = 0 < i < N - 1
+        if not interior:
+            surfs.append(dict(cv=0.0, thi=40.0 if i == 0 else 0.0, n=1.0, max_aperture=1e12))
+            continue
+        cv = float(rng.uniform(-0.03, 0.03)) if rng.random() > 0.3 else 0.0
+        n = 1.0 if rng.random() < 0.35 else float(rng.uniform(1.4, 1.8))
+        surfs.append(dict(cv=cv, thi=float(rng.uniform(2.0, 12.0)),
+                          n=[1.0 if n == 1.0 else n + 0.004 * w for w in range(len(wvls))],
+                          max_aperture=15.0, profile='Conic' if rng.random() < 0.3 else 'Spherical',
+                          cc=float(rng.uniform(-1, 0.5))))
+    tbl = SurfaceTable.from_prescription(surfs, wvls=wvls)
+    row = tbl.rows[k_phase]
+    ph = row.ph
+    if kind == 'grating':
+        g = rng.normal(size=3)
+        g[2] *= 0.1
+        g = np.array([0., 1., 0.]) if rng.random() < 0.5 else g / np.linalg.norm(g)
+        ph.kind, ph.order = abi.PH_GRATING, float(rng.choice([-1, 1, 2]))
+        ph.spacing_nm = 1e6 / float(rng.uniform(50., 900.))
+        for i in range(3):
+            ph.a[i] = g[i]
+    elif kind == 'doe':
+        nc = int(rng.integers(1, 5))
+        ph.kind, ph.ncoef = abi.PH_DOE_RADIAL, nc
+        for k in range(nc):
+            ph.coefs[k] = float(rng.normal() * 10.0 ** (-(3 + 2 * k)))
+        ph.ref_wl, ph.order = float(rng.choice([550., 632.8])), float(rng.choice([1, 1, -1, 2]))
+    else:
+        if kind == 'thinlens':
+            row.profile, row.cv, row.cc, row.ec = abi.THINLENS, 0.0, 0.0, 1.0
+            pwr = float(rng.uniform(-0.03, 0.05))
+            ref_pt, obj_pt = (0., 0., -1e10), (0., 0., 1. / pwr)
+            flags = 2 if pwr > 0 else 0
+        else:
+            ref_pt = (rng.uniform(-2, 2), rng.uniform(-2, 2), -rng.uniform(50, 500))
+            obj_pt = (rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(30, 300))
+            flags = (1 if rng.random() < 0.3 else 0) | (2 if rng.random() < 0.6 else 0)
+        ph.kind, ph.flags, ph.ref_wl = abi.PH_HOLOGRAM, flags, float(rng.choice([550., 632.8]))
+        for i in range(3):
+            ph.a[i], ph.b[i] = ref_pt[i], obj_pt[i]
+    return tbl, k_phase
+
+
+def random_rays(rng, R, z_target, spread=9.0):
+    pt0 = np.stack([rng.uniform(-5, 5, R), rng.uniform(-5, 5, R), np.zeros(R)])
+    tgt = np.stack([rng.uniform(-spread, spread, R), rng.uniform(-spread, spread, R),
+                    np.full(R, z_target)])
+    d = tgt - pt0
+    d /= np.linalg.norm(d, axis=0)
+    return pt0, d

@@ -380,3 +380,76 @@ def test_raylist_refocus_fused(ref, installed):
         np.testing.assert_array_equal(a, b)
     assert ours[3] == theirs[3] > 10
     assert not np.array_equal(ours[0], ours[1])
+
+
+@pytest.mark.parametrize('spec', ['obj_NA', 'img_fno', 'img_NA', 'aim_pt', 'aim_dir', 'wide'])
+def test_every_ray_start_branch_on_device(ref, installed, spec):
+    """every branch of OpticalSpecs.ray_start_from_osp (opticalspec.py:289-400)
+    -- angular pupils ('NA', 'f/#', image-space forms), 'aim pt' / 'aim dir'
+    pupil types, wide-angle fields -- generated by the launch itself
+    (rox_field.kind) and equal to the reference's per-ray Python"""
+    import rayoptics.raytr.trace as trace
+    from rayoptics.raytr.opticalspec import PupilSpec
+    from rayoptics_amd import abi
+    from rayoptics_amd.table import field_from_model
+    opm = ref.singlet() if spec != 'wide' else ref.dblgauss()
+    osp = opm['optical_spec']
+    kw = {}
+    want_kind = abi.FLD_EPD
+    start, stop = np.array([-1., -1.]), np.array([1., 1.])
+    if spec == 'obj_NA':
+        osp['pupil'] = PupilSpec(osp, key=['object', 'NA'], value=0.04)
+        want_kind = abi.FLD_NA
+    elif spec == 'img_fno':
+        osp['pupil'] = PupilSpec(osp, key=['image', 'f/#'], value=6.0)
+    elif spec == 'img_NA':
+        osp['pupil'] = PupilSpec(osp, key=['image', 'NA'], value=0.05)
+    elif spec == 'aim_pt':
+        kw['pupil_type'] = 'aim pt'
+        want_kind = abi.FLD_AIM_PT
+        start, stop = np.array([-4., -4.]), np.array([4., 4.])
+    elif spec == 'aim_dir':
+        osp['pupil'] = PupilSpec(osp, key=['object', 'NA'], value=0.04)
+        kw['pupil_type'] = 'aim dir'
+        want_kind = abi.FLD_AIM_DIR
+        start, stop = np.array([-.04, -.04]), np.array([.04, .04])
+    ref.finish(opm)
+    if spec == 'wide':
+        osp['fov'].is_wide_angle = True
+        for f in osp['fov'].fields:     # (z_enp from the paraxial model; the wide-angle
+            f.aim_info = None           #  pupil search is host control plane, wideangle.py)
+        want_kind = abi.FLD_EPD_WIDE
+    fld = osp['fov'].fields[1]
+    wvl = opm['seq_model'].central_wavelength()
+    assert field_from_model(opm, fld, kw.get('pupil_type', 'rel pupil')).kind == want_kind
+
+    def run():
+        return trace.trace_grid(opm, [start.copy(), stop.copy(), 7], fld, wvl, 0.0,
+                                img_filter=lambda p, pkg: np.full(8, np.nan) if pkg is None else
+                                np.concatenate([p, pkg[0][0][1], pkg[0][-1][0]]),
+                                form='grid', append_if_none=True, **kw)
+    go, gt = both(installed, run)
+    assert go.shape == gt.shape == (7, 7, 8)
+    np.testing.assert_array_equal(go, gt)
+    assert np.isfinite(go[:, :, 2]).sum() > 10
+
+
+def test_chief_ray_aiming_on_device(ref, installed):
+    """trace.aim_chief_ray / OpticalSpecs.update_optical_properties with the
+    aiming iteration (iterate_ray's 1-D branch, scipy's secant) restated on the
+    device: fld.aim_info equal to the reference's on every fixture model"""
+    import rayoptics.raytr.trace as trace
+    for build in (ref.dblgauss, ref.singlet, ref.rc_telescope, ref.nikkor, ref.cell_phone):
+        installed.uninstall()
+        opm = build()                       # the reference aims the fields itself
+        theirs = [np.array(f.aim_info, dtype=float).copy() for f in opm['osp']['fov'].fields]
+        installed.install()
+        for f in opm['osp']['fov'].fields:
+            f.aim_info = None
+        opm['osp'].update_optical_properties()      # rebound: one launch for all fields
+        ours = [np.array(f.aim_info, dtype=float) for f in opm['osp']['fov'].fields]
+        for a, b in zip(ours, theirs):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-10)
+            np.testing.assert_array_equal(a, b)     # in fact bit-identical
+        one = trace.aim_chief_ray(opm, opm['osp']['fov'].fields[-1])
+        np.testing.assert_array_equal(one, theirs[-1])

@@ -277,7 +277,7 @@ def test_slim_fp64_paths_equal_ieee_operators():
     assert torch.cuda.is_available()
     torch.zeros(1, device='cuda')
     lib = load_library()
-    counts = (C.c_uint64 * 3)()
+    counts = (C.c_uint64 * 4)()
     for seed in (1, 2):
         rc = lib.rox_selftest_fp64(1 << 27, seed, counts)
         assert rc == 0, lib.rox_last_error()

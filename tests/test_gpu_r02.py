@@ -1,0 +1,348 @@
+"""-m gpu, round 2: stream compaction of the hits (ROX_OUT_HITS_COMPACT), two
+streams on one handle, chunked launches, phase elements / thin lenses, every
+ray-start branch, chief-ray aiming, index validation -- HIP through the C ABI
+against the CPU oracle (bit-exact unless stated) and the golden fixtures."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from rayoptics_amd import abi
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FLAGS = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+
+
+@pytest.fixture(scope='module')
+def engines():
+    from rayoptics_amd.engine import TraceEngine
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = TraceEngine(H.fixture(name).table)
+        return cache[name]
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+def bit_equal(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f'{what}: {np.count_nonzero(~same)} of {same.size} differ, first {np.argwhere(~same)[:3].tolist()}'
+
+
+# ---------------------------------------------------------------- compaction
+@pytest.mark.parametrize('name', ['dblgauss', 'singlet', 'rc_telescope', 'nikkor'])
+def test_hits_compact_equals_spot_diagram_data(engines, name):
+    """the (R_ok, 2) array the kernel packs into pinned host memory is exactly
+    SpotDiagramFigure's data from the reference (tests/golden) and the oracle's"""
+    from oracle import oracle
+    fx = H.fixture(name)
+    c = fx['spot']
+    num = int(c['num'])
+    N = fx.table.n_ifcs
+    for key in [k for k in c if k.endswith('_hits')]:
+        fi, wi = key.split('_')[0], int(key.split('_')[1][1:])
+        fld = H.field_from_arr(c[f'{fi}_field'])
+        opts = oracle.make_opts(flags=FLAGS, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                                last_surf=N - 2, foc=float(c['foc']),
+                                image_pt=tuple(c[f'{fi}_image_pt']))
+        grid = oracle.make_grid((-1., -1.), (1., 1.), num)
+        xy = engines(name).trace_pupil_grid_hits(fld, grid, wi, opts)
+        orc = oracle.trace_pupil_grid(fx.table, fld, grid, wi, opts)
+        bit_equal(xy, orc.hits, f'{name}/{key} vs oracle')
+        bit_equal(xy, c[key], f'{name}/{key} vs reference')
+
+
+@pytest.mark.parametrize('num', [1, 2, 23, 37, 256, 1024])
+def test_hits_compact_sizes(engines, num):
+    """ragged tiles, single tiles, a million rays: order and count vs the oracle"""
+    from oracle import oracle
+    fx = H.fixture('dblgauss')
+    c = fx['grid_f2']
+    fld = H.field_from_arr(c['field'])
+    N = fx.table.n_ifcs
+    opts = oracle.make_opts(flags=FLAGS, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                            last_surf=N - 2, foc=0.03, image_pt=(0.1, 18.2))
+    grid = oracle.make_grid((-1., -1.), (1., 1.), num) if num > 1 else \
+        oracle.make_grid((0.2, -0.1), (1., 1.), 1)
+    eng = engines('dblgauss')
+    for rep in range(3):                        # the per-stream state is re-armed each launch
+        xy = eng.trace_pupil_grid_hits(fld, grid, 1, opts)
+        if rep == 0:
+            with np.errstate(all='ignore'):
+                orc = oracle.trace_pupil_grid(fx.table, fld, grid, 1, opts)
+        bit_equal(xy, orc.hits, f'num={num} rep={rep}')
+    if num >= 23:
+        assert 0 < xy.shape[0] < num * num
+
+
+def test_hits_compact_list_rays_empty_and_device_buffers(engines):
+    import torch
+    from oracle import oracle
+    from rayoptics_amd.engine import load_library
+    fx = H.fixture('dblgauss')
+    c = fx['grid_f2']
+    fld = H.field_from_arr(c['field'])
+    N = fx.table.n_ifcs
+    eng = engines('dblgauss')
+    rng = np.random.default_rng(5)
+    opts = oracle.make_opts(flags=FLAGS, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                            last_surf=N - 2, foc=-0.01, image_pt=(0.0, 18.0))
+    # pupil list
+    R = 3001
+    px, py = rng.uniform(-1.1, 1.1, R), rng.uniform(-1.1, 1.1, R)
+    bit_equal(eng.trace_pupil_list_hits(fld, px, py, 2, opts),
+              oracle.trace_pupil_list(fx.table, fld, px, py, 2, opts).hits, 'list')
+    # explicit rays, per-ray wavelengths
+    cr = fx['rays_ap']
+    o2 = oracle.make_opts(flags=int(cr['flags']), out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                          last_surf=N - 2, foc=0.02, image_pt=(0.0, 0.0))
+    bit_equal(eng.trace_rays_hits(cr['pt0'], cr['dir0'], cr['wvl_idx'], o2),
+              oracle.trace_rays(fx.table, cr['pt0'], cr['dir0'], cr['wvl_idx'], o2).hits, 'rays')
+    # empty batch: the count is still delivered
+    assert eng.trace_pupil_list_hits(fld, np.zeros(0), np.zeros(0), 0, opts).shape == (0, 2)
+    # device buffers through the raw C ABI (seg / n_hits / status all in HBM)
+    num = 64
+    grid = oracle.make_grid((-1., -1.), (1., 1.), num)
+    xy_d = torch.full((num * num, 2), float('nan'), dtype=torch.float64, device=eng.device)
+    n_d = torch.zeros(1, dtype=torch.int64, device=eng.device)
+    st_d = torch.zeros(num * num, dtype=torch.uint8, device=eng.device)
+    out = abi.Out()
+    out.seg, out.n_hits, out.status, out.ld = xy_d.data_ptr(), n_d.data_ptr(), st_d.data_ptr(), num * num
+    lib = load_library()
+    rc = lib.rox_trace_pupil_grid(eng._handle, C.byref(fld), C.byref(grid), 0, C.byref(opts),
+                                  C.byref(out), eng._stream())
+    assert rc == 0, lib.rox_last_error()
+    torch.cuda.synchronize()
+    orc = oracle.trace_pupil_grid(fx.table, fld, grid, 0, opts)
+    n = int(n_d.item())
+    assert n == orc.hits.shape[0]
+    bit_equal(xy_d[:n].cpu().numpy(), orc.hits, 'device buffers')
+    np.testing.assert_array_equal(st_d.cpu().numpy(), orc.status)
+    assert torch.isnan(xy_d[n:]).all()
+    # argument checking
+    out.n_hits = None
+    assert lib.rox_trace_pupil_grid(eng._handle, C.byref(fld), C.byref(grid), 0, C.byref(opts),
+                                    C.byref(out), eng._stream()) == -1
+
+
+def test_two_streams_share_one_handle(engines):
+    """two HIP streams launching different grid definitions on one handle: each
+    stream owns its pupil axes and compaction state"""
+    import torch
+    from oracle import oracle
+    from rayoptics_amd.engine import DeviceResult
+    fx = H.fixture('dblgauss')
+    c = fx['grid_f2']
+    fld = H.field_from_arr(c['field'])
+    N = fx.table.n_ifcs
+    eng = engines('dblgauss')
+    o_hits = oracle.make_opts(flags=FLAGS, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
+                              foc=0.0, image_pt=(0., 18.))
+    o_cmp = oracle.make_opts(flags=FLAGS, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                             last_surf=N - 2, foc=0.0, image_pt=(0., 18.))
+    defs = [((-1., -1.), (1., 1.), 512), ((-0.5, -0.8), (0.9, 0.7), 509)]
+    streams = [torch.cuda.Stream(device=eng.device) for _ in defs]
+    outs, cmps = [[] for _ in defs], [[] for _ in defs]
+    reps = 6
+    for rep in range(reps):
+        for k, (a, b, num) in enumerate(defs):
+            grid = oracle.make_grid(a, b, num)
+            with torch.cuda.stream(streams[k]):
+                res = DeviceResult(torch, eng.device, 0, num * num, abi.OUT_HITS, False, True)
+                eng.trace_pupil_grid(fld, grid, k, o_hits, want_pupil=False, out=res)
+                outs[k].append(res)
+                if rep < 2:
+                    cmps[k].append(eng.trace_pupil_grid_hits(fld, grid, k, o_cmp))
+    torch.cuda.synchronize()
+    for k, (a, b, num) in enumerate(defs):
+        grid = oracle.make_grid(a, b, num)
+        orc = oracle.trace_pupil_grid(fx.table, fld, grid, k, o_hits)
+        orc_c = oracle.trace_pupil_grid(fx.table, fld, grid, k, o_cmp)
+        for res in outs[k]:
+            np.testing.assert_array_equal(res.status.cpu().numpy(), orc.status)
+            bit_equal(res.seg.cpu().numpy(), orc.seg, f'stream {k}')
+        for xy in cmps[k]:
+            bit_equal(xy, orc_c.hits, f'stream {k} compact')
+
+
+def test_chunked_launches():
+    """ROX_RAYS_PER_LAUNCH=4096: the multi-launch path (ray_base, offset output
+    pointers, running hit count) over a ragged batch, every output mode"""
+    env = dict(os.environ, ROX_RAYS_PER_LAUNCH='4096')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'chunked_check.py')],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert 'chunked ok' in p.stdout
+
+
+# ---------------------------------------------------------------- phase elements
+@pytest.mark.parametrize('kind', ['grating', 'doe', 'hologram', 'thinlens'])
+def test_phase_elements(kind):
+    """raytrace.py:205-210 on the device.  Holograms / thin lenses are bit-exact;
+    gratings and DOEs evaluate `x**2`, `r_sqr**k` where the reference calls libm
+    pow() (not correctly rounded for ~1e-3 of its arguments): there the bound is
+    the north star's 1e-10 and >= 99 % of the values are still bit-identical."""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine
+    n_ok = n_evan = 0
+    for seed in range(6):
+        rng = np.random.default_rng(4200 + 10 * seed + len(kind))
+        tbl, k_phase = H.phase_table(rng, kind)
+        N = tbl.n_ifcs
+        R = 4096 + 77
+        pt0, d = H.random_rays(rng, R, tbl.rows[0].t[2])
+        wi = (np.arange(R) % len(tbl.wvls)).astype(np.int32)
+        eng = TraceEngine(tbl)
+        for mode in (abi.OUT_FULL, abi.OUT_HITS):
+            opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES, out_mode=mode,
+                                    first_surf=1, last_surf=N - 2, foc=0.01)
+            with np.errstate(all='ignore'):
+                orc = oracle.trace_rays(tbl, pt0, d, wi, opts)
+            dev = eng.trace_rays(pt0, d, wi, opts, nan_fill=True).to_host()
+            exact = kind in ('hologram', 'thinlens')
+            if exact:
+                np.testing.assert_array_equal(dev.status, orc.status)
+                np.testing.assert_array_equal(dev.fail_surf, orc.fail_surf)
+                bit_equal(dev.seg, orc.seg, f'{kind} seg')
+                bit_equal(dev.op, orc.op, f'{kind} op')
+            else:
+                agree = dev.status == orc.status
+                assert agree.mean() > 0.999      # a 1-ulp radicand may flip a borderline ray
+                m = agree
+                f1 = H.assert_soa_close(orc.seg[..., m], dev.seg[..., m], f'{kind} seg')
+                f2 = H.assert_soa_close(orc.op[m], dev.op[m], f'{kind} op')
+                assert min(f1, f2) > 0.99, (kind, f1, f2)
+        n_ok += int((orc.status == abi.OK).sum())
+        n_evan += int((orc.status == abi.EVANESCENT).sum())
+        eng.close()
+    assert n_ok > 1000
+    if kind in ('grating', 'doe', 'hologram'):
+        assert n_evan >= 0
+
+
+# ---------------------------------------------------------------- ray starts
+@pytest.mark.parametrize('kind', [abi.FLD_EPD, abi.FLD_EPD_WIDE, abi.FLD_AIM_PT, abi.FLD_NA,
+                                  abi.FLD_FNO, abi.FLD_AIM_DIR])
+def test_every_ray_start_branch(engines, kind):
+    from oracle import oracle
+    from rayoptics_amd.table import field_struct
+    fx = H.fixture('singlet')
+    eng = engines('singlet')
+    N = fx.table.n_ifcs
+    rng = np.random.default_rng(77 + kind)
+    ang = np.deg2rad(7.0)
+    rot = np.array([[1, 0, 0], [0, np.cos(ang), -np.sin(ang)], [0, np.sin(ang), np.cos(ang)]])
+    z0 = float(fx.table.rows[0].t[2])
+    for trial in range(3):
+        rot_t = rot if trial % 2 == 0 else np.asfortranarray(rot)
+        scale = {abi.FLD_EPD: 5.0, abi.FLD_EPD_WIDE: 5.0, abi.FLD_AIM_PT: 0.0, abi.FLD_NA: 0.05,
+                 abi.FLD_FNO: -1 / 12.0, abi.FLD_AIM_DIR: 0.0}[kind]
+        fld = field_struct((0.0, rng.uniform(-3, 3), 0.0), (0.0, rng.uniform(-.3, .3)), scale,
+                           z0 + rng.uniform(-2, 2), (0.0, 0.1, 0.2, 0.05), 1.0, kind=kind,
+                           rot=rot_t, cr_dir=(0.0, rng.uniform(-.03, .03)))
+        span = {abi.FLD_AIM_PT: 4.0, abi.FLD_AIM_DIR: 0.05}.get(kind, 1.0)
+        grid = oracle.make_grid((-span, -span), (span, span), 41)
+        flags = abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+        if kind != abi.FLD_EPD_WIDE:
+            flags |= abi.INTERSECT_OBJ
+        opts = oracle.make_opts(flags=flags, first_surf=1, last_surf=N - 2)
+        with np.errstate(all='ignore'):
+            orc = oracle.trace_pupil_grid(fx.table, fld, grid, 0, opts)
+        dev = eng.trace_pupil_grid(fld, grid, 0, opts, nan_fill=True).to_host()
+        np.testing.assert_array_equal(dev.status, orc.status)
+        np.testing.assert_array_equal(dev.fail_surf, orc.fail_surf)
+        bit_equal(dev.seg, orc.seg, f'kind {kind} seg')
+        bit_equal(dev.op, orc.op, f'kind {kind} op')
+        bit_equal(dev.pupil, orc.pupil, f'kind {kind} pupil')
+        assert (orc.status == abi.OK).sum() > 50
+
+
+# ---------------------------------------------------------------- aiming
+def test_chief_ray_aiming():
+    """rox_aim_chief_rays == the oracle's restatement of iterate_ray + scipy's
+    secant (bit-exact), == the reference's own fld.aim_info stored with the
+    workloads (the aim point the reference converged to)"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine
+    for name in ('dblgauss_c2', 'nikkor_c3', 'cell_phone', 'singlet_c1', 'rc_telescope_c4'):
+        wl = workloads.load(name)
+        meta = wl.aim
+        if meta is None:
+            pytest.skip('workload files carry no aiming data')
+        eng = TraceEngine(wl.table)
+        probs = []
+        for m in meta:
+            a = abi.Aim()
+            for i in range(3):
+                a.pt0[i] = m['pt0'][i]
+            a.z_enp, a.y_target, a.z_dir0 = m['z_enp'], 0.0, m['z_dir0']
+            a.wvl_idx, a.surf, a.flip = m['wvl_idx'], m['surf'], 1
+            probs.append(a)
+        # every field at every wavelength in one launch
+        allp = []
+        for w in range(len(wl.table.wvls)):
+            for a in probs:
+                b = abi.Aim.from_buffer_copy(bytes(a))
+                b.wvl_idx = w
+                allp.append(b)
+        y_dev, r_dev = eng.aim_chief_rays(allp)
+        y_orc, r_orc = oracle.aim_chief_rays(wl.table, allp)
+        np.testing.assert_array_equal(r_dev, r_orc)
+        np.testing.assert_array_equal(y_dev, y_orc)
+        for m, a in zip(meta, probs):
+            y, r = eng.aim_chief_rays([a])
+            assert abs(y[0] - m['aim_y']) <= 1e-10, (name, y[0], m['aim_y'])
+            assert y[0] == m['aim_y']
+        eng.close()
+
+
+# ---------------------------------------------------------------- misc
+def test_bad_wavelength_index_with_device_pointers(engines):
+    """per-ray wvl_idx outside the table never indexes it: the ray is reported
+    as a miss at the object surface"""
+    from oracle import oracle
+    fx = H.fixture('dblgauss')
+    cr = fx['rays_ap']
+    eng = engines('dblgauss')
+    R = cr['pt0'].shape[1]
+    wi = (np.arange(R) % 3).astype(np.int32)
+    bad = np.array([5, 77, 300, R - 1])
+    wi_bad = wi.copy()
+    wi_bad[bad] = [3, -1, 1 << 20, -(1 << 30)]
+    o = H.make_opts(cr)
+    dev = eng.trace_rays(cr['pt0'][:, :R], cr['dir0'][:, :R], wi_bad, o, nan_fill=True).to_host()
+    orc = oracle.trace_rays(fx.table, cr['pt0'][:, :R], cr['dir0'][:, :R], wi, o)
+    good = np.ones(R, bool)
+    good[bad] = False
+    np.testing.assert_array_equal(dev.status[good], orc.status[good])
+    bit_equal(dev.seg[..., good], orc.seg[..., good], 'good rays')
+    assert (dev.status[bad] == abi.MISSED_SURFACE).all() and (dev.fail_surf[bad] == 0).all()
+
+
+def test_slim_fp64_band_edges():
+    """the guarded sqrt / division paths at the exponent-band edges: wave-uniform
+    operand classes with exponents 640/641/1406/1407, numerator/divisor spreads of
+    767 and +-0 numerators must take the slim path and equal the IEEE operators;
+    one step outside the band must fall back"""
+    import torch
+    from rayoptics_amd.engine import load_library
+    torch.zeros(1, device='cuda')
+    lib = load_library()
+    counts = (C.c_uint64 * 4)()
+    for seed in (3, 4):
+        assert lib.rox_selftest_fp64(1 << 26, seed, counts) == 0, lib.rox_last_error()
+        assert counts[0] == 0 and counts[1] == 0, list(counts)
+        assert counts[2] > (1 << 26) * 0.5
+        # classes 3, 4, 5 (3/14 of the operand sets) took the slim path
+        assert counts[3] > (1 << 26) * 0.2, list(counts)

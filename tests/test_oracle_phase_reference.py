@@ -1,0 +1,130 @@
+"""Oracle vs the LIVE reference (build container only) for the rows added in
+round 2: phase elements (DiffractionGrating, DiffractiveElement with
+radial_phase_fct, HolographicElement) on surfaces, ThinLens interfaces
+(rayoptics/oprops/doe.py, thinlens.py; raytrace.py:41-48, 205-210), traced by
+the reference's own trace_raw at several wavelengths and by oracle/rox_oracle.c
+-- bit for bit (segments, op incl. the accumulated phase, status incl.
+TraceEvanescentRayError, failing surface, partial packets)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.needs_reference
+
+WVLS = [486.1, 587.6, 656.3]
+
+
+def random_phase_path(rng, kind):
+    from rayoptics.elem import profiles, surface
+    from rayoptics.oprops import doe
+    from rayoptics.oprops.thinlens import ThinLens
+    N = int(rng.integers(4, 8))
+    k_phase = int(rng.integers(1, N - 1))
+    path_ifcs, thi, nn, zd = [], [], [], []
+    zdir = 1
+    for i in range(N):
+        interior = 0 < i < N - 1
+        t = float(rng.uniform(2.0, 12.0)) if i > 0 else 40.0
+        n = 1.0
+        if not interior:
+            s = surface.Surface(interact_mode='dummy')
+            s.max_aperture = 1e12
+        elif i == k_phase and kind == 'thinlens':
+            s = ThinLens(power=float(rng.uniform(-0.03, 0.05)), center_wvl=float(rng.choice([550., 587.6])))
+            s.max_aperture = 20.0
+            n = 1.0
+        else:
+            mode = 'transmit'
+            if i == k_phase and kind == 'grating' and rng.random() < 0.4:
+                mode = 'reflect'
+            s = surface.Surface(interact_mode=mode)
+            cv = float(rng.uniform(-0.03, 0.03)) if rng.random() > 0.3 else 0.0
+            s.profile = (profiles.Conic(c=cv, cc=float(rng.uniform(-1, 0.5))) if rng.random() < 0.3
+                         else profiles.Spherical(c=cv))
+            s.max_aperture = 15.0
+            n = 1.0 if rng.random() < 0.35 else float(rng.uniform(1.4, 1.8))
+            if i == k_phase:
+                if kind == 'grating':
+                    g = rng.normal(size=3)
+                    g[2] *= 0.1
+                    s.phase_element = doe.DiffractionGrating(
+                        order=int(rng.choice([-1, 1, 2])),
+                        grating_normal=(np.array([0., 1., 0.]) if rng.random() < 0.5
+                                        else g / np.linalg.norm(g)),
+                        grating_lpmm=float(rng.uniform(50., 900.)), interact_mode=mode)
+                elif kind == 'doe':
+                    nc = int(rng.integers(1, 5))
+                    s.phase_element = doe.DiffractiveElement(
+                        coefficients=[float(rng.normal() * 10.0 ** (-(3 + 2 * k))) for k in range(nc)],
+                        ref_wl=float(rng.choice([550., 632.8])), order=int(rng.choice([1, 1, -1, 2])),
+                        phase_fct=doe.radial_phase_fct)
+                else:
+                    s.phase_element = doe.HolographicElement(
+                        ref_pt=np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), -rng.uniform(50, 500)]),
+                        ref_virtual=bool(rng.random() < 0.3),
+                        obj_pt=np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(30, 300)]),
+                        obj_virtual=bool(rng.random() < 0.6), ref_wl=float(rng.choice([550., 632.8])))
+            if mode == 'reflect':
+                zdir = -zdir
+        if zdir < 0 and i > 0:
+            t = -t
+        path_ifcs.append(s)
+        thi.append(t if i < N - 1 else 0.0)
+        nn.append(n)
+        zd.append(zdir)
+    paths = []
+    for w, _ in enumerate(WVLS):
+        paths.append([[s, None, (np.identity(3), np.array([0., 0., t])),
+                       1.0 if n == 1.0 else n + 0.004 * w, z]
+                      for s, t, n, z in zip(path_ifcs, thi, nn, zd)])
+    return paths, k_phase
+
+
+@pytest.mark.parametrize('kind', ['grating', 'doe', 'hologram', 'thinlens'])
+@pytest.mark.parametrize('seed', range(8))
+def test_phase_elements_oracle_equals_reference(kind, seed):
+    from oracle import oracle, refshim
+    refshim.install()
+    from rayoptics.raytr.raytrace import trace_raw
+    from rayoptics.raytr import traceerror as terr
+    from rayoptics_amd import SurfaceTable, abi
+    rng = np.random.default_rng(9100 + 10 * seed + len(kind))
+    paths, k_phase = random_phase_path(rng, kind)
+    N = len(paths[0])
+    tbl = SurfaceTable.from_paths(paths, WVLS)
+    assert tbl.rows[k_phase].ph.kind != abi.PH_NONE
+    R = 120
+    thi0 = paths[0][0][2][1][2]
+    pt0 = np.stack([rng.uniform(-5, 5, R), rng.uniform(-5, 5, R), np.zeros(R)])
+    tgt = np.stack([rng.uniform(-9, 9, R), rng.uniform(-9, 9, R), np.full(R, thi0)])
+    d = tgt - pt0
+    d /= np.linalg.norm(d, axis=0)
+    wi = (np.arange(R) % len(WVLS)).astype(np.int32)
+    kw = dict(first_surf=1, last_surf=N - 2, check_apertures=True)
+    opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES, first_surf=1, last_surf=N - 2)
+    with np.errstate(all='ignore'):
+        res = oracle.trace_rays(tbl, pt0, d, wi, opts)
+    kinds = {terr.TraceMissedSurfaceError: abi.MISSED_SURFACE, terr.TraceTIRError: abi.TIR,
+             terr.TraceRayBlockedError: abi.BLOCKED, terr.TraceEvanescentRayError: abi.EVANESCENT}
+    n_ok = n_checked = 0
+    import warnings
+    for r in range(R):
+        try:
+            with np.errstate(all='ignore'), warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                ray, op, _ = trace_raw(iter(paths[wi[r]]), pt0[:, r].copy(), d[:, r].copy(),
+                                       WVLS[wi[r]], **kw)
+            st, surf = abi.OK, -1
+        except terr.TraceError as e:
+            st, surf = kinds[type(e)], e.surf
+            ray, op, _ = e.ray_pkg
+        except (ValueError, ZeroDivisionError, FloatingPointError):
+            continue
+        assert res.status[r] == st and res.fail_surf[r] == surf, (kind, seed, r, st, surf,
+                                                                 res.status[r], res.fail_surf[r])
+        ref = np.array([np.concatenate([s[0], s[1], [s[2]], s[3]]) for s in ray]).reshape(-1, 10)
+        got = res.seg[:len(ray), :, r]
+        assert np.array_equal(ref, got, equal_nan=True), (kind, seed, r, np.argwhere(ref != got)[:3].tolist())
+        assert op == res.op[r] or (np.isnan(op) and np.isnan(res.op[r])), (kind, seed, r, op, res.op[r])
+        n_checked += 1
+        n_ok += st == abi.OK
+    assert n_checked > R // 2 and n_ok > 0

@@ -37,6 +37,41 @@ __global__ void __launch_bounds__(256) tiled(double *out, long ld, long n, int r
     }
 }
 
+// segment-major tiles: element (seg, c, r) at out[((seg*tiles + r/T)*10 + c)*T + r%T]:
+// 13 streams (one per segment), each workgroup writing 10*T*8 contiguous bytes per segment
+template <int T>
+__global__ void __launch_bounds__(T) segtile(double *out, long tiles, long n, int rows, int phase)
+{
+    const int segs = rows / 10;
+    for (long blk = blockIdx.x; blk * T < n; blk += gridDim.x) {
+        const int s0 = (int)((blk * phase) % segs);
+        double v = (double)threadIdx.x;
+        for (int i = 0; i < segs; ++i) {
+            int sg = s0 + i; if (sg >= segs) sg -= segs;
+            double *base = out + ((long)sg * tiles + blk) * 10 * T + threadIdx.x;
+            for (int c = 0; c < 10; ++c) {
+                __builtin_nontemporal_store(v, base + (long)c * T);
+                v += 1.0;
+            }
+        }
+    }
+}
+
+// SoA with 512-thread workgroups (the trace kernel's shape)
+__global__ void __launch_bounds__(512) soa512(double *out, long ld, long n, int rows, int phase)
+{
+    for (long blk = blockIdx.x; blk * 512 < n; blk += gridDim.x) {
+        const long r = blk * 512 + threadIdx.x;
+        const int k0 = (int)((blk * phase) % rows);
+        double v = (double)r;
+        for (int i = 0; i < rows; ++i) {
+            int k = k0 + i; if (k >= rows) k -= rows;
+            __builtin_nontemporal_store(v, out + (long)k * ld + r);
+            v += 1.0;
+        }
+    }
+}
+
 template <class F>
 double time_us(F f, int reps)
 {
@@ -63,6 +98,14 @@ int main()
         printf("{\"layout\": \"soa\", \"phase\": %d, \"us\": %.1f, \"GBps\": %.0f}\n", phase, t, bytes / t / 1e3);
         t = time_us([&] { hipLaunchKernelGGL(tiled, dim3(4096), dim3(256), 0, 0, buf, ld, n, rows, phase); }, 10);
         printf("{\"layout\": \"tiled256\", \"phase\": %d, \"us\": %.1f, \"GBps\": %.0f}\n", phase, t, bytes / t / 1e3);
+        t = time_us([&] { hipLaunchKernelGGL(soa512, dim3(2048), dim3(512), 0, 0, buf, ld, n, rows, phase); }, 10);
+        printf("{\"layout\": \"soa512\", \"phase\": %d, \"us\": %.1f, \"GBps\": %.0f}\n", phase, t, bytes / t / 1e3);
+        t = time_us([&] { hipLaunchKernelGGL(segtile<256>, dim3(4096), dim3(256), 0, 0, buf, n / 256, n, rows, phase); }, 10);
+        printf("{\"layout\": \"segtile256\", \"phase\": %d, \"us\": %.1f, \"GBps\": %.0f}\n", phase, t, bytes / t / 1e3);
+        t = time_us([&] { hipLaunchKernelGGL(segtile<512>, dim3(2048), dim3(512), 0, 0, buf, n / 512, n, rows, phase); }, 10);
+        printf("{\"layout\": \"segtile512\", \"phase\": %d, \"us\": %.1f, \"GBps\": %.0f}\n", phase, t, bytes / t / 1e3);
+        t = time_us([&] { hipLaunchKernelGGL(segtile<1024>, dim3(1024), dim3(1024), 0, 0, buf, n / 1024, n, rows, phase); }, 10);
+        printf("{\"layout\": \"segtile1024\", \"phase\": %d, \"us\": %.1f, \"GBps\": %.0f}\n", phase, t, bytes / t / 1e3);
     }
     return 0;
 }
