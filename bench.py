@@ -10,18 +10,34 @@ ray, written SoA to HBM), rays generated on the device -- the trace_grid-shaped
 entry of the C ABI.  One "step" = one such grid.  Inputs are resident in HBM
 (the surface table; there are no per-ray inputs).
 
-metric      ray-surface intersections per second, counting the intersections
-            actually performed (a ray blocked at surface s contributes s, not K)
-roofline    HBM-bound kernel: algorithmic bytes = what one launch must write
-            (80 B per appended segment + 8 B op + 3 B status, +16 B pupil)
-            divided by the trace kernel's mean duration from HIP events on the
-            launch stream
-cpu_baseline the plain-C oracle (oracle/rox_oracle.c, "port"), 1 thread, on a
-            bounded sample of the same grid, timed on this host
+metric        ray-surface intersections per second, counting the intersections
+              actually performed (a ray blocked at surface s contributes s, not K)
+roofline      HBM-bound kernel: algorithmic bytes = what one launch must write
+              (80 B per appended segment + 8 B op + 3 B status, +16 B pupil)
+              divided by the trace kernel's mean duration from HIP events on the
+              launch stream
+roofline_hits the HITS kernel behind spot diagrams / OPD / refocus is fp64-VALU
+              bound: TFLOP/s by SURVEY 8(d)'s 130 flop per intersection against the
+              78.6 TFLOP/s fp64 vector peak, and the VALU issue fraction from the
+              committed PMC summary
+spot_diagram  BASELINE's second metric at the PRODUCT boundary: wall-clock of
+              rayoptics_amd.trace.trace_grid_spot (the function SequentialModel.trace_grid
+              is rebound to for SpotDiagramFigure) from the Python call to the host
+              (R_ok, 2) array, on a table-backed model
+cpu_baseline  the plain-C oracle (oracle/rox_oracle.c, "port"), 1 thread, on a
+              bounded sample of the same grid, timed on this host; next to it the
+              reference's own Python path as timed by tools/time_reference.py in the
+              build container (the reference is not installed on the GPU box)
+strong_scaling  every run, any N: BASELINE configs[4]'s shape -- 9 fields x 5
+              wavelengths x 2048^2 pupil grids of the 44-interface lithography
+              lens (188.7 M rays, HITS) cut into pupil-row blocks over the ranks
+              (dist.partition), hits gathered to rank 0 over RCCL: kernel ms (max
+              over ranks), gather ms and end-to-end ms, separately
 
-N > 1: launched by torch.distributed.run, one rank per GPU; each rank traces
-its own (field, wavelength) grid of the same size (weak scaling, no data-path
-collective in the timed region); max-over-ranks time.
+N > 1: launched by torch.distributed.run, one rank per GPU.  The main line is
+weak scaling (each rank traces its own (field, wavelength) grid of the same
+size, no data-path collective in the timed region; max-over-ranks time); the
+strong_scaling object carries the fixed-size problem with its one exchange step.
 """
 import argparse
 import json
@@ -47,6 +63,9 @@ def parse():
                          'spot) even with one rank: a 1-GPU rehearsal of the N>1 run')
     ap.add_argument('--cpu-sample-rows', type=int, default=0,
                     help='pupil rows traced by the CPU baseline (0 = auto, ~10 s)')
+    ap.add_argument('--no-strong', action='store_true', help='skip the strong-scaling leg')
+    ap.add_argument('--strong-num', type=int, default=2048,
+                    help='pupil grid of the strong-scaling leg is num x num per (field, wvl)')
     return ap.parse_args()
 
 
@@ -124,44 +143,37 @@ def main():
 
     # dominant kernel: mean launch duration from HIP events on the launch stream
     kern_ms = eng.time_pupil_grid(fld, grid, wi, opts, out, max(args.steps, 10))
-    # spot-diagram wall-clock (HITS mode: Python call -> host (R_ok, 2) array)
+    # HITS kernel (spot diagrams, OPD, refocus): mean launch duration
     o_hits = make_opts(flags=flags, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
                        foc=wl.foc, image_pt=wl.image_pts[fi])
     hits = DeviceResult(torch, eng.device, 0, R, abi.OUT_HITS, want_pupil=False, nan_fill=False)
-    xy_pinned = torch.empty((R, 2), dtype=torch.float64).pin_memory()
+    hits_kern_ms = eng.time_pupil_grid(fld, grid, wi, o_hits, hits, max(args.steps, 10))
+    del hits
+
+    # spot-diagram wall-clock at the product boundary: the function the reference's
+    # SpotDiagramFigure reaches through SequentialModel.trace_grid, on a table-backed
+    # model (the extraction of table / field constants from a live reference model is
+    # what the stand-in skips; the reference is not installed on the GPU box)
+    from rayoptics_amd import trace as rox_trace
+    model = workloads.TableModel(wl)
+    mfld = model.fields[fi]
+    grid_rng = [np.array([-1., -1.]), np.array([1., 1.]), num]
+    wvl_nm = wl.table.wvls[wi]
+    xy = rox_trace.trace_grid_spot(model, grid_rng, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
     spot_ms = []
-    for _ in range(5):
+    for _ in range(15):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        eng.trace_pupil_grid(fld, grid, wi, o_hits, want_pupil=False, out=hits)
-        idx = torch.nonzero(hits.status == 0).squeeze(1)
-        xy_dev = torch.stack((hits.seg[0].index_select(0, idx),
-                              hits.seg[1].index_select(0, idx)), dim=1)
-        xy_pinned[:xy_dev.shape[0]].copy_(xy_dev, non_blocking=True)
-        torch.cuda.synchronize()
-        xy = xy_pinned[:xy_dev.shape[0]].numpy()
+        xy = rox_trace.trace_grid_spot(model, grid_rng, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
         spot_ms.append((time.perf_counter() - t1) * 1e3)
-    hits_kern_ms = eng.time_pupil_grid(fld, grid, wi, o_hits, hits, 10)
 
-    # N > 1: the path's one exchange step -- every (field, wavelength) spot
-    # diagram sharded by pupil-row blocks, hits gathered to rank 0 over RCCL
-    sharded = None
-    if multi:
+    # every run: the fixed-size problem with the path's one exchange step
+    strong = None
+    if not args.no_strong:
         try:
-            from rayoptics_amd.dist import trace_spot_sharded
-            trace_spot_sharded(eng, wl.fields, wl.image_pts, nw, num, wl.foc)      # warm-up
-            fence()
-            t1 = time.perf_counter()
-            res = trace_spot_sharded(eng, wl.fields, wl.image_pts, nw, num, wl.foc)
-            fence()
-            sharded = {'wallclock_ms': (time.perf_counter() - t1) * 1e3,
-                       'grids': nf * nw, 'rays': nf * nw * R,
-                       'what': 'all (field,wvl) spot diagrams, pupil-row blocks over ranks, '
-                               'HITS trace + gather to rank 0 + host reassembly'}
-            if rank == 0:
-                sharded['grids_returned'] = len(res)
+            strong = strong_scaling(args, torch, dist, multi, world, rank, fence)
         except Exception as e:      # never lose the main line to the extra leg
-            sharded = {'error': repr(e)}
+            strong = {'error': repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -198,15 +210,126 @@ def main():
                          'kernel': 'trace_kernel<FULL,PUPIL>', 'kernel_ms': kern_ms,
                          'algorithmic_bytes_per_launch': alg_bytes,
                          'frac_of_measured_copy_peak_6290': achieved / 6290.0},
-            'spot_diagram': {'wallclock_ms': float(np.median(spot_ms)), 'rays': R,
-                             'rays_through': int(xy.shape[0]), 'kernel_ms': hits_kern_ms,
-                             'what': 'Python call -> host (R_ok,2) array, HITS mode'},
+            'roofline_hits': roofline_hits(inters, R, hits_kern_ms),
+            'spot_diagram': {'wallclock_ms': float(np.median(spot_ms)),
+                             'wallclock_min_ms': float(np.min(spot_ms)), 'rays': R,
+                             'rays_through': int(xy.shape[0]), 'kernel_hits_ms': hits_kern_ms,
+                             'pcie_floor_ms': xy.shape[0] * 16 / 54.7e9 * 1e3,
+                             'what': 'rayoptics_amd.trace.trace_grid_spot(model, grid_rng, fld, wvl, '
+                                     'foc, image_pt): Python call -> host (R_ok, 2) float64 array '
+                                     '(survivors packed in ray order by the trace launch, written '
+                                     'straight into pinned host memory; 13 MB over PCIe at ~55 GB/s '
+                                     'is the floor)'},
             'cpu_baseline': cpu,
-            'sharded_spot': sharded,
+            'strong_scaling': strong,
         }
         print(json.dumps(line))
     if multi:
         dist.destroy_process_group()
+
+
+def roofline_hits(inters, R, kern_ms):
+    """the VALU-bound HITS kernel: achieved fp64 TFLOP/s by SURVEY 8(d)'s count of
+    130 flop per spherical refracting intersection (5 sqrt + 8 div counted as one
+    each) against the 78.6 TFLOP/s fp64 vector peak; VALU issue fraction from the
+    committed PMC summary of the same kernel when present"""
+    flops = 130.0 * inters
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+    out = {'bound': 'fp64 valu', 'achieved': achieved, 'peak': 78.6, 'unit': 'TFLOP/s',
+           'frac': achieved / 78.6, 'kernel': 'trace_kernel<HITS,PUPIL>', 'kernel_ms': kern_ms,
+           'flop_per_intersection': 130, 'algorithmic_bytes_per_launch': R * 19,
+           'hbm_GBps': R * 19 / (kern_ms * 1e-3) / 1e9}
+    ppath = os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')
+    if os.path.exists(ppath):
+        try:
+            with open(ppath) as f:
+                pj = json.load(f)
+            h = pj.get('hits', {})
+            if 'SQ_INSTS_VALU' in h:
+                # wave-level VALU instructions x 4 cycles (fp64: 16 lanes/clk/SIMD) over
+                # the SIMD-cycles of the launch (256 CUs x 4 SIMDs x 2.4 GHz)
+                out['valu_insts_per_launch'] = h['SQ_INSTS_VALU']
+                out['valu_issue_frac'] = h['SQ_INSTS_VALU'] * 4 / (256 * 4 * 2.4e9 * kern_ms * 1e-3)
+        except Exception:
+            pass
+    return out
+
+
+def strong_scaling(args, torch, dist, multi, world, rank, fence):
+    """BASELINE configs[4]'s shape on the 44-interface lithography lens: 9 fields
+    x 5 wavelengths x num^2 pupil grids, HITS, pupil-row blocks over the ranks,
+    hits gathered to rank 0.  Kernel, gather and end-to-end times separately."""
+    from rayoptics_amd import workloads
+    from rayoptics_amd import dist as rdist
+    from rayoptics_amd.engine import TraceEngine
+    wl = workloads.load('litho_c5')
+    eng = TraceEngine(wl.table)
+    nf, nw, num = len(wl.fields), len(wl.table.wvls), args.strong_num
+    plan = rdist.partition(nf, nw, num, world)
+    sizes = [sum(b.row_count for b in blocks) * num for blocks in plan]
+    cap = max(max(sizes), 1)
+    for _rep in range(2):               # the first pass warms allocations and RCCL
+        fence()
+        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        xy, st, n_local = rdist.trace_blocks(eng, plan[rank], cap, wl.fields, wl.image_pts, num, wl.foc)
+        e1.record()
+        torch.cuda.synchronize()
+        t_trace = time.perf_counter() - t0
+        kern_ms = e0.elapsed_time(e1)
+        fence()
+        t1 = time.perf_counter()
+        parts = rdist.gather_hits(xy, st)
+        fence()
+        t_gather = time.perf_counter() - t1
+        t_all = time.perf_counter() - t0
+        ok_local = int((st[:n_local] == 0).sum().item())
+        del parts, xy, st
+    vals = torch.tensor([kern_ms, t_trace * 1e3, t_gather * 1e3, t_all * 1e3],
+                        dtype=torch.float64, device=eng.device)
+    cnt = torch.tensor([n_local, ok_local], dtype=torch.float64, device=eng.device)
+    if multi:
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    K = wl.n_ifcs - 1
+    rays = int(cnt[0].item())
+    res = {'workload': f'litho_c5 ({wl.n_ifcs} interfaces, K={K}), {nf} fields x {nw} wvls x '
+                       f'{num}x{num} pupil grids, HITS, pupil-row blocks over ranks (dist.partition)',
+           'scaling': 'strong', 'ranks': world,
+           'backend': (dist.get_backend() if multi else 'none (single process)'),
+           'rays': rays, 'rays_through': int(cnt[1].item()),
+           'rays_per_rank_max': cap,
+           'kernel_ms_max_over_ranks': vals[0].item(),
+           'trace_wallclock_ms_max': vals[1].item(),
+           'gather_ms': vals[2].item(),
+           'end_to_end_ms': vals[3].item(),
+           'gather_bytes_to_root': int(17 * cap * (world - 1)),
+           'rays_per_s_end_to_end': rays / (vals[3].item() * 1e-3),
+           'ray_surface_per_s_kernel': rays * K / (vals[0].item() * 1e-3),
+           'note': 'nominal R*K intersections (blocked rays stop early); host reassembly of the '
+                   'gathered hits is not part of these times'}
+    eng.close()
+    return res
+
+
+def reference_python():
+    """the reference's own Python path on BASELINE configs[1], as timed by
+    tools/time_reference.py in the build container (it cannot run on the GPU box)"""
+    path = os.path.join(ROOT, 'profiles', 'reference_cpu.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        r = json.load(f)
+    return {'measured_on': r['host'], 'workload': r['workload'],
+            'driver_trace_grid_rays_per_s': r['driver_trace_grid']['rays_per_s'],
+            'driver_trace_grid_intersections_per_s': r['driver_trace_grid']['intersections_per_s'],
+            'extrapolated_1M_ray_spot_s': r['driver_trace_grid']['extrapolated_1M_ray_spot_s'],
+            'raw_rt_trace_rays_per_s': r['raw_rt_trace']['rays_per_s'],
+            'raw_rt_trace_intersections_per_s': r['raw_rt_trace']['intersections_per_s'],
+            'fanned': r['raw_rt_trace_fanned'],
+            'source': 'profiles/reference_cpu.json (tools/time_reference.py; mirrors the '
+                      "reference's own rayoptics/raytr/tests/time_trace.py)"}
 
 
 def cpu_baseline(wl, fld, wi, opts, num, rows):
@@ -247,7 +370,8 @@ def cpu_baseline(wl, fld, wi, opts, num, rows):
             'sample': f'{passes} passes over {rows} pupil rows x {num} = {rows * num} rays of the '
                       f'same grid, FULL packets, oracle/rox_oracle.c -O2 single thread, {dt:.1f} s',
             'rays_per_s': passes * rows * num / dt,
-            'host_cpu_count': os.cpu_count(), 'all_cores': allc}
+            'host_cpu_count': os.cpu_count(), 'all_cores': allc,
+            'reference_python': reference_python()}
 
 
 def cpu_all_cores(wl, fld, wi, opts, num, xs, ys):

@@ -157,6 +157,13 @@ class _Node:
             parent.children.append(self)
 
 
+class _Counter(dict):
+    """opticalglass.util.Counter: a dict whose missing keys count from zero"""
+
+    def __missing__(self, key):
+        return 0
+
+
 _installed = False
 
 
@@ -196,8 +203,26 @@ def install():
     ge = sys.modules['opticalglass.glasserror']
     for exc in ('GlassError', 'GlassNotFoundError', 'GlassCatalogNotFoundError'):
         setattr(ge, exc, type(exc, (Exception,), {}))
-    sys.modules['opticalglass.glassfactory']._cat_names = []
-    sys.modules['opticalglass.util'].Counter = dict
+    # an empty glass catalogue: every named glass is "not found", which the
+    # reference's importers turn into ConstantIndex(1.5, 'not NAME')
+    # (rayoptics/seq/medium.py:172-203); geometry import is unaffected
+    gf = sys.modules['opticalglass.glassfactory']
+    gf._cat_names = []
+    gf._cat_names_uc = []
+    gf._custom_glass_registry = {}
+
+    def _create_glass(name, catalog):
+        raise ge.GlassNotFoundError(name)
+
+    def _get_glass_catalog(name):
+        raise ge.GlassCatalogNotFoundError(name)
+    gf.create_glass = _create_glass
+    gf.get_glass_catalog = _get_glass_catalog
+    gf.register_glass = lambda mat: None
+    sys.modules['opticalglass.util'].Counter = _Counter
+    gl = sys.modules['opticalglass.glass']
+    gl.Robb1983Catalog = lambda: type('C', (), {'glass_list': []})()
+    gl.decode_glass_name = lambda name: ((name[:1] or '?', name[1:]), '', '')
 
     if REFERENCE_SRC not in sys.path:
         sys.path.insert(0, REFERENCE_SRC)

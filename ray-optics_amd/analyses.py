@@ -16,6 +16,18 @@ from .raypkg import HostPackets
 from .trace import opts_from_kwargs, emit, _trace_pupil, _launch_setup
 
 
+def _setup_pupil_coords(opt_model, fld, wvl, foc, image_pt=None, image_delta=None):
+    """trace.setup_pupil_coords (rayoptics/raytr/trace.py:608-624): the reference's
+    own for a live model (chief ray cached on the field, reference sphere host
+    math); table-backed models bring theirs"""
+    own = getattr(opt_model, 'setup_pupil_coords', None)
+    if own is not None:
+        return own(fld, wvl, foc, image_pt=image_pt, image_delta=image_delta)
+    from rayoptics.raytr import trace as ref_trace
+    return ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc, image_pt=image_pt,
+                                        image_delta=image_delta)
+
+
 def trace_list_of_rays(opt_model, rays, output_filter=None, rayerr_filter=None,
                        **kwargs):
     """explicit (pt0, dir0, wvl) rays; per-ray wavelengths allowed"""
@@ -145,12 +157,8 @@ def eval_wavefront(opt_model, fld, wvl, foc, image_pt_2d=None, image_delta=None,
     ``wave_abr_full_calc`` (rayoptics/raytr/waveabr.py:256-307) run in one
     launch (ROX_OUT_OPD).  Packet filters or an infinite reference sphere take
     the generic route: device trace, reference ``waveabr`` on the lazy views."""
-    from rayoptics.raytr import trace as ref_trace
-    from rayoptics.raytr import waveabr
     from .table import wavefront_from_model, UnsupportedModelError
-    ref_sphere, cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc,
-                                                      image_pt=image_pt_2d,
-                                                      image_delta=image_delta)
+    ref_sphere, cr_pkg = _setup_pupil_coords(opt_model, fld, wvl, foc, image_pt_2d, image_delta)
     fld.chief_ray = cr_pkg
     fld.ref_sphere = ref_sphere
     oversize = kwargs.get('oversize', 1.)
@@ -167,6 +175,7 @@ def eval_wavefront(opt_model, fld, wvl, foc, image_pt_2d=None, image_delta=None,
         except UnsupportedModelError:
             fused = False
     if not fused:
+        from rayoptics.raytr import waveabr
         fod = opt_model['analysis_results']['parax_data'].fod
         grid = trace_ray_grid(opt_model, grid_def, fld, wvl, foc, **kwargs)
         return np.array([[(px, py, convert_to_opd * waveabr.wave_abr_full_calc(
@@ -219,12 +228,8 @@ def _opd_grid(opt_model, fld, wvl, grid_def, kwargs, wf, value_if_none):
 def trace_wavefront(opt_model, fld, wvl, foc, image_pt_2d=None, image_delta=None,
                     num_rays=21, **kwargs):
     """rayoptics/raytr/analyses.py:735-766"""
-    from rayoptics.raytr import trace as ref_trace
-    from rayoptics.raytr import waveabr
     from .table import wavefront_from_model, UnsupportedModelError
-    ref_sphere, cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc,
-                                                      image_pt=image_pt_2d,
-                                                      image_delta=image_delta)
+    ref_sphere, cr_pkg = _setup_pupil_coords(opt_model, fld, wvl, foc, image_pt_2d, image_delta)
     fld.chief_ray = cr_pkg
     fld.ref_sphere = ref_sphere
     oversize = kwargs.get('oversize', 1.)
@@ -237,6 +242,7 @@ def trace_wavefront(opt_model, fld, wvl, foc, image_pt_2d=None, image_delta=None
             return _DeferredWavefront(grid_def, dict(kwargs)), None
         except UnsupportedModelError:
             pass
+    from rayoptics.raytr import waveabr
     fod = opt_model['analysis_results']['parax_data'].fod
     grid = trace_ray_grid(opt_model, grid_def, fld, wvl, foc, **kwargs)
     upd_grid = [[waveabr.wave_abr_pre_calc(fod, fld, wvl, foc, pkg, cr_pkg, ref_sphere)
@@ -247,24 +253,24 @@ def trace_wavefront(opt_model, fld, wvl, foc, image_pt_2d=None, image_delta=None
 def focus_wavefront(opt_model, grid_pkg, fld, wvl, foc, image_pt_2d=None,
                     image_delta=None, value_if_none=np.nan, **kwargs):
     """rayoptics/raytr/analyses.py:769-791"""
-    from rayoptics.raytr import trace as ref_trace
-    from rayoptics.raytr import waveabr
     from .table import wavefront_from_model, UnsupportedModelError
     grid, upd_grid = grid_pkg
-    ref_sphere, cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc,
-                                                      image_pt=image_pt_2d,
-                                                      image_delta=image_delta)
-    fod = opt_model['analysis_results']['parax_data'].fod
+    ref_sphere, cr_pkg = _setup_pupil_coords(opt_model, fld, wvl, foc, image_pt_2d, image_delta)
     if isinstance(grid, _DeferredWavefront):
         try:
-            wf = wavefront_from_model(opt_model, fld, cr_pkg, ref_sphere)
+            own = getattr(fld, 'rox_wavefront', None)   # table-backed models: prebuilt
+            wf = own if own is not None else wavefront_from_model(opt_model, fld, cr_pkg, ref_sphere)
             return _opd_grid(opt_model, fld, wvl, grid.grid_def, grid.kwargs, wf, value_if_none)
         except UnsupportedModelError:       # the sphere went infinite at this focus
+            from rayoptics.raytr import waveabr
+            fod = opt_model['analysis_results']['parax_data'].fod
             g = trace_ray_grid(opt_model, grid.grid_def, fld, wvl, foc, **dict(grid.kwargs))
             return np.array([[(px, py, waveabr.wave_abr_full_calc(fod, fld, wvl, foc, pkg, cr_pkg,
                                                                   ref_sphere)
                                / opt_model.nm_to_sys_units(wvl)) if pkg is not None
                               else (px, py, value_if_none) for px, py, pkg in row] for row in g])
+    from rayoptics.raytr import waveabr
+    fod = opt_model['analysis_results']['parax_data'].fod
     convert_to_opd = 1 / opt_model.nm_to_sys_units(wvl)
     return np.array([[(g[0], g[1], convert_to_opd * waveabr.wave_abr_calc(
         fod, fld, wvl, foc, g[2], cr_pkg, u, ref_sphere)) if g[2] is not None
@@ -302,10 +308,7 @@ class _DeferredRayList:
 def trace_pupil_coords(opt_model, pupil_coords, fld, wvl, foc,
                        image_pt_2d=None, image_delta=None, **kwargs):
     """rayoptics/raytr/analyses.py:545-558"""
-    from rayoptics.raytr import trace as ref_trace
-    ref_sphere, cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc,
-                                                      image_pt=image_pt_2d,
-                                                      image_delta=image_delta)
+    ref_sphere, cr_pkg = _setup_pupil_coords(opt_model, fld, wvl, foc, image_pt_2d, image_delta)
     fld.chief_ray = cr_pkg
     fld.ref_sphere = ref_sphere
     kwargs['check_apertures'] = kwargs.get('check_apertures', True)
@@ -319,10 +322,7 @@ def focus_pupil_coords(opt_model, ray_list, fld, wvl, foc,
     """rayoptics/raytr/analyses.py:561-580: transverse aberrations of
     pre-traced rays at a (new) focus.  For the deferred list this is one HITS
     launch over the pupil coordinates (the trace does not depend on focus)."""
-    from rayoptics.raytr import trace as ref_trace
-    ref_sphere, _cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc,
-                                                       image_pt=image_pt_2d,
-                                                       image_delta=image_delta)
+    ref_sphere, _cr_pkg = _setup_pupil_coords(opt_model, fld, wvl, foc, image_pt_2d, image_delta)
     image_pt = ref_sphere[0]
     if isinstance(ray_list, _DeferredRayList):
         kw = dict(ray_list.kwargs)

@@ -74,33 +74,22 @@ class _HitsWindow:
         return o
 
 
-def trace_spot_sharded(engine, fields, image_pts, n_wvls, num, foc, flags=None,
-                       group=None, all_ranks=False, first_surf=1, last_surf=None):
-    """spot diagrams for every (field, wavelength), sharded over the process
-    group.  Each rank traces its row blocks in HITS mode on its own GPU, then
-    the hits are gathered.  Returns on rank 0 (every rank if all_ranks) a dict
-    {(fi, wi): (xy[num*num, 2], status[num*num])} in the reference's
-    i-outer/j-inner order; None elsewhere."""
+def trace_blocks(engine, blocks, cap, fields, image_pts, num, foc, flags=None,
+                 first_surf=1, last_surf=None):
+    """HITS trace of this rank's row blocks straight into its exchange buffers
+    xy [2, cap] f64 and status [cap] u8 (17 B per ray on the wire); no
+    intermediate copies.  Returns (xy, status, rays traced)."""
     import torch
-    import torch.distributed as dist
     from .engine import make_opts, make_grid
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
     N = engine.table.n_ifcs
     if flags is None:
         flags = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
     last = N - 2 if last_surf is None else last_surf
-    plan = partition(len(fields), n_wvls, num, world)
-    sizes = [sum(b.row_count for b in blocks) * num for blocks in plan]
-    cap = max(max(sizes), 1)
-
-    # local trace straight into the exchange buffers: xy [2, cap] f64 and
-    # status [cap] u8 (17 B per ray on the wire), no intermediate copies
     dev = getattr(engine, 'device', 'cpu')
     xy_loc = torch.full((2, cap), float('nan'), dtype=torch.float64, device=dev)
     st_loc = torch.full((cap,), 255, dtype=torch.uint8, device=dev)
     off = 0
-    for b in plan[rank]:
+    for b in blocks:
         opts = make_opts(flags=flags, out_mode=abi.OUT_HITS, first_surf=first_surf,
                          last_surf=last, foc=foc, image_pt=image_pts[b.fi])
         grid = make_grid((-1., -1.), (1., 1.), num, row_begin=b.row_begin,
@@ -112,22 +101,51 @@ def trace_spot_sharded(engine, fields, image_pts, n_wvls, num, foc, flags=None,
             xy_loc[:, off:off + n] = res.seg
             st_loc[off:off + n] = res.status
         off += n
+    return xy_loc, st_loc, off
 
-    # the exchange step
+
+def gather_hits(xy_loc, st_loc, group=None, all_ranks=False):
+    """the path's one exchange step: (x, y, status) of every rank to rank 0
+    (7 peers -> 7 xGMI links in parallel), or to every rank (all_ranks, a ring
+    bound by one link).  Returns (xy_parts, st_parts) lists, None off the root."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1:
-        xy_parts, st_parts = [xy_loc], [st_loc]
-    elif all_ranks:
+        return [xy_loc], [st_loc]
+    if all_ranks:
         xy_parts = [torch.empty_like(xy_loc) for _ in range(world)]
         st_parts = [torch.empty_like(st_loc) for _ in range(world)]
         dist.all_gather(xy_parts, xy_loc, group=group)
         dist.all_gather(st_parts, st_loc, group=group)
-    else:
-        xy_parts = [torch.empty_like(xy_loc) for _ in range(world)] if rank == 0 else None
-        st_parts = [torch.empty_like(st_loc) for _ in range(world)] if rank == 0 else None
-        dist.gather(xy_loc, xy_parts, dst=0, group=group)
-        dist.gather(st_loc, st_parts, dst=0, group=group)
-        if rank != 0:
-            return None
+        return xy_parts, st_parts
+    xy_parts = [torch.empty_like(xy_loc) for _ in range(world)] if rank == 0 else None
+    st_parts = [torch.empty_like(st_loc) for _ in range(world)] if rank == 0 else None
+    dist.gather(xy_loc, xy_parts, dst=0, group=group)
+    dist.gather(st_loc, st_parts, dst=0, group=group)
+    return (xy_parts, st_parts) if rank == 0 else (None, None)
+
+
+def trace_spot_sharded(engine, fields, image_pts, n_wvls, num, foc, flags=None,
+                       group=None, all_ranks=False, first_surf=1, last_surf=None):
+    """spot diagrams for every (field, wavelength), sharded over the process
+    group.  Each rank traces its row blocks in HITS mode on its own GPU, then
+    the hits are gathered.  Returns on rank 0 (every rank if all_ranks) a dict
+    {(fi, wi): (xy[num*num, 2], status[num*num])} in the reference's
+    i-outer/j-inner order; None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    plan = partition(len(fields), n_wvls, num, world)
+    sizes = [sum(b.row_count for b in blocks) * num for blocks in plan]
+    cap = max(max(sizes), 1)
+    xy_loc, st_loc, _n = trace_blocks(engine, plan[rank], cap, fields, image_pts, num, foc,
+                                      flags, first_surf, last_surf)
+    xy_parts, st_parts = gather_hits(xy_loc, st_loc, group, all_ranks)
+    if xy_parts is None:
+        return None
 
     def to_numpy(t):
         if t.device.type == 'cpu':

@@ -1,0 +1,501 @@
+"""Prescription files -> :class:`~.table.SurfaceTable`, without the reference's
+object model: the on-disk formats either side of
+the trace path, read with the standard library only.
+
+  read_zmx   Zemax .zmx    <- rayoptics/zemax/zmxread.py:93-456, 540-600
+  read_seq   CODE V .seq   <- rayoptics/codev/cmdproc.py:56-99, 371-450, 544-580
+  read_roa   ray-optics .roa (JSON) <- rayoptics/gui/roafile.py:106-123 (structure:
+             SURVEY.md section 8c)
+
+Each reader returns a :class:`Prescription` (interfaces, gaps, stop, wavelengths);
+``Prescription.to_table()`` flattens it exactly as ``SurfaceTable.from_seq_model``
+flattens the live model the reference's importer would have built: same
+profile parameters, apertures, interact modes, z_dir bookkeeping
+(rayoptics/seq/sequential.py:611-668) and local transforms
+(rayoptics/elem/transform.py:86-118, 143-166 for undecentered interfaces).
+
+Scope: centred systems -- STANDARD / EVENASPH / CONI / MIRROR / PARAXIAL /
+DGRATING surfaces of .zmx; S / SO / SI / STO / SPH / CON / ASP / K / A..J / RDY /
+CUY / THI / REFL / WL of .seq; Spherical / Conic / EvenPolynomial /
+RadialPolynomial profiles and Circular / Rectangular apertures of .roa.
+Coordinate breaks and decentered surfaces raise :class:`UnsupportedModelError`
+(their tilt matrices come from transforms3d in the reference: unpinned).
+
+Refractive indices: the engine consumes evaluated indices, so a glass *name* has
+to be turned into n(wavelength) here.  ``index_of(name, wvl_nm)`` is the hook;
+the default, :func:`reference_fallback_index`, reproduces what the reference
+does when its catalogue does not know a glass: n = 1.5
+(rayoptics/seq/medium.py:172-203) -- the configuration the parity tests pin.
+:func:`nominal_index` adds dispersion formulas for the glasses of the
+reference's fixture prescriptions (checked against the CODE V listing
+rayoptics/codev/tests/ag_dblgauss.lis:30-34 to 1e-5).
+"""
+import json
+import math
+import re
+
+import numpy as np
+
+from . import abi
+from .table import SurfaceTable, UnsupportedModelError
+
+# ---------------------------------------------------------------- dispersion
+# Sellmeier-1 coefficients (B1 B2 B3 C1 C2 C3, wavelength in micrometres) of the
+# glasses named by the reference's fixture files.  Nominal catalogue values.
+SELLMEIER = {
+    'N-BK7': (1.03961212, 0.231792344, 1.01046945, 0.00600069867, 0.0200179144, 103.560653),
+    'N-SK2': (1.28189012, 0.257738258, 0.96818604, 0.0072719164, 0.0242823527, 110.377773),
+    'N-SK16': (1.34317774, 0.241144399, 0.994317969, 0.00704687339, 0.0229005, 92.7508526),
+    'N-SSK2': (1.4306027, 0.153150554, 1.01390904, 0.00823982975, 0.0333736841, 106.870822),
+    'F5': (1.3104463, 0.19603426, 0.96612977, 0.00958633048, 0.0457627627, 115.011883),
+    # fused silica, Malitson 1965
+    'SILICA': (0.6961663, 0.4079426, 0.8974794, 0.0684043 ** 2, 0.1162414 ** 2, 9.896161 ** 2),
+}
+
+
+def _canon(name):
+    """NSK16_SCHOTT / N-SK16 / nsk16 -> N-SK16"""
+    n = name.upper().split('_')[0]
+    if n in SELLMEIER:
+        return n
+    if n.startswith('N') and not n.startswith('N-') and ('N-' + n[1:]) in SELLMEIER:
+        return 'N-' + n[1:]
+    return n
+
+
+def sellmeier_index(name, wvl_nm):
+    b1, b2, b3, c1, c2, c3 = SELLMEIER[_canon(name)]
+    l2 = (wvl_nm * 1e-3) ** 2
+    return math.sqrt(1.0 + b1 * l2 / (l2 - c1) + b2 * l2 / (l2 - c2) + b3 * l2 / (l2 - c3))
+
+
+def reference_fallback_index(name, wvl_nm):
+    """what the reference's importers give a glass its catalogue does not have"""
+    return 1.5
+
+
+def nominal_index(name, wvl_nm):
+    """dispersion formula where one is on file, the reference's fallback otherwise"""
+    if _canon(name) in SELLMEIER:
+        return sellmeier_index(name, wvl_nm)
+    return 1.5
+
+
+# ---------------------------------------------------------------- data model
+class Ifc:
+    """one interface as the importers leave it"""
+
+    def __init__(self):
+        self.mode = 'transmit'
+        self.profile = 'Spherical'
+        self.cv = 0.0
+        self.cc = 0.0
+        self.coefs = []
+        self.max_aperture = 1.0
+        self.apertures = []         # dicts: kind, radius | x_half_width, y_half_width, offsets, obsc.
+        self.phase = None           # dict for rox_phase
+        self.thinlens_power = None
+        self.z_type = 'STANDARD'
+
+
+class Prescription:
+    """interfaces[N], media[N-1] (what fills the gap *after* interface i) and
+    thicknesses[N-1], stop index, wavelengths (nm)"""
+
+    def __init__(self):
+        self.ifcs = []
+        self.thi = []
+        self.media = []             # ('air',) | ('mirror',) | ('const', n) | ('glass', name) | ('model', nd, vd)
+        self.stop = None
+        self.wvls = []
+        self.ref_wvl = 0
+        self.title = ''
+
+    # rayoptics/seq/sequential.py:611-668 + rayoptics/elem/transform.py:86-118
+    def to_table(self, wvls=None, index_of=None):
+        index_of = index_of or reference_fallback_index
+        wvls = [float(w) for w in (wvls or self.wvls or [550.0])]
+        N = len(self.ifcs)
+        rows = (abi.Surface * N)()
+        n_table = np.ones((len(wvls), N))
+        zdir = 1.0
+        prev_n = [1.0] * len(wvls)
+        for i, s in enumerate(self.ifcs):
+            row = rows[i]
+            mode = s.mode if 0 < i < N - 1 else 'dummy'     # sequential.py:600-601
+            row.mode = abi.MODE_NAMES[mode]
+            if s.thinlens_power is not None:                # zmxread.py:327-330, thinlens.py
+                row.profile, row.ec = abi.THINLENS, 1.0
+                pwr = s.thinlens_power
+                ph = row.ph
+                ph.kind = abi.PH_HOLOGRAM
+                ph.ref_wl = wvls[self.ref_wvl] if self.ref_wvl < len(wvls) else wvls[0]
+                ph.a[2] = -1e10
+                ph.b[2] = 1. / pwr if pwr != 0 else 1e+10
+                ph.flags = 2 if pwr > 0. else 0
+            else:
+                row.profile = abi.PROFILE_NAMES[s.profile]
+                row.cv = float(s.cv)
+                if s.profile == 'Spherical':
+                    row.cc, row.ec = 0.0, 1.0
+                elif s.profile == 'RadialPolynomial':
+                    row.ec = float(s.cc) + 1.0 if not hasattr(s, 'ec') else float(s.ec)
+                    row.cc = row.ec - 1.0
+                else:
+                    row.cc = float(s.cc)
+                    row.ec = row.cc + 1.0
+                if s.profile in ('EvenPolynomial', 'RadialPolynomial'):
+                    mnc = 0
+                    for k, c in enumerate(s.coefs):
+                        if c != 0.0:
+                            mnc = k + 1
+                    if mnc > abi.MAX_COEF:
+                        raise UnsupportedModelError(f'{mnc} asphere coefficients')
+                    row.ncoef = mnc
+                    for k in range(mnc):
+                        row.coefs[k] = float(s.coefs[k])
+            if s.phase:
+                ph = row.ph
+                ph.kind = s.phase['kind']
+                ph.order = float(s.phase.get('order', 1))
+                ph.spacing_nm = float(s.phase.get('spacing_nm', 0.0))
+                ph.ref_wl = float(s.phase.get('ref_wl', 0.0))
+                for k in range(3):
+                    ph.a[k] = float(s.phase.get('a', (0., 1., 0.))[k])
+            row.max_aperture = float(s.max_aperture)
+            if len(s.apertures) > abi.MAX_AP:
+                raise UnsupportedModelError('too many clear apertures')
+            row.n_ap = len(s.apertures)
+            for k, ca in enumerate(s.apertures):
+                a = row.ap[k]
+                a.is_obscuration = 1 if ca.get('is_obscuration') else 0
+                a.x_offset, a.y_offset = float(ca.get('x_offset', 0.)), float(ca.get('y_offset', 0.))
+                if ca['kind'] == 'Circular':
+                    a.kind, a.a = abi.AP_CIRCULAR, float(ca['radius'])
+                elif ca['kind'] == 'Rectangular':
+                    a.kind = abi.AP_RECTANGULAR
+                    a.a, a.b = float(ca['x_half_width']), float(ca['y_half_width'])
+                else:
+                    a.kind = abi.AP_ALWAYS_BLOCK
+                    a.a, a.b = float(ca.get('x_half_width', 0.)), float(ca.get('y_half_width', 0.))
+            for a in range(3):
+                row.rt[4 * a] = 1.0
+            # compute_local_transforms holds r.transpose() (an F-ordered view) for every
+            # interface but the last, which gets a fresh np.identity(3); for the
+            # identity both dgemv chains are exact, the flag only mirrors the model
+            row.rt_order = abi.RT_F_ORDER if i < N - 1 else abi.RT_C_ORDER
+            row.t[2] = float(self.thi[i]) if i < N - 1 else 0.0
+            if mode == 'reflect':
+                zdir = -zdir
+            row.z_dir = zdir
+            # index of the gap after this interface, per wavelength
+            if i < N - 1:
+                m = self.media[i]
+                for w, wl in enumerate(wvls):
+                    if m[0] == 'air':
+                        n = 1.0
+                    elif m[0] == 'mirror':
+                        n = prev_n[w]
+                    elif m[0] == 'const':
+                        n = float(m[1])
+                    elif m[0] == 'model':
+                        n = float(index_of(f'{m[1]:.6g},{m[2]:.6g}', wl)) if index_of is not \
+                            reference_fallback_index else float(m[1])
+                    else:
+                        n = float(index_of(m[1], wl))
+                    n_table[w, i] = n
+                    prev_n[w] = n
+        return SurfaceTable(rows, n_table, wvls, self.stop)
+
+
+# ---------------------------------------------------------------- .zmx
+def _read_text(path):
+    for enc in ('utf-16', 'utf-8', 'utf-8-sig', 'iso-8859-1'):   # zmxread.py:60-70
+        try:
+            with open(path, encoding=enc) as f:
+                return f.read()
+        except UnicodeError:
+            continue
+    raise UnsupportedModelError(f'cannot decode {path}')
+
+
+def read_zmx(path):
+    """Zemax .zmx -> Prescription (rayoptics/zemax/zmxread.py:118-456)"""
+    p = Prescription()
+    cur = -1
+    n_clear_ap = 0
+    for raw in _read_text(path).splitlines():
+        line = raw.strip()
+        if not line:
+            continue
+        parts = line.split(' ', 1)
+        cmd = parts[0]
+        inputs = parts[1] if len(parts) == 2 else ''
+        if cmd == 'NAME':
+            p.title = inputs.strip('"')
+        elif cmd == 'SURF':
+            p.ifcs.append(Ifc())
+            p.thi.append(0.0)
+            p.media.append(('air',))
+            cur = len(p.ifcs) - 1
+        elif cmd == 'CURV':
+            p.ifcs[cur].cv = float(inputs.split()[0])
+        elif cmd == 'DISZ':
+            p.thi[cur] = float(inputs)
+        elif cmd == 'GLAS':
+            it = inputs.split()
+            name = it[0]
+            if name == 'MIRROR':
+                p.ifcs[cur].mode = 'reflect'
+                p.media[cur] = ('mirror',)
+            elif name == '___BLANK':
+                nd, vd = float(it[3]), float(it[4])
+                p.media[cur] = ('const', nd) if vd == 0 else ('model', nd, vd)
+            elif re.fullmatch(r'[-+]?\d+(\.\d*)?', name) and len(name) == 6:
+                p.media[cur] = ('model', 1 + float(name[:3]) / 1000, float(name[3:]) / 10)
+            else:
+                p.media[cur] = ('glass', name)
+        elif cmd == 'STOP':         # SequentialModel.set_stop, sequential.py:306-314
+            p.stop = (cur if cur > 0 else 1) if len(p.ifcs) > 2 else None
+        elif cmd == 'WAVM':             # WAVM 1 0.55 1
+            it = inputs.split()
+            w = float(it[1]) * 1e+3
+            if w not in p.wvls:
+                p.wvls.append(w)
+        elif cmd == 'WAVL':
+            p.wvls = [float(i) * 1e+3 for i in inputs.split() if i]
+        elif cmd == 'TYPE':
+            s = p.ifcs[cur]
+            typ = inputs.split()[0]
+            s.z_type = typ
+            if typ == 'EVENASPH':
+                s.profile = 'EvenPolynomial'
+                s.coefs = [0.0] * 10
+            elif typ == 'XOSPHERE':
+                s.profile = 'RadialPolynomial'
+                s.coefs = []
+            elif typ == 'PARAXIAL':
+                s.thinlens_power = 0.0
+            elif typ == 'DGRATING':
+                # DiffractionGrating() defaults: order 1, normal (0,1,0), 1 line/um
+                s.phase = dict(kind=abi.PH_GRATING, order=1, a=(0., 1., 0.), spacing_nm=1e6 / 1000.)
+            elif typ in ('COORDBRK', 'TOROIDAL'):
+                raise UnsupportedModelError(f'{typ} surfaces are not ingested')
+            elif typ != 'STANDARD':
+                raise UnsupportedModelError(f'Zemax surface type {typ}')
+        elif cmd == 'CONI':
+            s = p.ifcs[cur]
+            if s.profile == 'Spherical':
+                s.profile = 'Conic'
+            s.cc = float(inputs.split()[0])
+        elif cmd == 'PARM':
+            s = p.ifcs[cur]
+            i, val = inputs.split()
+            i, val = int(i), float(val)
+            if s.z_type == 'EVENASPH':
+                s.coefs[i - 1] = val
+            elif s.z_type == 'PARAXIAL':
+                if i == 1:
+                    s.thinlens_power = 1 / val
+            elif s.z_type == 'DGRATING':
+                if i == 1:
+                    s.phase['spacing_nm'] = 1e6 / (val * 1000)     # grating_freq_um -> lpmm
+                elif i == 2:
+                    s.phase['order'] = val
+        elif cmd == 'XDAT':
+            s = p.ifcs[cur]
+            it = inputs.split()
+            if s.z_type == 'XOSPHERE' and int(it[0]) >= 3:
+                s.coefs.append(float(it[1]))
+        elif cmd == 'DIAM':             # zmxread.py:391-444
+            s = p.ifcs[cur]
+            it = inputs.split()
+            ca_val = float(it[0])
+            if ca_val == 0.0:
+                ca_val = 1.0
+            ca_type = int(it[1])
+            if s.thinlens_power is None:
+                if not s.apertures:
+                    kinds = {0: ('Circular', False), 1: ('Circular', False), 2: ('Circular', True),
+                             4: ('Rectangular', False), 5: ('Rectangular', True),
+                             6: ('Elliptical', False), 7: ('Elliptical', True)}
+                    if ca_type not in kinds:
+                        continue
+                    kind, obsc = kinds[ca_type]
+                    # constructor defaults: surface.py:398-494
+                    s.apertures.append(dict(kind=kind, is_obscuration=obsc, radius=1.0,
+                                            x_half_width=1.0, y_half_width=1.0))
+                    if ca_type in (1, 4, 6):
+                        n_clear_ap += 1
+                s.apertures[-1]['radius'] = ca_val
+            # Surface.set_max_aperture -> ca.set_dimension(max_ap, max_ap), surface.py:174-179
+            s.max_aperture = ca_val
+            for ca in s.apertures:
+                if not ca.get('is_obscuration') or True:
+                    ca['radius'] = ca_val
+                    ca['x_half_width'] = ca['y_half_width'] = ca_val
+        elif cmd == 'OBDC':
+            it = inputs.split()
+            ca = p.ifcs[cur].apertures[0]
+            ca['x_offset'], ca['y_offset'] = float(it[0]), float(it[1])
+    # post_process_input, zmxread.py:222-272
+    p.thi.pop()
+    p.media.pop()
+    if math.isinf(p.thi[0]):
+        p.thi[0] = 1e10
+    if len(p.wvls) > 1 and p.wvls[-1] == 550.0:
+        p.wvls.pop()
+    p.ref_wvl = len(p.wvls) // 2
+    return p
+
+
+# ---------------------------------------------------------------- .seq
+_ORDER = {'A': 4, 'B': 6, 'C': 8, 'D': 10, 'E': 12, 'F': 14, 'G': 16, 'H': 18, 'J': 20}
+
+
+def read_seq(path):
+    """CODE V .seq -> Prescription (rayoptics/codev/cmdproc.py:56-99, 164-450).
+    Radius mode (RDM) decides whether S/SO/SI carry a radius or a curvature."""
+    text = _read_text(path)
+    p = Prescription()
+    rdm = False
+    cur = -1
+    for raw in text.splitlines():
+        raw = raw.split('!', 1)[0]
+        for stmt in raw.split(';'):
+            tok = stmt.strip().split()
+            if not tok:
+                continue
+            tla = tok[0].upper()[:3]
+            args = tok[1:]
+            if tla == 'RDM':
+                rdm = not args or args[0].upper() not in ('N', 'NO')
+            elif tla == 'TIT':
+                p.title = stmt.strip()[3:].strip().strip("'\"")
+            elif tla == 'WL':
+                p.wvls = [float(a) for a in args]
+            elif tla == 'REF':
+                p.ref_wvl = int(float(args[0])) - 1
+            elif tla in ('S', 'SO', 'SI'):
+                s = Ifc()
+                p.ifcs.append(s)
+                cur = len(p.ifcs) - 1
+                v = float(args[0]) if args else 0.0
+                s.cv = (1.0 / v if v != 0.0 else 0.0) if rdm else v
+                p.thi.append(float(args[1]) if len(args) > 1 else 0.0)
+                med = ('air',)
+                if len(args) > 2:
+                    g = args[2]
+                    if g.upper() == 'REFL':
+                        s.mode = 'reflect'
+                        med = ('mirror',)
+                    elif g.upper() != 'AIR':
+                        med = ('glass', g)
+                p.media.append(med)
+            elif tla == 'STO':
+                p.stop = cur
+            elif tla == 'CON':
+                p.ifcs[cur].profile = 'Conic'
+            elif tla == 'ASP':
+                p.ifcs[cur].profile = 'EvenPolynomial'
+                p.ifcs[cur].coefs = [0.0] * 10
+            elif tla == 'SPH':
+                p.ifcs[cur].profile = 'Spherical'
+            elif tla == 'K' and len(tok[0]) == 1:
+                p.ifcs[cur].cc = float(args[0])
+            elif len(tok[0]) == 1 and tok[0].upper() in _ORDER and p.ifcs and \
+                    p.ifcs[cur].profile == 'EvenPolynomial':
+                # set_by_order(order, v): coefs[order // 2 - 1] (profiles.py EvenPolynomial)
+                p.ifcs[cur].coefs[_ORDER[tok[0].upper()] // 2 - 1] = float(args[0])
+            elif tla in ('RDY', 'RDX'):
+                v = float(args[0])
+                p.ifcs[cur].cv = 1.0 / v if v != 0.0 else 0.0
+            elif tla in ('CUY', 'CUX'):
+                p.ifcs[cur].cv = float(args[0])
+            elif tla == 'THI':
+                p.thi[cur] = float(args[0])
+            elif tla in ('XDE', 'YDE', 'ZDE', 'ADE', 'BDE', 'CDE', 'DAR', 'BEN', 'REV'):
+                raise UnsupportedModelError('decentered .seq surfaces are not ingested')
+    p.thi.pop()
+    p.media.pop()
+    return p
+
+
+# ---------------------------------------------------------------- .roa
+def _roa_medium(m):
+    cls = m['__instance_type__'][1]
+    at = m.get('attributes', {})
+    if cls == 'Air':
+        return ('air',)
+    if cls == 'ConstantIndex':
+        return ('const', at.get('n', at.get('_n', 1.5)))
+    if cls in ('ModelGlass', 'InterpolatedMedium'):
+        return ('glass', at.get('label', at.get('gname', cls)))
+    name = at.get('gname') or at.get('label') or at.get('name') or cls
+    return ('glass', name)
+
+
+def read_roa(path):
+    """ray-optics .roa (json_tricks dump of the OpticalModel; nesting per SURVEY 8c)"""
+    with open(path) as f:
+        d = json.load(f)
+    om = d['optical_model']['attributes']
+    sm = om['seq_model']['attributes']
+    prof_dict = om.get('profile_dict', {})
+    p = Prescription()
+    for ifc in sm['ifcs']:
+        at = ifc['attributes']
+        cls = ifc['__instance_type__'][1]
+        s = Ifc()
+        s.mode = at.get('interact_mode', 'transmit')
+        s.max_aperture = at.get('max_aperture', 1.0)
+        if at.get('decenter') is not None:
+            raise UnsupportedModelError('decentered .roa surfaces are not ingested')
+        if cls == 'ThinLens':
+            s.thinlens_power = at.get('_power', at.get('optical_power', 0.0))
+        else:
+            prof = at.get('profile') or prof_dict[str(at['profile_id'])]
+            s.profile = prof['__instance_type__'][1]
+            pa = prof['attributes']
+            if s.profile not in abi.PROFILE_NAMES:
+                raise UnsupportedModelError(f'profile {s.profile}')
+            s.cv = pa.get('cv', 0.0)
+            s.cc = pa.get('cc', 0.0)
+            if 'ec' in pa:
+                s.ec = pa['ec']
+                s.cc = pa['ec'] - 1.0
+            s.coefs = list(pa.get('coefs', []))
+        for ca in at.get('clear_apertures', []) or []:
+            ca_at = ca['attributes']
+            s.apertures.append(dict(kind=ca['__instance_type__'][1],
+                                    radius=ca_at.get('radius', 1.0),
+                                    x_half_width=ca_at.get('x_half_width', 1.0),
+                                    y_half_width=ca_at.get('y_half_width', 1.0),
+                                    x_offset=ca_at.get('x_offset', 0.0),
+                                    y_offset=ca_at.get('y_offset', 0.0),
+                                    is_obscuration=ca_at.get('is_obscuration', False)))
+        p.ifcs.append(s)
+    for g in sm['gaps']:
+        at = g['attributes']
+        p.thi.append(at['thi'])
+        p.media.append(_roa_medium(at['medium']))
+    p.stop = sm.get('stop_surface')
+    osp = om.get('optical_spec', {}).get('attributes', {})
+    sr = osp.get('spectral_region', osp.get('wvls', {}))
+    at = sr.get('attributes', {}) if isinstance(sr, dict) else {}
+    p.wvls = list(at.get('wavelengths', []))
+    p.ref_wvl = at.get('reference_wvl', 0)
+    # a mirror's following gap repeats the medium before it (air stays air)
+    return p
+
+
+def read(path):
+    """dispatch on the file extension"""
+    ext = str(path).rsplit('.', 1)[-1].lower()
+    if ext == 'zmx':
+        return read_zmx(path)
+    if ext == 'seq':
+        return read_seq(path)
+    if ext == 'roa':
+        return read_roa(path)
+    raise UnsupportedModelError(f'unknown prescription format .{ext}')

@@ -425,6 +425,9 @@ def wavefront_from_model(opt_model, fld, chief_ray_pkg=None, ref_sphere=None):
     (rayoptics/raytr/trace.py:608-624), as ``wave_abr_full_calc_finite_pup``
     reads them (rayoptics/raytr/waveabr.py:256-307).  Infinite reference
     spheres (``is_kinda_big``, waveabr.py:213-216) stay on the host."""
+    pre = getattr(fld, 'rox_wavefront', None)
+    if pre is not None and chief_ray_pkg is None and ref_sphere is None:
+        return pre                                  # table-backed models (workloads.TableField)
     fod = opt_model['analysis_results']['parax_data'].fod
     cr_pkg = fld.chief_ray if chief_ray_pkg is None else chief_ray_pkg
     rs = fld.ref_sphere if ref_sphere is None else ref_sphere

@@ -24,7 +24,14 @@ class Workload:
         self.image_pts = []
         for fd in d['fields']:
             a = fd['field']
-            self.fields.append(field_struct(a[0:3], a[3:5], a[5], a[6], a[7:11], a[11]))
+            rot = fd.get('rot')
+            self.fields.append(field_struct(a[0:3], a[3:5], a[5], a[6], a[7:11], a[11],
+                                            kind=fd.get('kind', 0),
+                                            rot=None if rot is None else
+                                            [rot[0:3], rot[3:6], rot[6:9]],
+                                            cr_dir=fd.get('cr_dir', (0., 0.))))
+            if rot is not None:
+                self.fields[-1].rot_order = fd.get('rot_order', 0)
             self.image_pts.append(tuple(fd['image_pt']))
 
     @property
@@ -40,13 +47,34 @@ class TableField:
     """the slice of the reference's ``Field`` (rayoptics/raytr/opticalspec.py:1119-1353)
     the trace drop-ins read, backed by prebuilt ``rox_field`` constants"""
 
-    def __init__(self, rox_field, image_pt):
+    def __init__(self, rox_field, image_pt, rox_wavefront=None, vig_bbox=None):
         self.rox_field = rox_field
         self.vlx, self.vux = rox_field.vlx, rox_field.vux
         self.vly, self.vuy = rox_field.vly, rox_field.vuy
         self.aim_info = (rox_field.aim[0], rox_field.aim[1])
         self.chief_ray = None
         self.ref_sphere = (image_pt, None, None, None)
+        self.rox_wavefront = rox_wavefront      # prebuilt OPD constants (table.wavefront_from_model)
+        self._vig_bbox = vig_bbox
+
+    def vignetting_bbox(self, pupil_spec, oversize=1.):
+        """rayoptics/raytr/opticalspec.py Field.vignetting_bbox, prebuilt"""
+        if self._vig_bbox is None:
+            raise KeyError('this TableField carries no vignetting bounding box')
+        return self._vig_bbox
+
+
+class SimpleWorkload:
+    """a Workload assembled in memory (tests: golden fixture tables)"""
+
+    def __init__(self, table, fields, image_pts, foc=0.0, ref_wvl_idx=0, name='adhoc'):
+        self.name, self.description = name, name
+        self.table, self.fields, self.image_pts = table, list(fields), list(image_pts)
+        self.foc, self.ref_wvl_idx, self.aim = foc, ref_wvl_idx, None
+
+    @property
+    def n_ifcs(self):
+        return self.table.n_ifcs
 
 
 class _TableSeq:
@@ -68,14 +96,26 @@ class TableModel:
     ``analyses.trace_rays_soa`` ...) run on it unchanged; what it skips is the
     *extraction* of table and field constants from a live model."""
 
-    def __init__(self, name_or_workload):
+    def __init__(self, name_or_workload, sys_units_per_nm=1e-6):
         wl = load(name_or_workload) if isinstance(name_or_workload, str) else name_or_workload
         self.workload = wl
         self.seq_model = _TableSeq(wl)
         self.fields = [TableField(f, ip) for f, ip in zip(wl.fields, wl.image_pts)]
         self.foc = wl.foc
+        self._units_per_nm = sys_units_per_nm       # mm systems: 1e-6
 
     def __getitem__(self, key):
         if key in ('seq_model', 'sm'):
             return self.seq_model
+        if key in ('optical_spec', 'osp'):
+            return {'pupil': None}
         raise KeyError(f'{key!r}: a TableModel carries a surface table and field constants only')
+
+    def nm_to_sys_units(self, nm):
+        """rayoptics/optical/opticalmodel.py nm_to_sys_units"""
+        return self._units_per_nm * nm
+
+    def setup_pupil_coords(self, fld, wvl, foc, image_pt=None, image_delta=None):
+        """stands in for trace.setup_pupil_coords (trace.py:608-624): the chief-ray
+        package and reference sphere are the prebuilt ones of the field"""
+        return fld.ref_sphere, fld.chief_ray

@@ -327,7 +327,10 @@ def workload_file(opm, name, desc):
     for fld in osp['fov'].fields:
         rs_pkg, cr_pkg = trace.setup_pupil_coords(opm, fld, wvl, foc)
         fld.chief_ray, fld.ref_sphere = cr_pkg, rs_pkg
-        flds.append(dict(field=field_arr(field_from_model(opm, fld)).tolist(),
+        fs = field_from_model(opm, fld)
+        flds.append(dict(field=field_arr(fs).tolist(), kind=int(fs.kind),
+                         cr_dir=[float(v) for v in fs.cr_dir], rot=[float(v) for v in fs.rot],
+                         rot_order=int(fs.rot_order),
                          image_pt=[float(v) for v in rs_pkg[0][:2]]))
         # the chief-ray aiming problem the reference solved for this field
         # (trace.aim_chief_ray -> iterate_ray, trace.py:313-415, 627-640) and the
@@ -369,6 +372,12 @@ def main():
     workload_file(rm.nikkor(), 'nikkor_c3',
                   'BASELINE.json configs[2] stand-in: 29-interface zoom with 4 '
                   'even aspheres (rayoptics/optical/tests/Nikon Nikkor Z 14-30mm f-4 S.roa)')
+    workload_file(rm.litho_c5(), 'litho_c5',
+                  'BASELINE.json configs[4] stand-in: the largest prescription in the reference '
+                  'tree, rayoptics/zemax/tests/US05831776-1.zmx (44 interfaces, K=43, 248 nm '
+                  'lithography lens, object NA 0.15), imported by the reference\'s own zmxread; '
+                  '9 fields x 5 wavelengths as configs[4] asks; fused-silica indices from the '
+                  'Malitson formula (rayoptics_amd.ingest.SELLMEIER)')
     if '--workloads-only' in sys.argv:
         return
 

@@ -254,3 +254,30 @@ def toroid_lens():
     for ifc in sm.ifcs:
         ifc.max_aperture = 9.0
     return opm
+
+
+def litho_c5():
+    """BASELINE.json configs[4] stand-in: rayoptics/zemax/tests/US05831776-1.zmx
+    (44 interfaces) through the reference's own Zemax importer, 9 fields x 5
+    wavelengths; the catalogue glass (SILICA, unknown to the stubbed catalogue)
+    gets the Malitson dispersion formula so that the wavelengths differ."""
+    import pathlib
+    from rayoptics.zemax import zmxread
+    from rayoptics_amd import ingest
+    path = pathlib.Path(REF_SRC) / 'rayoptics' / 'zemax' / 'tests' / 'US05831776-1.zmx'
+    opm, _info = zmxread.read_lens(None, path.open(encoding='utf-8').read(), do_update=False)
+    sm, osp = opm['seq_model'], opm['optical_spec']
+
+    class Silica(refshim.OpticalMedium):
+        def __init__(self):
+            super().__init__(1.5084, 'SILICA', 'nominal')
+
+        def rindex(self, w):
+            return ingest.sellmeier_index('SILICA', refshim.get_wavelength(w))
+    for g in sm.gaps:
+        if g.medium.name().startswith('not '):
+            g.medium = Silica()
+    osp['wvls'] = WvlSpec([(247.8, 1.), (247.9, 1.), (248.0, 1.), (248.1, 1.), (248.2, 1.)], ref_wl=2)
+    osp['fov'] = FieldSpec(osp, key=list(osp['fov'].key), value=12.0,
+                           flds=[i / 8 for i in range(9)], is_relative=True)
+    return finish(opm, do_apertures=False)

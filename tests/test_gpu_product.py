@@ -1,0 +1,156 @@
+"""-m gpu: the PRODUCT entry points (rayoptics_amd.trace / analyses drop-ins)
+running over the HIP engine, on table-backed models built from the golden
+fixtures (the reference itself is not on the GPU box): results against the
+reference's own outputs stored in tests/golden and against the oracle.
+Plus BASELINE configs[4] at full size on one GPU."""
+import numpy as np
+import pytest
+
+from rayoptics_amd import abi
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+FLAGS = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+
+
+def model_of(fx, fields, image_pts, wf=None, bbox=None, foc=0.0):
+    from rayoptics_amd import workloads
+    wl = workloads.SimpleWorkload(fx.table, fields, image_pts, foc=foc)
+    m = workloads.TableModel(wl)
+    if wf is not None:
+        m.fields[0].rox_wavefront = wf
+    if bbox is not None:
+        m.fields[0]._vig_bbox = bbox
+    return m
+
+
+@pytest.mark.parametrize('name', ['dblgauss', 'singlet', 'rc_telescope', 'nikkor'])
+def test_trace_grid_spot_product_function(name):
+    """trace.trace_grid_spot (what SequentialModel.trace_grid is rebound to for
+    SpotDiagramFigure) == the data the reference's SpotDiagramFigure computed"""
+    from rayoptics_amd import trace, session
+    fx = H.fixture(name)
+    c = fx['spot']
+    num = int(c['num'])
+    for key in [k for k in c if k.endswith('_hits')]:
+        fi, wi = key.split('_')[0], int(key.split('_')[1][1:])
+        m = model_of(fx, [H.field_from_arr(c[f'{fi}_field'])], [tuple(c[f'{fi}_image_pt'])],
+                     foc=float(c['foc']))
+        xy = trace.trace_grid_spot(m, [np.array([-1., -1.]), np.array([1., 1.]), num], m.fields[0],
+                                   fx.table.wvls[wi], float(c['foc']), c[f'{fi}_image_pt'])
+        assert xy.dtype == np.float64 and xy.ndim == 2 and xy.shape[1] == 2
+        np.testing.assert_array_equal(xy, c[key])
+        # the caller may keep the array: a later call must not overwrite it
+        keep = xy.copy()
+        xy2 = trace.trace_grid_spot(m, [np.array([-1., -1.]), np.array([1., 1.]), num], m.fields[0],
+                                    fx.table.wvls[wi], float(c['foc']) + 0.01, c[f'{fi}_image_pt'])
+        np.testing.assert_array_equal(xy, keep)
+        assert xy2.shape == xy.shape and not np.array_equal(xy2, xy)
+    session.clear()
+
+
+from test_oracle_golden import OPD_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize('name,case', OPD_CASES)
+def test_eval_wavefront_product_function(name, case):
+    """analyses.eval_wavefront / trace_wavefront + focus_wavefront (RayGrid's pair)
+    on the device == the grid the reference's eval_wavefront returned"""
+    from rayoptics_amd import analyses, session
+    from rayoptics_amd.table import wavefront_from_array
+    fx = H.fixture(name)
+    c = fx[case]
+    m = model_of(fx, [H.field_from_arr(c['field'])], [(0., 0.)],
+                 wf=wavefront_from_array(c['wavefront']), bbox=(c['start'], c['stop']))
+    m._units_per_nm = 1.0 / (float(c['convert_to_opd']) * fx.table.wvls[int(c['wvl_idx'])])
+    wvl = fx.table.wvls[int(c['wvl_idx'])]
+    num = int(c['num'])
+    got = analyses.eval_wavefront(m, m.fields[0], wvl, 0.0, num_rays=num)
+    exp = c['opd_grid']
+    assert got.shape == exp.shape
+    np.testing.assert_array_equal(got[:, :, :2], exp[:, :, :2])
+    assert np.array_equal(np.isnan(got[:, :, 2]), np.isnan(exp[:, :, 2]))
+    ok = ~np.isnan(exp[:, :, 2])
+    assert np.abs(got[:, :, 2][ok] - exp[:, :, 2][ok]).max() <= 1e-10 * float(c['convert_to_opd'])
+    # RayGrid: trace_wavefront hands a deferred grid to focus_wavefront
+    grid_pkg = analyses.trace_wavefront(m, m.fields[0], wvl, 0.0, num_rays=num)
+    got2 = analyses.focus_wavefront(m, grid_pkg, m.fields[0], wvl, 0.0)
+    np.testing.assert_array_equal(got2, got)
+    session.clear()
+
+
+def test_trace_rays_soa_and_deferred_ray_list():
+    """analyses.trace_rays_soa (array form of trace_list_of_rays) and the
+    _DeferredRayList of trace_pupil_coords / focus_pupil_coords over the HIP engine"""
+    from oracle import oracle
+    from rayoptics_amd import analyses, session
+    fx = H.fixture('dblgauss')
+    cr = fx['rays_ap']
+    c = fx['grid_f2']
+    N = fx.table.n_ifcs
+    m = model_of(fx, [H.field_from_arr(c['field'])], [(0.0, 18.0)])
+    wv = [fx.table.wvls[int(i)] for i in np.atleast_1d(cr['wvl_idx'])]
+    if len(wv) == 1:
+        wv = wv[0]
+    pk = analyses.trace_rays_soa(m, cr['pt0'], cr['dir0'], wv, check_apertures=True)
+    np.testing.assert_array_equal(pk.status, cr['status'])
+    H.assert_result_matches(cr, pk, require_exact=False)
+    r_ok = int(np.flatnonzero(pk.status == abi.OK)[0])
+    ray, op, _w = pk.pkg(r_ok)
+    assert len(ray) == N and abs(op - cr['op'][r_ok]) <= 1e-10 * max(1.0, abs(cr['op'][r_ok]))
+    # RayList: deferred list -> one HITS_COMPACT launch per refocus
+    rng = np.random.default_rng(8)
+    pupil = rng.uniform(-1.05, 1.05, (500, 2))
+    lst = analyses.trace_pupil_coords(m, [p.copy() for p in pupil], m.fields[0], fx.table.wvls[1], 0.0)
+    assert isinstance(lst, analyses._DeferredRayList)
+    for foc in (0.0, 0.05):
+        xy = analyses.focus_pupil_coords(m, lst, m.fields[0], fx.table.wvls[1], foc)
+        opts = oracle.make_opts(flags=FLAGS, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                                last_surf=N - 2, foc=foc, image_pt=(0.0, 18.0))
+        orc = oracle.trace_pupil_list(fx.table, m.fields[0].rox_field, pupil[:, 0].copy(),
+                                      pupil[:, 1].copy(), 1, opts)
+        np.testing.assert_array_equal(xy, orc.hits)
+    session.clear()
+
+
+def test_config5_full_size_on_one_gpu():
+    """BASELINE configs[4] in full: 9 fields x 5 wavelengths x 2048 x 2048 pupil
+    grids (188.7 M rays, HITS, 3.2 GB) of the 44-interface lithography lens
+    imported from rayoptics/zemax/tests/US05831776-1.zmx, traced on ONE GPU through
+    the multi-GPU path's own code (dist.partition / trace_blocks); a 64-row block of
+    every (field, wavelength) grid bit-exact vs the oracle, and the whole-job
+    invariants (every ray accounted for, survivors finite, vignetted fraction sane)"""
+    import torch
+    from oracle import oracle
+    from rayoptics_amd import workloads, dist as rdist
+    from rayoptics_amd.engine import TraceEngine
+    wl = workloads.load('litho_c5')
+    assert wl.n_ifcs == 44 and len(wl.fields) == 9 and len(wl.table.wvls) == 5
+    eng = TraceEngine(wl.table)
+    num = 2048
+    plan = rdist.partition(9, 5, num, 1)
+    cap = sum(b.row_count for b in plan[0]) * num
+    assert cap == 45 * num * num
+    xy, st, n = rdist.trace_blocks(eng, plan[0], cap, wl.fields, wl.image_pts, num, wl.foc)
+    torch.cuda.synchronize()
+    assert n == cap
+    ok = st == 0
+    n_ok = int(ok.sum().item())
+    assert int((st == 255).sum().item()) == 0              # every ray was traced
+    assert 0.55 * cap < n_ok < 0.85 * cap                   # the circular pupil in the square grid
+    assert bool(torch.isfinite(xy[:, ok]).all().item())
+    N = wl.n_ifcs
+    rng = np.random.default_rng(5)
+    for g, b in enumerate(plan[0]):
+        i0 = int(rng.integers(0, num - 64))
+        opts = oracle.make_opts(flags=FLAGS, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
+                                foc=wl.foc, image_pt=wl.image_pts[b.fi])
+        grid = oracle.make_grid((-1., -1.), (1., 1.), num, row_begin=i0, row_count=64)
+        orc = oracle.trace_pupil_grid(wl.table, wl.fields[b.fi], grid, b.wi, opts)
+        lo = g * num * num + i0 * num
+        hi = lo + 64 * num
+        np.testing.assert_array_equal(st[lo:hi].cpu().numpy(), orc.status)
+        got = xy[:, lo:hi].cpu().numpy()
+        same = (got == orc.seg) | (np.isnan(got) & np.isnan(orc.seg))
+        assert same.all(), (b, int((~same).sum()))
+    eng.close()
