@@ -52,9 +52,12 @@
 #ifndef ROX_SLIM_FP64        // 1: range-guarded slim sqrt / shared-reciprocal division triples
 #define ROX_SLIM_FP64 1       //    (bit-identical to sqrt() and `/`; see slim_* below)
 #endif
-#ifndef ROX_BLOCK            // workgroup size (FULL: 128 -> 222, 256 -> 214, 512 -> 208, 1024 -> 212 us)
-#define ROX_BLOCK 512
+#ifndef ROX_BLOCK            // workgroup size of the reduced-output modes (HITS sustained: 512 -> 124 us,
+#define ROX_BLOCK 512         // 1024 -> 131 us) and tile size of the hit compaction
 #endif
+#ifndef ROX_BLOCK_FULL       // workgroup size of FULL mode: with the per-surface barrier the whole
+#define ROX_BLOCK_FULL 1024   // workgroup writes its packet rows together (sustained 256 -> 215 us,
+#endif                        // 512 -> 198 us, 1024 -> 192.5 us; without the barrier 217 us)
 #ifndef ROX_WG_SYNC          // 1: FULL mode: a workgroup barrier per surface keeps the waves of a
 #define ROX_WG_SYNC 1         //    workgroup on the same packet rows (218 -> 202 us)
 #endif
@@ -63,6 +66,8 @@ namespace rox {
 
 constexpr int kBlock = ROX_BLOCK;
 constexpr int kWaves = kBlock / 64;
+// threads per workgroup (= rays per tile) of an output mode
+constexpr int block_of(int out_mode) { return out_mode == ROX_OUT_FULL ? ROX_BLOCK_FULL : ROX_BLOCK; }
 static_assert(sizeof(rox_aperture) == 40, "rox_aperture layout");
 static_assert(sizeof(rox_phase) == 168, "rox_phase layout");
 static_assert(sizeof(rox_surface) == 576, "rox_surface layout");
@@ -1029,10 +1034,12 @@ __device__ __forceinline__ uint64_t ts_pack(uint32_t epoch, uint64_t flag, uint3
 
 // ------------------------------------------------------------------ the kernel
 template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT>
-__global__ void __launch_bounds__(kBlock, ROX_MIN_WAVES)
+__global__ void __launch_bounds__(block_of(OUT_MODE), ROX_MIN_WAVES)
 trace_kernel(const TraceArgs a)
 {
     constexpr bool kCompact = (OUT_MODE == ROX_OUT_HITS_COMPACT);
+    constexpr int kB = block_of(OUT_MODE);      // threads per workgroup = rays per tile
+    static_assert(!kCompact || kB == kBlock, "the compaction tile is kBlock rays");
     const int N = a.n_ifcs;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *tbl_w = lds;                               // [N][kRowDoubles]
@@ -1043,19 +1050,19 @@ trace_kernel(const TraceArgs a)
     int32_t *slot_w = reinterpret_cast<int32_t *>(wvls_w + a.n_wvls);
 
     // stage the surface table once per workgroup
-    for (int i = threadIdx.x; i < N * kRowDoubles; i += kBlock)
+    for (int i = threadIdx.x; i < N * kRowDoubles; i += kB)
         tbl_w[i] = a.rows[i];
     {
         const size_t w0 = PER_RAY_WVL ? 0 : (size_t)a.wvl_idx_all * N;
-        for (int i = threadIdx.x; i < nw_rows * N; i += kBlock)
+        for (int i = threadIdx.x; i < nw_rows * N; i += kB)
             ntab_w[i] = a.n_table[w0 + i];
         if (FEAT & F_PHASE)
-            for (int i = threadIdx.x; i < nw_rows * N * kPhaseConsts; i += kBlock)
+            for (int i = threadIdx.x; i < nw_rows * N * kPhaseConsts; i += kB)
                 phc_w[i] = a.ph_consts[w0 * kPhaseConsts + i];
     }
-    for (int i = threadIdx.x; i < a.n_wvls; i += kBlock)
+    for (int i = threadIdx.x; i < a.n_wvls; i += kB)
         wvls_w[i] = a.wvls[i];
-    for (int i = threadIdx.x; i < 2 * N; i += kBlock)
+    for (int i = threadIdx.x; i < 2 * N; i += kB)
         slot_w[i] = a.slots[i];
     __syncthreads();
 
@@ -1071,7 +1078,7 @@ trace_kernel(const TraceArgs a)
     c.eps = a.opts.eps; c.fuzz = a.opts.fuzz;
     c.probe_surf = -1;
     const int64_t ld = a.out.ld;
-    const int64_t n_tiles = (a.n_rays + kBlock - 1) / kBlock;
+    const int64_t n_tiles = (a.n_rays + kB - 1) / kB;
 
     // HITS_COMPACT: tiles are handed out by ticket, so that the tile a workgroup
     // waits for in the look-back is always held by a running workgroup
@@ -1092,7 +1099,7 @@ trace_kernel(const TraceArgs a)
         }
         if (tile >= n_tiles)
             break;
-        const int64_t r = tile * kBlock + threadIdx.x;
+        const int64_t r = tile * kB + threadIdx.x;
         const bool active = r < a.n_rays;
         RayEnd e;
         SegOut so;
@@ -1281,7 +1288,7 @@ struct LaunchCfg {
 template <int GEN, bool PRW, int FEAT>
 inline void launch_mode(const LaunchCfg &k, const TraceArgs &a)
 {
-    const dim3 block(kBlock);
+    const dim3 block(block_of(k.out_mode));
     switch (k.out_mode) {
     case ROX_OUT_FULL:
         hipLaunchKernelGGL((trace_kernel<ROX_OUT_FULL, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);

@@ -256,16 +256,15 @@ int check_opts(const rox_system *sys, const rox_opts *o, const rox_out *out, int
     return 0;
 }
 
-// workgroups per CU of a launch (the rest of the batch is grid-strided).
-// ROX_BLOCKS_PER_CU overrides it for experiments (tools/ab_bench.py).
-int blocks_per_cu()
+// workgroups per CU of a launch of `bs`-thread workgroups (the rest of the batch is
+// grid-strided).  ROX_BLOCKS_PER_CU overrides it for experiments.
+int blocks_per_cu(int bs)
 {
     static const int v = [] {
         const char *e = getenv("ROX_BLOCKS_PER_CU");
-        const int n = e ? atoi(e) : 0;
-        return n > 0 ? n : 32 * 256 / kBlock;      // measured: FULL 238 us at 8/CU, 228 us at 32/CU
+        return e ? atoi(e) : 0;
     }();
-    return v;
+    return v > 0 ? v : 32 * 256 / bs;      // measured: FULL 238 us at 8/CU, 228 us at 32/CU (256 threads)
 }
 
 // rays per kernel launch (lane byte offsets are 32-bit: at most 2^28).
@@ -384,8 +383,9 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
             a.out.pupil = out0.pupil ? out0.pupil + base : nullptr;
         }
         // enough workgroups to fill 256 CUs several times over, grid-stride the rest
-        int64_t blocks = (a.n_rays + kBlock - 1) / kBlock;
-        const int64_t cap = (int64_t)sys->num_cus * blocks_per_cu();
+        const int bs = block_of(a.opts.out_mode);
+        int64_t blocks = (a.n_rays + bs - 1) / bs;
+        const int64_t cap = (int64_t)sys->num_cus * blocks_per_cu(bs);
         if (blocks > cap)
             blocks = cap;
         k.grid = dim3((unsigned)blocks);

@@ -414,6 +414,20 @@ class TraceEngine:
                                                self._stream()), 'rox_aim_chief_rays')
         return aim_y, result
 
+    def time_pupil_grid_sustained(self, fld, grid, wvl_idx, opts, out, launches=20, batches=7,
+                                  warm_ms=120.0):
+        """median over `batches` of :meth:`time_pupil_grid` after `warm_ms` of
+        back-to-back launches: the GPU's clocks take tens of milliseconds of
+        continuous work to settle (a cold 20-launch batch reads 10-30 % slow,
+        tools/sustained_probe.py), so steady-state kernel times are quoted"""
+        import time as _time
+        t0 = _time.perf_counter()
+        while (_time.perf_counter() - t0) * 1e3 < warm_ms:
+            self.time_pupil_grid(fld, grid, wvl_idx, opts, out, launches)
+        ts = sorted(self.time_pupil_grid(fld, grid, wvl_idx, opts, out, launches)
+                    for _ in range(batches))
+        return ts[len(ts) // 2]
+
     def time_pupil_grid(self, fld, grid, wvl_idx, opts, out, launches):
         """mean duration (ms) of the trace kernel over `launches` launches,
         from HIP events recorded on the launch stream"""

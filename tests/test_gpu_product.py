@@ -94,7 +94,12 @@ def test_trace_rays_soa_and_deferred_ray_list():
         wv = wv[0]
     pk = analyses.trace_rays_soa(m, cr['pt0'], cr['dir0'], wv, check_apertures=True)
     np.testing.assert_array_equal(pk.status, cr['status'])
-    H.assert_result_matches(cr, pk, require_exact=False)
+    np.testing.assert_array_equal(pk.fail_surf, cr['fail_surf'])
+    # (device buffers are not pre-filled here: slots past a failure hold garbage
+    # that the views never read -- compare what the reference appended)
+    got = np.where(np.isnan(cr['seg']), np.nan, pk.seg[:cr['seg'].shape[0]])
+    H.assert_soa_close(cr['seg'], got, 'seg')
+    H.assert_soa_close(cr['op'], pk.op, 'op')
     r_ok = int(np.flatnonzero(pk.status == abi.OK)[0])
     ray, op, _w = pk.pkg(r_ok)
     assert len(ray) == N and abs(op - cr['op'][r_ok]) <= 1e-10 * max(1.0, abs(cr['op'][r_ok]))

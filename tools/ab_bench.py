@@ -64,10 +64,12 @@ def main():
                            want_pupil=(mode == abi.OUT_FULL), nan_fill=False,
                            ld=None if args.ld_pad < 0 else R + args.ld_pad)
         outs[name] = (o, out)
-        eng.time_pupil_grid(fld, grid, wi, o, out, 3)       # warm
+    # each mode measured at steady-state clocks (120 ms of launches first: a cold
+    # batch reads 10-30 % slow and A/B differences drown in the clock ramp)
     times = {k: [] for k in outs}
-    for _ in range(args.reps):
-        for name, (o, out) in outs.items():
+    for name, (o, out) in outs.items():
+        eng.time_pupil_grid_sustained(fld, grid, wi, o, out, args.launches, 1)
+        for _ in range(args.reps):
             times[name].append(eng.time_pupil_grid(fld, grid, wi, o, out, args.launches))
     for k, v in times.items():
         res[k + '_us'] = round(float(np.median(v)) * 1e3, 2)

@@ -38,8 +38,7 @@ def main():
                           foc=wl.foc, image_pt=wl.image_pts[0])
             out = DeviceResult(torch, eng.device, eng.num_segments(flags), R, mode,
                                want_pupil=False, nan_fill=False)
-            eng.time_pupil_grid(fld, grid, wi, o, out, 3)
-            ms = min(eng.time_pupil_grid(fld, grid, wi, o, out, 10) for _ in range(3))
+            ms = eng.time_pupil_grid_sustained(fld, grid, wi, o, out)     # steady-state clocks
             st = out.status.cpu().numpy()
             fs = out.fail_surf.cpu().numpy().astype('int64')
             ok = st == 0
