@@ -78,11 +78,14 @@ static_assert(sizeof(rox_field) == 192, "rox_field layout");
 // dcoefs[i] = c_coef_i * coefs[i], the product the df() loops of the polynomial
 // profiles form per evaluation (c_coef_i = 2(i+1), or i+1 for RadialPolynomial;
 // exact small integers, so the host product has the reference's rounding).
+// cd[] interleaves (coefs[i], dcoefs[i]): the sag and slope series read one
+// 16-byte LDS word per term.
 struct dev_surface {
     rox_surface pub;
-    double dcoefs[ROX_MAX_COEF];
+    double cd[2 * ROX_MAX_COEF];
 };
-constexpr int kRowDoubles = sizeof(dev_surface) / sizeof(double);   // 82
+constexpr int kRowDoubles = sizeof(dev_surface) / sizeof(double);   // 92
+static_assert(offsetof(dev_surface, cd) % 16 == 0 && sizeof(dev_surface) % 16 == 0, "16-byte LDS reads");
 // Per (wavelength, interface) constants of a DiffractionGrating, formed on the
 // host with libm pow() exactly as the reference's `mu**2` / `T**2` are:
 //   [0] mu = n_in/n_out  [1] mu**2  [2] T  [3] T**2          (doe.py:138-143)
@@ -349,7 +352,9 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
                                           int ncoef, tblp coefs,
                                           const v3 &p, double &f, v3 &df)
 {
-    tblp dcoefs = coefs + (offsetof(dev_surface, dcoefs) - offsetof(rox_surface, coefs)) / 8;
+    // (coefs[i], dcoefs[i]) pairs of the device row
+    const d2 *cd = reinterpret_cast<const d2 *>(
+        coefs + (offsetof(dev_surface, cd) - offsetof(rox_surface, coefs)) / 8);
     if ((FEAT & F_TOROID) && (!(FEAT & (F_EVEN | F_RADIAL)) || kind >= ROX_YTOROID)) {
         // profiles.py:1337-1377 YToroid.fY/f/df; XToroid swaps x and y (:1429-1434)
         const bool xt = (kind == ROX_XTOROID);
@@ -362,9 +367,10 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
         double z_asp = 0.0, y_pow = y2;
         double e_asp = 0.0, d_pow = 1;
         for (int i = 0; i < ncoef; ++i) {
-            z_asp += coefs[i] * y_pow;
+            const d2 c = cd[i];
+            z_asp += c.x * y_pow;
             y_pow *= y2;
-            e_asp += dcoefs[i] * d_pow;         // (c_coef*coefs[i])*y_pow
+            e_asp += c.y * d_pow;               // (c_coef*coefs[i])*y_pow
             d_pow *= y2;
         }
         const double fY = slim_div(cv * y2, 1. + srad) + z_asp;
@@ -393,42 +399,53 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
             const double srad = slim_sqrt(rad);
             srad_e = same ? srad : sqrt(rad_e);
             const double z = slim_div(cv * r2, 1. + srad);
-            double z_asp = 0.0, r_pow = r2;
+            const double e = slim_div(cv, srad_e);
+            // sag and slope series in one pass: two independent chains, the same
+            // operations in the same order as the reference's two loops
+            double z_asp = 0.0, z_pow = r2, e_asp = 0.0, e_pow = 1;
             for (int i = 0; i < ncoef; ++i) {
-                z_asp += coefs[i] * r_pow;
-                r_pow *= r2;
+                const d2 c = cd[i];
+                z_asp += c.x * z_pow;
+                z_pow *= r2;
+                e_asp += c.y * e_pow;           // (c_coef*coefs[i])*r_pow
+                e_pow *= r2;
             }
             f = p.z - (z + z_asp);
+            e_tot = e + e_asp;
         } else {
             srad_e = sqrt(rad_e);
+            const double e = slim_div(cv, srad_e);
+            double r_pow = 1, e_asp = 0.0;
+            for (int i = 0; i < ncoef; ++i) {
+                e_asp += cd[i].y * r_pow;       // (c_coef*coefs[i])*r_pow
+                r_pow *= r2;
+            }
+            e_tot = e + e_asp;
         }
-        const double e = slim_div(cv, srad_e);
-        double r_pow = 1, e_asp = 0.0;
-        for (int i = 0; i < ncoef; ++i) {
-            e_asp += dcoefs[i] * r_pow;         // (c_coef*coefs[i])*r_pow
-            r_pow *= r2;
-        }
-        e_tot = e + e_asp;
     } else {
         const double r = slim_sqrt(r2);
         if (WANT_F && rad_e < 0.0)
             return false;
         const double srad_e = WANT_F ? slim_sqrt(rad_e) : sqrt(rad_e);   // NaN when negative
-        if (WANT_F) {
-            const double z = slim_div(cv * r2, 1. + srad_e);
-            double z_asp = 0.0, r_pow = r;
-            for (int i = 0; i < ncoef; ++i) {
-                z_asp += coefs[i] * r_pow;
-                r_pow *= r;
-            }
-            f = p.z - (z + z_asp);
-        }
         const double e = slim_div(cv, srad_e);
         double e_asp = 0.0;
-        double r_pow = (r == 0.0) ? 1.0 : 1 / r;
-        for (int i = 0; i < ncoef; ++i) {
-            e_asp += dcoefs[i] * r_pow;         // (c_coef*coef)*r_pow
-            r_pow *= r;
+        double e_pow = (r == 0.0) ? 1.0 : slim_div(1.0, r);
+        if (WANT_F) {
+            const double z = slim_div(cv * r2, 1. + srad_e);
+            double z_asp = 0.0, z_pow = r;
+            for (int i = 0; i < ncoef; ++i) {   // both series in one pass (see above)
+                const d2 c = cd[i];
+                z_asp += c.x * z_pow;
+                z_pow *= r;
+                e_asp += c.y * e_pow;           // (c_coef*coef)*r_pow
+                e_pow *= r;
+            }
+            f = p.z - (z + z_asp);
+        } else {
+            for (int i = 0; i < ncoef; ++i) {
+                e_asp += cd[i].y * e_pow;
+                e_pow *= r;
+            }
         }
         e_tot = e + e_asp;
     }

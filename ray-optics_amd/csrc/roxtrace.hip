@@ -642,7 +642,8 @@ int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_t
             const double c0 = rows[i].profile == ROX_RADIALPOLY ? 1.0 : 2.0;
             double c_coef = c0;                 // profiles.py:877-882, 1104-1109, 1364-1369
             for (int k = 0; k < ROX_MAX_COEF; ++k) {
-                drows[i].dcoefs[k] = c_coef * rows[i].coefs[k];
+                drows[i].cd[2 * k] = rows[i].coefs[k];
+                drows[i].cd[2 * k + 1] = c_coef * rows[i].coefs[k];
                 c_coef += c0;
             }
         }
