@@ -53,8 +53,11 @@
 #define ROX_SLIM_FP64 1       //    (bit-identical to sqrt() and `/`; see slim_* below)
 #endif
 #ifndef ROX_BLOCK            // workgroup size of the reduced-output modes (HITS sustained: 512 -> 124 us,
-#define ROX_BLOCK 512         // 1024 -> 131 us) and tile size of the hit compaction
+#define ROX_BLOCK 512         // 1024 -> 131 us)
 #endif
+#ifndef ROX_BLOCK_COMPACT    // workgroup = tile size of HITS_COMPACT: fewer, larger tiles make the
+#define ROX_BLOCK_COMPACT 1024 // look-back cheaper (into pinned memory 128 -> 501, 256 -> 371,
+#endif                        // 512 -> 337, 1024 -> 316 us)
 #ifndef ROX_BLOCK_FULL       // workgroup size of FULL mode: with the per-surface barrier the whole
 #define ROX_BLOCK_FULL 1024   // workgroup writes its packet rows together (sustained 256 -> 215 us,
 #endif                        // 512 -> 198 us, 1024 -> 192.5 us; without the barrier 217 us)
@@ -67,7 +70,11 @@ namespace rox {
 constexpr int kBlock = ROX_BLOCK;
 constexpr int kWaves = kBlock / 64;
 // threads per workgroup (= rays per tile) of an output mode
-constexpr int block_of(int out_mode) { return out_mode == ROX_OUT_FULL ? ROX_BLOCK_FULL : ROX_BLOCK; }
+constexpr int block_of(int out_mode)
+{
+    return out_mode == ROX_OUT_FULL ? ROX_BLOCK_FULL
+         : out_mode == ROX_OUT_HITS_COMPACT ? ROX_BLOCK_COMPACT : ROX_BLOCK;
+}
 static_assert(sizeof(rox_aperture) == 40, "rox_aperture layout");
 static_assert(sizeof(rox_phase) == 168, "rox_phase layout");
 static_assert(sizeof(rox_surface) == 576, "rox_surface layout");
@@ -1056,7 +1063,7 @@ trace_kernel(const TraceArgs a)
 {
     constexpr bool kCompact = (OUT_MODE == ROX_OUT_HITS_COMPACT);
     constexpr int kB = block_of(OUT_MODE);      // threads per workgroup = rays per tile
-    static_assert(!kCompact || kB == kBlock, "the compaction tile is kBlock rays");
+
     const int N = a.n_ifcs;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *tbl_w = lds;                               // [N][kRowDoubles]
@@ -1100,7 +1107,7 @@ trace_kernel(const TraceArgs a)
     // HITS_COMPACT: tiles are handed out by ticket, so that the tile a workgroup
     // waits for in the look-back is always held by a running workgroup
     __shared__ int64_t s_tile;
-    __shared__ int32_t s_wcnt[kWaves];
+    __shared__ int32_t s_wcnt[kB / 64];
     __shared__ uint32_t s_excl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -1198,7 +1205,7 @@ trace_kernel(const TraceArgs a)
             __syncthreads();
             int woff = 0, total = 0;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) {
+            for (int w = 0; w < kB / 64; ++w) {
                 const int cnt = s_wcnt[w];
                 if (w < wave)
                     woff += cnt;

@@ -358,7 +358,8 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
         if (!cx)
             return fail(ROX_E_NOMEM, "out of host memory");
         const int64_t per = total < chunk_max ? total : chunk_max;
-        int rc = ensure_compact(cx, (per + kBlock - 1) / kBlock);
+        const int tb = block_of(ROX_OUT_HITS_COMPACT);
+        int rc = ensure_compact(cx, (per + tb - 1) / tb);
         if (rc)
             return rc;
     }

@@ -356,7 +356,7 @@ class TraceEngine:
 
     def _hits_finish(self, lease, R):
         self.torch.cuda.current_stream(self.device).synchronize()
-        n = int(lease.array((1,), np.int64, offset=16 * R)[0])
+        n = C.c_int64.from_address(lease.ptr + 16 * R).value
         return lease.array((n, 2), np.float64)
 
     def trace_pupil_grid_hits(self, fld, grid, wvl_idx, opts):
