@@ -200,9 +200,57 @@ class _DeferredWavefront:
     device for every refocus gives what the reference's pre-calc / refocus split
     gives (same formulas, same operation order, waveabr.py:309-353)."""
 
-    def __init__(self, grid_def, kwargs):
+    def __init__(self, grid_def, kwargs, ctx=None):
         self.grid_def = grid_def
         self.kwargs = kwargs
+        self._ctx = ctx             # (opt_model, fld, wvl, foc) for consumers of the grid itself
+        self._grid = None
+
+    # any other consumer of RayGrid.grid_pkg[0] sees the reference's grid of
+    # [px, py, ray_pkg] rows, traced on first use (FULL packets)
+    def _materialise(self):
+        if self._grid is None:
+            opt_model, fld, wvl, foc = self._ctx
+            self._grid = trace_ray_grid(opt_model, self.grid_def, fld, wvl, foc,
+                                        **dict(self.kwargs))
+        return self._grid
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __len__(self):
+        return len(self._materialise())
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+
+class _DeferredPreCalc:
+    """the second half of the reference's trace_wavefront result (the
+    wave_abr_pre_calc grid, rayoptics/raytr/analyses.py:755-764), computed from the
+    materialised packets only if a consumer other than focus_wavefront asks"""
+
+    def __init__(self, deferred, cr_pkg, ref_sphere):
+        self._d, self._cr, self._rs, self._upd = deferred, cr_pkg, ref_sphere, None
+
+    def _materialise(self):
+        if self._upd is None:
+            from rayoptics.raytr import waveabr
+            opt_model, fld, wvl, foc = self._d._ctx
+            fod = opt_model['analysis_results']['parax_data'].fod
+            self._upd = [[waveabr.wave_abr_pre_calc(fod, fld, wvl, foc, pkg, self._cr, self._rs)
+                          if pkg is not None else None for _px, _py, pkg in row]
+                         for row in self._d._materialise()]
+        return self._upd
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __len__(self):
+        return len(self._materialise())
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
 
 
 def _opd_fusable(kwargs):
@@ -239,7 +287,8 @@ def trace_wavefront(opt_model, fld, wvl, foc, image_pt_2d=None, image_delta=None
     if _opd_fusable(kwargs):
         try:
             wavefront_from_model(opt_model, fld)         # finite reference sphere?
-            return _DeferredWavefront(grid_def, dict(kwargs)), None
+            d = _DeferredWavefront(grid_def, dict(kwargs), (opt_model, fld, wvl, foc))
+            return d, _DeferredPreCalc(d, cr_pkg, ref_sphere)
         except UnsupportedModelError:
             pass
     from rayoptics.raytr import waveabr

@@ -114,7 +114,19 @@ class HostPackets:
         st, s = int(self.status[r]), int(self.fail_surf[r])
         ifc = ifcs[s] if ifcs is not None and 0 <= s < len(ifcs) else None
         pkg = self.pkg(r, named) if with_pkg and self.out_mode == abi.OUT_FULL else None
-        int_pt = None
+        int_pt = inc_dir = normal = n_in = n_out = None
         if pkg is not None and st != abi.MISSED_SURFACE and len(pkg[0]):
-            int_pt = pkg[0][-1][0]
-        return make_error(st, s, ifc, pkg, int_pt)
+            last = pkg[0][-1]               # [inc_pt, before_dir, 0.0, normal], raytrace.py:239-257
+            int_pt = last[0]
+            if st in (abi.TIR, abi.EVANESCENT) and s >= 1:
+                # bend()/phase() were given b4_dir = rt.dot(before_dir) (raytrace.py:172),
+                # the unit normal and the indices either side of the interface
+                row = self.table.rows[s - 1]
+                rt = np.array(list(row.rt)).reshape(3, 3)
+                if row.rt_order == abi.RT_F_ORDER:
+                    rt = np.asfortranarray(rt)      # the dgemv chain of the transpose view
+                inc_dir = rt.dot(last[1])
+                normal = last[3]
+                wi = self.table.wvl_index(self.wvl(r))
+                n_in, n_out = float(self.table.n_table[wi, s - 1]), float(self.table.n_table[wi, s])
+        return make_error(st, s, ifc, pkg, int_pt, inc_dir, normal, n_in, n_out)

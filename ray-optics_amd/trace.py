@@ -164,8 +164,12 @@ def trace_grid_spot(opt_model, grid_rng, fld, wvl, foc, image_pt, **kwargs):
 
 
 def _is_spot_filter(fct):
-    return getattr(fct, '__qualname__', '').endswith(
-        'SpotDiagramFigure.__init__.<locals>.spot')
+    """SpotDiagramFigure's own callback (rayoptics/mpl/axisarrayfigure.py:229-238):
+    a closure, so it can only be recognised by where it was defined -- module and
+    qualified name, and the four-variable closure (self is not among them) it has
+    in the reference"""
+    return (getattr(fct, '__module__', '') == 'rayoptics.mpl.axisarrayfigure'
+            and getattr(fct, '__qualname__', '') == 'SpotDiagramFigure.__init__.<locals>.spot')
 
 
 def seq_trace_grid(self, fct, fi, wl=None, num_rays=21, form='grid',

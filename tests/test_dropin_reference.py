@@ -453,3 +453,62 @@ def test_chief_ray_aiming_on_device(ref, installed):
             np.testing.assert_array_equal(a, b)     # in fact bit-identical
         one = trace.aim_chief_ray(opm, opm['osp']['fov'].fields[-1])
         np.testing.assert_array_equal(one, theirs[-1])
+
+
+def test_deferred_wavefront_still_serves_the_reference_grids(ref, installed):
+    """RayGrid.grid_pkg of the fused trace_wavefront behaves as the reference's
+    (grid, upd_grid) pair for any consumer that indexes it"""
+    import rayoptics.raytr.analyses as analyses
+    opm = ref.dblgauss()
+    fld = opm['osp']['fov'].fields[1]
+
+    def pk():
+        g, u = analyses.trace_wavefront(opm, fld, 587.6, 0.0, num_rays=6)
+        out = []
+        for row_g, row_u in zip(g, u):
+            for (px, py, pkg), upd in zip(row_g, row_u):
+                if pkg is None:
+                    out.append((px, py, None))
+                else:
+                    out.append((px, py, pkg[1], pkg[0][-1][0][1]) + tuple(
+                        np.ravel(np.asarray(u, dtype=float)).tolist() for u in upd))
+        return out
+    go, gt = both(installed, pk)
+    assert len(go) == len(gt) == 36
+    for a, b in zip(go, gt):
+        assert a[:2] == b[:2] and (a[2] is None) == (b[2] is None)
+        if a[2] is not None:
+            assert a[2:] == b[2:]
+
+
+def test_tir_error_objects_carry_the_reference_fields(ref, installed):
+    """TraceTIRError.inc_dir / normal / prev_indx / follow_indx as trace_raw fills
+    them (raytrace.py:239-245), from the partial packet and the table"""
+    import rayoptics.raytr.analyses as analyses
+    import rayoptics.raytr.raytrace as rt
+    from rayoptics.raytr.traceerror import TraceTIRError
+    opm = ref.singlet()
+    sm = opm['seq_model']
+    wvl = sm.central_wavelength()
+    # a steep ray that reaches the rear surface from inside the glass beyond the critical angle
+    found = None
+    for ang in np.linspace(0.3, 1.2, 40):
+        pt0 = np.array([0., 2.0, 0.])
+        d0 = np.array([0., np.sin(ang), np.cos(ang)])
+        try:
+            rt.trace(sm, pt0, d0, wvl)
+        except TraceTIRError as e:
+            found = (pt0, d0, e)
+            break
+        except Exception:
+            continue
+    if found is None:
+        pytest.skip('no TIR ray on this model')
+    pt0, d0, theirs = found
+    res = analyses.trace_list_of_rays(opm, [(pt0, d0, wvl)], rayerr_filter='full')
+    (_ray, ours), = res
+    assert isinstance(ours, TraceTIRError) and ours.surf == theirs.surf
+    np.testing.assert_array_equal(ours.inc_dir, theirs.inc_dir)
+    np.testing.assert_array_equal(ours.normal, theirs.normal)
+    assert ours.prev_indx == theirs.prev_indx and ours.follow_indx == theirs.follow_indx
+    np.testing.assert_array_equal(ours.int_pt, theirs.int_pt)
