@@ -54,8 +54,8 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--num', type=int, default=1024, help='pupil grid is num x num')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true',
@@ -85,9 +85,15 @@ def main():
                          f'{args.gpus} ranks (WORLD_SIZE={world})')
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_dist
+    saved_stdout = None
     if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
+        # RCCL prints a version banner on stdout when its communicator is built; stdout
+        # carries exactly one JSON line, so fd 1 points at stderr until that is over
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=torch.device('cuda', local_rank))
 
