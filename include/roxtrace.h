@@ -78,7 +78,8 @@ enum { ROX_OUT_FULL = 0,  /* seg[n_seg][10][ld]: the whole RayPkg.ray          *
        ROX_OUT_OPD = 3,   /* seg[1][ld]: wave_abr_full_calc_finite_pup, the OPD of
                              the ray w.r.t. the chief ray on a finite reference
                              sphere, system units (rayoptics/raytr/waveabr.py:256-307);
-                             constants in rox_opts.wf                           */
+                             constants in rox_opts.wf; on an infinite reference
+                             sphere wave_abr_full_calc_inf_ref (:356-424)       */
        ROX_OUT_HITS_COMPACT = 4 };
                           /* seg[n_hits][2]: the HITS pair (x, y) of the rays that
                              reach the image only, interleaved, packed in ray order
@@ -106,6 +107,8 @@ enum { ROX_CHECK_APERTURES = 1u,     /* raytrace.py:198-202                    *
  *   F: y_i = fma(a_i2,x2, fma(a_i1,x1, fma(a_i0,x0, 0)))
  *   C: y_i = fma(a_i2,x2, fma(a_i0,x0, fma(a_i1,x1, 0)))                       */
 enum { ROX_RT_F_ORDER = 0, ROX_RT_C_ORDER = 1 };
+/* rox_wavefront.kind */
+enum { ROX_WF_FINITE = 0, ROX_WF_INF_FULL = 1, ROX_WF_INF_SPLIT = 2 };
 /* rox_grid.kind */
 enum { ROX_GRID_PRODUCT = 0, /* trace_grid: ray r=(i*num+j), x_i outer, y_j inner */
        ROX_GRID_FAN = 1 };   /* trace_fan: ray r at (x_r, y_r), num rays          */
@@ -166,8 +169,7 @@ typedef struct rox_surface {
 /* Per (field, wavelength, focus) constants of the OPD calculation: the chief
  * ray package and reference sphere that trace.setup_pupil_coords() leaves in
  * fld.chief_ray / fld.ref_sphere (rayoptics/raytr/trace.py:608-624,
- * rayoptics/raytr/waveabr.py:23-76).  Finite reference sphere only: callers keep
- * is_kinda_big(ref_radius) cases on the host (waveabr.py:213-221). */
+ * rayoptics/raytr/waveabr.py:23-76). */
 typedef struct rox_wavefront {
     double cr1_p[3];         /* cr_ray[1][mc.p]                                 */
     double cr0_d[3];         /* cr_ray[0][mc.d]                                 */
@@ -186,6 +188,22 @@ typedef struct rox_wavefront {
     int32_t after_order;     /* ROX_RT_* of after_rt                            */
     double after_rt[9];
     double after_t[3];
+    /* Infinite reference sphere (is_kinda_big(ref_radius), waveabr.py:213-221):
+     * wave_abr_full_calc_inf_ref (waveabr.py:356-424, kind ROX_WF_INF_FULL) or its
+     * pre-calc / calc split (waveabr.py:427-488, ROX_WF_INF_SPLIT: the same
+     * quantities, the final sum associated differently).  Chief-ray-only terms
+     * are formed on the host as the reference forms them.                      */
+    int32_t kind;            /* ROX_WF_*                                        */
+    int32_t last_kind;       /* lcl_tfrm_last: 0 = None, 1 = (rt, t)            */
+    int32_t last_order;      /* ROX_RT_* of last_rt                             */
+    int32_t reserved;
+    double last_rt[9];       /* seq_model.lcl_tfrms[-2][0]                      */
+    double last_t[3];
+    double cr_last_p[3];     /* cr_ray[-1][mc.p]                                */
+    double cr_last_d[3];     /* cr_ray[-1][mc.d]                                */
+    double d_cr_b4[3];       /* rt.dot(cr_ray[-2][mc.d])                        */
+    double v_be;             /* cr_op + ray_dist_to_perp_from_origin(cr b4)     */
+    double image_pt[3];      /* ref_sphere[0]                                   */
 } rox_wavefront;
 
 typedef struct rox_opts {

@@ -37,6 +37,8 @@ HOST_POINTERS = 16
 RT_F_ORDER, RT_C_ORDER = 0, 1
 # grid kinds
 GRID_PRODUCT, GRID_FAN = 0, 1
+# rox_wavefront.kind
+WF_FINITE, WF_INF_FULL, WF_INF_SPLIT = 0, 1, 2
 # rox_field.kind: the branches of ray_start_from_osp (opticalspec.py:289-400)
 FLD_EPD, FLD_EPD_WIDE, FLD_AIM_PT, FLD_NA, FLD_FNO, FLD_AIM_DIR = 0, 1, 2, 3, 4, 5
 # rox_aim_chief_rays result codes
@@ -78,7 +80,13 @@ class Wavefront(C.Structure):
                 ('ref_radius', C.c_double), ('n_obj', C.c_double),
                 ('n_img', C.c_double), ('sign_soln', C.c_double),
                 ('after_kind', C.c_int32), ('after_order', C.c_int32),
-                ('after_rt', C.c_double * 9), ('after_t', C.c_double * 3)]
+                ('after_rt', C.c_double * 9), ('after_t', C.c_double * 3),
+                ('kind', C.c_int32), ('last_kind', C.c_int32),
+                ('last_order', C.c_int32), ('reserved', C.c_int32),
+                ('last_rt', C.c_double * 9), ('last_t', C.c_double * 3),
+                ('cr_last_p', C.c_double * 3), ('cr_last_d', C.c_double * 3),
+                ('d_cr_b4', C.c_double * 3), ('v_be', C.c_double),
+                ('image_pt', C.c_double * 3)]
 
 
 class Opts(C.Structure):
@@ -122,8 +130,8 @@ class Aim(C.Structure):
 assert C.sizeof(Aperture) == 40
 assert C.sizeof(Phase) == 168
 assert C.sizeof(Surface) == 576
-assert C.sizeof(Wavefront) == 296
-assert C.sizeof(Opts) == 352
+assert C.sizeof(Wavefront) == 512
+assert C.sizeof(Opts) == 568
 assert C.sizeof(Field) == 192
 assert C.sizeof(Grid) == 48
 assert C.sizeof(Out) == 56

@@ -309,6 +309,12 @@ def focus_wavefront(opt_model, grid_pkg, fld, wvl, foc, image_pt_2d=None,
         try:
             own = getattr(fld, 'rox_wavefront', None)   # table-backed models: prebuilt
             wf = own if own is not None else wavefront_from_model(opt_model, fld, cr_pkg, ref_sphere)
+            if wf.kind == abi.WF_INF_FULL:
+                # RayGrid's route is wave_abr_pre_calc + wave_abr_calc (waveabr.py:427-488):
+                # on an infinite reference sphere the final sum is associated differently
+                # from wave_abr_full_calc_inf_ref's
+                wf = abi.Wavefront.from_buffer_copy(bytes(wf))
+                wf.kind = abi.WF_INF_SPLIT
             return _opd_grid(opt_model, fld, wvl, grid.grid_def, grid.kwargs, wf, value_if_none)
         except UnsupportedModelError:       # the sphere went infinite at this focus
             from rayoptics.raytr import waveabr

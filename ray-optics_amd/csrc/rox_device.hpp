@@ -713,6 +713,57 @@ __device__ __forceinline__ double wave_abr_finite_pup(const rox_wavefront &w, co
     return -w.n_obj * e1 - ray_op + w.n_img * ekp + w.cr_op - w.n_img * ep;
 }
 
+// waveabr.py:356-424 wave_abr_full_calc_inf_ref (ROX_WF_INF_FULL) and its pre-calc /
+// calc split :427-488 (ROX_WF_INF_SPLIT); dist_to_shortest_join :178-196,
+// ray_dist_to_perp_from_origin :166-175.  Chief-ray-only terms come from the host.
+__device__ __forceinline__ double wave_abr_inf_ref(const rox_wavefront &w, const v3 &ray1_p,
+                                                   const v3 &ray0_d, const v3 &rayk_p,
+                                                   const v3 &rayk_d, const v3 &rayl_p,
+                                                   const v3 &rayl_d, double ray_op)
+{
+    const double e1 = eic_distance(ray1_p, ray0_d, w.cr1_p, w.cr0_d);
+    v3 p_b4 = rayk_p, d_b4 = rayk_d;
+    if (w.last_kind) {
+        p_b4 = rotate(w.last_rt, w.last_order, v3{rayk_p.x - w.last_t[0], rayk_p.y - w.last_t[1],
+                                                  rayk_p.z - w.last_t[2]});
+        d_b4 = rotate(w.last_rt, w.last_order, rayk_d);
+    }
+    const double op_b4 = dot3(d_b4, v3{-p_b4.x, -p_b4.y, -p_b4.z});
+    const v3 p1{w.cr_last_p[0], w.cr_last_p[1], w.cr_last_p[2]};
+    const v3 d1{w.cr_last_d[0], w.cr_last_d[1], w.cr_last_d[2]};
+    const v3 del_p{rayl_p.x - p1.x, rayl_p.y - p1.y, rayl_p.z - p1.z};
+    const v3 n = cross3(d1, rayl_d);
+    const double nn = dot3(n, n);
+    v3 P1, P2;
+    if (nn == 0) {
+        const double t2 = dot3(v3{p1.x - rayl_p.x, p1.y - rayl_p.y, p1.z - rayl_p.z}, d1) *
+                          dot3(d1, rayl_d);
+        P1 = p1;
+        P2 = v3{rayl_p.x + t2 * rayl_d.x, rayl_p.y + t2 * rayl_d.y, rayl_p.z + t2 * rayl_d.z};
+    } else {
+        const double t1 = dot3(cross3(rayl_d, n), del_p) / nn;
+        const double t2 = dot3(cross3(d1, n), del_p) / nn;
+        P1 = v3{p1.x + t1 * d1.x, p1.y + t1 * d1.y, p1.z + t1 * d1.z};
+        P2 = v3{rayl_p.x + t2 * rayl_d.x, rayl_p.y + t2 * rayl_d.y, rayl_p.z + t2 * rayl_d.z};
+    }
+    const v3 rF0{(P1.x + P2.x) / 2, (P1.y + P2.y) / 2, (P1.z + P2.z) / 2};
+    const v3 dcr{w.d_cr_b4[0], w.d_cr_b4[1], w.d_cr_b4[2]};
+    const double V_B = ray_op + op_b4;
+    const double W0 = V_B - w.v_be +
+                      w.n_img * dot3(v3{d_b4.x - dcr.x, d_b4.y - dcr.y, d_b4.z - dcr.z}, rF0);
+    const v3 ta{rayl_p.x - w.image_pt[0], rayl_p.y - w.image_pt[1], rayl_p.z - w.image_pt[2]};
+    const double dbc = dot3(d_b4, dcr);
+    const double numer = dot3(v3{dcr.x - d_b4.x * dbc, dcr.y - d_b4.y * dbc, dcr.z - d_b4.z * dbc}, ta);
+    const double denom = 1 + dot3(d_b4, dcr);
+    if (w.kind == ROX_WF_INF_SPLIT) {
+        const double pre_opd = -w.n_obj * e1 - W0;
+        const double W_inf = w.n_img * numer / denom;
+        return pre_opd - W_inf;
+    }
+    const double W_inf = W0 + w.n_img * numer / denom;
+    return -w.n_obj * e1 - W_inf;
+}
+
 // ------------------------------------------------------------------ stores
 // One packet component of ray r lives at seg[(slot*10 + c)*ld + r].  The
 // (slot, c) part is wave-uniform, so it goes into an SGPR base; the ray part
@@ -1176,8 +1227,11 @@ trace_kernel(const TraceArgs a)
                     so.pdn(0, e.inc, e.ad, e.nrm);
                     so.dst(0, 0.0);
                 } else if (OUT_MODE == ROX_OUT_OPD) {
-                    so.put(0, 0, wave_abr_finite_pup(a.opts.wf, e.ray1_p, dir0, e.rayk_p,
-                                                     e.rayk_d, e.phs + e.opl));
+                    const double op = e.phs + e.opl;
+                    so.put(0, 0, a.opts.wf.kind == ROX_WF_FINITE      // (wave-uniform)
+                           ? wave_abr_finite_pup(a.opts.wf, e.ray1_p, dir0, e.rayk_p, e.rayk_d, op)
+                           : wave_abr_inf_ref(a.opts.wf, e.ray1_p, dir0, e.rayk_p, e.rayk_d,
+                                              e.inc, e.ad, op));
                 } else if (OUT_MODE == ROX_OUT_HITS) {      // axisarrayfigure.py:229-238
                     const double dist = a.opts.foc / e.ad.z;
                     so.put(0, 0, (e.inc.x + dist * e.ad.x) - a.opts.image_pt[0]);

@@ -239,6 +239,8 @@ int check_opts(const rox_system *sys, const rox_opts *o, const rox_out *out, int
             return fail(ROX_E_UNSUPPORTED, "OPD output with filter_out_phantoms");
         if (!(o->wf.ref_radius != 0.0))
             return fail(ROX_E_ARG, "OPD output needs rox_opts.wf (ref_radius is 0)");
+        if (o->wf.kind < ROX_WF_FINITE || o->wf.kind > ROX_WF_INF_SPLIT)
+            return fail(ROX_E_ARG, "bad rox_wavefront.kind %d", o->wf.kind);
     }
     if (o->out_mode == ROX_OUT_HITS_COMPACT) {
         if (!out->n_hits)

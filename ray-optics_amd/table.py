@@ -13,6 +13,7 @@ element classes; DiffractiveElements with a phase function other than
 ``radial_phase_fct``) raise :class:`UnsupportedModelError` so that callers keep
 such models on the reference's own CPU path.
 """
+import ctypes as C
 import json
 import numpy as np
 
@@ -423,8 +424,9 @@ def wavefront_from_model(opt_model, fld, chief_ray_pkg=None, ref_sphere=None):
     """``rox_wavefront``: the chief-ray package and reference sphere that
     ``trace.setup_pupil_coords`` leaves in ``fld.chief_ray`` / ``fld.ref_sphere``
     (rayoptics/raytr/trace.py:608-624), as ``wave_abr_full_calc_finite_pup``
-    reads them (rayoptics/raytr/waveabr.py:256-307).  Infinite reference
-    spheres (``is_kinda_big``, waveabr.py:213-216) stay on the host."""
+    (rayoptics/raytr/waveabr.py:256-307) or, on an infinite reference sphere
+    (``is_kinda_big``, waveabr.py:213-216), ``wave_abr_full_calc_inf_ref``
+    (:356-424) reads them."""
     pre = getattr(fld, 'rox_wavefront', None)
     if pre is not None and chief_ray_pkg is None and ref_sphere is None:
         return pre                                  # table-backed models (workloads.TableField)
@@ -434,10 +436,30 @@ def wavefront_from_model(opt_model, fld, chief_ray_pkg=None, ref_sphere=None):
     cr, cr_exp_seg = cr_pkg
     cr_ray, cr_op, _wvl = cr
     cr_exp_pt, _cr_exp_dir, cr_exp_dist, ifc, _b4_pt, _b4_dir = cr_exp_seg
-    _image_pt, ref_dir, ref_radius, _lcl_tfrm_last = rs
-    if np.isinf(ref_radius) or abs(ref_radius) > 1e8:
-        raise UnsupportedModelError('infinite reference sphere: OPD stays on the host')
+    image_pt, ref_dir, ref_radius, lcl_tfrm_last = rs
     w = abi.Wavefront()
+    if np.isinf(ref_radius) or abs(ref_radius) > 1e8:       # is_kinda_big, misc_math.py:22-29
+        # wave_abr_full_calc_inf_ref (waveabr.py:356-424): the chief-ray-only terms
+        # are formed here exactly as the reference forms them per ray
+        w.kind = abi.WF_INF_FULL
+        if lcl_tfrm_last is not None:
+            rt, t = lcl_tfrm_last
+            w.last_kind = 1
+            w.last_order = rt_order_of(rt)
+            for a in range(3):
+                for b in range(3):
+                    w.last_rt[3 * a + b] = float(rt[a][b])
+                w.last_t[a] = float(t[a])
+            p_cr_b4, d_cr_b4 = rt.dot(cr_ray[-2][0] - t), rt.dot(cr_ray[-2][1])
+        else:
+            p_cr_b4, d_cr_b4 = cr_ray[-2][0], cr_ray[-2][1]
+        op_cr_b4 = np.dot(d_cr_b4, -p_cr_b4)                # ray_dist_to_perp_from_origin
+        w.v_be = float(cr_op + op_cr_b4)
+        for i in range(3):
+            w.d_cr_b4[i] = float(d_cr_b4[i])
+            w.cr_last_p[i] = float(cr_ray[-1][0][i])
+            w.cr_last_d[i] = float(cr_ray[-1][1][i])
+            w.image_pt[i] = float(image_pt[i])
     for i in range(3):
         w.cr1_p[i] = float(cr_ray[1][0][i])
         w.cr0_d[i] = float(cr_ray[0][1][i])
@@ -474,4 +496,6 @@ def wavefront_to_array(w):
 
 
 def wavefront_from_array(a):
-    return abi.Wavefront.from_buffer_copy(np.asarray(a, dtype=np.uint8).tobytes())
+    b = np.asarray(a, dtype=np.uint8).tobytes()
+    n = C.sizeof(abi.Wavefront)
+    return abi.Wavefront.from_buffer_copy(b + bytes(max(n - len(b), 0)))   # (ABI v2 fixtures: finite)

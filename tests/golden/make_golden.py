@@ -353,6 +353,13 @@ def workload_file(opm, name, desc):
 
 def main():
     rng = np.random.default_rng(SEED)
+    if '--only-telecentric' in sys.argv:
+        opm = rm.telecentric()
+        save('telecentric', ra.SurfaceTable.from_seq_model(opm['seq_model']), {
+            'opd_f0': case_opd(opm, 0, 550.0, 11),
+            'opd_f2': case_opd(opm, 2, 486.1, 10),
+        })
+        return
     if '--workloads-only' not in sys.argv:
         kat_dblgauss_seq()
     workload_file(rm.dblgauss(), 'dblgauss_c2',
@@ -442,6 +449,13 @@ def main():
         'rays_ap': case_rays(opm, 256, rng, True, pupil_scale=1.6),
         'grid_f1': case_grid(opm, 1, 650.0, 10),
         'opd_f1': case_opd(opm, 1, 550.0, 11),
+    })
+
+    # infinite reference sphere (image-space telecentric): wave_abr_full_calc_inf_ref
+    opm = rm.telecentric()
+    save('telecentric', ra.SurfaceTable.from_seq_model(opm['seq_model']), {
+        'opd_f0': case_opd(opm, 0, 550.0, 11),
+        'opd_f2': case_opd(opm, 2, 486.1, 10),
     })
 
     # aspheric toroids (Newton path, anamorphic)

@@ -281,3 +281,17 @@ def litho_c5():
     osp['fov'] = FieldSpec(osp, key=list(osp['fov'].key), value=12.0,
                            flds=[i / 8 for i in range(9)], is_relative=True)
     return finish(opm, do_apertures=False)
+
+
+def telecentric():
+    """image-space telecentric singlet (stop at the front focal plane): the
+    reference sphere of the axial field is 'kinda big' (waveabr.py:213-216), so the
+    OPD goes through wave_abr_full_calc_inf_ref (waveabr.py:356-424)"""
+    opm = new_model(('object', 'epd'), 6.0, ('object', 'angle'), 3.0, [0., 0.7, 1.0],
+                    [(486.1, 1.0), (550.0, 1.0)], 1, obj_thi=1e10)
+    sm = opm['seq_model']
+    sm.add_surface([0.0, 32.38806981225028])
+    sm.set_stop()
+    sm.add_surface([1 / 40.0, 5.0, 1.6, 50.0])
+    sm.add_surface([-1 / 40.0, 30.0])
+    return finish(opm)

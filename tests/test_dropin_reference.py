@@ -292,8 +292,8 @@ def test_host_generated_ray_starts(ref, installed):
 
 def test_eval_wavefront_infinite_reference_sphere(ref, installed):
     """image-space telecentric system, axial field: the reference sphere is
-    'kinda big' (waveabr.py:213-216), so the OPD is evaluated by the reference's
-    wave_abr_full_calc_inf_ref on lazy views of device-traced packets"""
+    'kinda big' (waveabr.py:213-216): wave_abr_full_calc_inf_ref (and RayGrid's
+    pre-calc / calc split) fused into the trace epilogue"""
     import rayoptics.raytr.analyses as analyses
     import rayoptics.raytr.trace as trace
     opm = ref.new_model(('object', 'epd'), 6.0, ('object', 'angle'), 3.0, [0., 1.0],
@@ -305,14 +305,28 @@ def test_eval_wavefront_infinite_reference_sphere(ref, installed):
     sm.add_surface([-1 / 40.0, 30.0])
     ref.finish(opm)
     fld = opm['osp']['fov'].fields[0]
-    rs, _cr = trace.setup_pupil_coords(opm, fld, 550.0, 0.0)
+    rs, cr = trace.setup_pupil_coords(opm, fld, 550.0, 0.0)
     assert rs[2] > 1e8
+    from rayoptics_amd import abi
+    from rayoptics_amd.table import wavefront_from_model
+    assert wavefront_from_model(opm, fld, cr, rs).kind == abi.WF_INF_FULL   # fused, not a host route
 
     def ew():
         return analyses.eval_wavefront(opm, fld, 550.0, 0.0, num_rays=9)
     go, gt = both(installed, ew)
     np.testing.assert_array_equal(go, gt)
     assert np.isfinite(go[:, :, 2]).sum() > 20
+
+    # RayGrid: wave_abr_pre_calc_inf_ref + wave_abr_calc_inf_ref (a differently associated sum)
+    def rg():
+        g = analyses.RayGrid(opm, f=0, wl=550.0, num_rays=9)
+        first = np.array(g.grid)
+        g.foc = 0.05
+        g.update_data(build='update')
+        return first, np.array(g.grid)
+    (a1, a2), (b1, b2) = both(installed, rg)
+    np.testing.assert_array_equal(a1, b1)
+    np.testing.assert_array_equal(a2, b2)
 
 
 def test_trace_rays_soa_matches_list_form(ref, installed):

@@ -148,7 +148,9 @@ def test_list_of_rays_last_segment():
 
 
 OPD_CASES = [('dblgauss', 'opd_f0'), ('dblgauss', 'opd_f2'), ('rc_telescope', 'opd_f3'),
-             ('nikkor', 'opd_f1'), ('tilted_singlet', 'opd_f1'), ('toroid_lens', 'opd_f1')]
+             ('nikkor', 'opd_f1'), ('tilted_singlet', 'opd_f1'), ('toroid_lens', 'opd_f1'),
+             # infinite reference sphere: wave_abr_full_calc_inf_ref (waveabr.py:356-424)
+             ('telecentric', 'opd_f0'), ('telecentric', 'opd_f2')]
 
 
 def opd_opts(c):
