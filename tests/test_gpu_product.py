@@ -75,7 +75,21 @@ def test_eval_wavefront_product_function(name, case):
     # RayGrid: trace_wavefront hands a deferred grid to focus_wavefront
     grid_pkg = analyses.trace_wavefront(m, m.fields[0], wvl, 0.0, num_rays=num)
     got2 = analyses.focus_wavefront(m, grid_pkg, m.fields[0], wvl, 0.0)
-    np.testing.assert_array_equal(got2, got)
+    if m.fields[0].rox_wavefront.kind == abi.WF_FINITE:
+        np.testing.assert_array_equal(got2, got)
+    else:
+        # infinite reference sphere: RayGrid's pre-calc + calc route associates the
+        # final sum differently from eval_wavefront's full calc (waveabr.py:427-488 vs
+        # :356-424) -- an ulp apart, and bit-identical to the oracle's split variant
+        from oracle import oracle
+        from test_oracle_golden import opd_opts
+        o = opd_opts(c)
+        o.wf.kind = abi.WF_INF_SPLIT
+        grid = oracle.make_grid(c['start'], c['stop'], num)
+        orc = oracle.trace_pupil_grid(fx.table, m.fields[0].rox_field, grid, int(c['wvl_idx']), o)
+        exp2 = np.where(orc.status == 0, float(c['convert_to_opd']) * orc.seg[0], np.nan)
+        np.testing.assert_array_equal(got2[:, :, 2].ravel(), exp2)
+        np.testing.assert_allclose(got2[:, :, 2], got[:, :, 2], rtol=0, atol=1e-9, equal_nan=True)
     session.clear()
 
 
