@@ -18,6 +18,9 @@
  *                             opticalspec.py:1339-1353 apply_vignetting)
  *   rox_aim_chief_rays     <- rayoptics/raytr/trace.py:313-415    iterate_ray() (1-D branch)
  *                             rayoptics/raytr/trace.py:627-640    aim_chief_ray()
+ *   rox_calc_vignetting    <- rayoptics/raytr/vigcalc.py:233-340, 396-461
+ *                             calc_vignetting_for_field() / calc_vignetted_ray() /
+ *                             iterate_pupil_ray()
  *   rox_system_create      <- rayoptics/seq/sequential.py:149-202 path()/path_sequence()
  *                             (the per-wavelength (Intfc, Gap, Tfrm, Indx, Zdir)
  *                             list flattened into one POD table)
@@ -297,6 +300,29 @@ int rox_system_destroy(rox_system *sys);
 /* number of segments a FULL packet holds (n_ifcs minus filtered phantoms) */
 int rox_system_num_segments(const rox_system *sys, uint32_t flags,
                             int32_t *n_seg);
+
+/* vignetting search ------------------------------------------------------ */
+/* One problem per (field, pupil direction): vigcalc.calc_vignetted_ray
+ * (rayoptics/raytr/vigcalc.py:259-340) -- trace the pupil-edge ray with aperture
+ * checks (pt_inside_fuzz 1e-4); where it is clipped, iterate the pupil coordinate
+ * (iterate_pupil_ray, vigcalc.py:396-461: scipy's secant, tol 1e-6, on rays traced
+ * without aperture checks) until the ray grazes that aperture's edge
+ * (edge_pt_target, rayoptics/elem/surface.py:210-218, 422-427, 459-464,
+ * rayoptics/seq/interface.py:94-111); repeat until no other aperture clips.  The
+ * four directions of calc_vignetting_for_field (vigcalc.py:233-256) of every
+ * field run as lanes of one launch.  probs / vig / clip are host memory;
+ * synchronous. */
+typedef struct rox_vig {
+    rox_field fld;           /* ray-start constants of the field               */
+    double start_dir[2];     /* pupil.pupil_rays[1 + i]                         */
+    double unit_dir[2];      /* normalize(start_dir), as NumPy forms it         */
+    int32_t xy;              /* i // 2: the pupil axis searched                 */
+    int32_t wvl_idx;
+    int32_t stop_surf;       /* seq_model.stop_surface, < 0: floating stop      */
+    int32_t max_iter;        /* max_iter_count (50)                             */
+} rox_vig;                   /* 240 bytes */
+int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs,
+                        double eps, double *vig, int32_t *clip_surf, void *stream);
 
 /* trace entries ---------------------------------------------------------- */
 /* explicit rays: pt0, dir0 are SoA [3][n_rays] with leading dimension

@@ -45,6 +45,9 @@ def lib():
         L.rox_oracle_aim_chief_rays.restype = C.c_int
         L.rox_oracle_aim_chief_rays.argtypes = [P(abi.Surface), i32, vp, vp, i32, i32,
                                                 P(abi.Aim), C.c_double, vp, vp]
+        L.rox_oracle_calc_vignetting.restype = C.c_int
+        L.rox_oracle_calc_vignetting.argtypes = [P(abi.Surface), i32, vp, vp, i32, i32,
+                                                 P(abi.Vig), C.c_double, vp, vp]
         _LIB = L
     return _LIB
 
@@ -187,3 +190,17 @@ def aim_chief_rays(table, probs, eps=1.0e-12):
     if rc:
         raise RuntimeError(f'oracle error {rc}')
     return aim_y, result
+
+
+def calc_vignetting(table, probs, eps=1.0e-12):
+    """probs: sequence of abi.Vig -> (vig float64[n], clip_surf int32[n])"""
+    n = len(probs)
+    arr = (abi.Vig * n)(*probs)
+    vig = np.zeros(n)
+    clip = np.zeros(n, dtype=np.int32)
+    rc = lib().rox_oracle_calc_vignetting(table.rows, table.n_ifcs, table.n_table.ctypes.data,
+                                          _wvls(table).ctypes.data, len(table.wvls), n, arr,
+                                          eps, vig.ctypes.data, clip.ctypes.data)
+    if rc:
+        raise RuntimeError(f'oracle error {rc}')
+    return vig, clip

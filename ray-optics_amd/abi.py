@@ -127,7 +127,14 @@ class Aim(C.Structure):
                 ('flip', C.c_int32), ('reserved', C.c_int32)]
 
 
+class Vig(C.Structure):
+    _fields_ = [('fld', Field), ('start_dir', C.c_double * 2), ('unit_dir', C.c_double * 2),
+                ('xy', C.c_int32), ('wvl_idx', C.c_int32), ('stop_surf', C.c_int32),
+                ('max_iter', C.c_int32)]
+
+
 assert C.sizeof(Aperture) == 40
+assert C.sizeof(Vig) == 240
 assert C.sizeof(Phase) == 168
 assert C.sizeof(Surface) == 576
 assert C.sizeof(Wavefront) == 512
@@ -142,7 +149,7 @@ EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_last_error', 'rox_system_create', 'rox_system_destroy',
            'rox_system_num_segments', 'rox_trace_rays',
            'rox_trace_pupil_grid', 'rox_trace_pupil_list',
-           'rox_aim_chief_rays')
+           'rox_aim_chief_rays', 'rox_calc_vignetting')
 # ... and the measurement / self-test helpers of include/roxtrace_diag.h
 DIAG_EXPORTS = ('rox_time_pupil_grid', 'rox_selftest_fp64')
 
@@ -175,6 +182,8 @@ def declare(lib):
                                          P(Opts), P(Out), vp]
     lib.rox_aim_chief_rays.restype = C.c_int
     lib.rox_aim_chief_rays.argtypes = [vp, i32, P(Aim), dbl, vp, vp, vp]
+    lib.rox_calc_vignetting.restype = C.c_int
+    lib.rox_calc_vignetting.argtypes = [vp, i32, P(Vig), dbl, vp, vp, vp]
     lib.rox_time_pupil_grid.restype = C.c_int
     lib.rox_time_pupil_grid.argtypes = [vp, P(Field), P(Grid), i32, P(Opts),
                                         P(Out), vp, i32, P(dbl)]

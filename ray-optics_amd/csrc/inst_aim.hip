@@ -108,7 +108,176 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
     a.result[i] = result;
 }
 
+
+// scipy.optimize.newton, secant branch (scipy/optimize/_zeros_py.py), disp=False,
+// rtol=0, maxiter=50: returns the root estimate; `converged` as scipy flags it;
+// `raised` is set by f when the reference's objective would raise -- the
+// iteration stops at once.
+template <class F>
+__device__ __forceinline__ double secant(F &f, double x0, double tol, bool &raised, bool &converged)
+{
+    converged = false;
+    double p0 = x0, p = x0;
+    const double eps = 1e-4;
+    double p1 = x0 * (1 + eps);
+    p1 += (p1 >= 0 ? eps : -eps);
+    double q0 = f(p0);
+    if (raised)
+        return p;
+    double q1 = f(p1);
+    if (raised)
+        return p;
+    if (fabs(q1) < fabs(q0)) {
+        double t = p0; p0 = p1; p1 = t;
+        t = q0; q0 = q1; q1 = t;
+    }
+    for (int itr = 0; itr < 50; ++itr) {
+        if (q1 == q0) {
+            p = (p1 + p0) / 2.0;
+            return p;                           // _ECONVERR, but the root is still used
+        }
+        if (fabs(q1) > fabs(q0))
+            p = (-q0 / q1 * p1 + p0) / (1 - q0 / q1);
+        else
+            p = (-q1 / q0 * p0 + p1) / (1 - q1 / q0);
+        // np.isclose(p, p1, rtol=0, atol=tol)
+        const bool close = (isfinite(p) && isfinite(p1)) ? (fabs(p - p1) <= tol) : (p == p1);
+        if (close) {
+            converged = true;
+            return p;
+        }
+        p0 = p1; q0 = q1;
+        p1 = p;
+        q1 = f(p1);
+        if (raised)
+            return p;
+    }
+    return p;
+}
+
+// rayoptics/raytr/vigcalc.py:259-340 calc_vignetted_ray + :396-461 iterate_pupil_ray,
+// one lane per (field, pupil direction)
+__global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
+{
+    const int N = a.n_ifcs, W = a.n_wvls;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *tbl_w = lds;
+    double *ntab_w = tbl_w + (size_t)N * kRowDoubles;
+    double *phc_w = ntab_w + (size_t)W * N;
+    double *wvls_w = phc_w + (size_t)W * N * kPhaseConsts;
+    int32_t *slot_w = reinterpret_cast<int32_t *>(wvls_w + W);
+    for (int i = threadIdx.x; i < N * kRowDoubles; i += 64)
+        tbl_w[i] = a.rows[i];
+    for (int i = threadIdx.x; i < W * N; i += 64)
+        ntab_w[i] = a.n_table[i];
+    for (int i = threadIdx.x; i < W * N * kPhaseConsts; i += 64)
+        phc_w[i] = a.ph_consts[i];
+    for (int i = threadIdx.x; i < W; i += 64)
+        wvls_w[i] = a.wvls[i];
+    for (int i = threadIdx.x; i < 2 * N; i += 64)
+        slot_w[i] = a.slots[i];
+    __syncthreads();
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n)
+        return;
+    const rox_vig pb = a.probs[i];
+    const int xy = pb.xy;
+
+    Ctx c;
+    c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
+    c.slot = slot_w; c.nslots_before = slot_w + N;
+    c.N = N;
+    c.filter_ph = false;
+    c.intersect_obj = pb.fld.kind != ROX_FLD_EPD_WIDE;      // trace.py:302-303
+    c.first_surf = 1; c.last_surf = N - 2;
+    c.eps = a.eps;
+    SegOut so{nullptr, 0, 0};
+
+    // trace_base(opm, (px, py), fld, wvl, apply_vignetting=False, check_apertures=check)
+    auto trace = [&](double px, double py, bool check, int probe, RayEnd &e) {
+        c.check_ap = check;
+        c.fuzz = check ? 1e-4 : 1e-5;           // pt_inside_fuzz=1e-4 on the checked trace
+        c.probe_surf = probe;
+        v3 pt0, dir0;
+        ray_start(pb.fld, 0u, px, py, pt0, dir0);
+        trace_ray<MODE_PROBE, true, F_ALL>(c, so, pt0, dir0, pb.wvl_idx, true, e);
+    };
+    // ifcs[s].edge_pt_target(start_dir)[xy]: surface.py:210-218, 422-427, 459-464,
+    // interface.py:94-111 (the first clear aperture that is not an obscuration)
+    auto edge = [&](int s) -> double {
+        tblp row = tbl_w + (size_t)s * kRowDoubles;
+        const int n_ap = ((tbli)row)[3];
+        tblp ap = row + (offsetof(rox_surface, ap) / sizeof(double));
+        for (int k = 0; k < n_ap; ++k, ap += sizeof(rox_aperture) / sizeof(double)) {
+            if (((tbli)ap)[1])
+                continue;
+            if (((tbli)ap)[0] == ROX_AP_CIRCULAR)
+                return ap[3] * pb.unit_dir[xy];
+            return (xy == 0 ? ap[3] : ap[4]) * pb.unit_dir[xy];
+        }
+        return row[offsetof(rox_surface, max_aperture) / sizeof(double)] * pb.unit_dir[xy];
+    };
+    // iterate_pupil_ray(opm, indx, xy, start_r0, r_target, fld, wvl)
+    auto iterate = [&](int indx, double start_r0, double r_target) -> double {
+        bool raised = false, conv;
+        double raised_x = 0.0;
+        auto f = [&](double x) -> double {      // r_pupil_coordinate, :418-446
+            RayEnd e;
+            trace(xy == 0 ? x : 0., xy == 1 ? x : 0., false, indx, e);
+            if (e.status != ROX_OK) {
+                const bool stop = (e.status == ROX_MISSED_SURFACE) ? (e.fail_surf <= indx)
+                                                                   : (e.fail_surf < indx);
+                if (stop) {
+                    raised = true;
+                    raised_x = x;
+                    return 0.0;
+                }
+            }
+            // ray_pkg[mc.ray][indx][mc.p]: the partial packet ends with inc_pt at the
+            // failing surface
+            const v3 p = (e.status != ROX_OK && e.fail_surf == indx) ? e.inc : e.probe_p;
+            const double r_ray = copysign(sqrt(p.x * p.x + p.y * p.y), r_target);
+            return r_ray - r_target;
+        };
+        const double root = secant(f, start_r0, 1e-6, raised, conv);
+        return raised ? 0.9 * raised_x : root;  // :456-459
+    };
+
+    double rel[2] = {pb.start_dir[0], pb.start_dir[1]};
+    int clip = -1;                              // None
+    bool iterating = true;
+    for (int it = 0; iterating && it < pb.max_iter; ++it) {
+        RayEnd e;
+        trace(rel[0], rel[1], true, -1, e);
+        int indx;
+        if (e.status != ROX_OK) {
+            indx = e.fail_surf;
+            if (indx == clip) {
+                iterating = false;
+                continue;
+            }
+        } else {
+            if (clip >= 0 || pb.stop_surf < 0) {
+                iterating = false;
+                continue;
+            }
+            indx = pb.stop_surf;                // first pass: go to the edge of the stop
+        }
+        const double r = iterate(indx, rel[xy], edge(indx));
+        rel[0] = rel[1] = 0.0;
+        rel[xy] = r;
+        clip = indx;
+    }
+    a.vig[i] = 1.0 - (rel[xy] / pb.start_dir[xy]);
+    a.clip[i] = clip;
+}
+
 }  // namespace
+
+void launch_vig(const VigArgs &a, size_t lds, hipStream_t st)
+{
+    hipLaunchKernelGGL(vig_kernel, dim3((a.n + 63) / 64), dim3(64), lds, st, a);
+}
 
 void launch_aim(const AimArgs &a, size_t lds, hipStream_t st)
 {

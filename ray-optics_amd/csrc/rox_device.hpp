@@ -1420,4 +1420,16 @@ struct AimArgs {
 };
 void launch_aim(const AimArgs &, size_t lds, hipStream_t);
 
+// vignetting search (csrc/inst_aim.hip)
+struct VigArgs {
+    const double *rows, *n_table, *ph_consts, *wvls;
+    const int32_t *slots;
+    int32_t n_ifcs, n_wvls, n;
+    const rox_vig *probs;      // device
+    double eps;
+    double *vig;               // device [n]
+    int32_t *clip;             // device [n]
+};
+void launch_vig(const VigArgs &, size_t lds, hipStream_t);
+
 }  // namespace rox

@@ -887,6 +887,57 @@ int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs, double 
     return 0;
 }
 
+int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs, double eps,
+                        double *vig, int32_t *clip_surf, void *stream)
+{
+    if (!sys || n < 0 || (n > 0 && (!probs || !vig || !clip_surf)))
+        return fail(ROX_E_ARG, "rox_calc_vignetting: bad argument");
+    if (n == 0)
+        return 0;
+    for (int i = 0; i < n; ++i) {
+        const rox_vig &p = probs[i];
+        if (p.wvl_idx < 0 || p.wvl_idx >= sys->n_wvls)
+            return fail(ROX_E_ARG, "probs[%d].wvl_idx %d out of range", i, p.wvl_idx);
+        if (p.stop_surf >= sys->n_ifcs || (p.xy != 0 && p.xy != 1) || p.max_iter < 0)
+            return fail(ROX_E_ARG, "probs[%d] is malformed", i);
+        int rc = check_field(&p.fld);
+        if (rc)
+            return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = sys->n_ifcs, W = sys->n_wvls;
+    const size_t lds = (N * sizeof(dev_surface) + W * N * sizeof(double) * (1 + kPhaseConsts) +
+                        W * sizeof(double) + 2 * N * sizeof(int32_t) + 15) & ~size_t(15);
+    if (lds > 160 * 1024 - 64)
+        return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
+    void *d = nullptr;
+    const size_t pb = sizeof(rox_vig) * n, vb = sizeof(double) * n, cb = sizeof(int32_t) * n;
+    HIP_TRY(hipMalloc(&d, pb + vb + cb));
+    VigArgs a{};
+    a.rows = sys->d_rows; a.n_table = sys->d_ntab; a.ph_consts = sys->d_phc; a.wvls = sys->d_wvls;
+    a.slots = sys->d_slots[0];
+    a.n_ifcs = sys->n_ifcs; a.n_wvls = sys->n_wvls; a.n = n;
+    a.probs = (const rox_vig *)d;
+    a.vig = (double *)((char *)d + pb);
+    a.clip = (int32_t *)((char *)d + pb + vb);
+    a.eps = eps;
+    hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        launch_vig(a, lds, st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(vig, a.vig, vb, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(clip_surf, a.clip, cb, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess)
+        return fail(ROX_E_HIP, "rox_calc_vignetting: %s", hipGetErrorString(e));
+    return 0;
+}
+
 // ---- include/roxtrace_diag.h ------------------------------------------------
 int rox_selftest_fp64(uint64_t n, uint64_t seed, uint64_t counts[4])
 {

@@ -414,6 +414,18 @@ class TraceEngine:
                                                self._stream()), 'rox_aim_chief_rays')
         return aim_y, result
 
+    def calc_vignetting(self, probs, eps=1.0e-12):
+        """probs: sequence of abi.Vig -> (vig float64[n], clip_surf int32[n])"""
+        n = len(probs)
+        arr = (abi.Vig * n)(*probs)
+        vig = np.zeros(n)
+        clip = np.zeros(n, dtype=np.int32)
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_calc_vignetting(self._handle, n, arr, float(eps),
+                                                vig.ctypes.data, clip.ctypes.data,
+                                                self._stream()), 'rox_calc_vignetting')
+        return vig, clip
+
     def time_pupil_grid_sustained(self, fld, grid, wvl_idx, opts, out, launches=20, batches=7,
                                   warm_ms=120.0):
         """median over `batches` of :meth:`time_pupil_grid` after `warm_ms` of

@@ -14,6 +14,7 @@ import functools
 from . import session
 from . import trace as _t
 from . import analyses as _a
+from . import vigcalc as _v
 from .table import UnsupportedModelError
 
 _saved = {}
@@ -35,6 +36,7 @@ def install(fallback='raise'):
     import rayoptics.raytr.trace as rtrace
     import rayoptics.raytr.analyses as ranalyses
     import rayoptics.raytr.opticalspec as ropticalspec
+    import rayoptics.raytr.vigcalc as rvigcalc
     from rayoptics.seq.sequential import SequentialModel
     if _saved:
         uninstall()
@@ -56,7 +58,11 @@ def install(fallback='raise'):
              (rtrace, 'aim_chief_ray', _t.aim_chief_ray),
              (ropticalspec, 'aim_chief_ray', _t.aim_chief_ray),
              (ropticalspec.OpticalSpecs, 'update_optical_properties',
-              _t.osp_update_optical_properties)]
+              _t.osp_update_optical_properties),
+             # vignetting search and the boundary rays behind set_clear_apertures
+             (rvigcalc, 'calc_vignetting_for_field', _v.calc_vignetting_for_field),
+             (rvigcalc, 'set_vig', _v.set_vig),
+             (rtrace, 'trace_boundary_rays_at_field', _v.trace_boundary_rays_at_field)]
     for owner, name, ours in seams:
         theirs = getattr(owner, name)
         _saved[(owner, name)] = theirs

@@ -1,0 +1,86 @@
+"""Drop-ins for the vignetting search of ``rayoptics.raytr.vigcalc`` and the
+boundary-ray trace behind ``set_clear_apertures`` (SURVEY.md section 8f row 2:
+they run on every model update and dominate interactive latency once grids are
+fast).
+
+  calc_vignetting_for_field <- rayoptics/raytr/vigcalc.py:233-256 (+ calc_vignetted_ray
+                               :259-340, iterate_pupil_ray :396-461)
+  set_vig                   <- rayoptics/raytr/vigcalc.py:99-105: every field's four
+                               pupil directions in one launch
+  trace_boundary_rays_at_field <- rayoptics/raytr/trace.py:436-452: the pupil-limiting
+                               rays of a field in one launch (set_clear_apertures,
+                               vigcalc.py:45-85, consumes them unchanged)
+"""
+import numpy as np
+
+from . import abi, session
+from .table import field_from_model
+
+
+def _problems(opt_model, fld, wvl, tbl, max_iter):
+    osp = opt_model['optical_spec']
+    stop = opt_model['seq_model'].stop_surface
+    f = field_from_model(opt_model, fld)
+    wi = tbl.wvl_index(wvl)
+    probs = []
+    for i, start in enumerate(osp['pupil'].pupil_rays[1:5]):
+        p = abi.Vig()
+        p.fld = f
+        start = np.array(start, dtype=float)
+        unit = start / np.linalg.norm(start) if np.linalg.norm(start) != 0.0 else start   # misc_math.normalize
+        p.start_dir[0], p.start_dir[1] = start
+        p.unit_dir[0], p.unit_dir[1] = unit
+        p.xy = i // 2
+        p.wvl_idx = wi
+        p.stop_surf = -1 if stop is None else int(stop)
+        p.max_iter = int(max_iter)
+        probs.append(p)
+    return probs
+
+
+def _store(fld, vig4):
+    fld.vux, fld.vlx, fld.vuy, fld.vly = (float(v) for v in vig4)       # vigcalc.py:252-256
+
+
+def calc_vignetting_for_field(opm, fld, wvl, **kwargs):
+    """rayoptics/raytr/vigcalc.py:233-256"""
+    eng = session.engine_for(opm)
+    vig, _clip = eng.calc_vignetting(_problems(opm, fld, wvl, eng.table,
+                                               kwargs.get('max_iter_count', 50)))
+    _store(fld, vig)
+
+
+def set_vig(opm, **kwargs):
+    """rayoptics/raytr/vigcalc.py:99-105, all fields in one launch.  The search of
+    one field never reads another field's vignetting, so batching changes nothing."""
+    osp = opm['osp']
+    eng = session.engine_for(opm)
+    probs, flds = [], []
+    for fi in range(len(osp['fov'].fields)):
+        fld, wvl, _foc = osp.lookup_fld_wvl_focus(fi)
+        probs += _problems(opm, fld, wvl, eng.table, kwargs.get('max_iter_count', 50))
+        flds.append(fld)
+    vig, _clip = eng.calc_vignetting(probs)
+    for k, fld in enumerate(flds):
+        _store(fld, vig[4 * k:4 * k + 4])
+
+
+def trace_boundary_rays_at_field(opt_model, fld, wvl, use_named_tuples=False, **kwargs):
+    """rayoptics/raytr/trace.py:436-452: a list of RayPkgs for the boundary rays of
+    `fld` (partial packets for rays that fail: rayerr_filter='full')"""
+    from .analyses import _setup_pupil_coords
+    from .trace import _trace_pupil, emit
+    kwargs['rayerr_filter'] = kwargs.get('rayerr_filter', 'full')
+    ref_sphere, cr_pkg = _setup_pupil_coords(opt_model, fld, wvl, 0.0)
+    fld.chief_ray = cr_pkg
+    fld.ref_sphere = ref_sphere
+    rayerr_filter = kwargs.pop('rayerr_filter')
+    output_filter = kwargs.pop('output_filter', None)
+    kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', True)
+    pupil_rays = opt_model.optical_spec.pupil.pupil_rays
+    pc = np.array([[p[0], p[1]] for p in pupil_rays], dtype=float)
+    pk = _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter,
+                      pupil_list=(pc[:, 0].copy(), pc[:, 1].copy()))
+    ifcs = opt_model['seq_model'].ifcs
+    return [emit(pk, r, output_filter, rayerr_filter, use_named_tuples, ifcs)[0]
+            for r in range(len(pupil_rays))]

@@ -342,8 +342,20 @@ def workload_file(opm, name, desc):
                             z_enp=float(fod.obj_dist + fod.enp_dist),
                             z_dir0=float(sm.z_dir[0]), wvl_idx=table.wvl_index(wvl),
                             surf=int(sm.stop_surface), aim_y=float(aim_ref[1])))
+    # the vignetting search the reference runs per field (vigcalc.calc_vignetting_for_field,
+    # vigcalc.py:233-340) and its answers; the field's own factors are restored afterwards
+    import rayoptics.raytr.vigcalc as vigcalc
+    vig = []
+    for fi, fld in enumerate(osp['fov'].fields):
+        keep = (fld.vux, fld.vlx, fld.vuy, fld.vly)
+        vigcalc.calc_vignetting_for_field(opm, fld, wvl)
+        vig.append(dict(field_index=fi, wvl_idx=table.wvl_index(wvl),
+                        stop=-1 if sm.stop_surface is None else int(sm.stop_surface),
+                        starts=[[float(v) for v in p] for p in osp['pupil'].pupil_rays[1:5]],
+                        vig=[float(fld.vux), float(fld.vlx), float(fld.vuy), float(fld.vly)]))
+        fld.vux, fld.vlx, fld.vuy, fld.vly = keep
     d = dict(description=desc, table=table.to_dict(), fields=flds, foc=float(foc),
-             ref_wvl_idx=int(osp['wvls'].reference_wvl), aim=aim)
+             ref_wvl_idx=int(osp['wvls'].reference_wvl), aim=aim, vig=vig)
     path = os.path.join(HERE, '..', '..', 'ray-optics_amd', 'data', name + '.json')
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, 'w') as f:

@@ -72,3 +72,6 @@ class OracleEngine:
 
     def aim_chief_rays(self, probs, eps=1.0e-12):
         return oracle.aim_chief_rays(self.table, probs, eps)
+
+    def calc_vignetting(self, probs, eps=1.0e-12):
+        return oracle.calc_vignetting(self.table, probs, eps)

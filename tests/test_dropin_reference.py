@@ -526,3 +526,45 @@ def test_tir_error_objects_carry_the_reference_fields(ref, installed):
     np.testing.assert_array_equal(ours.normal, theirs.normal)
     assert ours.prev_indx == theirs.prev_indx and ours.follow_indx == theirs.follow_indx
     np.testing.assert_array_equal(ours.int_pt, theirs.int_pt)
+
+
+def test_vignetting_search_on_device(ref, installed):
+    """vigcalc.set_vig / calc_vignetting_for_field: the clipped-ray search
+    (calc_vignetted_ray + iterate_pupil_ray's secant) restated per lane; the four
+    vignetting factors of every field equal to the reference's"""
+    import rayoptics.raytr.vigcalc as vigcalc
+    for build in (ref.dblgauss, ref.singlet, ref.rc_telescope, ref.nikkor, ref.cell_phone):
+        opm = build()
+        flds = opm['osp']['fov'].fields
+
+        def run():
+            for f in flds:
+                f.vux = f.vlx = f.vuy = f.vly = 0.0
+            vigcalc.set_vig(opm)
+            return [(f.vux, f.vlx, f.vuy, f.vly) for f in flds]
+        ours, theirs = both(installed, run)
+        np.testing.assert_allclose(np.array(ours), np.array(theirs), rtol=0, atol=1e-10)
+        np.testing.assert_array_equal(np.array(ours), np.array(theirs))      # bit-identical
+        # the single-field entry
+        f = flds[-1]
+        f.vuy = 0.0
+        vigcalc.calc_vignetting_for_field(opm, f, opm['seq_model'].central_wavelength())
+        assert (f.vux, f.vlx, f.vuy, f.vly) == theirs[-1]
+
+
+def test_boundary_rays_and_clear_apertures(ref, installed):
+    """trace.trace_boundary_rays_at_field in one launch; set_clear_apertures
+    (vigcalc.py:45-85) consumes the packets unchanged"""
+    import rayoptics.raytr.trace as trace
+    for build in (ref.dblgauss, ref.rc_telescope):
+        opm = build()
+        sm = opm['seq_model']
+
+        def run():
+            rs = trace.trace_boundary_rays(opm, use_named_tuples=True)
+            first = [[(len(p.ray), p.op, tuple(p.ray[-1].p)) for p in f] for f in rs]
+            sm.set_clear_apertures()
+            return first, [ifc.max_aperture for ifc in sm.ifcs]
+        (fo, ao), (ft, at) = both(installed, run)
+        assert fo == ft
+        assert ao == at

@@ -346,3 +346,38 @@ def test_slim_fp64_band_edges():
         assert counts[2] > (1 << 26) * 0.5
         # classes 3, 4, 5 (3/14 of the operand sets) took the slim path
         assert counts[3] > (1 << 26) * 0.2, list(counts)
+
+
+def test_vignetting_search():
+    """rox_calc_vignetting == the oracle's restatement of calc_vignetted_ray /
+    iterate_pupil_ray (bit-exact but for `p[0]**2`, where the reference calls libm
+    pow and the kernel squares: <= 1e-12), == the reference's own vignetting
+    factors stored with the workloads (<= 1e-10)"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine
+    for name in ('dblgauss_c2', 'nikkor_c3', 'cell_phone', 'singlet_c1', 'rc_telescope_c4',
+                 'litho_c5'):
+        wl = workloads.load(name)
+        if not wl.vig:
+            pytest.skip('workload files carry no vignetting data')
+        eng = TraceEngine(wl.table)
+        probs, expect = [], []
+        for v in wl.vig:
+            for i, start in enumerate(v['starts']):
+                p = abi.Vig()
+                p.fld = wl.fields[v['field_index']]
+                s = np.array(start, dtype=float)
+                u = s / np.linalg.norm(s)
+                p.start_dir[0], p.start_dir[1] = s
+                p.unit_dir[0], p.unit_dir[1] = u
+                p.xy, p.wvl_idx, p.stop_surf, p.max_iter = i // 2, v['wvl_idx'], v['stop'], 50
+                probs.append(p)
+            expect += v['vig']
+        vig_d, clip_d = eng.calc_vignetting(probs)
+        vig_o, clip_o = oracle.calc_vignetting(wl.table, probs)
+        np.testing.assert_array_equal(clip_d, clip_o)
+        np.testing.assert_allclose(vig_d, vig_o, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(vig_o, np.array(expect))          # oracle == reference
+        np.testing.assert_allclose(vig_d, np.array(expect), rtol=0, atol=1e-10)
+        eng.close()
