@@ -92,6 +92,14 @@ def build(force=False, extra=(), out=None):
     os.replace(tmp, lib)
     with open(_stamp(lib), 'w') as f:
         f.write(digest + '\n')
+    # keep the object cache small (it travels with the tree): the three newest digests
+    try:
+        dirs = sorted((os.path.join(OBJ_ROOT, d) for d in os.listdir(OBJ_ROOT)),
+                      key=os.path.getmtime, reverse=True)
+        for d in dirs[3:]:
+            shutil.rmtree(d, ignore_errors=True)
+    except OSError:
+        pass
     return lib
 
 
