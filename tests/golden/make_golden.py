@@ -363,8 +363,35 @@ def workload_file(opm, name, desc):
     print(f'data/{name}.json: {os.path.getsize(path) / 1024:.0f} KiB')
 
 
+def ingest_tables():
+    """tests/golden/ingest_tables.json: the surface tables rayoptics_amd.ingest parses
+    from the reference's prescription files (which do not travel to the GPU box), so
+    that the GPU tests can trace BASELINE's '.zmx import' / 'CODE V .seq' systems"""
+    from rayoptics_amd import ingest
+    files = {'zmx_354710': 'zemax/tests/354710-C-Zemax(ZMX).zmx',
+             'zmx_acl3026u': 'elem/tests/ACL3026U-Zemax(ZMX).zmx',
+             'zmx_us05831776': 'zemax/tests/US05831776-1.zmx',
+             'seq_ag_dblgauss': 'codev/tests/ag_dblgauss.seq',
+             'seq_rc_f16': 'codev/tests/rc_f16.seq',
+             'roa_ritchey_chretien': 'models/Ritchey_Chretien.roa',
+             'roa_cell_phone': 'optical/tests/cell_phone_camera.roa'}
+    out = {}
+    for key, rel in files.items():
+        pres = ingest.read(os.path.join(rm.REF_SRC, 'rayoptics', rel))
+        tbl = pres.to_table(index_of=ingest.nominal_index)
+        out[key] = dict(source=rel, table=tbl.to_dict())
+    path = os.path.join(HERE, 'ingest_tables.json')
+    with open(path, 'w') as f:
+        json.dump(out, f)
+    print(f'ingest_tables.json: {os.path.getsize(path) / 1024:.0f} KiB, {list(out)}')
+
+
 def main():
     rng = np.random.default_rng(SEED)
+    if '--only-ingest' in sys.argv or '--workloads-only' in sys.argv:
+        ingest_tables()
+        if '--only-ingest' in sys.argv:
+            return
     if '--only-telecentric' in sys.argv:
         opm = rm.telecentric()
         save('telecentric', ra.SurfaceTable.from_seq_model(opm['seq_model']), {
