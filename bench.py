@@ -117,9 +117,15 @@ def main():
     def step():
         eng.trace_pupil_grid(fld, grid, wi, opts, out=out)
 
+    _tok = torch.zeros(1, device=eng.device) if multi else None
+
     def fence():
+        # barrier + torch.cuda.synchronize(): the barrier is a one-element all-reduce on a
+        # preallocated tensor (every rank must enter it; dist.barrier() is the same
+        # collective behind more bookkeeping -- 2 ms per call on this stack)
         if multi:
-            dist.barrier()
+            torch.cuda.synchronize()
+            dist.all_reduce(_tok)
         torch.cuda.synchronize()
 
     # the GPU's clocks need tens of milliseconds of continuous work to settle (a cold
@@ -138,6 +144,9 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    t_f = time.perf_counter()
+    fence()
+    fence_ms = (time.perf_counter() - t_f) * 1e3      # cost of one (idle) fence, for the record
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -209,7 +218,7 @@ def main():
             'value': inters_all / dt * args.steps,
             'unit': 'ray-surface intersections/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_steps_run': n_w,
-            'ms_per_step': dt / args.steps * 1e3,
+            'ms_per_step': dt / args.steps * 1e3, 'fence_ms': fence_ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'double-Gauss 13 interfaces (K=12), 1 field, 1 wvl, '
