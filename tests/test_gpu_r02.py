@@ -381,3 +381,44 @@ def test_vignetting_search():
         np.testing.assert_array_equal(vig_o, np.array(expect))          # oracle == reference
         np.testing.assert_allclose(vig_d, np.array(expect), rtol=0, atol=1e-10)
         eng.close()
+
+
+def test_two_host_threads_share_one_handle(engines):
+    """two Python threads (ctypes releases the GIL), each on its own stream,
+    launching packed spot diagrams and plain HITS grids on ONE handle at once"""
+    import threading
+    import torch
+    from oracle import oracle
+    fx = H.fixture('dblgauss')
+    c = fx['grid_f2']
+    fld = H.field_from_arr(c['field'])
+    N = fx.table.n_ifcs
+    eng = engines('dblgauss')
+    o_cmp = oracle.make_opts(flags=FLAGS, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                             last_surf=N - 2, foc=0.01, image_pt=(0., 18.))
+    defs = [((-1., -1.), (1., 1.), 301), ((-0.7, -0.9), (0.8, 0.6), 257)]
+    want = []
+    for k, (a, b, num) in enumerate(defs):
+        orc = oracle.trace_pupil_grid(fx.table, fld, oracle.make_grid(a, b, num), k, o_cmp)
+        want.append(orc.hits.copy())
+    errs = []
+
+    def worker(k):
+        try:
+            a, b, num = defs[k]
+            grid = oracle.make_grid(a, b, num)
+            st = torch.cuda.Stream(device=eng.device)
+            with torch.cuda.stream(st):
+                for _ in range(25):
+                    xy = eng.trace_pupil_grid_hits(fld, grid, k, o_cmp)
+                    if not np.array_equal(xy, want[k]):
+                        errs.append((k, 'mismatch'))
+                        return
+        except Exception as e:      # noqa: BLE001
+            errs.append((k, repr(e)))
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
