@@ -133,7 +133,9 @@ class PinnedPool:
         return _Lease(self, n, t)
 
     def give_back(self, n, t):
-        self._free.setdefault(n, []).append(t)
+        lst = self._free.setdefault(n, [])
+        if len(lst) < (2 if n > (256 << 20) else 4):    # bounded: surplus blocks are unpinned
+            lst.append(t)
 
 
 class _Lease:
