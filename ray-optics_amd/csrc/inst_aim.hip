@@ -37,6 +37,7 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
     c.slot = slot_w; c.nslots_before = slot_w + N;
+    c.apthr = nullptr;          // (F_ALL instances test apertures through inside_aperture)
     c.N = N;
     c.check_ap = false; c.intersect_obj = true; c.filter_ph = false;    // raytrace.py:51-80, 83-99
     c.first_surf = 1; c.last_surf = N - 2;
@@ -186,6 +187,7 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
     c.slot = slot_w; c.nslots_before = slot_w + N;
+    c.apthr = nullptr;          // (F_ALL instances test apertures through inside_aperture)
     c.N = N;
     c.filter_ph = false;
     c.intersect_obj = pb.fld.kind != ROX_FLD_EPD_WIDE;      // trace.py:302-303

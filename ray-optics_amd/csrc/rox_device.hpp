@@ -272,6 +272,34 @@ __device__ __forceinline__ v3 slim_div3(const v3 &a, double b)
     return v3{a.x / b, a.y / b, a.z / b};
 }
 
+// Largest s with sqrt(s) <= t.  The aperture test of the reference is
+// `sqrt(x*x + y*y) <= max_aperture + fuzz` (interface.py:113-122); the correctly
+// rounded sqrt is monotonic, so that is the same predicate as `x*x + y*y <= u(t)`
+// with u = this threshold -- computed once per surface per workgroup, it takes the
+// square root out of the per-ray path without changing a single outcome (NaN and
+// infinities included).
+__device__ __forceinline__ double sqrt_le_threshold(double t)
+{
+    if (!(t >= 0.0))
+        return (t != t) ? t : -1.0;             // NaN: never true; negative: never true
+    if (t == __builtin_inf())
+        return t;
+    double s = t * t;
+    if (s == __builtin_inf())
+        s = 1.7976931348623157e308;
+    while (sqrt(s) > t)                         // at most a few steps either way
+        s = __longlong_as_double(__double_as_longlong(s) - 1);
+    for (;;) {
+        if (s >= 1.7976931348623157e308)
+            break;
+        const double n = __longlong_as_double(__double_as_longlong(s) + 1);
+        if (sqrt(n) > t)
+            break;
+        s = n;
+    }
+    return s;
+}
+
 // misc_math.py:48-54 normalize
 __device__ __forceinline__ v3 unit(const v3 &v)
 {
@@ -801,6 +829,7 @@ struct Ctx {
     tblp phc;               // [N][kPhaseConsts] or [W][N][kPhaseConsts]; FEAT & F_PHASE only
     tblp wvls;              // [W]
     tbli slot, nslots_before;
+    tblp apthr;             // [N] sqrt_le_threshold(max_aperture + fuzz) (instances without F_APLIST)
     int N;
     bool check_ap, intersect_obj, filter_ph;
     int first_surf, last_surf;
@@ -977,8 +1006,7 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
             mode != ROX_PHANTOM) {
             const bool in = (FEAT & F_APLIST)
                 ? inside_aperture(row, ((tbli)row)[3], inc.x, inc.y, c.fuzz)
-                : slim_sqrt(inc.x * inc.x + inc.y * inc.y) <=
-                      row[offsetof(rox_surface, max_aperture) / 8] + c.fuzz;
+                : (inc.x * inc.x + inc.y * inc.y) <= c.apthr[surf];   // sqrt-free, see above
             if (!in)
                 status = ROX_BLOCKED;               // :247-251
         }
@@ -1122,7 +1150,8 @@ trace_kernel(const TraceArgs a)
     double *ntab_w = tbl_w + (size_t)N * kRowDoubles;  // [W][N] (or [N] for one wavelength)
     double *phc_w = ntab_w + (size_t)nw_rows * N;      // [W][N][4] (F_PHASE only)
     double *wvls_w = phc_w + ((FEAT & F_PHASE) ? (size_t)nw_rows * N * kPhaseConsts : 0);
-    int32_t *slot_w = reinterpret_cast<int32_t *>(wvls_w + a.n_wvls);
+    double *apthr_w = wvls_w + a.n_wvls;                // [N]
+    int32_t *slot_w = reinterpret_cast<int32_t *>(apthr_w + N);
 
     // stage the surface table once per workgroup
     for (int i = threadIdx.x; i < N * kRowDoubles; i += kB)
@@ -1139,10 +1168,14 @@ trace_kernel(const TraceArgs a)
         wvls_w[i] = a.wvls[i];
     for (int i = threadIdx.x; i < 2 * N; i += kB)
         slot_w[i] = a.slots[i];
+    if (!(FEAT & F_APLIST))
+        for (int i = threadIdx.x; i < N; i += kB)
+            apthr_w[i] = sqrt_le_threshold(
+                a.rows[(size_t)i * kRowDoubles + offsetof(rox_surface, max_aperture) / 8] + a.opts.fuzz);
     __syncthreads();
 
     Ctx c;
-    c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
+    c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w; c.apthr = apthr_w;
     c.slot = slot_w; c.nslots_before = slot_w + N;
     c.N = N;
     const uint32_t flags = a.opts.flags;

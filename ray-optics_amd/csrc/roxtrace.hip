@@ -124,6 +124,20 @@ __global__ void __launch_bounds__(kBlock) selftest_kernel(uint64_t n, uint64_t s
             if (kind >= 3)
                 atomicAdd(&counts[3], 1ull);
         }
+        // the sqrt-free aperture test: (sqrt(s) <= t) == (s <= sqrt_le_threshold(t)) for s
+        // within a few ulps of t*t and far from it (mismatches are counted as sqrt mismatches)
+        {
+            const double t = (kind == 2) ? a1 : fabs(a1);
+            const double thr = sqrt_le_threshold(t);
+            const long long k9 = (long long)(mix64(k + 7) % 9) - 4;
+            double s2 = t * t;
+            if (s2 > 0 && s2 < 1e300)
+                s2 = __longlong_as_double(__double_as_longlong(s2) + k9);
+            const double cand[3] = {s2, fabs(a2), fabs(a0) * fabs(a0)};
+            for (int q = 0; q < 3; ++q)
+                if ((sqrt(cand[q]) <= t) != (cand[q] <= thr))
+                    atomicAdd(&counts[0], 1ull);
+        }
     }
 }
 
@@ -222,7 +236,7 @@ size_t lds_bytes(const rox_system *s, bool per_ray_wvl, bool phase)
     const size_t N = s->n_ifcs, Wn = per_ray_wvl ? (size_t)s->n_wvls : 1;
     size_t b = N * sizeof(dev_surface) + Wn * N * sizeof(double) +
                (phase ? Wn * N * kPhaseConsts * sizeof(double) : 0) +
-               (size_t)s->n_wvls * sizeof(double) + 2 * N * sizeof(int32_t);
+               ((size_t)s->n_wvls + N) * sizeof(double) + 2 * N * sizeof(int32_t);
     return (b + 15) & ~size_t(15);
 }
 
