@@ -83,7 +83,7 @@ enum { ROX_OUT_FULL = 0,  /* seg[n_seg][10][ld]: the whole RayPkg.ray          *
                              sphere, system units (rayoptics/raytr/waveabr.py:256-307);
                              constants in rox_opts.wf; on an infinite reference
                              sphere wave_abr_full_calc_inf_ref (:356-424)       */
-       ROX_OUT_HITS_COMPACT = 4 };
+       ROX_OUT_HITS_COMPACT = 4,
                           /* seg[n_hits][2]: the HITS pair (x, y) of the rays that
                              reach the image only, interleaved, packed in ray order
                              -- the (R_ok, 2) array SequentialModel.trace_grid(...,
@@ -95,6 +95,11 @@ enum { ROX_OUT_FULL = 0,  /* seg[n_seg][10][ld]: the whole RayPkg.ray          *
                              kernel then writes the spot straight into host memory.
                              op / fail_surf / pupil are not written in this mode;
                              status is optional.                                */
+       ROX_OUT_FAN = 5 }; /* seg[3][ld]: what analyses.eval_fan / focus_fan compute per
+                             ray of a RayFan (rayoptics/raytr/analyses.py:233-274,
+                             317-345): rows 0, 1 = the HITS pair (transverse
+                             aberration at rox_opts.foc w.r.t. rox_opts.image_pt),
+                             row 2 = the OPD as ROX_OUT_OPD gives it (rox_opts.wf) */
 /* rox_opts.flags */
 enum { ROX_CHECK_APERTURES = 1u,     /* raytrace.py:198-202                    */
        ROX_INTERSECT_OBJ = 2u,       /* raytrace.py:147-154                    */

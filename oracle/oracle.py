@@ -73,6 +73,8 @@ class HostResult:
             shape = (abi.SEG_DOUBLES, R)
         elif out_mode == abi.OUT_OPD:
             shape = (1, R)
+        elif out_mode == abi.OUT_FAN:
+            shape = (3, R)
         elif out_mode == abi.OUT_HITS_COMPACT:
             shape = (R, 2)              # packed (x, y) pairs; n_hits of them are valid
         else:

@@ -26,7 +26,7 @@ AP_CIRCULAR, AP_RECTANGULAR, AP_ALWAYS_BLOCK = 0, 1, 2
 # per-ray status (rayoptics/raytr/traceerror.py)
 OK, MISSED_SURFACE, TIR, BLOCKED, EVANESCENT = 0, 1, 2, 3, 4
 # output modes
-OUT_FULL, OUT_LAST, OUT_HITS, OUT_OPD, OUT_HITS_COMPACT = 0, 1, 2, 3, 4
+OUT_FULL, OUT_LAST, OUT_HITS, OUT_OPD, OUT_HITS_COMPACT, OUT_FAN = 0, 1, 2, 3, 4, 5
 # flags
 CHECK_APERTURES = 1
 INTERSECT_OBJ = 2

@@ -4,6 +4,8 @@
   trace_ray_list     <- rayoptics/raytr/analyses.py:437-455
   trace_ray_grid     <- rayoptics/raytr/analyses.py:666-696
   trace_ray_fan      <- rayoptics/raytr/analyses.py:212-230
+  eval_fan / trace_fan / focus_fan <- rayoptics/raytr/analyses.py:233-345 (RayFan: dx, dy
+                        and OPD of every fan ray in one launch, ROX_OUT_FAN)
   eval_wavefront     <- rayoptics/raytr/analyses.py:699-732 (OPD fused on device)
   trace_wavefront / focus_wavefront <- rayoptics/raytr/analyses.py:735-791 (RayGrid, PSF)
   trace_pupil_coords / focus_pupil_coords <- rayoptics/raytr/analyses.py:545-580 (RayList, RayGeoPSF)
@@ -398,3 +400,128 @@ def focus_pupil_coords(opt_model, ray_list, fld, wvl, foc,
         else:
             data.append(np.nan)
     return np.array(data)
+
+
+# ---- RayFan ------------------------------------------------------------------
+def _fan_def(xy, num_rays):
+    fan_start = np.array([0., 0.])
+    fan_stop = np.array([0., 0.])
+    fan_start[xy] = -1.0
+    fan_stop[xy] = 1.0
+    return [fan_start, fan_stop, num_rays]
+
+
+def _fan_data(opt_model, fld, wvl, foc, fan_def, kwargs, wf, image_pt):
+    """one ROX_OUT_FAN launch -> the reference's fan_data list: ((px, py), (dx, dy, opd))
+    for every ray that gets through (trace_ray_fan drops the others, analyses.py:212-230)"""
+    kw = dict(kwargs)
+    for k in ('output_filter', 'rayerr_filter'):
+        kw.pop(k, None)
+    kw['apply_vignetting'] = kw.get('apply_vignetting', True)
+    pk = _trace_pupil(opt_model, fld, wvl, kw, None, None,
+                      grid=make_grid(fan_def[0], fan_def[1], fan_def[2], abi.GRID_FAN),
+                      out_mode=abi.OUT_FAN, foc=foc, image_pt=image_pt[:2], wf=wf)
+    convert_to_opd = 1 / opt_model.nm_to_sys_units(wvl)
+    seg = pk.seg[0]
+    return [((pk.pupil[0, r], pk.pupil[1, r]), (seg[0, r], seg[1, r], convert_to_opd * seg[2, r]))
+            for r in range(fan_def[2]) if pk.status[r] == abi.OK]
+
+
+def eval_fan(opt_model, fld, wvl, foc, xy, image_pt_2d=None, image_delta=None, num_rays=21,
+             output_filter=None, rayerr_filter=None, **kwargs):
+    """rayoptics/raytr/analyses.py:233-274: dx, dy and OPD across a fan"""
+    from .table import wavefront_from_model
+    ref_sphere, cr_pkg = _setup_pupil_coords(opt_model, fld, wvl, foc, image_pt_2d, image_delta)
+    fld.chief_ray = cr_pkg
+    fld.ref_sphere = ref_sphere
+    fan_def = _fan_def(xy, num_rays)
+    if output_filter is None and rayerr_filter is None and not kwargs.get('filter_out_phantoms', False):
+        wf = wavefront_from_model(opt_model, fld)
+        return _fan_data(opt_model, fld, wvl, foc, fan_def, kwargs, wf, ref_sphere[0])
+    from rayoptics.raytr import waveabr
+    fod = opt_model['analysis_results']['parax_data'].fod
+    fan = trace_ray_fan(opt_model, fan_def, fld, wvl, foc, output_filter=output_filter,
+                        rayerr_filter=rayerr_filter, **kwargs)
+    convert_to_opd = 1 / opt_model.nm_to_sys_units(wvl)
+    out = []
+    for px, py, pkg in fan:
+        if pkg is not None:
+            seg = pkg[0][-1]
+            t_abr = (seg[0] + (foc / seg[1][2]) * seg[1]) - ref_sphere[0]
+            opd = convert_to_opd * waveabr.wave_abr_full_calc(fod, fld, wvl, foc, pkg, cr_pkg, ref_sphere)
+            out.append(((px, py), (t_abr[0], t_abr[1], opd)))
+        else:
+            out.append((px, py, np.nan))
+    return out
+
+
+class _DeferredFan(_DeferredWavefront):
+    """what the fused :func:`trace_fan` hands to :func:`focus_fan`: the fan
+    definition and trace options (a fan of [px, py, ray_pkg] for anyone else)"""
+
+    def _materialise(self):
+        if self._grid is None:
+            opt_model, fld, wvl, foc = self._ctx
+            kw = dict(self.kwargs)
+            self._grid = trace_ray_fan(opt_model, self.grid_def, fld, wvl, foc, **kw)
+        return self._grid
+
+
+class _DeferredFanPreCalc(_DeferredPreCalc):
+    def _materialise(self):
+        if self._upd is None:
+            from rayoptics.raytr import waveabr
+            opt_model, fld, wvl, foc = self._d._ctx
+            fod = opt_model['analysis_results']['parax_data'].fod
+            self._upd = [waveabr.wave_abr_pre_calc(fod, fld, wvl, foc, pkg, self._cr, self._rs)
+                         if pkg is not None else None for _px, _py, pkg in self._d._materialise()]
+        return self._upd
+
+
+def trace_fan(opt_model, fld, wvl, foc, xy, image_pt_2d=None, image_delta=None, num_rays=21,
+              output_filter=None, rayerr_filter=None, **kwargs):
+    """rayoptics/raytr/analyses.py:277-314"""
+    ref_sphere, cr_pkg = _setup_pupil_coords(opt_model, fld, wvl, foc, image_pt_2d, image_delta)
+    fld.chief_ray = cr_pkg
+    fld.ref_sphere = ref_sphere
+    fan_def = _fan_def(xy, num_rays)
+    if output_filter is None and rayerr_filter is None and not kwargs.get('filter_out_phantoms', False):
+        d = _DeferredFan(fan_def, dict(kwargs), (opt_model, fld, wvl, foc))
+        return d, _DeferredFanPreCalc(d, cr_pkg, ref_sphere)
+    from rayoptics.raytr import waveabr
+    from rayoptics.raytr import traceerror as terr
+    fod = opt_model['analysis_results']['parax_data'].fod
+    fan = trace_ray_fan(opt_model, fan_def, fld, wvl, foc, output_filter=output_filter,
+                        rayerr_filter=rayerr_filter, **kwargs)
+    upd_fan = [waveabr.wave_abr_pre_calc(fod, fld, wvl, foc, pkg, cr_pkg, ref_sphere)
+               if pkg is not None and not isinstance(pkg, terr.TraceError) else None
+               for _px, _py, pkg in fan]
+    return fan, upd_fan
+
+
+def focus_fan(opt_model, fan_pkg, fld, wvl, foc, image_pt_2d=None, image_delta=None, **kwargs):
+    """rayoptics/raytr/analyses.py:317-345"""
+    from .table import wavefront_from_model
+    fan, upd_fan = fan_pkg
+    ref_sphere, cr_pkg = _setup_pupil_coords(opt_model, fld, wvl, foc, image_pt_2d, image_delta)
+    if isinstance(fan, _DeferredFan):
+        own = getattr(fld, 'rox_wavefront', None)
+        wf = own if own is not None else wavefront_from_model(opt_model, fld, cr_pkg, ref_sphere)
+        if wf.kind == abi.WF_INF_FULL:          # the pre-calc / calc split, as in focus_wavefront
+            wf = abi.Wavefront.from_buffer_copy(bytes(wf))
+            wf.kind = abi.WF_INF_SPLIT
+        return _fan_data(opt_model, fld, wvl, foc, fan.grid_def, fan.kwargs, wf, ref_sphere[0])
+    from rayoptics.raytr import waveabr
+    from rayoptics.raytr import traceerror as terr
+    fod = opt_model['analysis_results']['parax_data'].fod
+    convert_to_opd = 1 / opt_model.nm_to_sys_units(wvl)
+    out = []
+    for (px, py, pkg), fiu in zip(fan, upd_fan):
+        if pkg is not None and not isinstance(pkg, terr.TraceError):
+            seg = pkg[0][-1]
+            t_abr = (seg[0] + (foc / seg[1][2]) * seg[1]) - ref_sphere[0]
+            opd = convert_to_opd * waveabr.wave_abr_calc(fod, fld, wvl, foc, pkg, cr_pkg, fiu, ref_sphere)
+            out.append(((px, py), (t_abr[0], t_abr[1], opd)))
+        else:
+            out.append((px, py, np.nan))
+    return out

@@ -1042,7 +1042,7 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
             ROX_LEAVE;
         }
 
-        if (OUT_MODE == ROX_OUT_OPD) {
+        if (OUT_MODE == ROX_OUT_OPD || OUT_MODE == ROX_OUT_FAN) {
             if (surf == 1)
                 e.ray1_p = inc;
             if (surf == N - 2) {
@@ -1259,12 +1259,18 @@ trace_kernel(const TraceArgs a)
                 if (OUT_MODE == ROX_OUT_LAST) {             // trace.py:214-217
                     so.pdn(0, e.inc, e.ad, e.nrm);
                     so.dst(0, 0.0);
-                } else if (OUT_MODE == ROX_OUT_OPD) {
+                } else if (OUT_MODE == ROX_OUT_OPD || OUT_MODE == ROX_OUT_FAN) {
                     const double op = e.phs + e.opl;
-                    so.put(0, 0, a.opts.wf.kind == ROX_WF_FINITE      // (wave-uniform)
+                    so.put(0, OUT_MODE == ROX_OUT_FAN ? 2 : 0,
+                           a.opts.wf.kind == ROX_WF_FINITE            // (wave-uniform)
                            ? wave_abr_finite_pup(a.opts.wf, e.ray1_p, dir0, e.rayk_p, e.rayk_d, op)
                            : wave_abr_inf_ref(a.opts.wf, e.ray1_p, dir0, e.rayk_p, e.rayk_d,
                                               e.inc, e.ad, op));
+                    if (OUT_MODE == ROX_OUT_FAN) {          // analyses.py:258-262
+                        const double dist = a.opts.foc / e.ad.z;
+                        so.put(0, 0, (e.inc.x + dist * e.ad.x) - a.opts.image_pt[0]);
+                        so.put(0, 1, (e.inc.y + dist * e.ad.y) - a.opts.image_pt[1]);
+                    }
                 } else if (OUT_MODE == ROX_OUT_HITS) {      // axisarrayfigure.py:229-238
                     const double dist = a.opts.foc / e.ad.z;
                     so.put(0, 0, (e.inc.x + dist * e.ad.x) - a.opts.image_pt[0]);
@@ -1412,6 +1418,9 @@ inline void launch_mode(const LaunchCfg &k, const TraceArgs &a)
         break;
     case ROX_OUT_HITS_COMPACT:
         hipLaunchKernelGGL((trace_kernel<ROX_OUT_HITS_COMPACT, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        break;
+    case ROX_OUT_FAN:
+        hipLaunchKernelGGL((trace_kernel<ROX_OUT_FAN, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
         break;
     default:
         hipLaunchKernelGGL((trace_kernel<ROX_OUT_HITS, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);

@@ -244,9 +244,9 @@ int check_opts(const rox_system *sys, const rox_opts *o, const rox_out *out, int
 {
     if (!sys || !o || !out)
         return fail(ROX_E_ARG, "null argument");
-    if (o->out_mode < ROX_OUT_FULL || o->out_mode > ROX_OUT_HITS_COMPACT)
+    if (o->out_mode < ROX_OUT_FULL || o->out_mode > ROX_OUT_FAN)
         return fail(ROX_E_ARG, "bad out_mode %d", o->out_mode);
-    if (o->out_mode == ROX_OUT_OPD) {
+    if (o->out_mode == ROX_OUT_OPD || o->out_mode == ROX_OUT_FAN) {
         if (sys->n_ifcs < 3)
             return fail(ROX_E_ARG, "OPD output needs at least 3 interfaces");
         if ((o->flags & ROX_FILTER_PHANTOMS) && sys->n_seg[1] != sys->n_seg[0])
@@ -420,6 +420,8 @@ int64_t seg_rows(const rox_system *sys, const rox_opts *o)
         return (int64_t)sys->n_seg[(o->flags & ROX_FILTER_PHANTOMS) ? 1 : 0] * ROX_SEG_DOUBLES;
     if (o->out_mode == ROX_OUT_OPD)
         return 1;
+    if (o->out_mode == ROX_OUT_FAN)
+        return 3;
     return o->out_mode == ROX_OUT_LAST ? ROX_SEG_DOUBLES : 2;
 }
 

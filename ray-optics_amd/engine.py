@@ -184,6 +184,8 @@ class DeviceResult:
             shape = (abi.SEG_DOUBLES, self.ld)
         elif out_mode == abi.OUT_OPD:
             shape = (1, self.ld)
+        elif out_mode == abi.OUT_FAN:
+            shape = (3, self.ld)
         else:
             shape = (2, self.ld)
         new = (lambda s: torch.full(s, float('nan'), dtype=torch.float64, device=device)) \

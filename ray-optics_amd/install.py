@@ -46,6 +46,9 @@ def install(fallback='raise'):
              (ranalyses, 'trace_ray_list', _a.trace_ray_list),
              (ranalyses, 'trace_ray_grid', _a.trace_ray_grid),
              (ranalyses, 'trace_ray_fan', _a.trace_ray_fan),
+             (ranalyses, 'eval_fan', _a.eval_fan),
+             (ranalyses, 'trace_fan', _a.trace_fan),
+             (ranalyses, 'focus_fan', _a.focus_fan),
              (ranalyses, 'eval_wavefront', _a.eval_wavefront),
              (ranalyses, 'trace_wavefront', _a.trace_wavefront),
              (ranalyses, 'focus_wavefront', _a.focus_wavefront),

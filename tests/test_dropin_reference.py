@@ -568,3 +568,29 @@ def test_boundary_rays_and_clear_apertures(ref, installed):
         (fo, ao), (ft, at) = both(installed, run)
         assert fo == ft
         assert ao == at
+
+
+@pytest.mark.parametrize('model', ['dblgauss', 'telecentric', 'rc_telescope'])
+def test_ray_fan_fused(ref, installed, model):
+    """RayFan (trace_fan + focus_fan) and eval_fan: dx, dy and OPD of every fan ray
+    in one launch (ROX_OUT_FAN), equal to the reference's per-ray Python"""
+    import rayoptics.raytr.analyses as analyses
+    opm = getattr(ref, model)()
+    nf = len(opm['osp']['fov'].fields)
+    wvl = opm['seq_model'].central_wavelength()
+
+    def run():
+        out = []
+        for fi in (0, nf - 1):
+            for xy in ('x', 'y'):
+                fan = analyses.RayFan(opm, f=fi, wl=wvl, xyfan=xy, num_rays=15)
+                first = [(tuple(p), tuple(v)) for p, v in fan.fan]
+                fan.foc = 0.03
+                fan.update_data(build='update')
+                out.append((first, [(tuple(p), tuple(v)) for p, v in fan.fan]))
+            fld = opm['osp']['fov'].fields[fi]
+            out.append([(tuple(p), tuple(v)) for p, v in analyses.eval_fan(opm, fld, wvl, 0.01, 1, num_rays=9)])
+        return out
+    go, gt = both(installed, run)
+    assert go == gt
+    assert sum(len(x[0]) if isinstance(x, tuple) else len(x) for x in go) > 40

@@ -422,3 +422,39 @@ def test_two_host_threads_share_one_handle(engines):
     for t in ths:
         t.join()
     assert not errs, errs
+
+
+from test_oracle_golden import OPD_CASES, opd_opts  # noqa: E402
+
+
+@pytest.mark.parametrize('name,case', OPD_CASES)
+def test_fan_mode(name, case):
+    """ROX_OUT_FAN (RayFan: dx, dy and OPD per ray) == the oracle, on fans through
+    the OPD fixtures' fields -- finite and infinite reference spheres, both the
+    full-calc and the pre-calc/calc-split variants"""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine
+    fx = H.fixture(name)
+    c = fx[case]
+    eng = TraceEngine(fx.table)
+    fld = H.field_from_arr(c['field'])
+    for xy in (0, 1):
+        start, stop = np.zeros(2), np.zeros(2)
+        start[xy], stop[xy] = -1.0, 1.0
+        grid = oracle.make_grid(start, stop, 33, abi.GRID_FAN)
+        for kind in (None, abi.WF_INF_SPLIT):
+            o = opd_opts(c)
+            o.out_mode = abi.OUT_FAN
+            o.flags |= abi.APPLY_VIGNETTING
+            o.foc, o.image_pt[0], o.image_pt[1] = 0.02, 0.01, -0.03
+            if kind is not None:
+                if o.wf.kind == abi.WF_FINITE:
+                    continue
+                o.wf.kind = kind
+            orc = oracle.trace_pupil_grid(fx.table, fld, grid, int(c['wvl_idx']), o)
+            dev = eng.trace_pupil_grid(fld, grid, int(c['wvl_idx']), o, nan_fill=True).to_host()
+            np.testing.assert_array_equal(dev.status, orc.status)
+            bit_equal(dev.seg, orc.seg, f'{name}/{case} fan xy={xy} kind={kind}')
+            bit_equal(dev.pupil, orc.pupil, 'pupil')
+            assert (orc.status == 0).sum() > 5
+    eng.close()
