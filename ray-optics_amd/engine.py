@@ -405,6 +405,35 @@ class TraceEngine:
                                            self._stream()), 'rox_trace_rays')
         return self._hits_finish(lease, R)
 
+    # -- one ray (raytrace.trace) -----------------------------------------------
+    def trace_one(self, pt0, dir0, wvl_idx, opts):
+        """one explicit ray, FULL packets.  The kernel reads the ray from, and
+        writes the packet into, one pooled pinned block (no staging copies, one
+        launch, one synchronisation); the returned arrays view that block."""
+        nseg = self.num_segments(opts.flags)
+        lease = _pool.take(self.torch, 64 + 8 * abi.SEG_DOUBLES * nseg)
+        base = lease.ptr
+        ray = lease.array((6,), np.float64)
+        ray[0:3] = pt0
+        ray[3:6] = dir0
+        o = abi.Out()
+        o.seg, o.op, o.status, o.fail_surf, o.ld = base + 64, base + 48, base + 56, base + 58, 1
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_trace_rays(self._handle, 1, base, base + 24, None, int(wvl_idx),
+                                           C.byref(opts), C.byref(o), self._stream()),
+                   'rox_trace_rays')
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+        class _H:
+            pass
+        h = _H()
+        h.R, h.out_mode, h.pupil = 1, abi.OUT_FULL, None
+        h.seg = lease.array((nseg, abi.SEG_DOUBLES, 1), np.float64, 64)
+        h.op = lease.array((1,), np.float64, 48)
+        h.status = lease.array((1,), np.uint8, 56)
+        h.fail_surf = lease.array((1,), np.int16, 58)
+        return h
+
     # -- chief-ray aiming ---------------------------------------------------------
     def aim_chief_rays(self, probs, eps=1.0e-12):
         """probs: sequence of abi.Aim -> (aim_y float64[n], result int32[n])"""

@@ -33,6 +33,7 @@ def _guard(ours, theirs):
 
 
 def install(fallback='raise'):
+    import rayoptics.raytr.raytrace as rraytrace
     import rayoptics.raytr.trace as rtrace
     import rayoptics.raytr.analyses as ranalyses
     import rayoptics.raytr.opticalspec as ropticalspec
@@ -41,7 +42,8 @@ def install(fallback='raise'):
     if _saved:
         uninstall()
     session.FALLBACK = fallback
-    seams = [(rtrace, 'trace_grid', _t.trace_grid), (rtrace, 'trace_fan', _t.trace_fan),
+    seams = [(rraytrace, 'trace', _t.raytrace_trace),
+             (rtrace, 'trace_grid', _t.trace_grid), (rtrace, 'trace_fan', _t.trace_fan),
              (ranalyses, 'trace_list_of_rays', _a.trace_list_of_rays),
              (ranalyses, 'trace_ray_list', _a.trace_ray_list),
              (ranalyses, 'trace_ray_grid', _a.trace_ray_grid),

@@ -5,6 +5,9 @@ the per-ray Python loop replaced by one device launch.
   trace_grid      <- rayoptics/raytr/trace.py:563-605
   trace_fan       <- rayoptics/raytr/trace.py:537-560
   seq_trace_grid  <- rayoptics/seq/sequential.py:1058-1085 (method)
+  raytrace_trace  <- rayoptics/raytr/raytrace.py:51-80 trace(): one ray per call, for the
+                     reference's own iterative callers (trace_base, iterate_ray's 2-D
+                     fsolve branch, the wide-angle pupil search, trace_chief_ray ...)
   aim_chief_ray   <- rayoptics/raytr/trace.py:627-640 (iterate_ray's 1-D branch on the device)
   osp_update_optical_properties <- rayoptics/raytr/opticalspec.py:263-281 (method; all
                                    fields aimed in one launch)
@@ -14,7 +17,7 @@ import numpy as np
 
 from . import abi, session
 from .engine import make_opts, make_grid
-from .raypkg import HostPackets, RayPkg, RaySeg
+from .raypkg import HostPackets, LazyRay, RayPkg, RaySeg
 from .table import field_from_model
 
 
@@ -56,6 +59,34 @@ def emit(pk, r, output_filter, rayerr_filter, named, ifcs):
         ray, op, wvl = pkg
         return RayPkg([ray[-1]], op, wvl), None
     return output_filter(pkg), None
+
+
+def raytrace_trace(seq_model, pt0, dir0, wvl, **kwargs):
+    """rayoptics/raytr/raytrace.py:51-80 ``trace``: one ray through the model;
+    returns ``(ray, op_delta, wvl)`` with ``ray`` a list of ``[p, d, dst, nrml]``
+    per interface, or raises the TraceError the reference raises (``.surf``,
+    ``.ifc``, ``.int_pt``, the partial ``.ray_pkg``, raytrace.py:231-257).
+
+    Rebinding this one function puts every per-ray caller the reference still
+    drives from Python -- ``trace_base``/``trace_safe``, scipy's MINPACK iteration
+    in ``iterate_ray`` (fields off the y axis), the wide-angle pupil search
+    (``wideangle.py:46-83``), ``SequentialModel.trace`` -- on the device trace,
+    bit-identical to the reference's own ``trace_raw``."""
+    eng = session.engine_for(seq_model.opt_model)
+    tbl = eng.table
+    wv = seq_model.central_wavelength() if wvl is None else wvl
+    wi = tbl.wvl_index(wv)
+    opts = opts_from_kwargs(tbl.n_ifcs, kwargs, abi.OUT_FULL)
+    opts.flags &= ~abi.APPLY_VIGNETTING             # a pupil-level notion (trace.py:291-295)
+    h = eng.trace_one(pt0, dir0, wi, opts)
+    pk = HostPackets(h, tbl, opts.flags, abi.OUT_FULL, wv)
+    st = int(h.status[0])
+    if st != abi.OK:
+        err = pk.error(0, getattr(seq_model, 'ifcs', None), with_pkg=True, named=False)
+        ray, op, _w = err.ray_pkg
+        err.ray_pkg = (ray.to_list(), op, wvl)
+        raise err
+    return LazyRay(pk.seg, 0, pk.nseg(0)).to_list(), float(h.op[0]), wvl
 
 
 def _launch_setup(opt_model, fld, wvl, kwargs, out_mode, foc=0.0, image_pt=(0., 0.), wf=None):

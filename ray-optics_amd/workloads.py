@@ -101,6 +101,7 @@ class TableModel:
         wl = load(name_or_workload) if isinstance(name_or_workload, str) else name_or_workload
         self.workload = wl
         self.seq_model = _TableSeq(wl)
+        self.seq_model.opt_model = self
         self.fields = [TableField(f, ip) for f, ip in zip(wl.fields, wl.image_pts)]
         self.foc = wl.foc
         self._units_per_nm = sys_units_per_nm       # mm systems: 1e-6

@@ -59,6 +59,12 @@ class OracleEngine:
     def trace_pupil_list(self, fld, px, py, wvl_idx=0, opts=None, **kw):
         return self._trim(oracle.trace_pupil_list(self.table, fld, px, py, wvl_idx, opts), opts)
 
+    def trace_one(self, pt0, dir0, wvl_idx, opts):
+        h = oracle.trace_rays(self.table, np.asarray(pt0, dtype=float).reshape(3, 1),
+                              np.asarray(dir0, dtype=float).reshape(3, 1), wvl_idx, opts)
+        h.seg = h.seg[:self.num_segments(opts.flags)]
+        return h
+
     # ROX_OUT_HITS_COMPACT entries: the (R_ok, 2) array
     def trace_pupil_grid_hits(self, fld, grid, wvl_idx, opts):
         return oracle.trace_pupil_grid(self.table, fld, grid, wvl_idx, opts).hits.copy()

@@ -594,3 +594,106 @@ def test_ray_fan_fused(ref, installed, model):
     go, gt = both(installed, run)
     assert go == gt
     assert sum(len(x[0]) if isinstance(x, tuple) else len(x) for x in go) > 40
+
+
+def _same_error(a, b):
+    assert type(a) is type(b) and a.surf == b.surf
+    assert (a.ifc is b.ifc)
+    ra, opa, wa = a.ray_pkg
+    rb, opb, wb = b.ray_pkg
+    same_pkg((ra, opa, wa), (rb, opb, wb))
+    if getattr(b, 'int_pt', None) is not None:
+        np.testing.assert_array_equal(a.int_pt, b.int_pt)
+
+
+def test_single_ray_trace_seam(ref, installed):
+    """raytrace.trace itself (rayoptics/raytr/raytrace.py:51-80) rebound: results,
+    kwargs and the raised TraceError objects equal the reference's, ray by ray"""
+    import rayoptics.raytr.raytrace as rt
+    import rayoptics.raytr.trace as trace
+    from rayoptics.raytr.traceerror import TraceError
+    rng = np.random.default_rng(7)
+    for build in (ref.dblgauss, ref.cell_phone, ref.rc_telescope):
+        opm = build()
+        sm = opm['seq_model']
+        wvls = opm['osp']['wvls'].wavelengths
+        fld = opm['osp']['fov'].fields[-1]
+        cases = []
+        for k in range(24):
+            px, py = rng.uniform(-1.3, 1.3, 2)
+            pt0, d0 = [np.array(v, dtype=float)
+                       for v in opm['osp'].ray_start_from_osp([px, py], fld, 'rel pupil')[:2]]
+            kw = {}
+            if k % 2:
+                kw['check_apertures'] = True
+            if k % 3 == 0:
+                kw['first_surf'], kw['last_surf'] = 2, 5
+            if k % 5 == 0:
+                kw['intersect_obj'] = False
+            cases.append((pt0, d0, wvls[k % len(wvls)], kw))
+
+        def run():
+            out = []
+            for pt0, d0, wvl, kw in cases:
+                try:
+                    out.append(rt.trace(sm, pt0, d0, wvl, **dict(kw)))
+                except TraceError as e:
+                    out.append(e)
+            # the reference's own per-ray drivers reach the seam too
+            out.append(tuple(trace.trace_base(opm, [0.3, -0.2], fld, wvls[0])))
+            out.append(tuple(sm.trace(cases[0][0], cases[0][1], wvls[0])))
+            return out
+        ours, theirs = both(installed, run)
+        n_err = 0
+        for a, b in zip(ours, theirs):
+            if isinstance(b, Exception):
+                n_err += 1
+                assert isinstance(a, Exception)
+                _same_error(a, b)
+            else:
+                assert isinstance(a[0], list) and isinstance(a[0][0], list)
+                same_pkg(a, b)
+        assert n_err >= 1 or build is ref.rc_telescope
+
+
+def test_two_dimensional_aiming_runs_on_the_device_trace(ref, installed):
+    """a field off the y axis takes iterate_ray's fsolve branch (trace.py:393-410):
+    scipy's MINPACK drives the rebound single-ray trace and lands on the
+    reference's aim point bit for bit"""
+    import rayoptics.raytr.trace as trace
+    opm = ref.dblgauss()
+    osp = opm['osp']
+    fld = osp['fov'].fields[1]
+    fld.x, fld.y = 0.35, 0.5
+
+    def run():
+        fld.aim_info = None
+        aim = np.array(trace.aim_chief_ray(opm, fld), dtype=float)
+        fld.aim_info = aim
+        ray, op, wvl = trace.trace_base(opm, [0., 0.], fld, 587.6)
+        return aim, (ray, op, wvl)
+    (aim_o, pkg_o), (aim_t, pkg_t) = both(installed, run)
+    assert aim_t[0] != 0.0
+    np.testing.assert_array_equal(aim_o, aim_t)
+    same_pkg(pkg_o, pkg_t)
+
+
+def test_wide_angle_pupil_search_runs_on_the_device_trace(ref, installed):
+    """with is_wide_angle the reference aims through wideangle.find_real_enp
+    (wideangle.py:86-427, scipy newton / brentq around rt.trace); with the seam
+    rebound that search traces on the device and finds the same z_enp"""
+    import rayoptics.raytr.trace as trace
+    opm = ref.dblgauss()
+    osp = opm['osp']
+    osp['fov'].is_wide_angle = True
+
+    def run():
+        out = []
+        for f in osp['fov'].fields:
+            f.aim_info = None
+            out.append(trace.aim_chief_ray(opm, f))
+        return out
+    ours, theirs = both(installed, run)
+    for a, b in zip(ours, theirs):
+        assert a is not None
+        np.testing.assert_array_equal(np.asarray(a, dtype=float), np.asarray(b, dtype=float))

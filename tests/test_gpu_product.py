@@ -132,6 +132,50 @@ def test_trace_rays_soa_and_deferred_ray_list():
     session.clear()
 
 
+def test_single_ray_trace_product_function():
+    """trace.raytrace_trace (what rayoptics.raytr.raytrace.trace is rebound to):
+    one ray per call through a pinned block, list-of-lists result, the raised
+    TraceError with the partial packet -- against the golden explicit rays the
+    reference traced (tests/golden) and bit-exactly against the oracle"""
+    from oracle import oracle
+    from rayoptics_amd import trace, session
+    from rayoptics_amd.traceerror import TraceError
+    for name in ('dblgauss', 'cell_phone'):
+        fx = H.fixture(name)
+        cr = fx['rays_ap']
+        N = fx.table.n_ifcs
+        m = model_of(fx, [H.field_from_arr(fx['grid_f2']['field'])], [(0., 0.)])
+        sm = m['seq_model']
+        R = cr['pt0'].shape[1]
+        wi_all = np.broadcast_to(np.atleast_1d(cr['wvl_idx']), (R,))
+        n_err = 0
+        for r in range(0, R, max(1, R // 48)):
+            pt0, d0 = cr['pt0'][:, r].copy(), cr['dir0'][:, r].copy()
+            wi = int(wi_all[r])
+            opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES,
+                                    first_surf=1, last_surf=N - 2)
+            o = oracle.trace_rays(fx.table, pt0.reshape(3, 1), d0.reshape(3, 1), wi, opts)
+            try:
+                ray, op, wvl = trace.raytrace_trace(sm, pt0, d0, fx.table.wvls[wi],
+                                                    check_apertures=True)
+            except TraceError as e:
+                n_err += 1
+                assert int(o.status[0]) != abi.OK and e.surf == int(o.fail_surf[0])
+                ray, op, wvl = e.ray_pkg
+            else:
+                assert int(o.status[0]) == abi.OK and len(ray) == N
+            assert int(cr['status'][r]) == int(o.status[0])
+            assert isinstance(ray, list) and wvl == fx.table.wvls[wi]
+            assert op == float(o.op[0])
+            for k, seg in enumerate(ray):
+                np.testing.assert_array_equal(seg[0], o.seg[k, 0:3, 0])
+                np.testing.assert_array_equal(seg[1], o.seg[k, 3:6, 0])
+                assert seg[2] == o.seg[k, 6, 0]
+                np.testing.assert_array_equal(seg[3], o.seg[k, 7:10, 0])
+        assert n_err >= 1
+    session.clear()
+
+
 def test_config5_full_size_on_one_gpu():
     """BASELINE configs[4] in full: 9 fields x 5 wavelengths x 2048 x 2048 pupil
     grids (188.7 M rays, HITS, 3.2 GB) of the 44-interface lithography lens
