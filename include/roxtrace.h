@@ -105,8 +105,14 @@ enum { ROX_CHECK_APERTURES = 1u,     /* raytrace.py:198-202                    *
        ROX_INTERSECT_OBJ = 2u,       /* raytrace.py:147-154                    */
        ROX_FILTER_PHANTOMS = 4u,     /* raytrace.py:185-188                    */
        ROX_APPLY_VIGNETTING = 8u,    /* trace.py:298-300 (pupil entries only)  */
-       ROX_HOST_POINTERS = 16u };    /* buffers are host memory: the library
-                                        stages them through HBM itself        */
+       ROX_HOST_POINTERS = 16u };    /* every buffer is ordinary host memory: the
+                                        library stages it itself (small batches
+                                        through a device-mapped pinned block the
+                                        kernel reads and writes directly, large
+                                        ones through HBM) and the call returns
+                                        when the results are in place.  seg
+                                        slots the trace does not produce come
+                                        back as NaN in this mode                */
 /* rox_surface.rt_order: NumPy hands `rt.dot(v)` to OpenBLAS dgemv, whose FMA
  * chain runs over the columns in a different order for an F-ordered rt (the
  * transpose view compute_local_transforms makes, rayoptics/elem/transform.py:86)

@@ -10,6 +10,7 @@
 //       -> pupil_axes_kernel (repeated +=)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -178,6 +179,10 @@ struct StreamCtx {
     uint32_t *d_ticket = nullptr;       // [0] ticket, [1] workgroups done
     int64_t *d_hits_base = nullptr;
     uint32_t epoch = 0;
+    // ROX_HOST_POINTERS staging: HBM arena for big batches, device-mapped pinned
+    // block for small ones (grow-only)
+    char *d_stage = nullptr, *h_stage = nullptr;
+    size_t d_stage_cap = 0, h_stage_cap = 0;
 };
 
 }  // namespace
@@ -425,47 +430,123 @@ int64_t seg_rows(const rox_system *sys, const rox_opts *o)
     return o->out_mode == ROX_OUT_LAST ? ROX_SEG_DOUBLES : 2;
 }
 
-// ROX_HOST_POINTERS: stage outputs through HBM (a convenience path for small
-// batches: synchronous, pageable copies, one allocation set per call)
+// ROX_HOST_POINTERS.  The caller's buffers are ordinary host memory; they are
+// staged through an arena the stream context keeps (grow-only: no allocation per
+// call).  Batches of up to kBounceBytes never touch the copy engine: inputs are
+// copied into, and results out of, one device-mapped pinned block that the
+// kernel reads and writes directly (one launch, one synchronise).  Larger
+// batches go through HBM and the runtime's pageable copies.  seg slots the trace
+// does not produce come back as NaN (include/roxtrace.h, ROX_HOST_POINTERS).
+constexpr size_t kBounceBytes = size_t(4) << 20;
+
+__global__ void fill_nan_kernel(double *p, size_t n)
+{
+    const double q = __longlong_as_double(0x7ff8000000000000ll);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        p[i] = q;
+}
+
 struct Staged {
-    rox_out dev{};          // device-side buffers
+    rox_out dev{};          // staging buffers (device-visible)
     rox_out host{};         // caller's host buffers
     int64_t n = 0, rows = 0;
-    ~Staged()
-    {
-        (void)hipFree(dev.seg); (void)hipFree(dev.op); (void)hipFree(dev.status); (void)hipFree(dev.fail_surf);
-        (void)hipFree(dev.pupil);
-    }
+    bool bounce = false;    // staging lives in the pinned block
+    char *in = nullptr;     // room for the staged inputs
 };
 
-int stage_out(Staged &s, const rox_system *sys, const rox_opts *o, const rox_out *out, int64_t n)
+inline size_t up16(size_t b) { return (b + 15) & ~size_t(15); }
+
+int stage_out(Staged &s, rox_system *sys, hipStream_t st, const rox_opts *o, const rox_out *out,
+              int64_t n, size_t in_bytes)
 {
+    StreamCtx *cx = ctx_for(sys, st);
+    if (!cx)
+        return fail(ROX_E_HIP, "out of host memory");
     s.host = *out;
     s.n = n;
     s.rows = seg_rows(sys, o);
+    const size_t N = (size_t)n;
+    const size_t b_seg = up16(sizeof(double) * (size_t)s.rows * N), b_in = up16(in_bytes),
+                 b_op = out->op ? up16(sizeof(double) * N) : 0,
+                 b_st = out->status ? up16(N) : 0,
+                 b_fs = out->fail_surf ? up16(sizeof(int16_t) * N) : 0,
+                 b_pu = out->pupil ? up16(sizeof(double) * 2 * N) : 0;
+    const size_t total = b_seg + b_in + b_op + b_st + b_fs + b_pu + 16;
+    s.bounce = total <= kBounceBytes;
+    char *base;
+    if (s.bounce) {
+        if (cx->h_stage_cap < total) {
+            if (cx->h_stage)
+                HIP_TRY(hipHostFree(cx->h_stage));
+            cx->h_stage = nullptr;
+            cx->h_stage_cap = 0;
+            size_t cap = size_t(64) << 10;
+            while (cap < total)
+                cap *= 2;
+            HIP_TRY(hipHostMalloc((void **)&cx->h_stage, cap, hipHostMallocMapped));
+            cx->h_stage_cap = cap;
+        }
+        base = cx->h_stage;
+    } else {
+        if (cx->d_stage_cap < total) {
+            if (cx->d_stage)
+                HIP_TRY(hipFree(cx->d_stage));
+            cx->d_stage = nullptr;
+            cx->d_stage_cap = 0;
+            const size_t cap = total + total / 8;
+            HIP_TRY(hipMalloc((void **)&cx->d_stage, cap));
+            cx->d_stage_cap = cap;
+        }
+        base = cx->d_stage;
+    }
     s.dev.ld = n;
-    HIP_TRY(hipMalloc(&s.dev.seg, sizeof(double) * s.rows * n));
-    // untouched slots keep the caller's bytes
-    HIP_TRY(hipMemcpy2D(s.dev.seg, sizeof(double) * n, out->seg, sizeof(double) * out->ld,
-                        sizeof(double) * n, s.rows, hipMemcpyHostToDevice));
-    if (out->op) {
-        HIP_TRY(hipMalloc(&s.dev.op, sizeof(double) * n));
+    s.dev.seg = (double *)base;             base += b_seg;
+    s.in = base;                            base += b_in;
+    if (out->op) { s.dev.op = (double *)base; base += b_op; }
+    if (out->status) { s.dev.status = (uint8_t *)base; base += b_st; }
+    if (out->fail_surf) { s.dev.fail_surf = (int16_t *)base; base += b_fs; }
+    if (out->pupil) { s.dev.pupil = (double *)base; base += b_pu; }
+    const size_t n_seg = (size_t)s.rows * N;
+    if (s.bounce) {
+        std::fill_n(s.dev.seg, n_seg, __builtin_nan(""));
+    } else if (n_seg) {
+        hipLaunchKernelGGL(fill_nan_kernel, dim3(1024), dim3(256), 0, st, s.dev.seg, n_seg);
+        HIP_TRY(hipGetLastError());
     }
-    if (out->status) {
-        HIP_TRY(hipMalloc(&s.dev.status, n));
-    }
-    if (out->fail_surf) {
-        HIP_TRY(hipMalloc(&s.dev.fail_surf, sizeof(int16_t) * n));
-    }
-    if (out->pupil) {
-        HIP_TRY(hipMalloc(&s.dev.pupil, sizeof(double) * 2 * n));
-    }
+    return 0;
+}
+
+// inputs of a ROX_HOST_POINTERS call -> s.in + off
+int stage_in(Staged &s, size_t off, const void *src, size_t bytes, hipStream_t st)
+{
+    if (!bytes)
+        return 0;
+    if (s.bounce)
+        memcpy(s.in + off, src, bytes);
+    else
+        HIP_TRY(hipMemcpyAsync(s.in + off, src, bytes, hipMemcpyHostToDevice, st));
     return 0;
 }
 
 int unstage_out(Staged &s, hipStream_t st)
 {
     HIP_TRY(hipStreamSynchronize(st));
+    const size_t N = (size_t)s.n;
+    if (s.bounce) {
+        for (int64_t r = 0; r < s.rows; ++r)
+            memcpy(s.host.seg + r * s.host.ld, s.dev.seg + r * s.n, sizeof(double) * N);
+        if (s.host.op)
+            memcpy(s.host.op, s.dev.op, sizeof(double) * N);
+        if (s.host.status)
+            memcpy(s.host.status, s.dev.status, N);
+        if (s.host.fail_surf)
+            memcpy(s.host.fail_surf, s.dev.fail_surf, sizeof(int16_t) * N);
+        if (s.host.pupil)
+            for (int r = 0; r < 2; ++r)
+                memcpy(s.host.pupil + r * s.host.ld, s.dev.pupil + r * s.n, sizeof(double) * N);
+        return 0;
+    }
     HIP_TRY(hipMemcpy2D(s.host.seg, sizeof(double) * s.host.ld, s.dev.seg, sizeof(double) * s.n,
                         sizeof(double) * s.n, s.rows, hipMemcpyDeviceToHost));
     if (s.host.op)
@@ -717,6 +798,8 @@ int rox_system_destroy(rox_system *sys)
         (void)hipFree(c->d_tiles);
         (void)hipFree(c->d_ticket);
         (void)hipFree(c->d_hits_base);
+        (void)hipFree(c->d_stage);
+        (void)hipHostFree(c->h_stage);
         delete c;
     }
     delete sys;
@@ -756,32 +839,20 @@ int rox_trace_rays(rox_system *sys, int64_t n_rays, const double *pt0, const dou
             if (wvl_idx[i] < 0 || wvl_idx[i] >= sys->n_wvls)
                 return fail(ROX_E_ARG, "wvl_idx[%lld] = %d out of range", (long long)i, wvl_idx[i]);
     Staged s;
-    rc = stage_out(s, sys, opts, out, n_rays);
+    const size_t vb = sizeof(double) * 3 * (size_t)n_rays;
+    const size_t wb = wvl_idx ? sizeof(int32_t) * (size_t)n_rays : 0;
+    rc = stage_out(s, sys, st, opts, out, n_rays, 2 * vb + wb);
     if (rc)
         return rc;
-    double *d_in = nullptr;
-    int32_t *d_w = nullptr;
-    const size_t vb = sizeof(double) * 3 * (size_t)n_rays;
-    hipError_t e = hipMalloc(&d_in, 2 * vb + 16);
-    if (e == hipSuccess && wvl_idx)
-        e = hipMalloc(&d_w, sizeof(int32_t) * (size_t)n_rays + 16);
-    if (e == hipSuccess)
-        e = hipMemcpy(d_in, pt0, vb, hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy(d_in + 3 * n_rays, dir0, vb, hipMemcpyHostToDevice);
-    if (e == hipSuccess && wvl_idx)
-        e = hipMemcpy(d_w, wvl_idx, sizeof(int32_t) * (size_t)n_rays, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        a.pt0 = d_in; a.dir0 = d_in + 3 * n_rays; a.wvl_idx = d_w; a.out = s.dev;
-        rc = launch(sys, a, GEN_RAYS, st);
-        if (!rc)
-            rc = unstage_out(s, st);
-    } else {
-        rc = fail(ROX_E_HIP, "staging inputs: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(d_in);
-    (void)hipFree(d_w);
-    return rc;
+    if ((rc = stage_in(s, 0, pt0, vb, st)) || (rc = stage_in(s, vb, dir0, vb, st)) ||
+        (rc = stage_in(s, 2 * vb, wvl_idx, wb, st)))
+        return rc;
+    a.pt0 = (const double *)s.in;
+    a.dir0 = (const double *)(s.in + vb);
+    a.wvl_idx = wvl_idx ? (const int32_t *)(s.in + 2 * vb) : nullptr;
+    a.out = s.dev;
+    rc = launch(sys, a, GEN_RAYS, st);
+    return rc ? rc : unstage_out(s, st);
 }
 
 int rox_trace_pupil_grid(rox_system *sys, const rox_field *fld, const rox_grid *grid,
@@ -797,7 +868,7 @@ int rox_trace_pupil_grid(rox_system *sys, const rox_field *fld, const rox_grid *
     if (!(opts->flags & ROX_HOST_POINTERS))
         return launch(sys, a, GEN_PUPIL, st);
     Staged s;
-    rc = stage_out(s, sys, opts, out, a.n_rays);
+    rc = stage_out(s, sys, st, opts, out, a.n_rays, 0);
     if (rc)
         return rc;
     a.out = s.dev;
@@ -832,25 +903,17 @@ int rox_trace_pupil_list(rox_system *sys, const rox_field *fld, int64_t n_rays, 
         return launch(sys, a, GEN_PUPIL, st);
     }
     Staged s;
-    rc = stage_out(s, sys, opts, out, n_rays);
+    const size_t pb = sizeof(double) * (size_t)n_rays;
+    rc = stage_out(s, sys, st, opts, out, n_rays, 2 * pb);
     if (rc)
         return rc;
-    double *d_p = nullptr;
-    hipError_t e = hipMalloc(&d_p, sizeof(double) * 2 * (size_t)n_rays + 16);
-    if (e == hipSuccess)
-        e = hipMemcpy(d_p, px, sizeof(double) * n_rays, hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy(d_p + n_rays, py, sizeof(double) * n_rays, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        a.px = d_p; a.py = d_p + n_rays; a.out = s.dev;
-        rc = launch(sys, a, GEN_PUPIL, st);
-        if (!rc)
-            rc = unstage_out(s, st);
-    } else {
-        rc = fail(ROX_E_HIP, "staging pupil coordinates: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(d_p);
-    return rc;
+    if ((rc = stage_in(s, 0, px, pb, st)) || (rc = stage_in(s, pb, py, pb, st)))
+        return rc;
+    a.px = (const double *)s.in;
+    a.py = (const double *)(s.in + pb);
+    a.out = s.dev;
+    rc = launch(sys, a, GEN_PUPIL, st);
+    return rc ? rc : unstage_out(s, st);
 }
 
 int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs, double eps,

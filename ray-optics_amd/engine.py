@@ -251,6 +251,7 @@ class TraceEngine:
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None
                                    else torch.device(device).index or 0)
         self.table = table
+        self._nseg = {}
         self._handle = C.c_void_p()
         with torch.cuda.device(self.device):
             _check(self.lib.rox_set_device(self.device.index), 'rox_set_device')
@@ -407,31 +408,43 @@ class TraceEngine:
 
     # -- one ray (raytrace.trace) -----------------------------------------------
     def trace_one(self, pt0, dir0, wvl_idx, opts):
-        """one explicit ray, FULL packets.  The kernel reads the ray from, and
-        writes the packet into, one pooled pinned block (no staging copies, one
-        launch, one synchronisation); the returned arrays view that block."""
-        nseg = self.num_segments(opts.flags)
-        lease = _pool.take(self.torch, 64 + 8 * abi.SEG_DOUBLES * nseg)
-        base = lease.ptr
-        ray = lease.array((6,), np.float64)
-        ray[0:3] = pt0
-        ray[3:6] = dir0
+        """one explicit ray, FULL packets, through the library's ROX_HOST_POINTERS
+        path: the ray and its packet live in one NumPy block; the library copies
+        the 48 input bytes into a device-mapped pinned block, the kernel reads and
+        writes that block directly, and the packet is copied back (one launch, one
+        synchronise, no copy-engine transfer).  Slots past a failure are NaN."""
+        key = opts.flags & abi.FILTER_PHANTOMS
+        nseg = self._nseg.get(key)
+        if nseg is None:
+            nseg = self._nseg[key] = self.num_segments(opts.flags)
+        buf = np.empty(8 + abi.SEG_DOUBLES * nseg)
+        buf[0:3] = pt0
+        buf[3:6] = dir0
+        base = buf.ctypes.data
         o = abi.Out()
         o.seg, o.op, o.status, o.fail_surf, o.ld = base + 64, base + 48, base + 56, base + 58, 1
-        with self.torch.cuda.device(self.device):
-            _check(self.lib.rox_trace_rays(self._handle, 1, base, base + 24, None, int(wvl_idx),
-                                           C.byref(opts), C.byref(o), self._stream()),
-                   'rox_trace_rays')
-        self.torch.cuda.current_stream(self.device).synchronize()
+        saved = opts.flags
+        opts.flags = saved | abi.HOST_POINTERS
+        try:
+            if self.torch.cuda.current_device() == self.device.index:
+                rc = self.lib.rox_trace_rays(self._handle, 1, base, base + 24, None, int(wvl_idx),
+                                             C.byref(opts), C.byref(o), None)
+            else:
+                with self.torch.cuda.device(self.device):
+                    rc = self.lib.rox_trace_rays(self._handle, 1, base, base + 24, None,
+                                                 int(wvl_idx), C.byref(opts), C.byref(o), None)
+        finally:
+            opts.flags = saved
+        _check(rc, 'rox_trace_rays')
 
         class _H:
             pass
         h = _H()
         h.R, h.out_mode, h.pupil = 1, abi.OUT_FULL, None
-        h.seg = lease.array((nseg, abi.SEG_DOUBLES, 1), np.float64, 64)
-        h.op = lease.array((1,), np.float64, 48)
-        h.status = lease.array((1,), np.uint8, 56)
-        h.fail_surf = lease.array((1,), np.int16, 58)
+        h.seg = buf[8:].reshape(nseg, abi.SEG_DOUBLES, 1)
+        h.op = buf[6:7]
+        h.status = buf[7:8].view(np.uint8)[0:1]
+        h.fail_surf = buf[7:8].view(np.int16)[1:2]
         return h
 
     # -- chief-ray aiming ---------------------------------------------------------

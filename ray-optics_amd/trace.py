@@ -17,7 +17,7 @@ import numpy as np
 
 from . import abi, session
 from .engine import make_opts, make_grid
-from .raypkg import HostPackets, LazyRay, RayPkg, RaySeg
+from .raypkg import HostPackets, RayPkg, RaySeg
 from .table import field_from_model
 
 
@@ -79,14 +79,15 @@ def raytrace_trace(seq_model, pt0, dir0, wvl, **kwargs):
     opts = opts_from_kwargs(tbl.n_ifcs, kwargs, abi.OUT_FULL)
     opts.flags &= ~abi.APPLY_VIGNETTING             # a pupil-level notion (trace.py:291-295)
     h = eng.trace_one(pt0, dir0, wi, opts)
+    if h.status[0] == abi.OK:
+        # the packet block is this call's own: the segments view it, no copies
+        return ([[s[0:3], s[3:6], float(s[6]), s[7:10]] for s in h.seg[:, :, 0]],
+                float(h.op[0]), wvl)
     pk = HostPackets(h, tbl, opts.flags, abi.OUT_FULL, wv)
-    st = int(h.status[0])
-    if st != abi.OK:
-        err = pk.error(0, getattr(seq_model, 'ifcs', None), with_pkg=True, named=False)
-        ray, op, _w = err.ray_pkg
-        err.ray_pkg = (ray.to_list(), op, wvl)
-        raise err
-    return LazyRay(pk.seg, 0, pk.nseg(0)).to_list(), float(h.op[0]), wvl
+    err = pk.error(0, getattr(seq_model, 'ifcs', None), with_pkg=True, named=False)
+    ray, op, _w = err.ray_pkg
+    err.ray_pkg = (ray.to_list(), op, wvl)
+    raise err
 
 
 def _launch_setup(opt_model, fld, wvl, kwargs, out_mode, foc=0.0, image_pt=(0., 0.), wf=None):

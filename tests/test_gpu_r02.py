@@ -458,3 +458,66 @@ def test_fan_mode(name, case):
             bit_equal(dev.pupil, orc.pupil, 'pupil')
             assert (orc.status == 0).sum() > 5
     eng.close()
+
+
+# ---------------------------------------------------------------- ROX_HOST_POINTERS staging
+@pytest.mark.parametrize('num', [1, 3, 40, 300])
+def test_host_pointer_staging_small_and_large(engines, num):
+    """plain host buffers through the C ABI: the pinned-block path (<= 4 MiB staged),
+    the HBM arena path (above), a padded leading dimension, every output mode; slots
+    the trace does not produce come back as NaN whatever the caller left in them"""
+    from oracle import oracle
+    from rayoptics_amd.engine import load_library
+    lib = load_library()
+    fx = H.fixture('dblgauss')
+    c = fx['grid_f2']
+    N = fx.table.n_ifcs
+    eng = engines('dblgauss')
+    fld = H.field_from_arr(c['field'])
+    grid = oracle.make_grid((-1., -1.), (1., 1.), num)
+    R = num * num
+    ld = R + 5
+    for mode in (abi.OUT_FULL, abi.OUT_LAST, abi.OUT_HITS):
+        opts = oracle.make_opts(flags=FLAGS, out_mode=mode, first_surf=1, last_surf=N - 2,
+                                foc=0.01, image_pt=(0.0, 18.0))
+        orc = oracle.trace_pupil_grid(fx.table, fld, grid, 1, opts)
+        rows = {abi.OUT_FULL: N * 10, abi.OUT_LAST: 10, abi.OUT_HITS: 2}[mode]
+        seg = np.full((rows, ld), 12345.0)                  # stale caller bytes
+        op = np.full(R, -7.0)
+        status = np.full(R, 99, dtype=np.uint8)
+        fail = np.full(R, 77, dtype=np.int16)
+        pupil = np.full((2, ld), 5.0)
+        o = abi.Out()
+        o.seg, o.op, o.status, o.fail_surf, o.pupil, o.ld = (seg.ctypes.data, op.ctypes.data,
+                                                            status.ctypes.data, fail.ctypes.data,
+                                                            pupil.ctypes.data, ld)
+        opts.flags |= abi.HOST_POINTERS
+        for _rep in range(2):                               # second call reuses the arena
+            rc = lib.rox_trace_pupil_grid(eng._handle, C.byref(fld), C.byref(grid), 1,
+                                          C.byref(opts), C.byref(o), None)
+            assert rc == 0, lib.rox_last_error()
+        bit_equal(seg[:, :R], np.asarray(orc.seg).reshape(rows, R), f'seg mode {mode} num {num}')
+        assert (seg[:, R:] == 12345.0).all()                # the padding is the caller's
+        bit_equal(status, orc.status, 'status')
+        bit_equal(fail, orc.fail_surf, 'fail_surf')
+        bit_equal(op, orc.op, 'op')
+        bit_equal(pupil[:, :R], orc.pupil, 'pupil')
+    # explicit rays with per-ray wavelengths, R around the 4 MiB switch
+    cr = fx['rays_ap']
+    reps = {1: 1, 3: 2, 40: 12, 300: 90}[num]
+    pt0 = np.ascontiguousarray(np.tile(cr['pt0'], (1, reps)))
+    dir0 = np.ascontiguousarray(np.tile(cr['dir0'], (1, reps)))
+    Rr = pt0.shape[1]
+    wi = np.ascontiguousarray(np.arange(Rr) % len(fx.table.wvls), dtype=np.int32)
+    o2 = H.make_opts(cr)
+    orc = oracle.trace_rays(fx.table, pt0, dir0, wi, o2)
+    o2.flags |= abi.HOST_POINTERS
+    res = oracle.HostResult(N, Rr, abi.OUT_FULL)
+    res.seg[:] = 4.0
+    out = res.out_struct()
+    rc = lib.rox_trace_rays(eng._handle, Rr, pt0.ctypes.data, dir0.ctypes.data, wi.ctypes.data, 0,
+                            C.byref(o2), C.byref(out), None)
+    assert rc == 0, lib.rox_last_error()
+    bit_equal(res.seg, orc.seg, 'explicit rays seg')
+    bit_equal(res.status, orc.status, 'explicit rays status')
+    bit_equal(res.op, orc.op, 'explicit rays op')
