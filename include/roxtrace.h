@@ -335,6 +335,19 @@ typedef struct rox_vig {
 int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs,
                         double eps, double *vig, int32_t *clip_surf, void *stream);
 
+/* point spread function ---------------------------------------------------
+ * analyses.calc_psf(wavefront, ndim, maxdim) (rayoptics/raytr/analyses.py:848-875;
+ * callers: analyses.update_psf_data :878-883, mpl/analysisfigure.py:418).
+ * opd: [ndim][ndim] OPD in waves as ROX_OUT_OPD / eval_wavefront produce it, NaN =
+ * no data; psf: [maxdim][maxdim], the normalised |FFT|^2 of the zero-padded pupil
+ * function with the reference's fftshift conventions.  ndim must be even and the
+ * block must fit (maxdim/2 + ndim/2 + 1 <= maxdim) -- the shapes for which the
+ * reference's slice assignment is valid; maxdim need not be a power of two.
+ * Computed as a pruned DFT (two complex GEMMs on the fp64 matrix cores).
+ * flags: 0 (device pointers, asynchronous on `stream`) or ROX_HOST_POINTERS. */
+int rox_calc_psf(const double *opd, int32_t ndim, int32_t maxdim, double *psf,
+                 uint32_t flags, void *stream);
+
 /* trace entries ---------------------------------------------------------- */
 /* explicit rays: pt0, dir0 are SoA [3][n_rays] with leading dimension
  * n_rays; wvl_idx is [n_rays] or NULL (then wvl_idx_all is used for all).

@@ -206,3 +206,17 @@ def calc_vignetting(table, probs, eps=1.0e-12):
     if rc:
         raise RuntimeError(f'oracle error {rc}')
     return vig, clip
+
+
+def calc_psf(opd, ndim, maxdim):
+    """rox_oracle_calc_psf: analyses.calc_psf restated (analyses.py:848-875)"""
+    w = np.ascontiguousarray(opd, dtype=np.float64)
+    assert w.shape == (ndim, ndim)
+    out = np.empty((maxdim, maxdim))
+    f = lib().rox_oracle_calc_psf
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    f.restype = C.c_int
+    rc = f(w.ctypes.data, int(ndim), int(maxdim), out.ctypes.data)
+    if rc:
+        raise ValueError(f'oracle calc_psf: shapes rejected ({rc})')
+    return out

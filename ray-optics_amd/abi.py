@@ -149,7 +149,7 @@ EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_last_error', 'rox_system_create', 'rox_system_destroy',
            'rox_system_num_segments', 'rox_trace_rays',
            'rox_trace_pupil_grid', 'rox_trace_pupil_list',
-           'rox_aim_chief_rays', 'rox_calc_vignetting')
+           'rox_aim_chief_rays', 'rox_calc_vignetting', 'rox_calc_psf')
 # ... and the measurement / self-test helpers of include/roxtrace_diag.h
 DIAG_EXPORTS = ('rox_time_pupil_grid', 'rox_selftest_fp64')
 
@@ -184,6 +184,8 @@ def declare(lib):
     lib.rox_aim_chief_rays.argtypes = [vp, i32, P(Aim), dbl, vp, vp, vp]
     lib.rox_calc_vignetting.restype = C.c_int
     lib.rox_calc_vignetting.argtypes = [vp, i32, P(Vig), dbl, vp, vp, vp]
+    lib.rox_calc_psf.restype = C.c_int
+    lib.rox_calc_psf.argtypes = [vp, i32, i32, vp, C.c_uint32, vp]
     lib.rox_time_pupil_grid.restype = C.c_int
     lib.rox_time_pupil_grid.argtypes = [vp, P(Field), P(Grid), i32, P(Opts),
                                         P(Out), vp, i32, P(dbl)]

@@ -525,3 +525,25 @@ def focus_fan(opt_model, fan_pkg, fld, wvl, foc, image_pt_2d=None, image_delta=N
         else:
             out.append((px, py, np.nan))
     return out
+
+
+# ---- point spread function ------------------------------------------------------
+PSF_BACKEND = None          # None -> engine.calc_psf (the HIP path); tests inject a double
+
+
+def calc_psf(wavefront, ndim, maxdim):
+    """rayoptics/raytr/analyses.py:848-875: the PSF of an OPD grid -- the zero-padded
+    pupil function exp(i 2 pi W), its shifted 2-D FFT, |.|^2, normalised.  One call
+    into the library (``rox_calc_psf``: a pruned DFT on the fp64 matrix cores) instead
+    of a maxdim x maxdim Python loop and a host FFT; any even ``ndim`` that fits,
+    any ``maxdim``."""
+    fn = PSF_BACKEND
+    if fn is None:
+        from .engine import calc_psf as fn
+    return fn(wavefront, ndim, maxdim)
+
+
+def update_psf_data(pupil_grid, build='rebuild'):
+    """rayoptics/raytr/analyses.py:878-883"""
+    pupil_grid.update_data(build=build)
+    return calc_psf(pupil_grid.grid[2], pupil_grid.num_rays, pupil_grid.maxdim)

@@ -187,6 +187,11 @@ struct StreamCtx {
 
 }  // namespace
 
+namespace rox {
+// for the other translation units of the library (psf.hip)
+int host_fail(int code, const char *msg) { return fail(code, "%s", msg); }
+}
+
 struct rox_system {
     int device = 0;
     int32_t n_ifcs = 0, n_wvls = 0;

@@ -88,6 +88,37 @@ def grid_rays(grid):
     return (grid.row_count or grid.num) * grid.num
 
 
+def calc_psf(opd, ndim, maxdim):
+    """analyses.calc_psf (rayoptics/raytr/analyses.py:848-875) on the device:
+    ``opd`` is the [ndim, ndim] OPD grid in waves (NumPy, NaN = no data, or a
+    float64 torch tensor already in HBM); returns the normalised [maxdim, maxdim]
+    PSF as the same kind of array.  A pruned DFT as two complex fp64 GEMMs on
+    the matrix cores (csrc/psf.hip)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise EngineError('no GPU visible: the PSF kernels have no CPU fallback')
+    lib = load_library()
+    ndim, maxdim = int(ndim), int(maxdim)
+    if isinstance(opd, torch.Tensor):
+        w = opd.to(dtype=torch.float64).contiguous()
+        if tuple(w.shape) != (ndim, ndim):
+            raise ValueError(f'opd is {tuple(w.shape)}, expected ({ndim}, {ndim})')
+        out = torch.empty((maxdim, maxdim), dtype=torch.float64, device=w.device)
+        with torch.cuda.device(w.device):
+            _check(lib.rox_calc_psf(w.data_ptr(), ndim, maxdim, out.data_ptr(), 0,
+                                    C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)),
+                   'rox_calc_psf')
+        out._keep = w
+        return out
+    w = np.ascontiguousarray(opd, dtype=np.float64)
+    if w.shape != (ndim, ndim):
+        raise ValueError(f'opd is {w.shape}, expected ({ndim}, {ndim})')
+    out = np.empty((maxdim, maxdim))
+    _check(lib.rox_calc_psf(w.ctypes.data, ndim, maxdim, out.ctypes.data, abi.HOST_POINTERS, None),
+           'rox_calc_psf')
+    return out
+
+
 _NP_DTYPES = {}
 
 

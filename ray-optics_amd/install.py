@@ -56,6 +56,8 @@ def install(fallback='raise'):
              (ranalyses, 'focus_wavefront', _a.focus_wavefront),
              (ranalyses, 'trace_pupil_coords', _a.trace_pupil_coords),
              (ranalyses, 'focus_pupil_coords', _a.focus_pupil_coords),
+             (ranalyses, 'calc_psf', _a.calc_psf),
+             (ranalyses, 'update_psf_data', _a.update_psf_data),
              (SequentialModel, 'trace_grid', _t.seq_trace_grid),
              # chief-ray aiming: trace.aim_chief_ray is imported by name into
              # opticalspec (opticalspec.py:19), so both bindings are replaced, and

@@ -17,6 +17,7 @@ The outputs come from the reference's own drivers:
   spot  -> rayoptics.mpl.axisarrayfigure.SpotDiagramFigure.update_data
            (axisarrayfigure.py:222-263) -> SequentialModel.trace_grid
   list  -> rayoptics.raytr.analyses.trace_list_of_rays (analyses.py:458-510)
+  psf   -> rayoptics.raytr.analyses.calc_psf          (analyses.py:848-875)
 """
 import json
 import os
@@ -386,8 +387,44 @@ def ingest_tables():
     print(f'ingest_tables.json: {os.path.getsize(path) / 1024:.0f} KiB, {list(out)}')
 
 
+def psf_cases():
+    """analyses.calc_psf (analyses.py:848-875) run by the reference on OPD grids its own
+    eval_wavefront produced, and on synthetic grids with exact zeros / NaN / a maxdim that
+    is not a power of two"""
+    out = {}
+    opm = rm.dblgauss()
+    osp = opm['osp']
+    for tag, fi, wvl, ndim, maxdim in (('dblgauss_f0', 0, 587.6, 32, 128),
+                                       ('dblgauss_f2', 2, 486.1, 64, 256),
+                                       ('dblgauss_f1_odd_size', 1, 656.3, 24, 90)):
+        fld = osp['fov'].fields[fi]
+        # RayGrid.update_data: grid = np.rollaxis(eval_wavefront(...), 2); grid[2] is the OPD plane
+        opd = np.array(np.rollaxis(analyses.eval_wavefront(opm, fld, wvl, 0.0, num_rays=ndim), 2)[2],
+                       dtype=float)
+        out[f'{tag}/opd'] = opd
+        out[f'{tag}/dims'] = np.array([ndim, maxdim])
+        out[f'{tag}/psf'] = analyses.calc_psf(opd, ndim, maxdim)
+    rng = np.random.default_rng(SEED + 5)
+    for tag, ndim, maxdim in (('synthetic_small', 8, 12), ('synthetic_coma', 16, 50)):
+        y, x = np.mgrid[-1:1:ndim * 1j, -1:1:ndim * 1j]
+        r2 = x * x + y * y
+        opd = 0.8 * r2 + 0.35 * (3 * r2 - 2) * y + 0.02 * rng.standard_normal((ndim, ndim))
+        opd[r2 > 1.0] = np.nan
+        opd[ndim // 2, ndim // 2] = 0.0             # an exact zero inside the pupil (-> phase 0)
+        opd[ndim // 2 - 1, 2] = 3.0                 # an integer number of waves (phase != 1 exactly)
+        out[f'{tag}/opd'] = opd
+        out[f'{tag}/dims'] = np.array([ndim, maxdim])
+        out[f'{tag}/psf'] = analyses.calc_psf(opd, ndim, maxdim)
+    path = os.path.join(HERE, 'psf.npz')
+    np.savez_compressed(path, **out)
+    print(f'psf.npz: {os.path.getsize(path) / 1024:.0f} KiB, {sorted(set(k.split("/")[0] for k in out))}')
+
+
 def main():
     rng = np.random.default_rng(SEED)
+    if '--only-psf' in sys.argv:
+        psf_cases()
+        return
     if '--only-ingest' in sys.argv or '--workloads-only' in sys.argv:
         ingest_tables()
         if '--only-ingest' in sys.argv:
@@ -496,6 +533,8 @@ def main():
         'opd_f0': case_opd(opm, 0, 550.0, 11),
         'opd_f2': case_opd(opm, 2, 486.1, 10),
     })
+
+    psf_cases()
 
     # aspheric toroids (Newton path, anamorphic)
     opm = rm.toroid_lens()
