@@ -192,6 +192,15 @@ def main():
         xy = rox_trace.trace_grid_spot(model, grid_rng, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
         spot_ms.append((time.perf_counter() - t1) * 1e3)
 
+    # the PSF of an OPD grid (analyses.calc_psf): the GEMM-shaped neighbour of the path,
+    # on the fp64 matrix cores; device-resident, mean of back-to-back calls
+    psf = None
+    if rank == 0:
+        try:
+            psf = psf_leg(torch)
+        except Exception as e:
+            psf = {'error': repr(e)}
+
     # every run: the fixed-size problem with the path's one exchange step
     strong = None
     if not args.no_strong:
@@ -245,12 +254,42 @@ def main():
                                      '(survivors packed in ray order by the trace launch, written '
                                      'straight into pinned host memory; 13 MB over PCIe at ~55 GB/s '
                                      'is the floor)'},
+            'psf': psf,
             'cpu_baseline': cpu,
             'strong_scaling': strong,
         }
         print(json.dumps(line))
     if multi:
         dist.destroy_process_group()
+
+
+def psf_leg(torch):
+    """rox_calc_psf at two sizes: ms per call and fp64 TFLOP/s by 8 M n (n + M) flop
+    (two complex GEMMs) against the 78.6 TFLOP/s fp64 peak (matrix = vector rate)"""
+    from rayoptics_amd.engine import calc_psf
+    out = {'what': 'rayoptics_amd.engine.calc_psf (rox_calc_psf: analyses.calc_psf as a pruned DFT, '
+                   'v_mfma_f64_16x16x4), OPD grid and PSF resident in HBM',
+           'bound': 'mfma fp64', 'peak_tflops': 78.6, 'sizes': []}
+    for ndim, maxdim, reps in ((64, 256, 200), (256, 1024, 100), (1024, 4096, 20)):
+        y, x = np.mgrid[-1:1:ndim * 1j, -1:1:ndim * 1j]
+        opd = 1.5 * (x * x + y * y) + 0.4 * x * y * y
+        opd[x * x + y * y > 1.0] = np.nan
+        d = torch.from_numpy(opd).cuda()
+        for _ in range(3):
+            calc_psf(d, ndim, maxdim)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            calc_psf(d, ndim, maxdim)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        flop = 8.0 * maxdim * ndim * (ndim + maxdim)
+        out['sizes'].append({'ndim': ndim, 'maxdim': maxdim, 'ms': ms,
+                             'tflops': flop / (ms * 1e-3) / 1e12,
+                             'frac': flop / (ms * 1e-3) / 78.6e12})
+    return out
 
 
 def roofline_hits(inters, R, kern_ms):

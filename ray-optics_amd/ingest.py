@@ -14,12 +14,21 @@ profile parameters, apertures, interact modes, z_dir bookkeeping
 (rayoptics/seq/sequential.py:611-668) and local transforms
 (rayoptics/elem/transform.py:86-118, 143-166 for undecentered interfaces).
 
-Scope: centred systems -- STANDARD / EVENASPH / CONI / MIRROR / PARAXIAL /
-DGRATING surfaces of .zmx; S / SO / SI / STO / SPH / CON / ASP / K / A..J / RDY /
-CUY / THI / REFL / WL of .seq; Spherical / Conic / EvenPolynomial /
-RadialPolynomial profiles and Circular / Rectangular apertures of .roa.
-Coordinate breaks and decentered surfaces raise :class:`UnsupportedModelError`
-(their tilt matrices come from transforms3d in the reference: unpinned).
+Scope: STANDARD / EVENASPH / CONI / MIRROR / PARAXIAL / DGRATING / COORDBRK
+surfaces of .zmx; S / SO / SI / STO / SPH / CON / ASP / K / A..J / RDY / CUY / THI /
+REFL / WL, the aperture commands CIR / REX / REY / ELX / ELY / ADX / ADY and the
+decenter commands XDE / YDE / ZDE / ADE / BDE / CDE / DAR / BEN / REV of .seq;
+Spherical / Conic / EvenPolynomial / RadialPolynomial profiles, Circular /
+Rectangular apertures and ``decenter`` records of .roa.
+
+Decentered and tilted interfaces: the local transforms are composed exactly as
+``compute_local_transforms`` / ``forward_transform`` compose them
+(rayoptics/elem/transform.py:79-166) from ``DecenterData``'s before/after
+transforms (rayoptics/elem/surface.py:312-337), with the same NumPy calls so the
+rounding is the reference's.  The tilt matrix itself is
+``transforms3d.euler.euler2mat(..., 'rxyz')`` in the reference (a third-party
+package, absent from the build container): restated as Rx.Ry.Rz -- tilt parity
+is unpinned.
 
 Refractive indices: the engine consumes evaluated indices, so a glass *name* has
 to be turned into n(wavelength) here.  ``index_of(name, wvl_nm)`` is the hook;
@@ -37,7 +46,7 @@ import re
 import numpy as np
 
 from . import abi
-from .table import SurfaceTable, UnsupportedModelError
+from .table import SurfaceTable, UnsupportedModelError, rt_order_of
 
 # ---------------------------------------------------------------- dispersion
 # Sellmeier-1 coefficients (B1 B2 B3 C1 C2 C3, wavelength in micrometres) of the
@@ -96,6 +105,69 @@ class Ifc:
         self.phase = None           # dict for rox_phase
         self.thinlens_power = None
         self.z_type = 'STANDARD'
+        self.decenter = None        # dict(dtype, dec[3], euler[3]) <- surface.py DecenterData
+
+
+def new_decenter(dtype='decenter'):
+    return dict(dtype=dtype, dec=[0., 0., 0.], euler=[0., 0., 0.])
+
+
+def _euler2rot3d(euler):
+    """rayoptics/util/misc_math.py:151-161: euler2mat(*deg2rad(-alpha, -beta, gamma), 'rxyz')
+    = Rx(ai).Ry(aj).Rz(ak) (transforms3d; restated, see the module docstring)"""
+    ai, aj, ak = np.deg2rad(np.array([-euler[0], -euler[1], euler[2]]))
+    cx, sx = math.cos(ai), math.sin(ai)
+    cy, sy = math.cos(aj), math.sin(aj)
+    cz, sz = math.cos(ak), math.sin(ak)
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=float)
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=float)
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=float)
+    return rx @ ry @ rz
+
+
+def _dec_arrays(d):
+    """(rot_mat or None, dec) of a decenter record: DecenterData.update, surface.py:312-316"""
+    euler = np.array([float(v) for v in d['euler']])
+    rot = _euler2rot3d(euler) if euler.any() else None
+    return rot, np.array([float(v) for v in d['dec']])
+
+
+def _tform_before_surf(d):          # surface.py:322-326
+    rot, dec = _dec_arrays(d)
+    if d['dtype'] != 'reverse':
+        return rot, dec
+    return None, np.array([0., 0., 0.])
+
+
+def _tform_after_surf(d):           # surface.py:328-337
+    rot, dec = _dec_arrays(d)
+    if d['dtype'] in ('reverse', 'dec and return'):
+        return (rot.transpose() if rot is not None else None), -dec
+    if d['dtype'] == 'bend':
+        return rot, np.array([0., 0., 0.])
+    return None, np.array([0., 0., 0.])
+
+
+def forward_transform(dec1, zdist, dec2):
+    """rayoptics/elem/transform.py:143-166: rotation and translation from the frame of
+    interface 1 (decenter record dec1 or None) to that of interface 2"""
+    t_orig = np.array([0., 0., zdist])
+    r_after_s1 = r_before_s2 = None
+    if dec1:
+        r_after_s1, t_after_s1 = _tform_after_surf(dec1)
+        t_orig += t_after_s1
+    if dec2:
+        r_before_s2, t_before_s2 = _tform_before_surf(dec2)
+        t_orig += t_before_s2
+    r_cascade = np.identity(3)
+    if r_after_s1 is not None:
+        t_orig = np.matmul(r_after_s1, t_orig)
+        r_cascade = r_after_s1
+        if r_before_s2 is not None:
+            r_cascade = np.matmul(r_after_s1, r_before_s2)
+    elif r_before_s2 is not None:
+        r_cascade = r_before_s2
+    return r_cascade, t_orig
 
 
 class Prescription:
@@ -178,13 +250,19 @@ class Prescription:
                 else:
                     a.kind = abi.AP_ALWAYS_BLOCK
                     a.a, a.b = float(ca.get('x_half_width', 0.)), float(ca.get('y_half_width', 0.))
+            # compute_local_transforms (transform.py:79-107) holds r.transpose() -- an
+            # F-ordered view -- for every interface but the last, which gets a fresh
+            # np.identity(3)
+            if i < N - 1:
+                r, t = forward_transform(s.decenter, float(self.thi[i]), self.ifcs[i + 1].decenter)
+                rt = r.transpose()
+            else:
+                rt, t = np.identity(3), np.array([0., 0., 0.])
+            row.rt_order = rt_order_of(rt)
             for a in range(3):
-                row.rt[4 * a] = 1.0
-            # compute_local_transforms holds r.transpose() (an F-ordered view) for every
-            # interface but the last, which gets a fresh np.identity(3); for the
-            # identity both dgemv chains are exact, the flag only mirrors the model
-            row.rt_order = abi.RT_F_ORDER if i < N - 1 else abi.RT_C_ORDER
-            row.t[2] = float(self.thi[i]) if i < N - 1 else 0.0
+                for b in range(3):
+                    row.rt[3 * a + b] = float(rt[a][b])
+                row.t[a] = float(t[a])
             if mode == 'reflect':
                 zdir = -zdir
             row.z_dir = zdir
@@ -279,7 +357,10 @@ def read_zmx(path):
             elif typ == 'DGRATING':
                 # DiffractionGrating() defaults: order 1, normal (0,1,0), 1 line/um
                 s.phase = dict(kind=abi.PH_GRATING, order=1, a=(0., 1., 0.), spacing_nm=1e6 / 1000.)
-            elif typ in ('COORDBRK', 'TOROIDAL'):
+            elif typ == 'COORDBRK':         # zmxread.py:318-320
+                s.mode = 'phantom'
+                s.decenter = new_decenter('decenter')
+            elif typ == 'TOROIDAL':
                 raise UnsupportedModelError(f'{typ} surfaces are not ingested')
             elif typ != 'STANDARD':
                 raise UnsupportedModelError(f'Zemax surface type {typ}')
@@ -302,6 +383,13 @@ def read_zmx(path):
                     s.phase['spacing_nm'] = 1e6 / (val * 1000)     # grating_freq_um -> lpmm
                 elif i == 2:
                     s.phase['order'] = val
+            elif s.z_type == 'COORDBRK':    # zmxread.py:341-355
+                if i in (1, 2):
+                    s.decenter['dec'][i - 1] = val
+                elif i in (3, 4, 5):
+                    s.decenter['euler'][i - 3] = val
+                elif i == 6 and val != 0:
+                    s.decenter['dtype'] = 'reverse'
         elif cmd == 'XDAT':
             s = p.ifcs[cur]
             it = inputs.split()
@@ -350,6 +438,14 @@ def read_zmx(path):
 
 
 # ---------------------------------------------------------------- .seq
+def _is_number(a):
+    try:
+        float(a)
+        return True
+    except ValueError:
+        return False
+
+
 _ORDER = {'A': 4, 'B': 6, 'C': 8, 'D': 10, 'E': 12, 'F': 14, 'G': 16, 'H': 18, 'J': 20}
 
 
@@ -411,11 +507,42 @@ def read_seq(path):
                 v = float(args[0])
                 p.ifcs[cur].cv = 1.0 / v if v != 0.0 else 0.0
             elif tla in ('CUY', 'CUX'):
-                p.ifcs[cur].cv = float(args[0])
+                if _is_number(args[0]):         # with a qualifier it is a solve: ignored (cmdproc.py:380-383)
+                    p.ifcs[cur].cv = float(args[0])
             elif tla == 'THI':
-                p.thi[cur] = float(args[0])
+                if _is_number(args[0]):         # 'THI HMY 0.0' etc.: a solve, ignored (:384-387)
+                    p.thi[cur] = float(args[0])
             elif tla in ('XDE', 'YDE', 'ZDE', 'ADE', 'BDE', 'CDE', 'DAR', 'BEN', 'REV'):
-                raise UnsupportedModelError('decentered .seq surfaces are not ingested')
+                s = p.ifcs[cur]                 # cmdproc.py:544-576 decenter_data
+                if s.decenter is None:
+                    s.decenter = new_decenter('decenter')
+                if tla in ('XDE', 'YDE', 'ZDE'):
+                    s.decenter['dec']['XYZ'.index(tla[0])] = float(args[0])
+                elif tla in ('ADE', 'BDE', 'CDE'):
+                    s.decenter['euler']['ABC'.index(tla[0])] = float(args[0])
+                else:
+                    s.decenter['dtype'] = {'DAR': 'dec and return', 'BEN': 'bend',
+                                           'REV': 'reverse'}[tla]
+            elif tla in ('CIR', 'REX', 'REY', 'ELX', 'ELY'):
+                # cmdproc.py:452-497 aperture_data: a new aperture unless the last one is
+                # of the same shape; EDG / HOL qualified ones are not clear apertures
+                quals = [a.upper() for a in args if not _is_number(a)]
+                vals = [float(a) for a in args if _is_number(a)]
+                if 'EDG' in quals or 'HOL' in quals or not vals:
+                    continue
+                kind = {'C': 'Circular', 'R': 'Rectangular', 'E': 'Elliptical'}[tla[0]]
+                cas = p.ifcs[cur].apertures
+                if not cas or cas[-1]['kind'] != kind:
+                    cas.append(dict(kind=kind, is_obscuration=False, radius=1.0,
+                                    x_half_width=1.0, y_half_width=1.0))
+                ca = cas[-1]
+                if 'OBS' in quals:
+                    ca['is_obscuration'] = True
+                ca[{'R': 'radius', 'X': 'x_half_width', 'Y': 'y_half_width'}[tla[2]]] = vals[0]
+            elif tla in ('ADX', 'ADY'):         # cmdproc.py:525-541 aperture_offset
+                vals = [float(a) for a in args if _is_number(a)]
+                if p.ifcs[cur].apertures and vals:
+                    p.ifcs[cur].apertures[-1]['x_offset' if tla == 'ADX' else 'y_offset'] = vals[0]
     p.thi.pop()
     p.media.pop()
     return p

@@ -374,6 +374,9 @@ def ingest_tables():
              'zmx_us05831776': 'zemax/tests/US05831776-1.zmx',
              'seq_ag_dblgauss': 'codev/tests/ag_dblgauss.seq',
              'seq_rc_f16': 'codev/tests/rc_f16.seq',
+             'seq_threemir': 'codev/tests/threemir.seq',            # decentered + tilted mirrors
+             'seq_codv_35571': 'codev/tests/CODV_35571.seq',        # off-axis parabola
+             'zmx_zmax_37992': 'zemax/tests/zmax_37992.zmx',        # COORDBRK
              'roa_ritchey_chretien': 'models/Ritchey_Chretien.roa',
              'roa_cell_phone': 'optical/tests/cell_phone_camera.roa'}
     out = {}

@@ -35,7 +35,8 @@ def rows_equal(a, b, what):
 
 @pytest.mark.needs_reference
 @pytest.mark.parametrize('rel', ['zemax/tests/US05831776-1.zmx', 'zemax/tests/354710-C-Zemax(ZMX).zmx',
-                                 'elem/tests/ACL3026U-Zemax(ZMX).zmx'])
+                                 'elem/tests/ACL3026U-Zemax(ZMX).zmx',
+                                 'zemax/tests/zmax_37992.zmx'])         # a COORDBRK fold
 def test_zmx_table_equals_reference_import(rel):
     from oracle import refshim
     refshim.install()
@@ -57,14 +58,27 @@ def test_zmx_table_equals_reference_import(rel):
 
 @pytest.mark.needs_reference
 @pytest.mark.parametrize('rel', ['codev/tests/ag_dblgauss.seq', 'codev/tests/rc_f16.seq',
-                                 'codev/tests/singlet.seq'])
+                                 'codev/tests/singlet.seq',
+                                 'codev/tests/threemir.seq',            # DAR decenters + tilts, REX/REY/ADY
+                                 'codev/tests/CODV_35571.seq'])         # off-axis parabola, XDE..CDE, CIR
 def test_seq_table_equals_reference_import(rel):
     from oracle import refshim
     refshim.install()
     from rayoptics.codev import cmdproc
     from rayoptics_amd import SurfaceTable, ingest
     path = pathlib.Path(REF) / rel
-    opm, _info = cmdproc.read_lens(path, do_update=False)
+    # files that carry aperture data make read_lens trace rays to size the *other* surfaces
+    # (set_clear_apertures, cmdproc.py:89-95: control plane, it needs the element model);
+    # max_aperture is neutralised below, so that step is skipped
+    from rayoptics.seq.sequential import SequentialModel
+    from rayoptics.optical.opticalmodel import OpticalModel
+    saved = SequentialModel.set_clear_apertures, OpticalModel.update_model
+    SequentialModel.set_clear_apertures = lambda self, **kw: None
+    OpticalModel.update_model = lambda self, **kw: None
+    try:
+        opm, _info = cmdproc.read_lens(path, do_update=False)
+    finally:
+        SequentialModel.set_clear_apertures, OpticalModel.update_model = saved
     sm = opm['seq_model']
     sm.update_model()
     theirs = SurfaceTable.from_seq_model(sm)
@@ -117,3 +131,55 @@ def test_nominal_dispersion_matches_the_codev_listing():
     assert abs(ingest.nominal_index('N-BK7', 587.5618) - 1.5168) < 1e-5
     assert abs(ingest.nominal_index('SILICA', 248.0) - 1.5084) < 5e-4
     assert ingest.nominal_index('UNOBTAINIUM', 500.) == 1.5
+
+
+@pytest.mark.needs_reference
+@pytest.mark.parametrize('rel', ['codev/tests/threemir.seq', 'codev/tests/CODV_35571.seq'])
+def test_decentered_ingest_traces_like_the_reference(rel):
+    """end to end on a decentered, tilted system: the table parsed from the file, traced
+    by the oracle, against the reference's rt.trace on the model its own importer built"""
+    from oracle import refshim
+    refshim.install()
+    from rayoptics.codev import cmdproc
+    from rayoptics.seq.sequential import SequentialModel
+    from rayoptics.optical.opticalmodel import OpticalModel
+    import rayoptics.raytr.raytrace as rt
+    from rayoptics.raytr.traceerror import TraceError
+    from oracle import oracle
+    from rayoptics_amd import abi, ingest
+    path = pathlib.Path(REF) / rel
+    saved = SequentialModel.set_clear_apertures, OpticalModel.update_model
+    SequentialModel.set_clear_apertures = lambda self, **kw: None
+    OpticalModel.update_model = lambda self, **kw: None
+    try:
+        opm, _info = cmdproc.read_lens(path, do_update=False)
+    finally:
+        SequentialModel.set_clear_apertures, OpticalModel.update_model = saved
+    sm = opm['seq_model']
+    sm.update_model()
+    tbl = ingest.read_seq(str(path)).to_table()
+    N = tbl.n_ifcs
+    wvl = tbl.wvls[0]
+    rng = np.random.default_rng(5)
+    R = 40
+    tgt = np.stack([rng.uniform(-10, 10, R), rng.uniform(-10, 10, R), np.full(R, 1e3)])
+    pt0 = np.zeros((3, R))
+    pt0[2] = tbl.rows[0].t[2] - 1e3
+    d0 = tgt / np.linalg.norm(tgt, axis=0)
+    opts = oracle.make_opts(flags=abi.INTERSECT_OBJ, first_surf=1, last_surf=N - 2)
+    orc = oracle.trace_rays(tbl, pt0, d0, 0, opts)
+    n_ok = 0
+    for r in range(R):
+        try:
+            ray, op, _w = rt.trace(sm, pt0[:, r].copy(), d0[:, r].copy(), wvl)
+        except TraceError:
+            assert orc.status[r] != abi.OK
+            continue
+        n_ok += 1
+        assert orc.status[r] == abi.OK and op == orc.op[r]
+        for k, seg in enumerate(ray):
+            np.testing.assert_array_equal(seg[0], orc.seg[k, 0:3, r])
+            np.testing.assert_array_equal(seg[1], orc.seg[k, 3:6, r])
+            assert seg[2] == orc.seg[k, 6, r]
+            np.testing.assert_array_equal(seg[3], orc.seg[k, 7:10, r])
+    assert n_ok > 20
