@@ -14,8 +14,8 @@ profile parameters, apertures, interact modes, z_dir bookkeeping
 (rayoptics/seq/sequential.py:611-668) and local transforms
 (rayoptics/elem/transform.py:86-118, 143-166 for undecentered interfaces).
 
-Scope: STANDARD / EVENASPH / CONI / MIRROR / PARAXIAL / DGRATING / COORDBRK
-surfaces of .zmx; S / SO / SI / STO / SPH / CON / ASP / K / A..J / RDY / CUY / THI /
+Scope: STANDARD / EVENASPH / CONI / MIRROR / PARAXIAL / DGRATING / COORDBRK /
+TOROIDAL surfaces of .zmx; S / SO / SI / STO / SPH / CON / ASP / K / A..J / RDY / CUY / THI /
 REFL / WL, the aperture commands CIR / REX / REY / ELX / ELY / ADX / ADY and the
 decenter commands XDE / YDE / ZDE / ADE / BDE / CDE / DAR / BEN / REV of .seq;
 Spherical / Conic / EvenPolynomial / RadialPolynomial profiles, Circular /
@@ -216,7 +216,9 @@ class Prescription:
                 else:
                     row.cc = float(s.cc)
                     row.ec = row.cc + 1.0
-                if s.profile in ('EvenPolynomial', 'RadialPolynomial'):
+                if s.profile in ('YToroid', 'XToroid'):
+                    row.cR = float(getattr(s, 'cR', 0.0))
+                if s.profile in ('EvenPolynomial', 'RadialPolynomial', 'YToroid', 'XToroid'):
                     mnc = 0
                     for k, c in enumerate(s.coefs):
                         if c != 0.0:
@@ -360,8 +362,10 @@ def read_zmx(path):
             elif typ == 'COORDBRK':         # zmxread.py:318-320
                 s.mode = 'phantom'
                 s.decenter = new_decenter('decenter')
-            elif typ == 'TOROIDAL':
-                raise UnsupportedModelError(f'{typ} surfaces are not ingested')
+            elif typ == 'TOROIDAL':         # zmxread.py:308-312 -> YToroid
+                s.profile = 'YToroid'
+                s.cR = 0.0
+                s.coefs = []
             elif typ != 'STANDARD':
                 raise UnsupportedModelError(f'Zemax surface type {typ}')
         elif cmd == 'CONI':
@@ -383,6 +387,11 @@ def read_zmx(path):
                     s.phase['spacing_nm'] = 1e6 / (val * 1000)     # grating_freq_um -> lpmm
                 elif i == 2:
                     s.phase['order'] = val
+            elif s.z_type == 'TOROIDAL':    # zmxread.py:366-370
+                if i == 1:
+                    s.cR = 1.0 / val if val != 0.0 else 0.0     # rR setter, profiles.py:1216-1221
+                elif i > 1:
+                    s.coefs.append(val)
             elif s.z_type == 'COORDBRK':    # zmxread.py:341-355
                 if i in (1, 2):
                     s.decenter['dec'][i - 1] = val

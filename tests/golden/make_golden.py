@@ -377,6 +377,7 @@ def ingest_tables():
              'seq_threemir': 'codev/tests/threemir.seq',            # decentered + tilted mirrors
              'seq_codv_35571': 'codev/tests/CODV_35571.seq',        # off-axis parabola
              'zmx_zmax_37992': 'zemax/tests/zmax_37992.zmx',        # COORDBRK
+             'zmx_hoo_ex46': 'zemax/tests/HoO-V2C18Ex46.zmx',       # COORDBRKs + TOROIDAL
              'roa_ritchey_chretien': 'models/Ritchey_Chretien.roa',
              'roa_cell_phone': 'optical/tests/cell_phone_camera.roa'}
     out = {}

@@ -36,7 +36,8 @@ def rows_equal(a, b, what):
 @pytest.mark.needs_reference
 @pytest.mark.parametrize('rel', ['zemax/tests/US05831776-1.zmx', 'zemax/tests/354710-C-Zemax(ZMX).zmx',
                                  'elem/tests/ACL3026U-Zemax(ZMX).zmx',
-                                 'zemax/tests/zmax_37992.zmx'])         # a COORDBRK fold
+                                 'zemax/tests/zmax_37992.zmx',          # a COORDBRK fold
+                                 'zemax/tests/HoO-V2C18Ex46.zmx'])      # 5 COORDBRK + a TOROIDAL
 def test_zmx_table_equals_reference_import(rel):
     from oracle import refshim
     refshim.install()
