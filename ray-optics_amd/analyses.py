@@ -195,6 +195,28 @@ def eval_wavefront(opt_model, fld, wvl, foc, image_pt_2d=None, image_delta=None,
     return out.reshape(num_rays, num_rays, 3)
 
 
+def seq_trace_wavefront(self, fld, wvl, foc, num_rays=32):
+    """rayoptics/seq/sequential.py:1087-1114 as a replacement *method* of
+    SequentialModel: [x, y, opd] over the unit pupil square, opd in waves
+    (``opd / nm_to_sys_units(wvl)``), 0.0 where the ray failed.  The reference
+    reaches this through trace.trace_grid with a per-ray ``wave_abr_full_calc``
+    callback; here trace and OPD are one ROX_OUT_OPD launch."""
+    from .table import wavefront_from_model
+    opt_model = self.opt_model
+    rs_pkg, cr_pkg = _setup_pupil_coords(opt_model, fld, wvl, foc)
+    fld.chief_ray = cr_pkg
+    fld.ref_sphere = rs_pkg
+    wf = wavefront_from_model(opt_model, fld)
+    # trace.trace_grid forces check_apertures (trace.py:583); trace_base's default vignetting
+    pk = _trace_pupil(opt_model, fld, wvl, dict(check_apertures=True, apply_vignetting=True),
+                      None, None, grid=make_grid((-1., -1.), (1., 1.), num_rays),
+                      out_mode=abi.OUT_OPD, wf=wf)
+    ok = pk.status == abi.OK
+    with np.errstate(invalid='ignore'):
+        opd = np.where(ok, pk.seg[0, 0] / opt_model.nm_to_sys_units(wvl), 0.0)
+    return np.stack([pk.pupil[0], pk.pupil[1], opd], axis=1).reshape(num_rays, num_rays, 3)
+
+
 class _DeferredWavefront:
     """what the fused :func:`trace_wavefront` hands to :func:`focus_wavefront`
     in place of a grid of ray packets: the grid definition and trace options.

@@ -697,3 +697,21 @@ def test_wide_angle_pupil_search_runs_on_the_device_trace(ref, installed):
     for a, b in zip(ours, theirs):
         assert a is not None
         np.testing.assert_array_equal(np.asarray(a, dtype=float), np.asarray(b, dtype=float))
+
+
+@pytest.mark.parametrize('model', ['dblgauss', 'telecentric'])
+def test_sequential_model_trace_wavefront_fused(ref, installed, model):
+    """SequentialModel.trace_wavefront (sequential.py:1087-1114): the reference's
+    trace_grid + per-ray wave_abr_full_calc callback against the fused OPD launch
+    (finite and infinite reference spheres)"""
+    opm = getattr(ref, model)()
+    sm = opm['seq_model']
+    fld = opm['osp']['fov'].fields[-1]
+    wvl = sm.central_wavelength()
+
+    def run():
+        return np.array(sm.trace_wavefront(fld, wvl, 0.0, num_rays=9), dtype=float)
+    ours, theirs = both(installed, run)
+    assert ours.shape == theirs.shape == (9, 9, 3)
+    np.testing.assert_array_equal(ours, theirs)
+    assert np.count_nonzero(ours[:, :, 2]) > 10
