@@ -83,6 +83,12 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with '
                          f'{args.gpus} ranks (WORLD_SIZE={world})')
+    # rehearsal switches (a 1-GPU box cannot run RCCL with two ranks): ROX_BENCH_SHARE_GPU=1
+    # puts every rank on device 0 and ROX_BENCH_BACKEND=gloo carries the collectives --
+    # the N > 1 control flow, partitioning and gathers run as they will over RCCL
+    backend = os.environ.get('ROX_BENCH_BACKEND', 'nccl')
+    if os.environ.get('ROX_BENCH_SHARE_GPU') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_dist
     saved_stdout = None
@@ -94,8 +100,11 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = workloads.load('dblgauss_c2')
     N = wl.n_ifcs
@@ -258,8 +267,19 @@ def main():
             'cpu_baseline': cpu,
             'strong_scaling': strong,
         }
-        print(json.dumps(line))
+        # the one JSON line goes to the real stdout (fd 1 was pointed at stderr while the
+        # communicator was being built and the collectives ran)
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
+            saved_stdout = None
+        print(json.dumps(line), flush=True)
     if multi:
+        if saved_stdout is not None:            # other ranks: keep their fd 1 on stderr
+            os.close(saved_stdout)
+        sys.stdout.flush()
+        os.dup2(2, 1)                           # teardown chatter does not belong on stdout
         dist.destroy_process_group()
 
 
