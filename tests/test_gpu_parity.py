@@ -460,3 +460,61 @@ def test_pupil_list_entry(engines):
                                        C.byref(o2), C.byref(out), None)
     assert rc == 0, load_library().rox_last_error()
     assert_same_as_oracle(res, orc, 'explicit rays, host pointers')
+
+
+@pytest.mark.parametrize('name', ['dblgauss', 'dblgauss_finite', 'singlet', 'rc_telescope', 'nikkor',
+                                  'cell_phone', 'tilted_singlet', 'toroid_lens', 'telecentric'])
+def test_random_ray_differential_set(engines, name):
+    """SURVEY 8(d)'s differential set: 2^20 random rays per fixture (rng 20260925), landing
+    uniformly in the first surface's aperture disc from 10...1000 units in front of it with
+    directions normalise(U(-.3,.3), U(-.3,.3), 1), random wavelengths; FULL packets, status,
+    failing surface and op bit-exact against the oracle, in chunks of 2^18 rays"""
+    import threading
+    from oracle import oracle
+    fx = H.fixture(name)
+    tbl = fx.table
+    N = tbl.n_ifcs
+    eng = engines(name)
+    rng = np.random.default_rng(20260925)
+    ap1 = float(tbl.rows[1].max_aperture)
+    thi0 = float(tbl.rows[0].t[2])
+    chunk, n_chunks = 1 << 18, 4
+    flags = abi.CHECK_APERTURES                             # rays start in front of surface 1
+    opts = oracle.make_opts(flags=flags, first_surf=1, last_surf=N - 2)
+    n_ok = 0
+    for c in range(n_chunks):
+        R = chunk
+        rad = ap1 * np.sqrt(rng.uniform(0, 1, R))
+        phi = rng.uniform(0, 2 * np.pi, R)
+        d = np.stack([rng.uniform(-.3, .3, R), rng.uniform(-.3, .3, R), np.ones(R)])
+        d /= np.linalg.norm(d, axis=0)
+        dz = rng.uniform(10., 1000., R)
+        pt0 = np.stack([rad * np.cos(phi) - dz * d[0] / d[2], rad * np.sin(phi) - dz * d[1] / d[2],
+                        thi0 - dz])
+        wi = rng.integers(0, len(tbl.wvls), R).astype(np.int32)
+        # the oracle is single-threaded C behind ctypes (the GIL is released): 8 slices
+        parts = [None] * 8
+        bounds = [(R * k) // 8 for k in range(9)]
+
+        def work(k):
+            s = slice(bounds[k], bounds[k + 1])
+            with np.errstate(all='ignore'):
+                parts[k] = oracle.trace_rays(tbl, np.ascontiguousarray(pt0[:, s]),
+                                             np.ascontiguousarray(d[:, s]),
+                                             np.ascontiguousarray(wi[s]), opts)
+        thr = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+        for t in thr:
+            t.start()
+        dev = eng.trace_rays(pt0, d, wi, opts, nan_fill=True).to_host()
+        for t in thr:
+            t.join()
+        status = np.concatenate([p.status for p in parts])
+        np.testing.assert_array_equal(dev.status, status, err_msg=f'{name} chunk {c}')
+        np.testing.assert_array_equal(dev.fail_surf, np.concatenate([p.fail_surf for p in parts]))
+        op = np.concatenate([p.op for p in parts])
+        assert np.array_equal(dev.op, op, equal_nan=True), (name, c)
+        seg = np.concatenate([p.seg for p in parts], axis=2)
+        same = (dev.seg == seg) | (np.isnan(dev.seg) & np.isnan(seg))
+        assert same.all(), (name, c, int((~same).sum()))
+        n_ok += int((status == abi.OK).sum())
+    assert n_ok > 50, (name, n_ok)          # (the RC telescope passes ~1e-4 of such rays)
