@@ -303,7 +303,10 @@ const char *rox_last_error(void);
  * Threading: launches on different HIP streams and from different host threads
  * may share one handle -- per-launch scratch (cached pupil axes, compaction
  * state) is kept per stream behind a mutex.  Launches on one stream run in
- * stream order as usual. */
+ * stream order as usual.  The scratch of a stream (a few KB, plus the staging
+ * arena of ROX_HOST_POINTERS calls made on it) lives until rox_system_destroy:
+ * use a bounded set of streams per handle, and do not issue launches on one
+ * stream from two host threads at once. */
 int rox_system_create(const rox_surface *rows, int32_t n_ifcs,
                       const double *n_table, const double *wvls, int32_t n_wvls,
                       rox_system **out_sys);
