@@ -408,6 +408,16 @@ def psf_cases():
         out[f'{tag}/opd'] = opd
         out[f'{tag}/dims'] = np.array([ndim, maxdim])
         out[f'{tag}/psf'] = analyses.calc_psf(opd, ndim, maxdim)
+        # what the device needs to reproduce that OPD grid itself (trace -> OPD -> PSF)
+        from rayoptics_amd.table import wavefront_from_model, wavefront_to_array
+        vig_bbox = fld.vignetting_bbox(osp['pupil'], oversize=1.)
+        out[f'{tag}/field'] = field_arr(field_from_model(opm, fld))
+        out[f'{tag}/wavefront'] = wavefront_to_array(wavefront_from_model(opm, fld))
+        out[f'{tag}/bbox'] = np.array([vig_bbox[0], vig_bbox[1]], dtype=float)
+        out[f'{tag}/wvl_idx'] = np.int64(list(osp['wvls'].wavelengths).index(wvl))
+        out[f'{tag}/convert_to_opd'] = np.float64(1 / opm.nm_to_sys_units(wvl))
+    out['dblgauss_table_json'] = np.array(json.dumps(
+        ra.SurfaceTable.from_seq_model(opm['seq_model']).to_dict()))
     rng = np.random.default_rng(SEED + 5)
     for tag, ndim, maxdim in (('synthetic_small', 8, 12), ('synthetic_coma', 16, 50)):
         y, x = np.mgrid[-1:1:ndim * 1j, -1:1:ndim * 1j]
