@@ -305,8 +305,9 @@ const char *rox_last_error(void);
  * state) is kept per stream behind a mutex.  Launches on one stream run in
  * stream order as usual.  The scratch of a stream (a few KB, plus the staging
  * arena of ROX_HOST_POINTERS calls made on it) lives until rox_system_destroy:
- * use a bounded set of streams per handle, and do not issue launches on one
- * stream from two host threads at once. */
+ * use a bounded set of streams per handle, and do not issue device-pointer
+ * launches on one stream from two host threads at once (ROX_HOST_POINTERS
+ * calls, which are synchronous, take turns per stream by themselves). */
 int rox_system_create(const rox_surface *rows, int32_t n_ifcs,
                       const double *n_table, const double *wvls, int32_t n_wvls,
                       rox_system **out_sys);

@@ -183,6 +183,7 @@ struct StreamCtx {
     // block for small ones (grow-only)
     char *d_stage = nullptr, *h_stage = nullptr;
     size_t d_stage_cap = 0, h_stage_cap = 0;
+    std::mutex stage_mu;                // one ROX_HOST_POINTERS call at a time per stream
 };
 
 }  // namespace
@@ -453,6 +454,7 @@ __global__ void fill_nan_kernel(double *p, size_t n)
 }
 
 struct Staged {
+    std::unique_lock<std::mutex> lock;  // holds the stream's staging arena until the call returns
     rox_out dev{};          // staging buffers (device-visible)
     rox_out host{};         // caller's host buffers
     int64_t n = 0, rows = 0;
@@ -461,6 +463,19 @@ struct Staged {
 };
 
 inline size_t up16(size_t b) { return (b + 15) & ~size_t(15); }
+
+// ROX_HOST_POINTERS calls are synchronous; two host threads on one stream (typically the
+// NULL stream of ctypes callers) take turns with the stream's scratch -- the cached pupil
+// axes as well as the staging arena -- from before the launch is prepared until the
+// results are in place
+int stage_lock(Staged &s, rox_system *sys, hipStream_t st)
+{
+    StreamCtx *cx = ctx_for(sys, st);
+    if (!cx)
+        return fail(ROX_E_NOMEM, "out of host memory");
+    s.lock = std::unique_lock<std::mutex>(cx->stage_mu);
+    return 0;
+}
 
 int stage_out(Staged &s, rox_system *sys, hipStream_t st, const rox_opts *o, const rox_out *out,
               int64_t n, size_t in_bytes)
@@ -844,6 +859,8 @@ int rox_trace_rays(rox_system *sys, int64_t n_rays, const double *pt0, const dou
             if (wvl_idx[i] < 0 || wvl_idx[i] >= sys->n_wvls)
                 return fail(ROX_E_ARG, "wvl_idx[%lld] = %d out of range", (long long)i, wvl_idx[i]);
     Staged s;
+    if ((rc = stage_lock(s, sys, st)))
+        return rc;
     const size_t vb = sizeof(double) * 3 * (size_t)n_rays;
     const size_t wb = wvl_idx ? sizeof(int32_t) * (size_t)n_rays : 0;
     rc = stage_out(s, sys, st, opts, out, n_rays, 2 * vb + wb);
@@ -867,12 +884,15 @@ int rox_trace_pupil_grid(rox_system *sys, const rox_field *fld, const rox_grid *
         return fail(ROX_E_ARG, "null system");
     hipStream_t st = (hipStream_t)stream;
     TraceArgs a;
-    int rc = prepare_grid(sys, fld, grid, wvl_idx, opts, out, st, a);
+    Staged s;
+    int rc;
+    if (opts && (opts->flags & ROX_HOST_POINTERS) && (rc = stage_lock(s, sys, st)))
+        return rc;
+    rc = prepare_grid(sys, fld, grid, wvl_idx, opts, out, st, a);
     if (rc)
         return rc;
     if (!(opts->flags & ROX_HOST_POINTERS))
         return launch(sys, a, GEN_PUPIL, st);
-    Staged s;
     rc = stage_out(s, sys, st, opts, out, a.n_rays, 0);
     if (rc)
         return rc;
@@ -908,6 +928,8 @@ int rox_trace_pupil_list(rox_system *sys, const rox_field *fld, int64_t n_rays, 
         return launch(sys, a, GEN_PUPIL, st);
     }
     Staged s;
+    if ((rc = stage_lock(s, sys, st)))
+        return rc;
     const size_t pb = sizeof(double) * (size_t)n_rays;
     rc = stage_out(s, sys, st, opts, out, n_rays, 2 * pb);
     if (rc)

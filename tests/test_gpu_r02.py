@@ -521,3 +521,55 @@ def test_host_pointer_staging_small_and_large(engines, num):
     bit_equal(res.seg, orc.seg, 'explicit rays seg')
     bit_equal(res.status, orc.status, 'explicit rays status')
     bit_equal(res.op, orc.op, 'explicit rays op')
+
+
+def test_host_pointer_calls_from_several_threads_on_the_null_stream(engines):
+    """the maintainer stub's usage: plain NumPy buffers, stream NULL, and
+    several Python threads calling into one handle at once (ctypes releases the GIL);
+    calls on one stream take turns with the staging arena"""
+    import threading
+    from oracle import oracle
+    from rayoptics_amd.engine import load_library
+    lib = load_library()
+    fx = H.fixture('dblgauss')
+    c = fx['grid_f2']
+    fld = H.field_from_arr(c['field'])
+    N = fx.table.n_ifcs
+    eng = engines('dblgauss')
+    nums = [5, 9, 33, 120]                  # pinned-block path and (120 x 120 FULL = 15 MB) the arena path
+    want = []
+    for k, num in enumerate(nums):
+        opts = oracle.make_opts(flags=FLAGS, first_surf=1, last_surf=N - 2)
+        want.append(oracle.trace_pupil_grid(fx.table, fld, oracle.make_grid((-1., -1.), (1., 1.), num),
+                                            k % 3, opts))
+    errs = []
+
+    def worker(k):
+        try:
+            num = nums[k]
+            R = num * num
+            grid = oracle.make_grid((-1., -1.), (1., 1.), num)
+            opts = oracle.make_opts(flags=FLAGS | abi.HOST_POINTERS, first_surf=1, last_surf=N - 2)
+            for _ in range(12):
+                res = oracle.HostResult(N, R, abi.OUT_FULL, want_pupil=True)
+                res.seg[:] = 7.0
+                out = res.out_struct()
+                rc = lib.rox_trace_pupil_grid(eng._handle, C.byref(fld), C.byref(grid), k % 3,
+                                              C.byref(opts), C.byref(out), None)
+                if rc:
+                    errs.append((k, lib.rox_last_error()))
+                    return
+                w = want[k]
+                same = (res.seg == w.seg) | (np.isnan(res.seg) & np.isnan(w.seg))
+                if not (same.all() and np.array_equal(res.status, w.status)
+                        and np.array_equal(res.op, w.op, equal_nan=True)):
+                    errs.append((k, 'mismatch'))
+                    return
+        except Exception as e:      # noqa: BLE001
+            errs.append((k, repr(e)))
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(len(nums))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
