@@ -170,6 +170,7 @@ struct Workspace {
     hipStream_t stream = nullptr;
     char *buf = nullptr;
     size_t cap = 0;
+    std::mutex mu;          // one call at a time builds / enqueues on this workspace
 };
 std::mutex g_mu;
 std::vector<Workspace *> g_ws;
@@ -228,6 +229,9 @@ extern "C" int rox_calc_psf(const double *opd, int32_t ndim, int32_t maxdim, dou
     Workspace *ws = workspace_for(device, st);
     if (!ws)
         return rox::host_fail(ROX_E_NOMEM, "rox_calc_psf: out of host memory");
+    // calls on one stream share the workspace: enqueue them whole, one after the other
+    // (stream order then keeps their kernels apart); host-pointer calls hold it until done
+    std::lock_guard<std::mutex> turn(ws->mu);
 
     const bool host = (flags & ROX_HOST_POINTERS) != 0;
     const int64_t kp = round_up(n, kKBlock), mp = round_up(M, kTile), np_ = round_up(n, kTile);

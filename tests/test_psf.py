@@ -149,3 +149,29 @@ def test_trace_to_psf_on_the_device(tag):
     psf = analyses.calc_psf(opd, ndim, maxdim)
     np.testing.assert_allclose(psf, z[f'{tag}/psf'], rtol=0, atol=1e-9)
     session.clear()
+
+
+@pytest.mark.gpu
+def test_psf_calls_from_several_threads():
+    """host-array calls from several Python threads (NULL stream, shared workspace)"""
+    import threading
+    from rayoptics_amd.engine import calc_psf
+    rng = np.random.default_rng(9)
+    jobs = []
+    for ndim, maxdim in ((8, 20), (16, 64), (32, 100), (64, 256)):
+        opd = 0.7 * rng.standard_normal((ndim, ndim))
+        jobs.append((opd, ndim, maxdim, calc_psf(opd, ndim, maxdim)))
+    errs = []
+
+    def worker(k):
+        opd, ndim, maxdim, want = jobs[k]
+        for _ in range(30):
+            if not np.array_equal(calc_psf(opd, ndim, maxdim), want):
+                errs.append(k)
+                return
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(len(jobs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
