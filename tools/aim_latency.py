@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Latency of the batched chief-ray aiming entry (rox_aim_chief_rays: every field of a model
+in one launch, secant iteration per lane).  The reference aims field by field with ~10 Python
+single-ray traces each on every update_optical_properties().
+
+    python tools/aim_latency.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import rayoptics_amd  # noqa: F401
+    from rayoptics_amd import abi, workloads
+    from rayoptics_amd.engine import TraceEngine
+    for name in ('dblgauss_c2', 'nikkor_c3', 'cell_phone', 'rc_telescope_c4'):
+        wl = workloads.load(name)
+        if not wl.aim:
+            continue
+        eng = TraceEngine(wl.table)
+        probs = []
+        for m in wl.aim:
+            a = abi.Aim()
+            for i in range(3):
+                a.pt0[i] = m['pt0'][i]
+            a.z_enp, a.y_target, a.z_dir0 = m['z_enp'], 0.0, m['z_dir0']
+            a.wvl_idx, a.surf, a.flip = m['wvl_idx'], m['surf'], 1
+            probs.append(a)
+        for _ in range(5):
+            eng.aim_chief_rays(probs)
+        t = []
+        for _ in range(60):
+            t0 = time.perf_counter()
+            eng.aim_chief_rays(probs)
+            t.append(time.perf_counter() - t0)
+        print(json.dumps({'workload': name, 'interfaces': wl.n_ifcs, 'fields_aimed': len(probs),
+                          'ms_median': float(np.median(t) * 1e3), 'ms_min': float(np.min(t) * 1e3)}))
+        eng.close()
+
+
+if __name__ == '__main__':
+    main()
