@@ -109,13 +109,23 @@ __global__ __launch_bounds__(256) void cgemm_nt(const double *__restrict__ ar_, 
     const double *pb_r = br_ + (size_t)(j0 + r) * kp + 4 * g;
     const double *pb_i = bi_ + (size_t)(j0 + r) * kp + 4 * g;
     const size_t t16 = (size_t)16 * kp;
+    // software pipeline: the operands of k block i + 1 are in flight while the 64 MFMAs of
+    // block i issue (a lone wave per SIMD has nobody else to hide the load latency behind)
+    d4 xr[2], xi[2], yr[2], yi[2];
+    for (int t = 0; t < 2; ++t) {
+        xr[t] = *(const d4 *)(pa_r + t * t16);
+        xi[t] = *(const d4 *)(pa_i + t * t16);
+        yr[t] = *(const d4 *)(pb_r + t * t16);
+        yi[t] = *(const d4 *)(pb_i + t * t16);
+    }
     for (int k0 = 0; k0 < kp; k0 += kKBlock) {
-        d4 xr[2], xi[2], yr[2], yi[2], xn[2];
+        d4 nxr[2], nxi[2], nyr[2], nyi[2], xn[2];
+        const int kn = (k0 + kKBlock < kp) ? k0 + kKBlock : k0;     // last block: a harmless reload
         for (int t = 0; t < 2; ++t) {
-            xr[t] = *(const d4 *)(pa_r + t * t16 + k0);
-            xi[t] = *(const d4 *)(pa_i + t * t16 + k0);
-            yr[t] = *(const d4 *)(pb_r + t * t16 + k0);
-            yi[t] = *(const d4 *)(pb_i + t * t16 + k0);
+            nxr[t] = *(const d4 *)(pa_r + t * t16 + kn);
+            nxi[t] = *(const d4 *)(pa_i + t * t16 + kn);
+            nyr[t] = *(const d4 *)(pb_r + t * t16 + kn);
+            nyi[t] = *(const d4 *)(pb_i + t * t16 + kn);
             xn[t] = -xi[t];
         }
 #pragma unroll
@@ -129,6 +139,9 @@ __global__ __launch_bounds__(256) void cgemm_nt(const double *__restrict__ ar_, 
                     ci[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[a][e], yi[b][e], ci[a][b], 0, 0, 0);
                     ci[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xi[a][e], yr[b][e], ci[a][b], 0, 0, 0);
                 }
+        for (int t = 0; t < 2; ++t) {
+            xr[t] = nxr[t]; xi[t] = nxi[t]; yr[t] = nyr[t]; yi[t] = nyi[t];
+        }
     }
     double vmax = 0.0;
     for (int a = 0; a < 2; ++a)
