@@ -43,6 +43,7 @@ def install(fallback='raise'):
         uninstall()
     session.FALLBACK = fallback
     seams = [(rraytrace, 'trace', _t.raytrace_trace),
+             (rraytrace, 'trace_raw', _t.raytrace_trace_raw),
              (rtrace, 'trace_grid', _t.trace_grid), (rtrace, 'trace_fan', _t.trace_fan),
              (ranalyses, 'trace_list_of_rays', _a.trace_list_of_rays),
              (ranalyses, 'trace_ray_list', _a.trace_ray_list),

@@ -131,7 +131,28 @@ def _weakrefable(obj):
         return False
 
 
+_by_table = {}              # table bytes -> engine (paths handed to trace_raw), LRU order
+MAX_TABLE_ENGINES = 8
+
+
+def engine_for_table(table):
+    """the engine of a surface table that did not come from a SequentialModel (a path
+    list handed to ``raytrace.trace_raw``: ``gen_sequence`` output, reversed paths),
+    cached by the table's bytes"""
+    sig = bytes(table.rows) + table.n_table.tobytes() + repr(table.wvls).encode()
+    eng = _by_table.pop(sig, None)
+    if eng is None:
+        eng = _factory()(table)
+    _by_table[sig] = eng                # most recently used last
+    while len(_by_table) > MAX_TABLE_ENGINES:
+        _by_table.pop(next(iter(_by_table))).close()
+    return eng
+
+
 def clear():
     for ent in _cache.values():
         ent.engine.close()
     _cache.clear()
+    for eng in _by_table.values():
+        eng.close()
+    _by_table.clear()

@@ -5,6 +5,7 @@ the per-ray Python loop replaced by one device launch.
   trace_grid      <- rayoptics/raytr/trace.py:563-605
   trace_fan       <- rayoptics/raytr/trace.py:537-560
   seq_trace_grid  <- rayoptics/seq/sequential.py:1058-1085 (method)
+  raytrace_trace_raw <- rayoptics/raytr/raytrace.py:83-264 trace_raw() on an explicit path list
   raytrace_trace  <- rayoptics/raytr/raytrace.py:51-80 trace(): one ray per call, for the
                      reference's own iterative callers (trace_base, iterate_ray's 2-D
                      fsolve branch, the wide-angle pupil search, trace_chief_ray ...)
@@ -85,6 +86,50 @@ def raytrace_trace(seq_model, pt0, dir0, wvl, **kwargs):
                 float(h.op[0]), wvl)
     pk = HostPackets(h, tbl, opts.flags, abi.OUT_FULL, wv)
     err = pk.error(0, getattr(seq_model, 'ifcs', None), with_pkg=True, named=False)
+    ray, op, _w = err.ray_pkg
+    err.ray_pkg = (ray.to_list(), op, wvl)
+    raise err
+
+
+def raytrace_trace_raw(path, pt0, dir0, wvl, eps=1.0e-12, check_apertures=False,
+                       intersect_obj=True, filter_out_phantoms=False, **kwargs):
+    """rayoptics/raytr/raytrace.py:83-264 ``trace_raw``: one ray through an explicit path
+    -- any iterable of ``(Intfc, Gap, Tfrm, Index, Z_Dir)`` tuples: ``gen_sequence`` output
+    (the reference's own unit test, raytr/tests/test_sequential.py), a reversed path
+    (``iterate_ray_raw``, wideangle.py:646).  The path is flattened to a surface table on
+    every call (it may be a one-shot generator) and the device handle is cached by the
+    table's bytes; first_surf / last_surf default as in trace_raw itself (0, None)."""
+    from .table import SurfaceTable, UnsupportedModelError
+    path = list(path)
+    try:
+        tbl = SurfaceTable.from_paths([path], [0.0 if wvl is None else float(wvl)])
+    except UnsupportedModelError:
+        # the path may have been a one-shot iterator: under install('reference') the
+        # reference's own trace_raw gets the materialised list, not the spent iterator
+        if session.FALLBACK == 'reference':
+            from . import install
+            import rayoptics.raytr.raytrace as rraytrace
+            theirs = install._saved.get((rraytrace, 'trace_raw'))
+            if theirs is not None:
+                return theirs(iter(path), pt0, dir0, wvl, eps=eps, check_apertures=check_apertures,
+                              intersect_obj=intersect_obj,
+                              filter_out_phantoms=filter_out_phantoms, **kwargs)
+        raise
+    eng = session.engine_for_table(tbl)
+    flags = (abi.CHECK_APERTURES if check_apertures else 0) | \
+        (abi.INTERSECT_OBJ if intersect_obj else 0) | \
+        (abi.FILTER_PHANTOMS if filter_out_phantoms else 0)
+    last = kwargs.get('last_surf', None)
+    fuzz = kwargs.get('pt_inside_fuzz', None)
+    opts = make_opts(flags=flags, out_mode=abi.OUT_FULL, first_surf=kwargs.get('first_surf', 0),
+                     last_surf=-1 if last is None else last, eps=eps,
+                     fuzz=1e-5 if fuzz is None else fuzz)
+    h = eng.trace_one(pt0, dir0, 0, opts)
+    if h.status[0] == abi.OK:
+        return ([[s[0:3], s[3:6], float(s[6]), s[7:10]] for s in h.seg[:, :, 0]],
+                float(h.op[0]), wvl)
+    pk = HostPackets(h, tbl, opts.flags, abi.OUT_FULL, tbl.wvls[0])
+    err = pk.error(0, [seg[0] for seg in path], with_pkg=True, named=False)
     ray, op, _w = err.ray_pkg
     err.ray_pkg = (ray.to_list(), op, wvl)
     raise err

@@ -715,3 +715,64 @@ def test_sequential_model_trace_wavefront_fused(ref, installed, model):
     assert ours.shape == theirs.shape == (9, 9, 3)
     np.testing.assert_array_equal(ours, theirs)
     assert np.count_nonzero(ours[:, :, 2]) > 10
+
+
+def test_the_references_own_raytrace_unit_test_over_the_seam(ref, installed):
+    """the recipe of raytr/tests/test_sequential.py (the reference's unit test of this path:
+    trace_raw over a gen_sequence path, the CODE V marginal ray) with raytrace.trace_raw
+    rebound: the same packet bit for bit (the unit test's own verdict in this container is the
+    same either way: its image-plane row is outside its 3e-6 tolerance with the reference's own
+    code too); and trace_raw on a sequential model's own path, errors included"""
+    import copy
+    import sys
+    import rayoptics.raytr.raytrace as rt
+    from rayoptics.raytr.traceerror import TraceError
+    from rayoptics.seq.sequential import gen_sequence
+    from rayoptics.util.misc_math import normalize
+    sys.path.insert(0, '/root/reference/src/rayoptics/raytr/tests')
+    import ag_dblgauss_s as dblg
+    import marginal_ray as f1r2
+    data = copy.deepcopy(dblg.ag_dblgauss)
+    data[-2][1] += data[-1][1]                      # setUp: defocus lumped into the back focus
+    data[-1][1] = 0.
+    p0 = np.array([0., 0., 0.])
+    d0 = normalize((np.array([0., 0., data[0][1]]) + np.array([25., 0., 0.])) - p0)
+
+    def unit_test_ray():
+        assert getattr(rt.trace_raw, '__wrapped__', None) is not None or not _installed_now()
+        return rt.trace_raw(gen_sequence(data, wvl=587.6, radius_mode=False), p0, d0, 587.6)
+
+    def _installed_now():
+        from rayoptics_amd import install
+        return bool(install._saved)
+    ours, theirs = both(installed, unit_test_ray)
+    same_pkg(ours, theirs)
+    for i, (seg, truth) in enumerate(zip(ours[0], f1r2.rayf1r2)):
+        if 0 < i < len(ours[0]) - 1:                # (object and image rows: see the docstring)
+            np.testing.assert_allclose(seg[0], truth[0], rtol=1e-4, atol=1e-6)
+
+    opm = ref.dblgauss()
+    sm = opm['seq_model']
+    fld = opm['osp']['fov'].fields[2]
+    rng = np.random.default_rng(3)
+    cases = []
+    for k in range(10):
+        pt0, d0 = [np.array(v, dtype=float) for v in
+                   opm['osp'].ray_start_from_osp(list(rng.uniform(-1.2, 1.2, 2)), fld, 'rel pupil')[:2]]
+        cases.append((pt0, d0, dict(check_apertures=bool(k % 2), first_surf=1,
+                                    last_surf=len(sm.ifcs) - 2)))
+
+    def run():
+        out = []
+        for pt0, d0, kw in cases:
+            try:
+                out.append(rt.trace_raw(sm.path(587.6), pt0, d0, 587.6, **kw))
+            except TraceError as e:
+                out.append(e)
+        return out
+    ours, theirs = both(installed, run)
+    for a, b in zip(ours, theirs):
+        if isinstance(b, Exception):
+            _same_error(a, b)
+        else:
+            same_pkg(a, b)

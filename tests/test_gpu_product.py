@@ -176,6 +176,69 @@ def test_single_ray_trace_product_function():
     session.clear()
 
 
+def test_trace_raw_on_an_explicit_path_list():
+    """trace.raytrace_trace_raw (what raytrace.trace_raw is rebound to): a path of
+    (Intfc, Gap, Tfrm, Index, Z_Dir) tuples -- stand-in objects with the attributes the
+    reference's carry -- flattened per call, the handle cached by the table's bytes;
+    first_surf / last_surf defaulting to 0 / None as in trace_raw"""
+    from oracle import oracle
+    from rayoptics_amd import SurfaceTable, session, trace
+    from rayoptics_amd.traceerror import TraceError
+
+    class Spherical:
+        def __init__(self, cv):
+            self.cv = cv
+
+    class Conic(Spherical):
+        def __init__(self, cv, cc):
+            self.cv, self.cc, self.ec = cv, cc, cc + 1.0
+
+    class Circular:
+        def __init__(self, radius):
+            self.radius = radius
+
+    class Ifc:
+        def __init__(self, profile, mode='transmit', max_aperture=1.0, ca=None):
+            self.profile, self.interact_mode, self.max_aperture = profile, mode, max_aperture
+            self.clear_apertures = ca or []
+
+    eye, zero = np.identity(3), np.zeros(3)
+    th = np.deg2rad(3.0)
+    tilt = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]])
+
+    def path():     # a generator, as seq_model.path() hands one out
+        yield (Ifc(Spherical(0.0), 'dummy'), None, (eye, np.array([0., 0., 50.])), 1.0, 1.0)
+        yield (Ifc(Conic(0.02, -0.4), max_aperture=9.0, ca=[Circular(9.0)]), None,
+               (tilt.T, np.array([0., 0.3, 4.])), 1.5168, 1.0)
+        yield (Ifc(Spherical(-0.015), max_aperture=9.0), None, (eye, np.array([0., 0., 60.])), 1.0, 1.0)
+        yield (Ifc(Spherical(0.0), 'dummy'), None, None, 1.0, 1.0)
+    tbl = SurfaceTable.from_paths([list(path())], [550.0])
+    rng = np.random.default_rng(2)
+    n_err = 0
+    for k in range(40):
+        pt0 = np.array([rng.uniform(-6, 6), rng.uniform(-6, 6), 0.])
+        d0 = np.array([rng.uniform(-.15, .15), rng.uniform(-.15, .15), 1.])
+        d0 /= np.linalg.norm(d0)
+        ca = bool(k % 2)
+        opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | (abi.CHECK_APERTURES if ca else 0))
+        o = oracle.trace_rays(tbl, pt0.reshape(3, 1), d0.reshape(3, 1), 0, opts)
+        try:
+            ray, op, wvl = trace.raytrace_trace_raw(path(), pt0, d0, 550.0, check_apertures=ca)
+            assert int(o.status[0]) == abi.OK and len(ray) == 4
+        except TraceError as e:
+            n_err += 1
+            assert int(o.status[0]) != abi.OK and e.surf == int(o.fail_surf[0])
+            ray, op, wvl = e.ray_pkg
+        assert op == float(o.op[0]) and wvl == 550.0
+        for j, seg in enumerate(ray):
+            np.testing.assert_array_equal(seg[0], o.seg[j, 0:3, 0])
+            np.testing.assert_array_equal(seg[1], o.seg[j, 3:6, 0])
+            assert seg[2] == o.seg[j, 6, 0]
+    assert n_err >= 1
+    assert len(session._by_table) == 1              # one handle for the 40 calls
+    session.clear()
+
+
 def test_config5_full_size_on_one_gpu():
     """BASELINE configs[4] in full: 9 fields x 5 wavelengths x 2048 x 2048 pupil
     grids (188.7 M rays, HITS, 3.2 GB) of the 44-interface lithography lens
