@@ -776,3 +776,24 @@ def test_the_references_own_raytrace_unit_test_over_the_seam(ref, installed):
             _same_error(a, b)
         else:
             same_pkg(a, b)
+
+
+def test_reverse_path_trace_through_the_trace_raw_seam(ref, installed):
+    """wideangle.eval_real_image_ht (wideangle.py:620-664): iterate_ray_raw over the
+    *reversed* path of the model, i.e. raytrace.trace_raw on an explicit path list driven by
+    scipy's secant -- rebound, it runs on the device trace and returns the reference's values"""
+    import rayoptics.raytr.wideangle as wideangle
+    for build in (ref.dblgauss, ref.singlet):
+        opm = build()
+        sm = opm['seq_model']
+        wvl = sm.central_wavelength()
+
+        def run():
+            out = []
+            for fld in opm['osp']['fov'].fields:
+                (p_o, d_o), z_enp = wideangle.eval_real_image_ht(opm, fld, wvl)
+                out.append(np.concatenate([np.asarray(p_o, float), np.asarray(d_o, float), [z_enp]]))
+            return np.array(out)
+        ours, theirs = both(installed, run)
+        assert np.isfinite(theirs).all()
+        np.testing.assert_array_equal(ours, theirs)
