@@ -84,3 +84,35 @@ def test_struct_layouts_match_header(tmp_path):
         assert int(got[cname]) == C.sizeof(st), cname
         for fname, _t in st._fields_:
             assert int(got[f'{cname}.{fname}']) == getattr(st, fname).offset, f'{cname}.{fname}'
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: no module of the product package (nor the examples)
+    imports, loads or names it; importing the package does not pull it in either"""
+    import ast
+    import subprocess
+    import sys
+    pkg = os.path.join(ROOT, 'ray-optics_amd')
+    files = [os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith('.py')]
+    files += [os.path.join(ROOT, 'rayoptics_amd.py')]
+    files += [os.path.join(ROOT, 'examples', f) for f in os.listdir(os.path.join(ROOT, 'examples'))
+              if f.endswith('.py')]
+    for path in files:
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ''] + [a.name for a in node.names]
+            assert not any(n.split('.')[0] == 'oracle' or 'rox_oracle' in n for n in names), path
+            if isinstance(node, ast.Constant) and isinstance(node.value, str):
+                assert 'librox_oracle' not in node.value, path
+    for src in os.listdir(os.path.join(pkg, 'csrc')):
+        assert 'oracle' not in open(os.path.join(pkg, 'csrc', src)).read().lower(), src
+    code = ('import sys; sys.path.insert(0, %r); import rayoptics_amd; '
+            'import rayoptics_amd.trace, rayoptics_amd.analyses, rayoptics_amd.ingest, '
+            'rayoptics_amd.dist, rayoptics_amd.vigcalc; '
+            'assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules), '
+            '[m for m in sys.modules if m.startswith("oracle")]' % ROOT)
+    subprocess.check_call([sys.executable, '-c', code])
