@@ -125,6 +125,20 @@ __global__ void __launch_bounds__(kBlock) selftest_kernel(uint64_t n, uint64_t s
             if (kind >= 3)
                 atomicAdd(&counts[3], 1ull);
         }
+        // unit(): one decision for its sqrt and quotients (the numerators' upper edge is
+        // implied by |v_i| <= |v|).  Components of very different magnitudes, some scaled
+        // down to the band's lower edge and below, zeros included.
+        {
+            const double sc[4] = {1.0, 0x1p-200, 0x1p-381, 0x1p-390};
+            // (scales are wave-uniform so that whole waves sit on either side of the edge)
+            const double k0 = sc[(wv >> 4) & 3], k1 = sc[(wv >> 6) & 3], k2 = sc[(wv >> 8) & 3];
+            const v3 w{a0 * k0, (mix64(k + 9) & 7) == 0 ? 0.0 : a1 * k1, a2 * k2};
+            const v3 u = unit(w);
+            const double len = sqrt(dot3(w, w));
+            const v3 r = (len == 0.0) ? w : v3{w.x / len, w.y / len, w.z / len};
+            if (!same_bits(u.x, r.x) || !same_bits(u.y, r.y) || !same_bits(u.z, r.z))
+                atomicAdd(&counts[1], 1ull);
+        }
         // the sqrt-free aperture test: (sqrt(s) <= t) == (s <= sqrt_le_threshold(t)) for s
         // within a few ulps of t*t and far from it (mismatches are counted as sqrt mismatches)
         {
