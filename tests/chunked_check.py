@@ -1,6 +1,7 @@
 """run by tests/test_gpu_r02.py::test_chunked_launches in a subprocess with
 ROX_RAYS_PER_LAUNCH set (the library reads it once): a ragged batch over the
-multi-launch path, every output mode, vs the oracle."""
+multi-launch path, every output mode (OPD and FAN epilogues, host-pointer staging
+included), vs the oracle."""
 import os
 import sys
 
@@ -45,6 +46,36 @@ for name in ('dblgauss', 'tilted_singlet'):
         same(dev.seg, orc.seg, f'{name} mode {mode} seg')
         same(dev.op, orc.op, f'{name} mode {mode} op')
         same(dev.pupil, orc.pupil, f'{name} mode {mode} pupil')
+    # OPD and FAN epilogues over several launches (dblgauss: finite reference sphere)
+    if name == 'dblgauss':
+        from test_oracle_golden import opd_opts
+        co = fx['opd_f2']
+        f2 = H.field_from_arr(co['field'])
+        g2 = oracle.make_grid(co['start'], co['stop'], 97)      # 9409 rays: 3 launches
+        for mode in (abi.OUT_OPD, abi.OUT_FAN):
+            o = opd_opts(co)
+            o.out_mode = mode
+            o.foc, o.image_pt[0], o.image_pt[1] = 0.01, 0.0, 18.0
+            orc = oracle.trace_pupil_grid(fx.table, f2, g2, int(co['wvl_idx']), o)
+            dev = eng.trace_pupil_grid(f2, g2, int(co['wvl_idx']), o, nan_fill=True).to_host()
+            assert np.array_equal(dev.status, orc.status)
+            same(dev.seg, np.asarray(orc.seg).reshape(np.asarray(dev.seg).shape), f'mode {mode} seg')
+        # plain host buffers (ROX_HOST_POINTERS) over several launches, both staging paths
+        import ctypes as C
+        for num2 in (70, 190):                                  # 4900 rays (pinned block), 36100 (arena)
+            g3 = oracle.make_grid((-1., -1.), (1., 1.), num2)
+            o = H.make_opts(c, out_mode=abi.OUT_FULL)
+            orc = oracle.trace_pupil_grid(fx.table, fld, g3, 0, o)
+            o.flags |= abi.HOST_POINTERS
+            res = oracle.HostResult(N, num2 * num2, abi.OUT_FULL, want_pupil=True)
+            res.seg[:] = 3.0
+            out = res.out_struct()
+            rc = eng.lib.rox_trace_pupil_grid(eng._handle, C.byref(fld), C.byref(g3), 0, C.byref(o),
+                                              C.byref(out), None)
+            assert rc == 0, eng.lib.rox_last_error()
+            assert np.array_equal(res.status, orc.status)
+            same(res.seg, orc.seg, f'host pointers {num2} seg')
+            same(res.pupil, orc.pupil, f'host pointers {num2} pupil')
     # explicit rays with per-ray wavelengths, OPD-free modes
     if name == 'dblgauss':
         cr = fx['rays_ap']
