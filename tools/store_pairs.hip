@@ -57,6 +57,26 @@ __global__ void __launch_bounds__(1024) x4(double *out, long ld, long n, int seg
     }
 }
 
+// tiled: the 130 rows of a workgroup's 1024 rays are contiguous (1.04 MB per workgroup):
+// element (row k, ray r) at out[((r / 1024) * rows + k) * 1024 + r % 1024]
+__global__ void __launch_bounds__(1024) tiled(double *out, long ld, long n, int segs, int phase, int sync)
+{
+    const long blk = blockIdx.x;
+    const int s0 = (int)((blk * phase) % segs);
+    double v = (double)threadIdx.x;
+    for (int i = 0; i < segs; ++i) {
+        if (sync)
+            __builtin_amdgcn_s_barrier();
+        int sg = s0 + i; if (sg >= segs) sg -= segs;
+        double *base = out + ((long)blk * segs * 10 + (long)sg * 10) * 1024 + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+            __builtin_nontemporal_store(v, base + (long)c * 1024);
+            v += 1.0;
+        }
+    }
+}
+
 template <class F>
 double time_us(F f, int reps)
 {
@@ -84,6 +104,8 @@ int main()
             printf("{\"stores\": \"10 x 8 B\", \"barrier\": %d, \"phase\": %d, \"us\": %.1f, \"GBps\": %.0f}\n", sync, phase, t, bytes / t / 1e3);
             t = time_us([&] { hipLaunchKernelGGL(x4, dim3(1024), dim3(1024), 0, 0, buf, ld, n, segs, phase, sync); }, 300);
             printf("{\"stores\": \"5 x 16 B\", \"barrier\": %d, \"phase\": %d, \"us\": %.1f, \"GBps\": %.0f}\n", sync, phase, t, bytes / t / 1e3);
+            t = time_us([&] { hipLaunchKernelGGL(tiled, dim3(1024), dim3(1024), 0, 0, buf, ld, n, segs, phase, sync); }, 300);
+            printf("{\"stores\": \"tiled per workgroup, 10 x 8 B\", \"barrier\": %d, \"phase\": %d, \"us\": %.1f, \"GBps\": %.0f}\n", sync, phase, t, bytes / t / 1e3);
         }
     return 0;
 }
