@@ -797,3 +797,34 @@ def test_reverse_path_trace_through_the_trace_raw_seam(ref, installed):
         ours, theirs = both(installed, run)
         assert np.isfinite(theirs).all()
         np.testing.assert_array_equal(ours, theirs)
+
+
+def test_generic_routes_of_the_wavefront_and_fan_dropins(ref, installed):
+    """kwargs the fused OPD / FAN launches do not cover (packet filters, filter_out_phantoms)
+    take the generic route -- device trace, the reference's own waveabr on the lazy views --
+    in eval_wavefront, trace_wavefront + focus_wavefront, eval_fan and trace_fan + focus_fan"""
+    import rayoptics.raytr.analyses as analyses
+    opm = ref.dblgauss()
+    fld = opm['osp']['fov'].fields[1]
+    wvl = 587.6
+    kw = dict(filter_out_phantoms=True)
+
+    def run():
+        out = {}
+        out['eval_wf'] = np.array(analyses.eval_wavefront(opm, fld, wvl, 0.0, num_rays=7, **kw), dtype=float)
+        gp = analyses.trace_wavefront(opm, fld, wvl, 0.0, num_rays=7, **kw)
+        assert isinstance(gp[0], (list, np.ndarray))            # a real grid, not a deferred one
+        out['focus_wf'] = np.array(analyses.focus_wavefront(opm, gp, fld, wvl, 0.02), dtype=float)
+        out['eval_fan'] = [np.array([np.r_[np.atleast_1d(p), np.atleast_1d(v)] for p, v in
+                                     analyses.eval_fan(opm, fld, wvl, 0.0, 1, num_rays=9, **kw)], dtype=float)]
+        fp = analyses.trace_fan(opm, fld, wvl, 0.0, 1, num_rays=9, **kw)
+        out['focus_fan'] = [np.array([np.r_[np.atleast_1d(p), np.atleast_1d(v)] for p, v in
+                                      analyses.focus_fan(opm, fp, fld, wvl, 0.02)], dtype=float)]
+        return out
+    ours, theirs = both(installed, run)
+    for key in theirs:
+        a, b = ours[key], theirs[key]
+        if isinstance(b, list):
+            a, b = a[0], b[0]
+        assert a.shape == b.shape, key
+        np.testing.assert_array_equal(a, b, err_msg=key)
