@@ -828,3 +828,87 @@ def test_generic_routes_of_the_wavefront_and_fan_dropins(ref, installed):
             a, b = a[0], b[0]
         assert a.shape == b.shape, key
         np.testing.assert_array_equal(a, b, err_msg=key)
+
+
+def test_trace_grid_with_packet_filters(ref, installed):
+    """trace.trace_grid with the packet filters of trace_safe (trace.py:186-221):
+    output_filter='last' and rayerr_filter='full' / 'summary' reach the callback as the
+    reference hands them over.  (Without a callback the reference's own np.array(grid) at
+    trace.py:605 raises on ragged packets under NumPy >= 1.24, so that form has no reference.)"""
+    import rayoptics.raytr.trace as trace
+    opm = ref.dblgauss()
+    fld = opm['osp']['fov'].fields[2]
+
+    def run():
+        out = {}
+        for tag, kw in (('last', dict(output_filter='last')), ('full', dict(rayerr_filter='full')),
+                        ('summary', dict(rayerr_filter='summary'))):
+            seen = []
+
+            def filt(p, pkg):
+                seen.append((tuple(p), None if pkg is None else
+                             (len(pkg[0]), float(pkg[1]), tuple(np.ravel(pkg[0][-1][0]).tolist()))))
+                return 0.0
+            trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 5], fld, 587.6, 0.0,
+                             img_filter=filt, form='list', **kw)
+            out[tag] = seen
+        return out
+    ours, theirs = both(installed, run)
+    assert ours == theirs
+    assert all(n is None or n[0] == 1 for _p, n in theirs['last'])
+    assert any(n is not None and n[0] < 13 for _p, n in theirs['full'])  # partial packets came through
+
+
+def test_focus_pupil_coords_on_a_materialised_ray_list(ref, installed):
+    """focus_pupil_coords (analyses.py:561-580) handed a plain list of [px, py, pkg] (what
+    trace_ray_list returns) rather than the deferred list of the fused trace_pupil_coords"""
+    import rayoptics.raytr.analyses as analyses
+    opm = ref.dblgauss()
+    fld = opm['osp']['fov'].fields[1]
+    pupil = [np.array(p) for p in np.random.default_rng(4).uniform(-1.1, 1.1, (40, 2))]
+
+    def run():
+        # (with failed rays kept as None the reference's own np.array(...) at analyses.py:580
+        # is ragged under NumPy >= 1.24: only the rays that get through)
+        lst = analyses.trace_ray_list(opm, [p.copy() for p in pupil], fld, 587.6, 0.0,
+                                      append_if_none=False, check_apertures=True)
+        assert isinstance(lst, list)
+        return np.array(analyses.focus_pupil_coords(opm, lst, fld, 587.6, 0.03), dtype=object)
+    ours, theirs = both(installed, run)
+    assert len(ours) == len(theirs)
+    for a, b in zip(ours, theirs):
+        np.testing.assert_array_equal(np.asarray(a, dtype=float), np.asarray(b, dtype=float))
+
+
+def test_fused_fan_result_still_serves_the_reference_pair(ref, installed):
+    """RayFan.fan_pkg of the fused trace_fan indexed the way the reference's (fan, upd_fan)
+    pair would be by any other consumer"""
+    import rayoptics.raytr.analyses as analyses
+    opm = ref.dblgauss()
+    fld = opm['osp']['fov'].fields[2]
+
+    def run():
+        fan, upd = analyses.trace_fan(opm, fld, 587.6, 0.0, 1, num_rays=9)
+        out = []
+        for i in range(len(fan)):
+            px, py, pkg = fan[i]
+            u = upd[i]
+            out.append((float(px), float(py), None if pkg is None else (len(pkg[0]), float(pkg[1])),
+                        None if u is None else tuple(np.ravel(np.asarray(x, dtype=float)).tolist() for x in u)))
+        return out
+    ours, theirs = both(installed, run)
+    assert ours == theirs and len(theirs) == 9
+
+
+def test_floating_stop_aiming(ref, installed):
+    """no stop surface: iterate_ray returns the target itself (trace.py:411-413)"""
+    import rayoptics.raytr.trace as trace
+    opm = ref.singlet()
+    opm['seq_model'].stop_surface = None
+    fld = opm['osp']['fov'].fields[-1]
+
+    def run():
+        return np.array(trace.aim_chief_ray(opm, fld), dtype=float)
+    ours, theirs = both(installed, run)
+    np.testing.assert_array_equal(ours, theirs)
+    np.testing.assert_array_equal(theirs, [0., 0.])
