@@ -1,0 +1,113 @@
+"""session.engine_for: the device handle of a live model is reused while the model is
+unchanged, re-validated after an update_model() that changed nothing, replaced after an edit the
+reference would see (with or without update_model()), and evicted least-recently-used first."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.needs_reference
+
+
+class CountingEngine:
+    made, closed = 0, 0
+
+    def __init__(self, table, device=None):
+        type(self).made += 1
+        self.table = table
+        self.open = True
+
+    def close(self):
+        if self.open:
+            type(self).closed += 1
+        self.open = False
+
+
+@pytest.fixture()
+def sess():
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    import refmodels as rm
+    from rayoptics_amd import session
+    session.clear()
+    CountingEngine.made = CountingEngine.closed = 0
+    session.ENGINE_FACTORY = CountingEngine
+    yield session, rm
+    session.clear()
+    session.ENGINE_FACTORY = None
+
+
+def test_handle_reuse_revalidation_and_replacement(sess):
+    session, rm = sess
+    opm = rm.dblgauss()
+    sm = opm['seq_model']
+    e1 = session.engine_for(opm)
+    assert session.engine_for(opm) is e1 and CountingEngine.made == 1
+    # update_model() rebuilds lcl_tfrms / rndx (new list objects) but nothing changed:
+    # the table is re-extracted once, found identical, and the handle is kept
+    sm.update_model()
+    assert session.engine_for(opm) is e1 and CountingEngine.made == 1
+    assert session.engine_for(opm) is e1
+    # an edit the reference sees through the live profile object, without update_model()
+    sm.ifcs[3].profile.cv *= 1.01
+    e2 = session.engine_for(opm)
+    assert e2 is not e1 and CountingEngine.made == 2 and CountingEngine.closed == 1 and not e1.open
+    # an aperture edit, and a thickness edit followed by update_model()
+    sm.ifcs[4].max_aperture *= 0.9
+    e3 = session.engine_for(opm)
+    assert e3 is not e2
+    sm.gaps[2].thi += 0.05
+    sm.update_model()
+    e4 = session.engine_for(opm)
+    assert e4 is not e3 and e4.table.rows[2].t[2] == sm.gaps[2].thi
+    assert CountingEngine.made == 4 and CountingEngine.closed == 3
+
+
+def test_phase_element_edits_are_seen(sess):
+    session, rm = sess
+    from rayoptics.oprops import doe
+    opm = rm.singlet()
+    sm = opm['seq_model']
+    sm.ifcs[2].phase_element = doe.DiffractionGrating(grating_lpmm=300.0, order=1)
+    e1 = session.engine_for(opm)
+    assert session.engine_for(opm) is e1
+    sm.ifcs[2].phase_element.order = 2
+    e2 = session.engine_for(opm)
+    assert e2 is not e1 and e2.table.rows[2].ph.order == 2.0
+
+
+def test_least_recently_used_handles_are_closed(sess):
+    session, rm = sess
+    session.MAX_ENGINES, saved = 3, session.MAX_ENGINES
+    try:
+        models = [rm.singlet() for _ in range(5)]
+        engines = [session.engine_for(m) for m in models[:3]]
+        session.engine_for(models[0])                           # touch: 1 is now the oldest
+        engines.append(session.engine_for(models[3]))
+        assert not engines[1].open and engines[0].open and engines[2].open
+        engines.append(session.engine_for(models[4]))
+        assert not engines[2].open and engines[0].open
+        assert len(session._cache) == 3
+    finally:
+        session.MAX_ENGINES = saved
+
+
+def test_table_keyed_handles_for_explicit_paths(sess):
+    session, rm = sess
+    from rayoptics_amd import SurfaceTable
+    session.MAX_TABLE_ENGINES, saved = 2, session.MAX_TABLE_ENGINES
+    try:
+        tabs = []
+        for k in range(3):
+            opm = rm.singlet()
+            opm['seq_model'].ifcs[1].profile.cv *= 1 + 0.01 * k
+            tabs.append(SurfaceTable.from_paths([list(opm['seq_model'].path(opm['seq_model'].central_wavelength()))],
+                                                [opm['seq_model'].central_wavelength()]))
+        a = session.engine_for_table(tabs[0])
+        assert session.engine_for_table(SurfaceTable.from_dict(tabs[0].to_dict())) is a   # same bytes
+        b = session.engine_for_table(tabs[1])
+        session.engine_for_table(tabs[0])                       # touch
+        c = session.engine_for_table(tabs[2])
+        assert not b.open and a.open and c.open
+    finally:
+        session.MAX_TABLE_ENGINES = saved
