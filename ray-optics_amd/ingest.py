@@ -465,8 +465,21 @@ def read_seq(path):
     p = Prescription()
     rdm = False
     cur = -1
+    # '&' continues the command on the next line: the text before the last '&' of a line is
+    # joined with the following line, then comments are cut (codev/reader.py:25-38)
+    lines, carry = [], None
     for raw in text.splitlines():
-        raw = raw.split('!', 1)[0]
+        if carry is not None:
+            raw = carry + raw
+            carry = None
+        k = raw.rfind('&')
+        if k >= 0:
+            carry = raw[:k]
+            continue
+        lines.append(raw.split('!', 1)[0])
+    if carry is not None:
+        lines.append(carry.split('!', 1)[0])
+    for raw in lines:
         for stmt in raw.split(';'):
             tok = stmt.strip().split()
             if not tok:
@@ -494,6 +507,13 @@ def read_seq(path):
                     if g.upper() == 'REFL':
                         s.mode = 'reflect'
                         med = ('mirror',)
+                    elif _is_number(g):
+                        # a fictitious glass code 'nnn.vvv' (cmdproc.py:47-53, 628-638):
+                        # n = 1.nnn, v = vv.v; the dispersion model is opticalglass's
+                        gc = float(g)
+                        ipart = int(gc)
+                        mag = int(math.floor(math.log10(ipart))) + 1
+                        med = ('model', 1.0 + ipart / 10 ** mag, round(100.0 * (gc - ipart), 6))
                     elif g.upper() != 'AIR':
                         med = ('glass', g)
                 p.media.append(med)
