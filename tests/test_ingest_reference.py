@@ -184,3 +184,98 @@ def test_decentered_ingest_traces_like_the_reference(rel):
             assert seg[2] == orc.seg[k, 6, r]
             np.testing.assert_array_equal(seg[3], orc.seg[k, 7:10, r])
     assert n_ok > 20
+
+
+SYNTHETIC_ZMX = """VERS 140124 258 36214
+MODE SEQ
+NAME synthetic: every surface type the reader knows
+UNIT MM X W X CM MR CPMM
+ENPD 8.0
+WAVM 1 0.4861 1
+WAVM 2 0.5876 1
+WAVM 3 0.6563 1
+PWAV 2
+SURF 0
+  TYPE STANDARD
+  CURV 0.0 0 0 0 0 ""
+  DISZ INFINITY
+  DIAM 0 0 0 0 1 ""
+SURF 1
+  TYPE STANDARD
+  CURV 0.02 0 0 0 0 ""
+  DISZ 3.0
+  GLAS ___BLANK 1 0 1.5168 0 0 0 0 0 0
+  DIAM 6.0 1 0 0 1 ""
+  OBDC 0.25 -0.5
+SURF 2
+  STOP
+  TYPE XOSPHERE
+  CURV -0.01 0 0 0 0 ""
+  CONI -0.3
+  XDAT 1 4
+  XDAT 2 1.0
+  XDAT 3 0.0
+  XDAT 4 1.5e-05
+  XDAT 5 0.0
+  XDAT 6 -2.0e-08
+  DISZ 5.0
+  DIAM 5.5 0 0 0 1 ""
+SURF 3
+  TYPE PARAXIAL
+  CURV 0.0 0 0 0 0 ""
+  PARM 1 80.0
+  DISZ 10.0
+  DIAM 5.0 0 0 0 1 ""
+SURF 4
+  TYPE DGRATING
+  CURV 0.0 0 0 0 0 ""
+  PARM 1 0.3
+  PARM 2 -1
+  DISZ 20.0
+  DIAM 5.0 0 0 0 1 ""
+SURF 5
+  TYPE STANDARD
+  CURV 0.0 0 0 0 0 ""
+  GLAS MIRROR 0 0 1.5 40.0
+  DISZ -15.0
+  DIAM 7.0 4 0 0 1 ""
+SURF 6
+  TYPE EVENASPH
+  CURV 0.005 0 0 0 0 ""
+  PARM 1 0.0
+  PARM 2 1.0e-05
+  PARM 3 0.0
+  PARM 4 0.0
+  PARM 5 0.0
+  PARM 6 0.0
+  PARM 7 0.0
+  PARM 8 0.0
+  DISZ -4.0
+  DIAM 6.0 2 0 0 1 ""
+SURF 7
+  TYPE STANDARD
+  CURV 0.0 0 0 0 0 ""
+  DISZ 0.0
+  DIAM 3.0 0 0 0 1 ""
+"""
+
+
+@pytest.mark.needs_reference
+def test_synthetic_zmx_with_every_surface_type(tmp_path):
+    """no file of the reference tree carries XOSPHERE, PARAXIAL, DGRATING, an offset or
+    obscuring aperture: a synthetic .zmx with all of them, through both importers"""
+    from oracle import refshim
+    refshim.install()
+    from rayoptics.zemax import zmxread
+    from rayoptics_amd import SurfaceTable, ingest
+    path = tmp_path / 'synthetic.zmx'
+    path.write_text(SYNTHETIC_ZMX, encoding='utf-8')
+    opm, _info = zmxread.read_lens(None, SYNTHETIC_ZMX, do_update=False)
+    opm['seq_model'].update_model()
+    theirs = SurfaceTable.from_seq_model(opm['seq_model'])
+    ours = ingest.read_zmx(str(path)).to_table()
+    rows_equal(ours, theirs, 'synthetic.zmx')
+    from rayoptics_amd import abi
+    kinds = [r.profile for r in ours.rows]
+    assert abi.PROFILE_NAMES['RadialPolynomial'] in kinds and abi.THINLENS in kinds
+    assert ours.rows[4].ph.kind == abi.PH_GRATING and ours.rows[5].mode == abi.MODE_NAMES['reflect']
