@@ -279,3 +279,48 @@ def test_synthetic_zmx_with_every_surface_type(tmp_path):
     kinds = [r.profile for r in ours.rows]
     assert abi.PROFILE_NAMES['RadialPolynomial'] in kinds and abi.THINLENS in kinds
     assert ours.rows[4].ph.kind == abi.PH_GRATING and ours.rows[5].mode == abi.MODE_NAMES['reflect']
+
+
+@pytest.mark.needs_reference
+def test_synthetic_zmx_traces_like_the_reference(tmp_path):
+    """... and the table parsed from that file, traced by the oracle, against the reference's
+    rt.trace on the model its own importer built: thin lens, grating, radial and even aspheres,
+    a mirror, offset / rectangular / obscuring apertures in one path, three wavelengths"""
+    from oracle import refshim
+    refshim.install()
+    from rayoptics.zemax import zmxread
+    import rayoptics.raytr.raytrace as rt
+    from rayoptics.raytr.traceerror import TraceError
+    from oracle import oracle
+    from rayoptics_amd import abi, ingest
+    path = tmp_path / 'synthetic.zmx'
+    path.write_text(SYNTHETIC_ZMX, encoding='utf-8')
+    opm, _info = zmxread.read_lens(None, SYNTHETIC_ZMX, do_update=False)
+    sm = opm['seq_model']
+    sm.update_model()
+    tbl = ingest.read_zmx(str(path)).to_table()
+    N = tbl.n_ifcs
+    rng = np.random.default_rng(12)
+    R = 60
+    tgt = np.stack([rng.uniform(-5, 5, R), rng.uniform(-5, 5, R), np.full(R, 1e3)])
+    pt0 = np.zeros((3, R))
+    pt0[2] = tbl.rows[0].t[2] - 1e3
+    d0 = tgt / np.linalg.norm(tgt, axis=0)
+    n_ok = n_err = 0
+    for wi, wvl in enumerate(tbl.wvls):
+        opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES, first_surf=1, last_surf=N - 2)
+        orc = oracle.trace_rays(tbl, pt0, d0, wi, opts)
+        for r in range(R):
+            try:
+                ray, op, _w = rt.trace(sm, pt0[:, r].copy(), d0[:, r].copy(), wvl, check_apertures=True)
+            except TraceError as e:
+                n_err += 1
+                assert orc.status[r] != abi.OK and orc.fail_surf[r] == e.surf
+                continue
+            n_ok += 1
+            assert orc.status[r] == abi.OK and op == orc.op[r]
+            for k, seg in enumerate(ray):
+                np.testing.assert_array_equal(seg[0], orc.seg[k, 0:3, r])
+                np.testing.assert_array_equal(seg[1], orc.seg[k, 3:6, r])
+                assert seg[2] == orc.seg[k, 6, r]
+    assert n_ok > 20 and n_err > 5
