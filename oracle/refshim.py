@@ -96,7 +96,27 @@ class ConstantIndex(OpticalMedium):
 
 
 class InterpolatedMedium(OpticalMedium):
-    pass
+    """a glass given by index samples (CODE V private catalogue, cmdproc.py:146-158).
+    opticalglass interpolates them with its own scheme; this stand-in is linear in
+    wavelength -- parity tests neutralise the indices behind such glasses."""
+
+    def __init__(self, label='', pairs=None, rndx=None, wvls=None, cat=''):
+        super().__init__(1.5, str(label), cat)
+        if pairs is not None:
+            wvls = [p[0] for p in pairs]
+            rndx = [p[1] for p in pairs]
+        self.wvls = list(wvls) if wvls is not None else []
+        self.rndx = list(rndx) if rndx is not None else []
+
+    def rindex(self, wv_nm):
+        import numpy as np
+        if not self.wvls:
+            return self.n
+        w = get_wavelength(wv_nm)
+        order = np.argsort(self.wvls)
+        return float(np.interp(w, np.asarray(self.wvls)[order], np.asarray(self.rndx)[order]))
+
+    calc_rindex = meas_rindex = rindex
 
 
 class ModelGlass(OpticalMedium):

@@ -182,6 +182,7 @@ class Prescription:
         self.wvls = []
         self.ref_wvl = 0
         self.title = ''
+        self.private_glasses = {}   # name -> (wavelengths nm, indices): CODE V PRV ... END
 
     # rayoptics/seq/sequential.py:611-668 + rayoptics/elem/transform.py:86-118
     def to_table(self, wvls=None, index_of=None):
@@ -228,7 +229,19 @@ class Prescription:
                     row.ncoef = mnc
                     for k in range(mnc):
                         row.coefs[k] = float(s.coefs[k])
-            if s.phase:
+            if s.phase and s.phase['kind'] == abi.PH_DOE_RADIAL:
+                # table._phase_row for a DiffractiveElement (doe.py:225-323)
+                if not s.phase.get('radial'):
+                    raise UnsupportedModelError('DiffractiveElement without a radial phase function')
+                coefs = [float(c) for c in s.phase.get('coefs', [])]
+                if len(coefs) > abi.MAX_COEF:
+                    raise UnsupportedModelError(f'DiffractiveElement with {len(coefs)} coefficients')
+                ph = row.ph
+                ph.kind, ph.ncoef = abi.PH_DOE_RADIAL, len(coefs)
+                for k, c in enumerate(coefs):
+                    ph.coefs[k] = c
+                ph.order, ph.ref_wl = float(s.phase.get('order', 1)), float(s.phase.get('ref_wl', 550.))
+            elif s.phase:
                 ph = row.ph
                 ph.kind = s.phase['kind']
                 ph.order = float(s.phase.get('order', 1))
@@ -281,6 +294,13 @@ class Prescription:
                     elif m[0] == 'model':
                         n = float(index_of(f'{m[1]:.6g},{m[2]:.6g}', wl)) if index_of is not \
                             reference_fallback_index else float(m[1])
+                    elif m[1] in self.private_glasses and index_of is reference_fallback_index:
+                        # a glass the file defines itself (CODE V PRV ... END: index samples at
+                        # the PWL wavelengths); the reference interpolates them with
+                        # opticalglass.InterpolatedMedium -- here: linear in wavelength
+                        pw, pn = self.private_glasses[m[1]]
+                        order = np.argsort(pw)
+                        n = float(np.interp(wl, np.asarray(pw)[order], np.asarray(pn)[order]))
                     else:
                         n = float(index_of(m[1], wl))
                     n_table[w, i] = n
@@ -465,6 +485,7 @@ def read_seq(path):
     p = Prescription()
     rdm = False
     cur = -1
+    in_prv, prv_wvls = False, []
     # '&' continues the command on the next line: the text before the last '&' of a line is
     # joined with the following line, then comments are cut (codev/reader.py:25-38)
     lines, carry = [], None
@@ -486,7 +507,17 @@ def read_seq(path):
                 continue
             tla = tok[0].upper()[:3]
             args = tok[1:]
-            if tla == 'RDM':
+            if in_prv:                      # private catalogue, cmdproc.py:146-158, 358-369
+                if tla == 'END':
+                    in_prv = False
+                elif tla == 'PWL':
+                    prv_wvls = [float(a) for a in args]
+                elif tok[0][:1] in "'\"" and len(args) == len(prv_wvls) and all(_is_number(a) for a in args):
+                    p.private_glasses[tok[0].strip("'\"")] = (prv_wvls, [float(a) for a in args])
+                continue
+            if tla == 'PRV':
+                in_prv, prv_wvls = True, []
+            elif tla == 'RDM':
                 rdm = not args or args[0].upper() not in ('N', 'NO')
             elif tla == 'TIT':
                 p.title = stmt.strip()[3:].strip().strip("'\"")
@@ -503,7 +534,7 @@ def read_seq(path):
                 p.thi.append(float(args[1]) if len(args) > 1 else 0.0)
                 med = ('air',)
                 if len(args) > 2:
-                    g = args[2]
+                    g = args[2].strip("'\"")        # (the reference's tokenizer drops the quotes)
                     if g.upper() == 'REFL':
                         s.mode = 'reflect'
                         med = ('mirror',)
@@ -568,6 +599,33 @@ def read_seq(path):
                 if 'OBS' in quals:
                     ca['is_obscuration'] = True
                 ca[{'R': 'radius', 'X': 'x_half_width', 'Y': 'y_half_width'}[tla[2]]] = vals[0]
+            elif tla == 'DIF':                  # cmdproc.py:583-618 diffractive_optic
+                if 'DOE' in [a.upper() for a in args]:
+                    p.ifcs[cur].phase = dict(kind=abi.PH_DOE_RADIAL, order=1, ref_wl=550., coefs=[],
+                                             radial=False)
+                elif args:
+                    raise UnsupportedModelError(f'.seq diffractive surface DIF {args[0]}')
+            elif tla in ('HOR', 'HWL', 'HCT', 'HCO') and p.ifcs[cur].phase and \
+                    p.ifcs[cur].phase['kind'] == abi.PH_DOE_RADIAL:
+                ph = p.ifcs[cur].phase
+                if tla == 'HOR':
+                    ph['order'] = float(args[0])
+                elif tla == 'HWL':
+                    ph['ref_wl'] = float(args[0])
+                elif tla == 'HCT':
+                    if 'R' in [a.upper() for a in args]:
+                        ph['radial'] = True
+                else:                           # HCO Cn value
+                    cidx = int(args[0][1:])
+                    val = float(args[1])
+                    coefs = ph['coefs']
+                    if cidx <= len(coefs):
+                        coefs[cidx - 1] = val
+                    elif cidx == len(coefs) + 1:
+                        coefs.append(val)
+                    else:
+                        coefs.extend([0.] * (cidx - len(coefs)))
+                        coefs[cidx - 1] = val
             elif tla in ('ADX', 'ADY'):         # cmdproc.py:525-541 aperture_offset
                 vals = [float(a) for a in args if _is_number(a)]
                 if p.ifcs[cur].apertures and vals:

@@ -20,9 +20,7 @@ pytestmark = pytest.mark.needs_reference
 FILES = sorted(os.path.relpath(p, REF) for ext in ('zmx', 'seq')
                for p in glob.glob(os.path.join(REF, '**', f'*.{ext}'), recursive=True))
 UNSUPPORTED = {'zemax/tests/ASL5040-UV-Zemax(ZMX).zmx': 'QED_TYPE'}    # a Q-type asphere
-# the reference's importer does not get through these under the import shim (private-catalogue
-# glasses -> opticalglass.InterpolatedMedium, absent here)
-REFERENCE_FAILS = {'codev/tests/CODV_65988.seq', 'codev/tests/CODV_65988_noDOE.seq'}
+REFERENCE_FAILS = set()
 
 
 def reference_table(path, kind):
@@ -77,7 +75,10 @@ def test_every_prescription_file_of_the_reference_tree(rel):
             for t in (ours, theirs):
                 for r in t.rows:
                     r.max_aperture = 1.0
-        model_cols = [i for i, m in enumerate(pres.media) if m[0] == 'model']
+        # (glasses the file defines itself -- CODE V PRV ... END -- are interpolated by
+        # opticalglass in the reference: treated like model glasses)
+        model_cols = [i for i, m in enumerate(pres.media)
+                      if m[0] == 'model' or (m[0] == 'glass' and m[1] in pres.private_glasses)]
         if model_cols:
             d = min(range(len(ours.wvls)), key=lambda w: abs(ours.wvls[w] - 587.5618))
             for t in (ours, theirs):
