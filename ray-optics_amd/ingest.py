@@ -557,6 +557,10 @@ def read_seq(path):
                 p.ifcs[cur].coefs = [0.0] * 10
             elif tla == 'SPH':
                 p.ifcs[cur].profile = 'Spherical'
+            elif tla in ('XTO', 'YTO'):         # cmdproc.py:394-397: mutate_profile, nothing else is read
+                p.ifcs[cur].profile = 'XToroid' if tla == 'XTO' else 'YToroid'
+                p.ifcs[cur].cR = 0.0
+                p.ifcs[cur].coefs = []
             elif tla == 'K' and len(tok[0]) == 1:
                 p.ifcs[cur].cc = float(args[0])
             elif len(tok[0]) == 1 and tok[0].upper() in _ORDER and p.ifcs and \

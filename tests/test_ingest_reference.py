@@ -324,3 +324,100 @@ def test_synthetic_zmx_traces_like_the_reference(tmp_path):
                 np.testing.assert_array_equal(seg[1], orc.seg[k, 3:6, r])
                 assert seg[2] == orc.seg[k, 6, r]
     assert n_ok > 20 and n_err > 5
+
+
+SYNTHETIC_SEQ = """RDM;LEN "synthetic: every command the reader knows"
+TITLE 'synthetic'
+EPD   8.0
+DIM   M
+WL    656.3 587.6 486.1
+REF   2
+WTW   1 1 1
+XAN   0.0 0.0
+YAN   0.0 3.0
+PRV
+  PWL 700.0 600.0 500.0 400.0
+  'MYGLASS' 1.6010 1.6060 1.6150 1.6330
+END
+SO    0.0 0.1e14
+S     40.0 4.0 'MYGLASS'
+  CIR 9.0
+  CIR OBS 1.5
+  ADX 0.25; ADY -0.5
+S     -60.0 2.0 517.642
+  ASP
+  K   -0.7
+  A   1.5e-06; B -2.0e-09; C 0.0; D&
+   1.0e-14
+  REX 8.0; REY 7.0
+S     0.0 12.0
+  STO
+  XDE 0.1; YDE -0.2; ZDE 0.05
+  ADE 2.0; BDE -1.5; CDE 0.5
+S     0.0 -10.0 REFL
+  CON
+  K -1.0
+  DAR
+  ADE 12.0
+  ELX 6.0; ELY 5.0
+S     0.0 -5.0
+  YTO
+  BEN
+  BDE 3.0
+S     25.0 -3.0 NBK7_SCHOTT
+  CUY 0.03
+  DIF DOE
+  HOR 1.0
+  HWL 587.6; HCT R
+  HCO C1 -0.002; HCO C3 1.0e-07
+S     0.0 -20.0
+  RDY -80.0
+  REV
+  XDE 0.3
+  THI HMY 0.0
+SI    0.0 0.0
+GO
+"""
+
+
+@pytest.mark.needs_reference
+def test_synthetic_seq_with_every_command(tmp_path):
+    """one synthetic CODE V sequence with every command read_seq knows -- private catalogue,
+    fictitious glass code, continuation lines, aspheric terms, all aperture and decenter
+    commands (DAR / BEN / REV), a toroid, a radial DOE, solves -- through both importers"""
+    from oracle import refshim
+    refshim.install()
+    from rayoptics.codev import cmdproc
+    from rayoptics.seq.sequential import SequentialModel
+    from rayoptics.optical.opticalmodel import OpticalModel
+    from rayoptics_amd import SurfaceTable, ingest, abi
+    path = tmp_path / 'synthetic.seq'
+    path.write_text(SYNTHETIC_SEQ)
+    saved = SequentialModel.set_clear_apertures, OpticalModel.update_model
+    SequentialModel.set_clear_apertures = lambda self, **kw: None
+    OpticalModel.update_model = lambda self, **kw: None
+    try:
+        opm, _info = cmdproc.read_lens(path, do_update=False)
+    finally:
+        SequentialModel.set_clear_apertures, OpticalModel.update_model = saved
+    sm = opm['seq_model']
+    sm.update_model()
+    theirs = SurfaceTable.from_seq_model(sm)
+    pres = ingest.read_seq(str(path))
+    ours = pres.to_table()
+    assert ours.n_ifcs == theirs.n_ifcs == 9
+    for t in (ours, theirs):
+        t.n_table = t.n_table.copy()
+        for r in t.rows:
+            r.max_aperture = 1.0
+    # private and fictitious glasses: dispersion is opticalglass's (not here); the named
+    # catalogue glass is unknown on both sides (1.5)
+    for i, m in enumerate(pres.media):
+        if m[0] == 'model' or (m[0] == 'glass' and m[1] in pres.private_glasses):
+            theirs.n_table[:, i] = ours.n_table[:, i]
+    for i, m in enumerate(pres.media):
+        if m[0] == 'mirror':
+            theirs.n_table[:, i] = ours.n_table[:, i] = ours.n_table[:, i - 1]
+    rows_equal(ours, theirs, 'synthetic.seq')
+    assert ours.rows[5].profile == abi.PROFILE_NAMES['YToroid'] and ours.rows[6].ph.kind == abi.PH_DOE_RADIAL
+    assert ours.rows[1].n_ap == 1 and ours.rows[2].n_ap == 1 and ours.rows[4].ap[0].kind == abi.AP_ALWAYS_BLOCK
