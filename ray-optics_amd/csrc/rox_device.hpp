@@ -52,6 +52,9 @@
 #ifndef ROX_SLIM_FP64        // 1: range-guarded slim sqrt / shared-reciprocal division triples
 #define ROX_SLIM_FP64 1       //    (bit-identical to sqrt() and `/`; see slim_* below)
 #endif
+#ifndef ROX_IDENT_RT         // 1: interfaces whose rotation is exactly the identity skip the dgemv chains
+#define ROX_IDENT_RT 1        //    (HITS 117.0 -> 111.2 us; FULL keeps the chains: 190.8 vs 194.5 us)
+#endif
 #ifndef ROX_UNIT_FUSED       // 1: unit() decides once for its sqrt and its three quotients
 #define ROX_UNIT_FUSED 1      //    (6 fewer band-test instructions per surface: HITS 120.5 -> 117.1 us)
 #endif
@@ -964,9 +967,26 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
 
         // :170-174 transform to the new vertex frame, closest approach
         const int rt_order = ((tbli)prow)[4];
-        const v3 b4p = rotate(prow + O_RT, rt_order, v3{bp.x - prow[O_T], bp.y - prow[O_T + 1],
-                                                        bp.z - prow[O_T + 2]});
-        const v3 b4d = rotate(prow + O_RT, rt_order, bd);
+        const v3 dp{bp.x - prow[O_T], bp.y - prow[O_T + 1], bp.z - prow[O_T + 2]};
+        v3 b4p, b4d;
+#if ROX_IDENT_RT
+        // rt exactly the identity (flagged on the device row when the system is created): each
+        // dgemv chain fma(0, z, fma(0, y, fma(1, x, 0.0))) is x + 0.0 for finite operands in
+        // either column order (-0 becomes +0 as in the chain).  A non-finite component would
+        // turn the other rows into NaN through 0 * inf, so the short cut is taken only when
+        // every active lane's six components are finite (their sum is: a conservative test).
+        // (reduced-output modes only: in FULL mode, which is bound by its packet stores, the
+        // extra branch measured 2 % slower)
+        if (OUT_MODE != ROX_OUT_FULL && ((tbli)prow)[5] != 0 &&
+            __all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((bd.x + bd.y) + bd.z)))) {
+            b4p = v3{dp.x + 0.0, dp.y + 0.0, dp.z + 0.0};
+            b4d = v3{bd.x + 0.0, bd.y + 0.0, bd.z + 0.0};
+        } else
+#endif
+        {
+            b4p = rotate(prow + O_RT, rt_order, dp);
+            b4d = rotate(prow + O_RT, rt_order, bd);
+        }
         const double pp_dst = -dot3(b4p, b4d);
         const v3 pp{b4p.x + pp_dst * b4d.x, b4p.y + pp_dst * b4d.y, b4p.z + pp_dst * b4d.z};
 

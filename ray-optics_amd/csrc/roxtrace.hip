@@ -773,6 +773,15 @@ int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_t
         std::vector<dev_surface> drows(n_ifcs);
         for (int i = 0; i < n_ifcs; ++i) {
             drows[i].pub = rows[i];
+            // device copy only: rt is exactly the identity (every centred interface) -- the
+            // kernels then transform with `v + 0.0` instead of the dgemv chain (rox_device.hpp)
+            {
+                static const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+                bool ident = true;
+                for (int k = 0; k < 9; ++k)
+                    ident = ident && rows[i].rt[k] == eye[k] && !std::signbit(rows[i].rt[k]);
+                drows[i].pub.reserved = ident ? 1 : 0;
+            }
             const double c0 = rows[i].profile == ROX_RADIALPOLY ? 1.0 : 2.0;
             double c_coef = c0;                 // profiles.py:877-882, 1104-1109, 1364-1369
             for (int k = 0; k < ROX_MAX_COEF; ++k) {
