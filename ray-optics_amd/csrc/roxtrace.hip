@@ -675,7 +675,11 @@ int prepare_grid(rox_system *sys, const rox_field *fld, const rox_grid *grid, in
 }
 
 // DiffractionGrating constants per (wavelength, interface), doe.py:138-143,
-// with libm pow() for `mu**2` and `T**2` as CPython / NumPy scalars evaluate them
+// with libm pow() for `mu**2` and `T**2` as CPython / NumPy scalars evaluate them.
+// (Called through a volatile pointer: the compiler folds a direct pow(x, 2.0) into x * x,
+// which is not what libm returns for about one argument in a thousand.)
+double (*volatile libm_pow)(double, double) = pow;
+
 void phase_consts(const rox_surface *rows, int N, const double *n_table, const double *wvls,
                   int W, std::vector<double> &pc)
 {
@@ -691,9 +695,9 @@ void phase_consts(const rox_surface *rows, int N, const double *n_table, const d
             const double T = refl * (wvls[w] * ph.order) / (ph.spacing_nm * n_out);
             double *o = &pc[((size_t)w * N + i) * kPhaseConsts];
             o[0] = mu;
-            o[1] = pow(mu, 2.0);
+            o[1] = libm_pow(mu, 2.0);
             o[2] = T;
-            o[3] = pow(T, 2.0);
+            o[3] = libm_pow(T, 2.0);
         }
 }
 

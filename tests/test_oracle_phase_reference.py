@@ -79,8 +79,11 @@ def random_phase_path(rng, kind):
     return paths, k_phase
 
 
+# (range(8) was enough for everything but libm pow: `x**2` in the reference is pow(), one ulp off
+# x*x for about one argument in a thousand, and gcc folds pow(x, 2.0) into x*x unless told not to
+# -- oracle/Makefile's -fno-builtin-pow; seeds 17, 18, 26 ... of the grating case catch that)
 @pytest.mark.parametrize('kind', ['grating', 'doe', 'hologram', 'thinlens'])
-@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('seed', list(range(8)) + [17, 18, 26, 31, 34, 50])
 def test_phase_elements_oracle_equals_reference(kind, seed):
     from oracle import oracle, refshim
     refshim.install()
