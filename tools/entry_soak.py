@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Soak of the small entries, device vs oracle: every ray-start branch with random field
+constants (bit for bit), chief-ray aiming on perturbed problems (bit for bit), the vignetting
+search on perturbed fields (<= 1e-12: the objective squares a coordinate, libm pow in the
+reference and the oracle, an exact product in the kernel).
+
+    python tools/entry_soak.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def main():
+    import rayoptics_amd  # noqa: F401
+    from rayoptics_amd import abi, workloads
+    from rayoptics_amd.engine import TraceEngine
+    from rayoptics_amd.table import field_struct
+    from oracle import oracle
+    import helpers as H
+    out = {}
+    t0 = time.time()
+    # ---- ray starts
+    fx = H.fixture('singlet')
+    eng = TraceEngine(fx.table)
+    N = fx.table.n_ifcs
+    z0 = float(fx.table.rows[0].t[2])
+    rng = np.random.default_rng(5)
+    n_bad = n = 0
+    for kind in (abi.FLD_EPD, abi.FLD_EPD_WIDE, abi.FLD_AIM_PT, abi.FLD_NA, abi.FLD_FNO, abi.FLD_AIM_DIR):
+        for trial in range(150):
+            ang = np.deg2rad(rng.uniform(-12, 12))
+            rot = np.array([[1, 0, 0], [0, np.cos(ang), -np.sin(ang)], [0, np.sin(ang), np.cos(ang)]])
+            if trial % 2:
+                rot = np.asfortranarray(rot)
+            scale = {abi.FLD_EPD: rng.uniform(1, 6), abi.FLD_EPD_WIDE: rng.uniform(1, 6), abi.FLD_AIM_PT: 0.0,
+                     abi.FLD_NA: rng.uniform(0.01, 0.08), abi.FLD_FNO: -1 / rng.uniform(6, 20),
+                     abi.FLD_AIM_DIR: 0.0}[kind]
+            fld = field_struct((rng.uniform(-1, 1) if trial % 3 == 0 else 0.0, rng.uniform(-3, 3), 0.0),
+                               (rng.uniform(-.1, .1), rng.uniform(-.3, .3)), scale, z0 + rng.uniform(-2, 2),
+                               tuple(rng.uniform(0, 0.3, 4)), 1.0, kind=kind, rot=rot,
+                               cr_dir=(rng.uniform(-.02, .02), rng.uniform(-.03, .03)))
+            span = {abi.FLD_AIM_PT: 4.0, abi.FLD_AIM_DIR: 0.05}.get(kind, 1.0)
+            grid = oracle.make_grid((-span, -span), (span, span), 17)
+            flags = abi.CHECK_APERTURES | abi.APPLY_VIGNETTING | (0 if kind == abi.FLD_EPD_WIDE else abi.INTERSECT_OBJ)
+            opts = oracle.make_opts(flags=flags, first_surf=1, last_surf=N - 2)
+            with np.errstate(all='ignore'):
+                orc = oracle.trace_pupil_grid(fx.table, fld, grid, 0, opts)
+            dev = eng.trace_pupil_grid(fld, grid, 0, opts, nan_fill=True).to_host()
+            same = (np.array_equal(dev.status, orc.status)
+                    and np.array_equal(dev.seg, orc.seg, equal_nan=True)
+                    and np.array_equal(dev.op, orc.op, equal_nan=True)
+                    and np.array_equal(dev.pupil, orc.pupil, equal_nan=True))
+            n += 1
+            n_bad += not same
+    eng.close()
+    out['ray_starts'] = {'fields': n, 'mismatching': n_bad}
+    # ---- aiming and vignetting on perturbed problems
+    n_aim = bad_aim = n_vig = bad_clip = 0
+    worst_vig = 0.0
+    for name in ('dblgauss_c2', 'nikkor_c3', 'cell_phone', 'singlet_c1', 'rc_telescope_c4'):
+        wl = workloads.load(name)
+        eng = TraceEngine(wl.table)
+        probs = []
+        for trial in range(60):
+            for m in wl.aim or []:
+                a = abi.Aim()
+                f = rng.uniform(0.3, 1.3)
+                a.pt0[0], a.pt0[1], a.pt0[2] = 0.0, m['pt0'][1] * f, m['pt0'][2]
+                a.z_enp = m['z_enp'] * rng.uniform(0.95, 1.05)
+                a.y_target, a.z_dir0 = 0.0, m['z_dir0']
+                a.wvl_idx, a.surf, a.flip = int(rng.integers(0, len(wl.table.wvls))), m['surf'], 1
+                probs.append(a)
+        if probs:
+            yd, rd = eng.aim_chief_rays(probs)
+            yo, ro = oracle.aim_chief_rays(wl.table, probs)
+            n_aim += len(probs)
+            bad_aim += int((~((yd == yo) | (np.isnan(yd) & np.isnan(yo)))).sum() + (rd != ro).sum())
+        vp = []
+        for trial in range(20):
+            for v in wl.vig or []:
+                for i, start in enumerate(v['starts']):
+                    p = abi.Vig()
+                    p.fld = wl.fields[v['field_index']]
+                    p.fld.pt0[1] *= rng.uniform(0.6, 1.1)
+                    p.fld.aim[1] *= rng.uniform(0.9, 1.1)
+                    s = np.array(start, dtype=float)
+                    u = s / np.linalg.norm(s)
+                    p.start_dir[0], p.start_dir[1] = s
+                    p.unit_dir[0], p.unit_dir[1] = u
+                    p.xy, p.wvl_idx, p.stop_surf, p.max_iter = i // 2, v['wvl_idx'], v['stop'], 50
+                    vp.append(p)
+        if vp:
+            vd, cd = eng.calc_vignetting(vp)
+            vo, co = oracle.calc_vignetting(wl.table, vp)
+            n_vig += len(vp)
+            bad_clip += int((cd != co).sum())
+            ok = np.isfinite(vd) & np.isfinite(vo)
+            worst_vig = max(worst_vig, float(np.abs(vd[ok] - vo[ok]).max()) if ok.any() else 0.0)
+        eng.close()
+    out['aiming'] = {'problems': n_aim, 'mismatching': bad_aim}
+    out['vignetting'] = {'problems': n_vig, 'clip_surface_mismatches': bad_clip, 'max_abs_diff': worst_vig}
+    out['seconds'] = round(time.time() - t0, 1)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
