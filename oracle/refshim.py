@@ -244,6 +244,29 @@ def install():
     gl.Robb1983Catalog = lambda: type('C', (), {'glass_list': []})()
     gl.decode_glass_name = lambda name: ((name[:1] or '?', name[1:]), '', '')
 
+    _redirect_importer_logs()
     if REFERENCE_SRC not in sys.path:
         sys.path.insert(0, REFERENCE_SRC)
     _installed = True
+
+
+def _redirect_importer_logs():
+    """The reference's importers open ``logging.FileHandler('zmx_read_lens.log')`` /
+    ``('cv_cmd_proc.log')`` at import time (rayoptics/zemax/zmxread.py:31-33,
+    rayoptics/codev/cmdproc.py:30-32): a relative name, resolved against the
+    current directory -- i.e. into this repository whenever a test imports them.
+    Relative ``*.log`` handlers are sent to a scratch directory instead."""
+    import logging
+    import tempfile
+    if getattr(logging.FileHandler, '_rox_redirected', False):
+        return
+    scratch = tempfile.mkdtemp(prefix='rox_ref_logs_')
+    orig = logging.FileHandler.__init__
+
+    def init(self, filename, *a, **k):
+        name = os.fspath(filename)
+        if not os.path.isabs(name) and name.endswith('.log'):
+            filename = os.path.join(scratch, os.path.basename(name))
+        orig(self, filename, *a, **k)
+    logging.FileHandler.__init__ = init
+    logging.FileHandler._rox_redirected = True

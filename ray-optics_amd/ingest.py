@@ -31,13 +31,19 @@ package, absent from the build container): restated as Rx.Ry.Rz -- tilt parity
 is unpinned.
 
 Refractive indices: the engine consumes evaluated indices, so a glass *name* has
-to be turned into n(wavelength) here.  ``index_of(name, wvl_nm)`` is the hook;
-the default, :func:`reference_fallback_index`, reproduces what the reference
-does when its catalogue does not know a glass: n = 1.5
-(rayoptics/seq/medium.py:172-203) -- the configuration the parity tests pin.
-:func:`nominal_index` adds dispersion formulas for the glasses of the
-reference's fixture prescriptions (checked against the CODE V listing
-rayoptics/codev/tests/ag_dblgauss.lis:30-34 to 1e-5).
+to be turned into n(wavelength) here.  ``index_of(name, wvl_nm)`` is the hook.
+The default, :func:`nominal_index`, evaluates the dispersion formulas on file
+(:data:`SELLMEIER`, checked against the CODE V listing
+rayoptics/codev/tests/ag_dblgauss.lis:30-34 to 1e-5 and against the catalogue
+nd / vd of each glass) and the index samples a file defines itself; a glass
+it does not know gets the reference's own not-in-catalogue value n = 1.5
+(rayoptics/seq/medium.py:172-203) **with an** :class:`UnknownGlassWarning`, and the
+table records it in ``SurfaceTable.fallback_glasses``.
+:func:`reference_fallback_index` (pass it explicitly) gives *every* named glass
+n = 1.5: that is what the reference's importers produce when ``opticalglass``
+has an empty catalogue -- the configuration of the build container, and the one
+the importer-parity tests pin.  In a real installation ``opticalglass`` resolves
+catalogue glasses to dispersive indices: hand such a lookup in as ``index_of``.
 """
 import json
 import math
@@ -49,8 +55,10 @@ from . import abi
 from .table import SurfaceTable, UnsupportedModelError, rt_order_of
 
 # ---------------------------------------------------------------- dispersion
-# Sellmeier-1 coefficients (B1 B2 B3 C1 C2 C3, wavelength in micrometres) of the
-# glasses named by the reference's fixture files.  Nominal catalogue values.
+# Sellmeier-1 coefficients (B1 B2 B3 C1 C2 C3, wavelength in micrometres): nominal
+# catalogue values of the glasses named by the reference's fixture files and of the
+# most common Schott types.  ND_VD holds the catalogue (nd, vd) of each entry;
+# tests/test_ingest_glasses.py checks every formula against it (1e-5 / 0.03).
 SELLMEIER = {
     'N-BK7': (1.03961212, 0.231792344, 1.01046945, 0.00600069867, 0.0200179144, 103.560653),
     'N-SK2': (1.28189012, 0.257738258, 0.96818604, 0.0072719164, 0.0242823527, 110.377773),
@@ -59,12 +67,54 @@ SELLMEIER = {
     'F5': (1.3104463, 0.19603426, 0.96612977, 0.00958633048, 0.0457627627, 115.011883),
     # fused silica, Malitson 1965
     'SILICA': (0.6961663, 0.4079426, 0.8974794, 0.0684043 ** 2, 0.1162414 ** 2, 9.896161 ** 2),
+    'N-BAK1': (1.12365662, 0.309276848, 0.881511957, 0.00644742752, 0.0222284402, 107.297751),
+    'N-BAK4': (1.28834642, 0.132817724, 0.945395373, 0.00779980626, 0.0315631177, 105.965875),
+    'N-BALF4': (1.31004128, 0.142038259, 0.964929351, 0.0079659645, 0.0330672072, 109.19732),
+    'N-BAF10': (1.5851495, 0.143559385, 1.08521269, 0.00926681282, 0.0424489805, 105.613573),
+    'N-K5': (1.08511833, 0.199562005, 0.930511663, 0.00661099503, 0.024110866, 111.982777),
+    'N-FK5': (0.844309338, 0.344147824, 0.910790213, 0.00475111955, 0.0149814849, 97.8600293),
+    'N-PSK53A': (1.38121836, 0.196745645, 0.886089205, 0.00706416337, 0.0233251345, 97.4847345),
+    'N-KZFS4': (1.35055424, 0.197575506, 1.09962992, 0.0087628207, 0.0371767201, 90.3866994),
+    'N-SK4': (1.32993741, 0.228542996, 0.988465211, 0.00716874107, 0.0246455892, 100.886364),
+    'N-SK5': (0.991463823, 0.495982121, 0.987393925, 0.00522730467, 0.0172733646, 98.3594579),
+    'N-SK14': (0.936155374, 0.594052018, 1.04374583, 0.00461716525, 0.016885927, 103.736265),
+    'N-LAK9': (1.46231905, 0.344399589, 1.15508372, 0.00724270156, 0.0243353131, 85.4686868),
+    'N-LAK22': (1.14229781, 0.535138441, 1.04088385, 0.00585778594, 0.0198546147, 100.834017),
+    'N-LAF2': (1.80984227, 0.15729555, 1.0930037, 0.0101711622, 0.0442431765, 100.687748),
+    'N-LASF9': (2.00029547, 0.298926886, 1.80691843, 0.0121426017, 0.0538736236, 156.530829),
+    'F2': (1.34533359, 0.209073176, 0.937357162, 0.00997743871, 0.0470450767, 111.886764),
+    'N-F2': (1.39757037, 0.159201403, 1.2686543, 0.00995906143, 0.0546931752, 119.248346),
+    'N-SF1': (1.60865158, 0.237725916, 1.51530653, 0.0119654879, 0.0590589722, 135.521676),
+    'N-SF2': (1.47343127, 0.163681849, 1.36920899, 0.0109019098, 0.0585683687, 127.404933),
+    'N-SF4': (1.67780282, 0.282849893, 1.63539276, 0.012679345, 0.0602038419, 145.760496),
+    'N-SF5': (1.52481889, 0.187085527, 1.42729015, 0.011254756, 0.0588995392, 129.141675),
+    'N-SF6': (1.77931763, 0.338149866, 2.08734474, 0.0133714182, 0.0617533621, 174.01759),
+    'SF6': (1.72448482, 0.390104889, 1.04572858, 0.0134871947, 0.0569318095, 118.557185),
+    'N-SF8': (1.55075812, 0.209816918, 1.46205491, 0.0114338344, 0.0582725652, 133.24165),
+    'N-SF10': (1.62153902, 0.256287842, 1.64447552, 0.0122241457, 0.0595736775, 147.468793),
+    'N-SF11': (1.73759695, 0.313747346, 1.89878101, 0.013188707, 0.0623068142, 155.23629),
+    'N-SF57': (1.87543831, 0.37375749, 2.30001797, 0.0141749518, 0.0640509927, 177.389795),
 }
+ND_VD = {
+    'N-BK7': (1.51680, 64.17), 'N-SK2': (1.60738, 56.65), 'N-SK16': (1.62041, 60.32),
+    'N-SSK2': (1.62229, 53.27), 'F5': (1.60342, 38.03), 'SILICA': (1.45846, 67.82),
+    'N-BAK1': (1.57250, 57.55), 'N-BAK4': (1.56883, 55.98), 'N-BALF4': (1.57956, 53.87),
+    'N-BAF10': (1.67003, 47.11), 'N-K5': (1.52249, 59.48), 'N-FK5': (1.48749, 70.41),
+    'N-PSK53A': (1.61800, 63.39), 'N-KZFS4': (1.61336, 44.49), 'N-SK4': (1.61272, 58.63),
+    'N-SK5': (1.58913, 61.27), 'N-SK14': (1.60311, 60.60), 'N-LAK9': (1.69100, 54.71),
+    'N-LAK22': (1.65113, 55.89), 'N-LAF2': (1.74397, 44.85), 'N-LASF9': (1.85025, 32.17),
+    'F2': (1.62004, 36.37), 'N-F2': (1.62005, 36.43), 'N-SF1': (1.71736, 29.62),
+    'N-SF2': (1.64769, 33.82), 'N-SF4': (1.75513, 27.38), 'N-SF5': (1.67271, 32.25),
+    'N-SF6': (1.80518, 25.36), 'SF6': (1.80518, 25.43), 'N-SF8': (1.68894, 31.31),
+    'N-SF10': (1.72828, 28.53), 'N-SF11': (1.78472, 25.68), 'N-SF57': (1.84666, 23.78),
+}
+ALIASES = {'BK7': 'N-BK7', 'FUSEDSILICA': 'SILICA', 'F_SILICA': 'SILICA'}
 
 
 def _canon(name):
     """NSK16_SCHOTT / N-SK16 / nsk16 -> N-SK16"""
     n = name.upper().split('_')[0]
+    n = ALIASES.get(n, n)
     if n in SELLMEIER:
         return n
     if n.startswith('N') and not n.startswith('N-') and ('N-' + n[1:]) in SELLMEIER:
@@ -78,13 +128,34 @@ def sellmeier_index(name, wvl_nm):
     return math.sqrt(1.0 + b1 * l2 / (l2 - c1) + b2 * l2 / (l2 - c2) + b3 * l2 / (l2 - c3))
 
 
+def model_glass_index(nd, vd, wvl_nm):
+    """a glass given by (nd, vd) only (Zemax model glasses, CODE V fictitious
+    ``nnn.vvv`` codes): two-term Cauchy n = A + B / lambda^2 through nd with
+    nF - nC = (nd - 1) / vd.  ``opticalglass.modelglass.ModelGlass`` (absent here)
+    fits a Buchdahl model instead -- catalogue parity is unpinned."""
+    if not vd:
+        return float(nd)
+    inv2 = lambda w: 1.0 / (w * 1e-3) ** 2      # noqa: E731
+    b = (nd - 1.0) / vd / (inv2(486.1327) - inv2(656.2725))
+    return float(nd + b * (inv2(wvl_nm) - inv2(587.5618)))
+
+
+class UnknownGlassWarning(UserWarning):
+    """a named glass without dispersion data on file was given n = 1.5"""
+
+
 def reference_fallback_index(name, wvl_nm):
     """what the reference's importers give a glass its catalogue does not have"""
     return 1.5
 
 
+def knows_glass(name):
+    return _canon(name) in SELLMEIER
+
+
 def nominal_index(name, wvl_nm):
-    """dispersion formula where one is on file, the reference's fallback otherwise"""
+    """dispersion formula where one is on file, the reference's fallback otherwise
+    (``Prescription.to_table`` warns about and records the glasses that fell back)"""
     if _canon(name) in SELLMEIER:
         return sellmeier_index(name, wvl_nm)
     return 1.5
@@ -186,7 +257,12 @@ class Prescription:
 
     # rayoptics/seq/sequential.py:611-668 + rayoptics/elem/transform.py:86-118
     def to_table(self, wvls=None, index_of=None):
-        index_of = index_of or reference_fallback_index
+        """``index_of(name, wvl_nm)``: see the module docstring.  Default
+        :func:`nominal_index`; glasses it does not know are reported
+        (:class:`UnknownGlassWarning`) and listed in ``table.fallback_glasses``."""
+        default_lookup = index_of is None
+        index_of = index_of or nominal_index
+        fell_back = []
         wvls = [float(w) for w in (wvls or self.wvls or [550.0])]
         N = len(self.ifcs)
         rows = (abi.Surface * N)()
@@ -292,9 +368,14 @@ class Prescription:
                     elif m[0] == 'const':
                         n = float(m[1])
                     elif m[0] == 'model':
-                        n = float(index_of(f'{m[1]:.6g},{m[2]:.6g}', wl)) if index_of is not \
-                            reference_fallback_index else float(m[1])
-                    elif m[1] in self.private_glasses and index_of is reference_fallback_index:
+                        if default_lookup:
+                            n = model_glass_index(m[1], m[2], wl)
+                        elif index_of is reference_fallback_index:
+                            n = float(m[1])
+                        else:
+                            n = float(index_of(f'{m[1]:.6g},{m[2]:.6g}', wl))
+                    elif m[1] in self.private_glasses and (default_lookup or
+                                                          index_of is reference_fallback_index):
                         # a glass the file defines itself (CODE V PRV ... END: index samples at
                         # the PWL wavelengths); the reference interpolates them with
                         # opticalglass.InterpolatedMedium -- here: linear in wavelength
@@ -302,10 +383,20 @@ class Prescription:
                         order = np.argsort(pw)
                         n = float(np.interp(wl, np.asarray(pw)[order], np.asarray(pn)[order]))
                     else:
+                        if default_lookup and not knows_glass(m[1]) and m[1] not in fell_back:
+                            fell_back.append(m[1])
                         n = float(index_of(m[1], wl))
                     n_table[w, i] = n
                     prev_n[w] = n
-        return SurfaceTable(rows, n_table, wvls, self.stop)
+        if fell_back:
+            import warnings
+            warnings.warn('no dispersion data on file for ' + ', '.join(fell_back) +
+                          ": traced with n = 1.5 at every wavelength (the reference's "
+                          'not-in-catalogue value); pass index_of= to resolve them',
+                          UnknownGlassWarning, stacklevel=2)
+        tbl = SurfaceTable(rows, n_table, wvls, self.stop)
+        tbl.fallback_glasses = tuple(fell_back)
+        return tbl
 
 
 # ---------------------------------------------------------------- .zmx

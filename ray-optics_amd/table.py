@@ -140,6 +140,8 @@ class SurfaceTable:
         self.wvls = [float(w) for w in wvls]
         self.wvls_arr = np.ascontiguousarray(self.wvls, dtype=np.float64)   # nm, for the C ABI
         self.stop_idx = stop_idx
+        # glass names that ingest.Prescription.to_table gave n = 1.5 for want of dispersion data
+        self.fallback_glasses = ()
         assert self.n_table.shape == (len(self.wvls), len(rows))
 
     @property

@@ -53,7 +53,7 @@ def test_zmx_table_equals_reference_import(rel):
     opm, _info = zmxread.read_lens(None, inpt, do_update=False)     # the reference's importer
     opm['seq_model'].update_model()
     theirs = SurfaceTable.from_seq_model(opm['seq_model'])
-    ours = ingest.read_zmx(str(path)).to_table()
+    ours = ingest.read_zmx(str(path)).to_table(index_of=ingest.reference_fallback_index)
     rows_equal(ours, theirs, rel)
 
 
@@ -83,7 +83,7 @@ def test_seq_table_equals_reference_import(rel):
     sm = opm['seq_model']
     sm.update_model()
     theirs = SurfaceTable.from_seq_model(sm)
-    ours = ingest.read_seq(str(path)).to_table()
+    ours = ingest.read_seq(str(path)).to_table(index_of=ingest.reference_fallback_index)
     # CODE V listings give max_aperture no value: the reference derives it later
     # from traced rays (set_clear_apertures, control plane); compare with it neutralised
     for t in (ours, theirs):
@@ -109,7 +109,7 @@ def test_roa_table_equals_reference_model(rel):
     for i, g in enumerate(sm.gaps):                 # the media the reference model holds
         idx[i] = [g.medium.rindex(w) for w in wvls]
     pres = ingest.read_roa(path)
-    ours = pres.to_table(wvls=wvls)
+    ours = pres.to_table(wvls=wvls, index_of=ingest.reference_fallback_index)
     # refractive indices: the .roa names catalogue glasses; both sides take the
     # evaluated numbers of the reference model (catalogue parity is out of scope)
     ours.n_table[:, :len(sm.gaps)] = np.array([idx[i] for i in range(len(sm.gaps))]).T
@@ -158,7 +158,7 @@ def test_decentered_ingest_traces_like_the_reference(rel):
         SequentialModel.set_clear_apertures, OpticalModel.update_model = saved
     sm = opm['seq_model']
     sm.update_model()
-    tbl = ingest.read_seq(str(path)).to_table()
+    tbl = ingest.read_seq(str(path)).to_table(index_of=ingest.reference_fallback_index)
     N = tbl.n_ifcs
     wvl = tbl.wvls[0]
     rng = np.random.default_rng(5)
@@ -273,7 +273,7 @@ def test_synthetic_zmx_with_every_surface_type(tmp_path):
     opm, _info = zmxread.read_lens(None, SYNTHETIC_ZMX, do_update=False)
     opm['seq_model'].update_model()
     theirs = SurfaceTable.from_seq_model(opm['seq_model'])
-    ours = ingest.read_zmx(str(path)).to_table()
+    ours = ingest.read_zmx(str(path)).to_table(index_of=ingest.reference_fallback_index)
     rows_equal(ours, theirs, 'synthetic.zmx')
     from rayoptics_amd import abi
     kinds = [r.profile for r in ours.rows]
@@ -298,7 +298,7 @@ def test_synthetic_zmx_traces_like_the_reference(tmp_path):
     opm, _info = zmxread.read_lens(None, SYNTHETIC_ZMX, do_update=False)
     sm = opm['seq_model']
     sm.update_model()
-    tbl = ingest.read_zmx(str(path)).to_table()
+    tbl = ingest.read_zmx(str(path)).to_table(index_of=ingest.reference_fallback_index)
     N = tbl.n_ifcs
     rng = np.random.default_rng(12)
     R = 60
@@ -404,7 +404,7 @@ def test_synthetic_seq_with_every_command(tmp_path):
     sm.update_model()
     theirs = SurfaceTable.from_seq_model(sm)
     pres = ingest.read_seq(str(path))
-    ours = pres.to_table()
+    ours = pres.to_table(index_of=ingest.reference_fallback_index)
     assert ours.n_ifcs == theirs.n_ifcs == 9
     for t in (ours, theirs):
         t.n_table = t.n_table.copy()

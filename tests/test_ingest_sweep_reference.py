@@ -66,7 +66,7 @@ def test_every_prescription_file_of_the_reference_tree(rel):
                 ingest.read(path)
             return
         pres = ingest.read(path)
-        ours = pres.to_table()
+        ours = pres.to_table(index_of=ingest.reference_fallback_index)
         if rel in REFERENCE_FAILS:
             assert ours.n_ifcs >= 3
             return
@@ -115,7 +115,7 @@ def test_every_roa_file_of_the_reference_tree(rel):
         opm = rm.load_roa(path)
     except (ValueError, KeyError):
         try:
-            assert pres.to_table().n_ifcs == len(pres.ifcs) >= 3
+            assert pres.to_table(index_of=ingest.reference_fallback_index).n_ifcs == len(pres.ifcs) >= 3
         except UnsupportedModelError:
             pass
         return
@@ -124,10 +124,10 @@ def test_every_roa_file_of_the_reference_tree(rel):
         theirs = SurfaceTable.from_seq_model(sm)
     except UnsupportedModelError:
         with pytest.raises(UnsupportedModelError):
-            pres.to_table()
+            pres.to_table(index_of=ingest.reference_fallback_index)
         return
     wvls = theirs.wvls
-    ours = pres.to_table(wvls=wvls)
+    ours = pres.to_table(wvls=wvls, index_of=ingest.reference_fallback_index)
     ours.n_table[:, :len(sm.gaps)] = np.array([[g.medium.rindex(w) for w in wvls] for g in sm.gaps]).T
     ours.n_table[:, len(sm.gaps):] = theirs.n_table[:, len(sm.gaps):]
     for t in (ours, theirs):
