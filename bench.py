@@ -3,6 +3,11 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
+``--gpus N`` with N > 1 needs one process per GPU: when this script is started
+plainly (no WORLD_SIZE in the environment) it re-executes itself under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` on 127.0.0.1;
+rank 0 prints the one JSON line on the original stdout.
+
 Workload (configs[1]): the 13-interface double Gauss (K = 12 intersections per
 ray), 1 field, 1 wavelength, 1024 x 1024 pupil grid = 1,048,576 rays per step,
 FULL ray packets (the RayPkg return shape kept intact: 13 segments x 10 f64 per
@@ -12,36 +17,46 @@ entry of the C ABI.  One "step" = one such grid.  Inputs are resident in HBM
 
 metric        ray-surface intersections per second, counting the intersections
               actually performed (a ray blocked at surface s contributes s, not K)
+cold_ms_per_step  the same K launches issued right after an idle second, before any
+              warm-up (the GPU's clocks ramp over the first ~100 launches)
 roofline      HBM-bound kernel: algorithmic bytes = what one launch must write
               (80 B per appended segment + 8 B op + 3 B status, +16 B pupil)
               divided by the trace kernel's mean duration from HIP events on the
-              launch stream
+              launch stream; `traffic` is a committed PMC figure (traffic_source says
+              from which library build) -- null when the library has changed since
 roofline_hits the HITS kernel behind spot diagrams / OPD / refocus is fp64-VALU
               bound: TFLOP/s by SURVEY 8(d)'s 130 flop per intersection against the
               78.6 TFLOP/s fp64 vector peak, and the VALU issue fraction from the
               committed PMC summary
+configs       every BASELINE.json configuration at its own shape: kernel ms, rays/s,
+              intersections/s, roofline fraction (HBM for FULL packets, VALU issue /
+              flop rate for HITS)
 spot_diagram  BASELINE's second metric at the PRODUCT boundary: wall-clock of
-              rayoptics_amd.trace.trace_grid_spot (the function SequentialModel.trace_grid
-              is rebound to for SpotDiagramFigure) from the Python call to the host
+              rayoptics_amd.trace.trace_grid_spot from the Python call to the host
               (R_ok, 2) array, on a table-backed model
 cpu_baseline  the plain-C oracle (oracle/rox_oracle.c, "port"), 1 thread, on a
               bounded sample of the same grid, timed on this host; next to it the
-              reference's own Python path as timed by tools/time_reference.py in the
-              build container (the reference is not installed on the GPU box)
+              reference's own Python path AND the same port as timed together in the
+              build container (tools/time_reference.py) -- the same-host ratio bridges
+              the two hosts (the reference is not installed on the GPU box)
 strong_scaling  every run, any N: BASELINE configs[4]'s shape -- 9 fields x 5
               wavelengths x 2048^2 pupil grids of the 44-interface lithography
-              lens (188.7 M rays, HITS) cut into pupil-row blocks over the ranks
-              (dist.partition), hits gathered to rank 0 over RCCL: kernel ms (max
-              over ranks), gather ms and end-to-end ms, separately
+              lens (188.7 M rays) cut into pupil-row blocks over the ranks, packed
+              hits (no padding for blocked rays), brought to rank 0's host memory
+              (a) by the RCCL gather + one D2H copy and (b) by every rank's kernel
+              writing into a shared pinned host segment over its own PCIe link; kernel,
+              count exchange, gather, D2H, host reassembly and end-to-end, separately;
+              plus configs[3] sharded by field
 
-N > 1: launched by torch.distributed.run, one rank per GPU.  The main line is
-weak scaling (each rank traces its own (field, wavelength) grid of the same
-size, no data-path collective in the timed region; max-over-ranks time); the
-strong_scaling object carries the fixed-size problem with its one exchange step.
+N > 1: one rank per GPU.  The main line is weak scaling (each rank traces its
+own (field, wavelength) grid of the same size, no data-path collective in the
+timed region; max-over-ranks time); strong_scaling carries the fixed-size
+problem with its one exchange step.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -49,6 +64,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
+
+SPOT_FLAGS = None       # set in main (abi constants)
 
 
 def parse():
@@ -64,28 +81,52 @@ def parse():
     ap.add_argument('--cpu-sample-rows', type=int, default=0,
                     help='pupil rows traced by the CPU baseline (0 = auto, ~10 s)')
     ap.add_argument('--no-strong', action='store_true', help='skip the strong-scaling leg')
+    ap.add_argument('--no-configs', action='store_true', help='skip the per-config leg')
     ap.add_argument('--strong-num', type=int, default=2048,
                     help='pupil grid of the strong-scaling leg is num x num per (field, wvl)')
     return ap.parse_args()
 
 
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: become `torch.distributed.run` with N local
+    ranks (exec: same stdout, same exit status)"""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
+    global SPOT_FLAGS
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
     import torch
     import torch.distributed as dist
     import rayoptics_amd  # noqa: F401
     from rayoptics_amd import abi, workloads
     from rayoptics_amd.engine import TraceEngine, make_opts, make_grid, DeviceResult
+    SPOT_FLAGS = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with '
-                         f'{args.gpus} ranks (WORLD_SIZE={world})')
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started {world} ranks')
     # rehearsal switches (a 1-GPU box cannot run RCCL with two ranks): ROX_BENCH_SHARE_GPU=1
     # puts every rank on device 0 and ROX_BENCH_BACKEND=gloo carries the collectives --
-    # the N > 1 control flow, partitioning and gathers run as they will over RCCL
+    # the N > 1 control flow, partitioning and exchanges run as they will over RCCL
     backend = os.environ.get('ROX_BENCH_BACKEND', 'nccl')
     if os.environ.get('ROX_BENCH_SHARE_GPU') == '1':
         local_rank = 0
@@ -118,7 +159,7 @@ def main():
     wi = (wl.ref_wvl_idx + rank // nf) % nw
     fld = wl.fields[fi]
     grid = make_grid((-1., -1.), (1., 1.), num)
-    flags = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+    flags = SPOT_FLAGS
     opts = make_opts(flags=flags, out_mode=abi.OUT_FULL, first_surf=1, last_surf=N - 2)
     out = DeviceResult(torch, eng.device, eng.num_segments(flags), R, abi.OUT_FULL,
                        want_pupil=True, nan_fill=False)
@@ -136,6 +177,25 @@ def main():
             torch.cuda.synchronize()
             dist.all_reduce(_tok)
         torch.cuda.synchronize()
+
+    # how many ranks the backend really connects (an all-reduce of ones)
+    ranks_seen = 1
+    if multi:
+        ones = torch.ones(1, device=eng.device)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+
+    # cold: the K launches as a caller meets them after an idle second (one launch first, so
+    # that module load and allocation are not in it)
+    step()
+    torch.cuda.synchronize()
+    time.sleep(1.0)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    cold_dt = time.perf_counter() - t0
 
     # the GPU's clocks need tens of milliseconds of continuous work to settle (a cold
     # start reads 10-30 % slow, tools/sustained_probe.py): untimed launches first, at
@@ -157,17 +217,12 @@ def main():
     fence()
     fence_ms = (time.perf_counter() - t_f) * 1e3      # cost of one (idle) fence, for the record
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        t = torch.tensor([dt, cold_dt], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        dt, cold_dt = t[0].item(), t[1].item()
 
     # work actually done by this rank's grid
-    status = out.status.cpu().numpy()
-    fail = out.fail_surf.cpu().numpy().astype(np.int64)
-    ok = status == abi.OK
-    inters = int(ok.sum()) * K + int(fail[~ok].sum())
-    nseg = np.where(ok, N, np.where(status == abi.MISSED_SURFACE, fail, fail + 1))
-    alg_bytes = int(nseg.sum()) * 80 + R * (8 + 1 + 2 + 16)
+    inters, alg_bytes = work_of(out.status, out.fail_surf, N, abi, full=True)
     tot = torch.tensor([inters, R], dtype=torch.float64, device=eng.device)
     if multi:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -200,6 +255,8 @@ def main():
         t1 = time.perf_counter()
         xy = rox_trace.trace_grid_spot(model, grid_rng, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
         spot_ms.append((time.perf_counter() - t1) * 1e3)
+    n_through = int(xy.shape[0])
+    del xy, out
 
     # the PSF of an OPD grid (analyses.calc_psf): the GEMM-shaped neighbour of the path,
     # on the fp64 matrix cores; device-resident, mean of back-to-back calls
@@ -210,12 +267,24 @@ def main():
         except Exception as e:
             psf = {'error': repr(e)}
 
-    # every run: the fixed-size problem with the path's one exchange step
+    # every BASELINE configuration at its own shape (rank 0's GPU; the others wait at the
+    # next fence)
+    configs = None
+    if rank == 0 and not args.no_configs:
+        try:
+            configs = configs_leg(torch, abi, workloads)
+        except Exception as e:
+            configs = {'error': repr(e)}
+    torch.cuda.empty_cache()
+
+    # every run: the fixed-size problems with the path's one exchange step
     strong = None
     if not args.no_strong:
         try:
-            strong = strong_scaling(args, torch, dist, multi, world, rank, fence)
+            strong = strong_scaling(args, torch, dist, multi, world, rank, fence, ranks_seen)
         except Exception as e:      # never lose the main line to the extra leg
+            import traceback
+            traceback.print_exc(file=sys.stderr)
             strong = {'error': repr(e)}
 
     cpu = None
@@ -223,22 +292,19 @@ def main():
         cpu = cpu_baseline(wl, fld, wi, opts, num, args.cpu_sample_rows)
 
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get('num') == num and tj.get('workload') == wl.name:
-                traffic = tj.get('hbm_bytes_per_launch')
+        traffic, traffic_source = committed_traffic(num, wl.name)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         line = {
             'metric': 'ray-surface intersections/sec',
             'value': inters_all / dt * args.steps,
             'unit': 'ray-surface intersections/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_steps_run': n_w,
-            'ms_per_step': dt / args.steps * 1e3, 'fence_ms': fence_ms,
+            'ms_per_step': dt / args.steps * 1e3,
+            'cold_ms_per_step': cold_dt / args.steps * 1e3,
+            'fence_ms': fence_ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
+            'ranks_seen_by_backend': ranks_seen,
             'config': {'workload': 'double-Gauss 13 interfaces (K=12), 1 field, 1 wvl, '
                                    f'{num}x{num} pupil grid per GPU, FULL ray packets, '
                                    'device-generated rays (BASELINE.json configs[1])',
@@ -250,22 +316,25 @@ def main():
             'rays_per_s': rays_all / dt * args.steps,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic,
+                         'traffic_source': traffic_source,
                          'kernel': 'trace_kernel<FULL,PUPIL>', 'kernel_ms': kern_ms,
                          'algorithmic_bytes_per_launch': alg_bytes,
                          'frac_of_measured_copy_peak_6290': achieved / 6290.0},
             'roofline_hits': roofline_hits(inters, R, hits_kern_ms),
             'spot_diagram': {'wallclock_ms': float(np.median(spot_ms)),
                              'wallclock_min_ms': float(np.min(spot_ms)), 'rays': R,
-                             'rays_through': int(xy.shape[0]), 'kernel_hits_ms': hits_kern_ms,
-                             'pcie_floor_ms': xy.shape[0] * 16 / 54.7e9 * 1e3,
+                             'rays_through': n_through, 'kernel_hits_ms': hits_kern_ms,
+                             'pcie_floor_ms': n_through * 16 / 54.7e9 * 1e3,
                              'what': 'rayoptics_amd.trace.trace_grid_spot(model, grid_rng, fld, wvl, '
                                      'foc, image_pt): Python call -> host (R_ok, 2) float64 array '
                                      '(survivors packed in ray order by the trace launch, written '
                                      'straight into pinned host memory; 13 MB over PCIe at ~55 GB/s '
                                      'is the floor)'},
+            'configs': configs,
             'psf': psf,
             'cpu_baseline': cpu,
             'strong_scaling': strong,
+            'library': library_id(),
         }
         # the one JSON line goes to the real stdout (fd 1 was pointed at stderr while the
         # communicator was being built and the collectives ran)
@@ -283,8 +352,66 @@ def main():
         dist.destroy_process_group()
 
 
+# ----------------------------------------------------------------------------- helpers
+def work_of(status, fail_surf, N, abi, full):
+    """(intersections actually performed, algorithmic bytes) of one traced batch from its
+    status / fail_surf arrays (torch, on the device): a ray that got through did N - 1
+    intersections, a ray that failed at surface s did s; FULL packets hold N segments for
+    a survivor, s (missed) or s + 1 (blocked / TIR) for a failed ray"""
+    import torch
+    ok = status == abi.OK
+    fs = fail_surf.to(torch.int64)
+    n_ok = int(ok.sum().item())
+    R = status.numel()
+    inters = n_ok * (N - 1) + int(fs[~ok].sum().item())
+    if not full:
+        return inters, R * 19
+    missed = status == abi.MISSED_SURFACE
+    nseg = n_ok * N + int(fs[missed].sum().item()) + int((fs[~ok & ~missed] + 1).sum().item())
+    return inters, nseg * 80 + R * (8 + 1 + 2 + 16)
+
+
+def library_id():
+    """the digest build.py stamps next to libroxtrace.so (sources + headers + flags)"""
+    try:
+        with open(os.path.join(ROOT, 'ray-optics_amd', 'libroxtrace.so.srchash')) as f:
+            return {'source_hash': f.read().strip()[:16]}
+    except OSError:
+        return {'source_hash': None}
+
+
+def committed_traffic(num, workload):
+    """roofline.traffic is not measured in this run (PMC passes need rocprofv3): it is the
+    committed figure of tools/make_traffic.py, valid for the workload / grid AND the library
+    build it was taken with -- says so, and is withheld when the kernels have changed since"""
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if not os.path.exists(tpath):
+        return None, 'no committed PMC figure'
+    with open(tpath) as f:
+        tj = json.load(f)
+    if tj.get('num') != num or tj.get('workload') != workload:
+        return None, 'committed PMC figure is for another workload / grid'
+    have = library_id()['source_hash']
+    src = f"profiles/traffic.json ({tj.get('source')}; separate rocprofv3 --pmc passes)"
+    if tj.get('library_source_hash') and tj['library_source_hash'] != have:
+        return None, src + f" -- taken with library {tj['library_source_hash']}, this is {have}: withheld"
+    if not tj.get('library_source_hash'):
+        src += ' -- library build of that run not recorded'
+    return tj.get('hbm_bytes_per_launch'), src
+
+
+def committed_pmc(workload):
+    """VALU wave instructions per intersection of the HITS kernel from the committed PMC
+    summaries (profiles/valu_per_intersection.json, tools/pmc_summary.py)"""
+    p = os.path.join(ROOT, 'profiles', 'valu_per_intersection.json')
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        return json.load(f).get(workload)
+
+
 def psf_leg(torch):
-    """rox_calc_psf at two sizes: ms per call and fp64 TFLOP/s by 8 M n (n + M) flop
+    """rox_calc_psf at three sizes: ms per call and fp64 TFLOP/s by 8 M n (n + M) flop
     (two complex GEMMs) against the 78.6 TFLOP/s fp64 peak (matrix = vector rate)"""
     from rayoptics_amd.engine import calc_psf
     out = {'what': 'rayoptics_amd.engine.calc_psf (rox_calc_psf: analyses.calc_psf as a pruned DFT, '
@@ -312,108 +439,252 @@ def psf_leg(torch):
     return out
 
 
-def roofline_hits(inters, R, kern_ms):
+def roofline_hits(inters, R, kern_ms, workload='dblgauss_c2'):
     """the VALU-bound HITS kernel: achieved fp64 TFLOP/s by SURVEY 8(d)'s count of
     130 flop per spherical refracting intersection (5 sqrt + 8 div counted as one
     each) against the 78.6 TFLOP/s fp64 vector peak; VALU issue fraction from the
-    committed PMC summary of the same kernel when present"""
+    committed PMC instruction count per intersection of the same kernel when present"""
     flops = 130.0 * inters
     achieved = flops / (kern_ms * 1e-3) / 1e12
     out = {'bound': 'fp64 valu', 'achieved': achieved, 'peak': 78.6, 'unit': 'TFLOP/s',
            'frac': achieved / 78.6, 'kernel': 'trace_kernel<HITS,PUPIL>', 'kernel_ms': kern_ms,
            'flop_per_intersection': 130, 'algorithmic_bytes_per_launch': R * 19,
            'hbm_GBps': R * 19 / (kern_ms * 1e-3) / 1e9}
-    ppath = os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')
-    if os.path.exists(ppath):
-        try:
-            with open(ppath) as f:
-                pj = json.load(f)
-            h = pj.get('HITS', {})
-            if 'SQ_INSTS_VALU' in h:
-                # wave-level VALU instructions x 4 cycles (fp64: 16 lanes/clk/SIMD) over
-                # the SIMD-cycles of the launch (256 CUs x 4 SIMDs x 2.4 GHz)
-                out['valu_insts_per_launch'] = h['SQ_INSTS_VALU']
-                out['valu_issue_frac'] = h['SQ_INSTS_VALU'] * 4 / (256 * 4 * 2.4e9 * kern_ms * 1e-3)
-        except Exception:
-            pass
+    pmc = committed_pmc(workload)
+    if pmc:
+        # wave-level VALU instructions x 4 cycles (fp64: 16 lanes/clk/SIMD) over the
+        # SIMD-cycles of the launch (256 CUs x 4 SIMDs x 2.4 GHz)
+        insts = pmc['valu_wave_insts_per_intersection'] * inters
+        out['valu_insts_per_launch'] = insts
+        out['valu_issue_frac'] = insts * 4 / (256 * 4 * 2.4e9 * kern_ms * 1e-3)
+        out['valu_source'] = pmc.get('source')
     return out
 
 
-def strong_scaling(args, torch, dist, multi, world, rank, fence):
-    """BASELINE configs[4]'s shape on the 44-interface lithography lens: 9 fields
-    x 5 wavelengths x num^2 pupil grids, HITS, pupil-row blocks over the ranks,
-    hits gathered to rank 0.  Kernel, gather and end-to-end times separately."""
+def configs_leg(torch, abi, workloads):
+    """Every BASELINE.json configuration at its own shape on this GPU: one pass = every
+    (field, wavelength) grid of the configuration launched back to back; steady-state ms
+    per pass from events on the launch stream (median of 5 timed batches after >= 100 ms of
+    untimed passes).  FULL packets where they fit HBM (config 5's 666 GB do not)."""
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid, DeviceResult
+    specs = [
+        ('c1', 'singlet_c1', [0], [None], 64, True,
+         'configs[0]: singlet (4 interfaces), 1 field, 1 wvl, 64x64'),
+        ('c2', 'dblgauss_c2', [0], [None], 1024, True,
+         'configs[1]: double Gauss (13 interfaces), 1 field, 1 wvl, 1024x1024 (the main line)'),
+        ('c3', 'nikkor_c3', [0, 1, 2], [0, 1, 2], 512, True,
+         'configs[2] stand-in: 29-interface zoom with 4 even aspheres (.roa), 3 fields x 3 wvls x 512x512'),
+        ('c3_zmx', 'zmx_evenasph_c3', [0, 1, 2], [0, 1, 2], 512, True,
+         'configs[2]: Zemax .zmx import US08427765-1.ZMX, 13 interfaces incl. an EVENASPH, '
+         '3 fields x 3 wvls x 512x512'),
+        ('c4', 'rc_telescope_c4', [0, 1, 2, 3, 4], [None], 256, True,
+         'configs[3]: Ritchey-Chretien mirror pair + field stop (5 interfaces), 5 fields x 256x256'),
+        ('c5', 'litho_c5', list(range(9)), list(range(5)), 2048, False,
+         'configs[4]: 44-interface lithography lens, 9 fields x 5 wvls x 2048x2048 (HITS: FULL packets '
+         'would be 666 GB)'),
+    ]
+    out = {}
+    for key, name, fis, wis, num, do_full, what in specs:
+        wl = workloads.load(name)
+        N = wl.n_ifcs
+        eng = TraceEngine(wl.table)
+        wis = [wl.ref_wvl_idx if w is None else w for w in wis]
+        R = num * num
+        grid = make_grid((-1., -1.), (1., 1.), num)
+        wide = [abi.INTERSECT_OBJ if (f.kind != abi.FLD_EPD_WIDE and f.z_dir0 != 0.0) else 0
+                for f in wl.fields]
+        pairs = [(f, w) for f in fis for w in wis]
+        rec = {'what': what, 'workload': name, 'interfaces': N, 'grids': len(pairs),
+               'rays': R * len(pairs)}
+        for mode, label in ((abi.OUT_HITS, 'hits'), (abi.OUT_FULL, 'full')):
+            if mode == abi.OUT_FULL and not do_full:
+                continue
+            res = DeviceResult(torch, eng.device, eng.num_segments(0), R, mode,
+                               want_pupil=(mode == abi.OUT_FULL), nan_fill=False)
+
+            def one_pass(count=False):
+                inters = nbytes = 0
+                for f, w in pairs:
+                    o = make_opts(flags=(SPOT_FLAGS & ~abi.INTERSECT_OBJ) | wide[f], out_mode=mode,
+                                  first_surf=1, last_surf=N - 2, foc=wl.foc, image_pt=wl.image_pts[f])
+                    eng.trace_pupil_grid(wl.fields[f], grid, w, o, out=res)
+                    if count:
+                        i, b = work_of(res.status, res.fail_surf, N, abi, full=(mode == abi.OUT_FULL))
+                        inters += i
+                        nbytes += b
+                return inters, nbytes
+            inters, nbytes = one_pass(count=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_warm = 0
+            while (time.perf_counter() - t0) < 0.1 or n_warm < 2:
+                one_pass()
+                n_warm += 1
+                if n_warm % 16 == 0:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            per = max(1, min(50, int(0.02 / max((time.perf_counter() - t0) / n_warm, 1e-6))))
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(per):
+                    one_pass()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / per)
+            ms = sorted(ts)[len(ts) // 2]
+            r = {'kernel_ms_per_pass': ms, 'rays_per_s': R * len(pairs) / (ms * 1e-3),
+                 'intersections': inters, 'intersections_per_s': inters / (ms * 1e-3)}
+            if mode == abi.OUT_FULL:
+                gbps = nbytes / (ms * 1e-3) / 1e9
+                r.update({'bound': 'hbm', 'algorithmic_bytes': nbytes, 'GBps': gbps,
+                          'frac_of_8000': gbps / 8000.0, 'frac_of_measured_copy_peak_6290': gbps / 6290.0})
+            else:
+                r.update({'bound': 'fp64 valu', 'tflops_130_per_intersection': 130.0 * inters / (ms * 1e-3) / 1e12})
+                pmc = committed_pmc(name)
+                if pmc:
+                    r['valu_issue_frac'] = (pmc['valu_wave_insts_per_intersection'] * inters * 4 /
+                                            (256 * 4 * 2.4e9 * ms * 1e-3))
+                    r['valu_source'] = pmc.get('source')
+            rec[label] = r
+            del res
+        out[key] = rec
+        eng.close()
+        torch.cuda.empty_cache()
+    return out
+
+
+def strong_scaling(args, torch, dist, multi, world, rank, fence, ranks_seen):
+    """BASELINE configs[4]'s shape on the 44-interface lithography lens (9 fields x 5
+    wavelengths x num^2 pupil grids, pupil-row blocks over the ranks) and configs[3]
+    (Ritchey-Chretien, 5 fields x 256^2, whole fields per rank): packed hits brought to
+    rank 0's host memory by both exchanges of rayoptics_amd.dist, every phase timed."""
     from rayoptics_amd import workloads
     from rayoptics_amd import dist as rdist
     from rayoptics_amd.engine import TraceEngine
-    wl = workloads.load('litho_c5')
-    eng = TraceEngine(wl.table)
-    nf, nw, num = len(wl.fields), len(wl.table.wvls), args.strong_num
-    plan = rdist.partition(nf, nw, num, world)
-    sizes = [sum(b.row_count for b in blocks) * num for blocks in plan]
-    cap = max(max(sizes), 1)
-    for _rep in range(2):               # the first pass warms allocations and RCCL
-        fence()
-        t0 = time.perf_counter()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        xy, st, n_local = rdist.trace_blocks(eng, plan[rank], cap, wl.fields, wl.image_pts, num, wl.foc)
-        e1.record()
-        torch.cuda.synchronize()
-        t_trace = time.perf_counter() - t0
-        kern_ms = e0.elapsed_time(e1)
-        fence()
-        t1 = time.perf_counter()
-        parts = rdist.gather_hits(xy, st)
-        fence()
-        t_gather = time.perf_counter() - t1
-        t_all = time.perf_counter() - t0
-        ok_local = int((st[:n_local] == 0).sum().item())
-        del parts, xy, st
-    vals = torch.tensor([kern_ms, t_trace * 1e3, t_gather * 1e3, t_all * 1e3],
-                        dtype=torch.float64, device=eng.device)
-    cnt = torch.tensor([n_local, ok_local], dtype=torch.float64, device=eng.device)
-    if multi:
-        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    K = wl.n_ifcs - 1
-    rays = int(cnt[0].item())
-    res = {'workload': f'litho_c5 ({wl.n_ifcs} interfaces, K={K}), {nf} fields x {nw} wvls x '
-                       f'{num}x{num} pupil grids, HITS, pupil-row blocks over ranks (dist.partition)',
-           'scaling': 'strong', 'ranks': world,
-           'backend': (dist.get_backend() if multi else 'none (single process)'),
-           'rays': rays, 'rays_through': int(cnt[1].item()),
-           'rays_per_rank_max': cap,
-           'kernel_ms_max_over_ranks': vals[0].item(),
-           'trace_wallclock_ms_max': vals[1].item(),
-           'gather_ms': vals[2].item(),
-           'end_to_end_ms': vals[3].item(),
-           'gather_bytes_to_root': int(17 * cap * (world - 1)),
-           'rays_per_s_end_to_end': rays / (vals[3].item() * 1e-3),
-           'ray_surface_per_s_kernel': rays * K / (vals[0].item() * 1e-3),
-           'note': 'nominal R*K intersections (blocked rays stop early); host reassembly of the '
-                   'gathered hits is not part of these times'}
-    eng.close()
-    return res
+
+    def problem(name, num, by):
+        wl = workloads.load(name)
+        eng = TraceEngine(wl.table)
+        nf, nw = len(wl.fields), len(wl.table.wvls)
+        plan = rdist.partition(nf, nw, num, world, by)
+        caps = [rdist.rays_of(b, num) for b in plan]
+        K = wl.n_ifcs - 1
+        res = {'workload': f'{name} ({wl.n_ifcs} interfaces, K={K}), {nf} fields x {nw} wvls x '
+                           f'{num}x{num} pupil grids, packed hits (HITS_COMPACT | HITS_APPEND), '
+                           f"partition by {by}",
+               'rays': sum(caps), 'rays_per_rank_max': max(caps), 'blocks_per_rank': [len(b) for b in plan]}
+        for exchange in ('rccl', 'host'):
+            seg = None
+            try:
+                setup_ms = 0.0
+                if exchange == 'host':
+                    t_s = time.perf_counter()
+                    tag = f"rox_seg_{os.environ.get('MASTER_PORT', '0')}_{name}_{num}"
+                    err = torch.zeros(1, device=eng.device)
+                    if rank == 0:
+                        try:
+                            seg = rdist.HostSegment(eng, tag, caps, rank, create=True)
+                        except Exception as e:      # every rank must learn of it
+                            err += 1
+                            first_err = repr(e)
+                    if multi:
+                        dist.all_reduce(err)
+                    if err.item() > 0:
+                        raise RuntimeError(first_err if rank == 0 else 'rank 0 could not create the segment')
+                    if rank != 0:
+                        seg = rdist.HostSegment(eng, tag, caps, rank, create=False)
+                    fence()
+                    setup_ms = (time.perf_counter() - t_s) * 1e3
+                recs = []
+                n_views = 0
+                for _rep in range(3):               # the first pass warms allocations, pinning and RCCL
+                    fence()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    tm = {}
+                    # kernel time alone: the same launches bracketed by events on the launch stream
+                    probe = rdist.trace_blocks(eng, plan[rank], num, wl.fields, wl.image_pts, wl.foc,
+                                               dest=None if seg is None else seg.dest(rank))
+                    e1.record()
+                    probe.counts()
+                    kern_ms = e0.elapsed_time(e1)
+                    del probe
+                    fence()
+                    t1 = time.perf_counter()
+                    views = rdist.trace_spot_sharded(eng, wl.fields, wl.image_pts, nw, num, wl.foc, by=by,
+                                                     exchange=exchange, segment=seg, timings=tm)
+                    fence()
+                    t_all = time.perf_counter() - t1
+                    n_views = 0 if views is None else len(views)
+                    del views
+                    tm.update(kernel_ms=kern_ms, end_to_end_ms=t_all * 1e3)
+                    recs.append(tm)
+                best = recs[-1]
+                vals = torch.tensor([best['kernel_ms'], best['trace_ms'], best['counts_ms'], best['gather_ms'],
+                                     best['end_to_end_ms']], dtype=torch.float64, device=eng.device)
+                if multi:
+                    dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+                pairs = best['pairs_total']
+                out = {'kernel_ms_max_over_ranks': vals[0].item(),
+                       'trace_ms_max_over_ranks': vals[1].item(),
+                       'counts_exchange_ms': vals[2].item(),
+                       'gather_ms': vals[3].item(),
+                       'd2h_ms': best.get('d2h_ms') if rank == 0 else None,
+                       'reassembly_ms': best.get('reassembly_ms') if rank == 0 else None,
+                       'end_to_end_ms': vals[4].item(),
+                       'pairs': pairs, 'bytes_to_host': pairs * 16,
+                       'rays_per_s_end_to_end': sum(caps) / (vals[4].item() * 1e-3),
+                       'grids_delivered': n_views if rank == 0 else None}
+                if exchange == 'host':
+                    out['segment_setup_ms'] = setup_ms
+                    out['segment'] = None if seg is None else {'path': seg.path, 'MiB': seg.nbytes >> 20}
+                res[exchange] = out
+            except Exception as e:
+                res[exchange] = {'error': repr(e)}
+            finally:
+                if seg is not None:
+                    seg.close(unlink=(rank == 0))
+                torch.cuda.empty_cache()
+        res['ray_surface_per_s_kernel'] = (res['rays'] * K / (res['rccl']['kernel_ms_max_over_ranks'] * 1e-3)
+                                           if 'kernel_ms_max_over_ranks' in res.get('rccl', {}) else None)
+        eng.close()
+        return res
+
+    return {'scaling': 'strong', 'ranks': world, 'ranks_seen_by_backend': ranks_seen,
+            'backend': (dist.get_backend() if multi else 'none (single process)'),
+            'what': 'end_to_end_ms = fence -> launches -> counts -> exchange -> rank 0 holds '
+                    '{(field, wvl): (R_ok, 2) host array} -> fence; rccl = grouped send/recv of the '
+                    'packed pairs to rank 0 + one D2H copy; host = kernels write into a shared pinned '
+                    'host segment, no xGMI step (nominal R*K intersections: blocked rays stop early)',
+            'c5': problem('litho_c5', args.strong_num, 'rows'),
+            'c4': problem('rc_telescope_c4', 256, 'field')}
 
 
 def reference_python():
-    """the reference's own Python path on BASELINE configs[1], as timed by
-    tools/time_reference.py in the build container (it cannot run on the GPU box)"""
+    """the reference's own Python path on BASELINE configs[1], and the C port on the same
+    rays on the same host, as timed by tools/time_reference.py in the build container (the
+    reference cannot run on the GPU box)"""
     path = os.path.join(ROOT, 'profiles', 'reference_cpu.json')
     if not os.path.exists(path):
         return None
     with open(path) as f:
         r = json.load(f)
-    return {'measured_on': r['host'], 'workload': r['workload'],
-            'driver_trace_grid_rays_per_s': r['driver_trace_grid']['rays_per_s'],
-            'driver_trace_grid_intersections_per_s': r['driver_trace_grid']['intersections_per_s'],
-            'extrapolated_1M_ray_spot_s': r['driver_trace_grid']['extrapolated_1M_ray_spot_s'],
-            'raw_rt_trace_rays_per_s': r['raw_rt_trace']['rays_per_s'],
-            'raw_rt_trace_intersections_per_s': r['raw_rt_trace']['intersections_per_s'],
-            'fanned': r['raw_rt_trace_fanned'],
-            'source': 'profiles/reference_cpu.json (tools/time_reference.py; mirrors the '
-                      "reference's own rayoptics/raytr/tests/time_trace.py)"}
+    out = {'measured_on': r['host'], 'workload': r['workload'],
+           'driver_trace_grid_rays_per_s': r['driver_trace_grid']['rays_per_s'],
+           'driver_trace_grid_intersections_per_s': r['driver_trace_grid']['intersections_per_s'],
+           'extrapolated_1M_ray_spot_s': r['driver_trace_grid']['extrapolated_1M_ray_spot_s'],
+           'raw_rt_trace_rays_per_s': r['raw_rt_trace']['rays_per_s'],
+           'raw_rt_trace_intersections_per_s': r['raw_rt_trace']['intersections_per_s'],
+           'fanned': r['raw_rt_trace_fanned'],
+           'source': 'profiles/reference_cpu.json (tools/time_reference.py; mirrors the '
+                     "reference's own rayoptics/raytr/tests/time_trace.py)"}
+    if 'port_same_host' in r:
+        out['port_same_host'] = r['port_same_host']
+    if 'config1_singlet_64' in r:
+        out['config1_singlet_64'] = r['config1_singlet_64']
+    return out
 
 
 def cpu_baseline(wl, fld, wi, opts, num, rows):
@@ -449,13 +720,23 @@ def cpu_baseline(wl, fld, wi, opts, num, rows):
     inters = int(ok.sum()) * (N - 1) + int(res.fail_surf[~ok].astype(np.int64).sum())
     inters *= passes
     allc = cpu_all_cores(wl, fld, wi, opts, num, xs, ys)
-    return {'value': inters / dt, 'unit': 'ray-surface intersections/s', 'cores': 1,
-            'kind': 'port',
-            'sample': f'{passes} passes over {rows} pupil rows x {num} = {rows * num} rays of the '
-                      f'same grid, FULL packets, oracle/rox_oracle.c -O2 single thread, {dt:.1f} s',
-            'rays_per_s': passes * rows * num / dt,
-            'host_cpu_count': os.cpu_count(), 'all_cores': allc,
-            'reference_python': reference_python()}
+    ref = reference_python()
+    out = {'value': inters / dt, 'unit': 'ray-surface intersections/s', 'cores': 1,
+           'kind': 'port',
+           'sample': f'{passes} passes over {rows} pupil rows x {num} = {rows * num} rays of the '
+                     f'same grid, FULL packets, oracle/rox_oracle.c -O2 single thread, {dt:.1f} s',
+           'rays_per_s': passes * rows * num / dt,
+           'host_cpu_count': os.cpu_count(), 'all_cores': allc,
+           'reference_python': ref}
+    if ref and ref.get('port_same_host'):
+        # the bridge between the two hosts: port / reference on ONE host (build container),
+        # and from it the reference's rate this host would show if it could run here
+        ratio = ref['port_same_host']['port_over_reference']
+        out['port_over_reference_same_host'] = ratio
+        out['reference_estimated_on_this_host'] = {
+            'value': inters / dt / ratio, 'unit': 'ray-surface intersections/s',
+            'how': 'this host\'s single-thread port rate / the build container\'s port:reference ratio'}
+    return out
 
 
 def cpu_all_cores(wl, fld, wi, opts, num, xs, ys):

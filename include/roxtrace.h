@@ -40,13 +40,14 @@
 #ifndef ROXTRACE_H
 #define ROXTRACE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define ROX_ABI_VERSION 3
+#define ROX_ABI_VERSION 4
 #define ROX_MAX_COEF 10   /* EvenPolynomial r^2..r^20 / RadialPolynomial r^1..r^10 */
 #define ROX_MAX_AP 4      /* clear apertures per surface carried in the table */
 #define ROX_SEG_DOUBLES 10 /* p[3], d[3], dst, nrml[3]  (model_constants.py:31) */
@@ -113,6 +114,13 @@ enum { ROX_CHECK_APERTURES = 1u,     /* raytrace.py:198-202                    *
                                         when the results are in place.  seg
                                         slots the trace does not produce come
                                         back as NaN in this mode                */
+/* ROX_HITS_APPEND (HITS_COMPACT only): the pairs of this call go *behind* the
+ * *rox_out.n_hits pairs already in rox_out.seg, and n_hits becomes the new total --
+ * a running count kept on the device side, so that several grids (the pupil-row
+ * blocks of one rank of a sharded spot diagram, every (field, wavelength) of a
+ * figure) pack into one buffer with no host round trip between the launches.
+ * seg must have room for the old count + this call's rays.                    */
+#define ROX_HITS_APPEND 32u
 /* rox_surface.rt_order: NumPy hands `rt.dot(v)` to OpenBLAS dgemv, whose FMA
  * chain runs over the columns in a different order for an F-ordered rt (the
  * transpose view compute_local_transforms makes, rayoptics/elem/transform.py:86)
@@ -257,7 +265,9 @@ typedef struct rox_field {
     double eprad;            /* pupil_value/2 (see the kinds above)            */
     double z_enp;            /* fod.obj_dist + fod.enp_dist (pt1[2])           */
     double vlx, vux, vly, vuy;   /* opticalspec.py:1339-1353                   */
-    double z_dir0;           /* seq_model.z_dir[0] (trace.py:307)              */
+    double z_dir0;           /* seq_model.z_dir[0] (trace.py:307); 0 = wide-angle
+                                model: dir0 is never flipped (trace.py:302-303;
+                                callers also clear ROX_INTERSECT_OBJ)            */
     int32_t kind;            /* ROX_FLD_*                                      */
     int32_t rot_order;       /* ROX_RT_* of rot (np.matmul -> dgemv)           */
     double rot[9];           /* EPD_WIDE: rot_v1_into_v2(d0, z), row-major     */
@@ -291,6 +301,15 @@ int rox_abi_version(void);
 int rox_device_count(int *count);
 int rox_set_device(int device);
 const char *rox_last_error(void);
+
+/* Host memory the kernels write directly (ROX_OUT_HITS_COMPACT's seg / n_hits may be
+ * such memory).  rox_pin_host_memory page-locks [p, p + bytes) -- ordinary or
+ * MAP_SHARED memory, e.g. a segment several ranks of a node map (the multi-GPU
+ * spot diagram: every rank's kernel writes its packed hits over its own PCIe link
+ * into the consumer's address space) -- and returns the pointer device code uses
+ * for it.  The registration lasts until rox_unpin_host_memory(p).               */
+int rox_pin_host_memory(void *p, size_t bytes, void **device_ptr);
+int rox_unpin_host_memory(void *p);
 
 /* system table ----------------------------------------------------------- */
 /* rows[n_ifcs]; n_table[n_wvls][n_ifcs], n_table[w][i] = refractive index of

@@ -5,7 +5,7 @@ by :mod:`rayoptics_amd.engine`, which fails loudly when it is missing.
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_COEF = 10
 MAX_AP = 4
 SEG_DOUBLES = 10
@@ -33,6 +33,7 @@ INTERSECT_OBJ = 2
 FILTER_PHANTOMS = 4
 APPLY_VIGNETTING = 8
 HOST_POINTERS = 16
+HITS_APPEND = 32
 # summation order of rt.dot(v) (see include/roxtrace.h)
 RT_F_ORDER, RT_C_ORDER = 0, 1
 # grid kinds
@@ -149,7 +150,8 @@ EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_last_error', 'rox_system_create', 'rox_system_destroy',
            'rox_system_num_segments', 'rox_trace_rays',
            'rox_trace_pupil_grid', 'rox_trace_pupil_list',
-           'rox_aim_chief_rays', 'rox_calc_vignetting', 'rox_calc_psf')
+           'rox_aim_chief_rays', 'rox_calc_vignetting', 'rox_calc_psf',
+           'rox_pin_host_memory', 'rox_unpin_host_memory')
 # ... and the measurement / self-test helpers of include/roxtrace_diag.h
 DIAG_EXPORTS = ('rox_time_pupil_grid', 'rox_selftest_fp64')
 
@@ -186,6 +188,10 @@ def declare(lib):
     lib.rox_calc_vignetting.argtypes = [vp, i32, P(Vig), dbl, vp, vp, vp]
     lib.rox_calc_psf.restype = C.c_int
     lib.rox_calc_psf.argtypes = [vp, i32, i32, vp, C.c_uint32, vp]
+    lib.rox_pin_host_memory.restype = C.c_int
+    lib.rox_pin_host_memory.argtypes = [vp, C.c_size_t, P(vp)]
+    lib.rox_unpin_host_memory.restype = C.c_int
+    lib.rox_unpin_host_memory.argtypes = [vp]
     lib.rox_time_pupil_grid.restype = C.c_int
     lib.rox_time_pupil_grid.argtypes = [vp, P(Field), P(Grid), i32, P(Opts),
                                         P(Out), vp, i32, P(dbl)]

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     c.apthr = nullptr;          // (F_ALL instances test apertures through inside_aperture)
     c.N = N;
     c.filter_ph = false;
-    c.intersect_obj = pb.fld.kind != ROX_FLD_EPD_WIDE;      // trace.py:302-303
+    c.intersect_obj = pb.fld.kind != ROX_FLD_EPD_WIDE && pb.fld.z_dir0 != 0.0;     // trace.py:302-303
     c.first_surf = 1; c.last_surf = N - 2;
     c.eps = a.eps;
     SegOut so{nullptr, 0, 0};
@@ -278,11 +278,17 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
 
 void launch_vig(const VigArgs &a, size_t lds, hipStream_t st)
 {
+    if (lds > kDefaultDynLds)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vig_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(vig_kernel, dim3((a.n + 63) / 64), dim3(64), lds, st, a);
 }
 
 void launch_aim(const AimArgs &a, size_t lds, hipStream_t st)
 {
+    if (lds > kDefaultDynLds)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(aim_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(aim_kernel, dim3((a.n + 63) / 64), dim3(64), lds, st, a);
 }
 

@@ -149,9 +149,13 @@ struct TraceArgs {
     // HITS_COMPACT: decoupled look-back state of this launch
     uint64_t *tile_state;      // [tiles] (epoch << 32 | flag << 30 | count)
     uint32_t *ticket;          // [0] next tile, [1] workgroups done
-    int64_t *hits_base;        // hits of the earlier launches of this call (device)
+    // pairs already in out.seg when this launch starts (earlier launches of a chunked
+    // call; earlier calls with ROX_HITS_APPEND) -- nullptr = none -- and where the running
+    // total goes.  Never the same word: a tile may still be reading the base while the
+    // last tile already knows the total (the host ping-pongs two slots between launches).
+    const int64_t *hits_base_in;
+    int64_t *hits_total_out;
     uint32_t epoch;
-    int32_t first_chunk, last_chunk;
     rox_field fld;
     rox_opts opts;
     rox_out out;
@@ -1411,7 +1415,7 @@ trace_kernel(const TraceArgs a)
                     s_excl = excl;
             }
             __syncthreads();
-            const int64_t base = a.first_chunk ? 0 : *a.hits_base;
+            const int64_t base = a.hits_base_in ? *a.hits_base_in : 0;
             const int64_t at = base + (int64_t)s_excl + woff + lrank;
             if (ok) {
                 const double dist = a.opts.foc / e.ad.z;
@@ -1420,13 +1424,8 @@ trace_kernel(const TraceArgs a)
                 xy.y = (e.inc.y + dist * e.ad.y) - a.opts.image_pt[1];
                 __builtin_nontemporal_store(xy, reinterpret_cast<d2 *>(a.out.seg) + at);
             }
-            if (tile == n_tiles - 1 && threadIdx.x == 0) {
-                const int64_t all = base + (int64_t)s_excl + total;
-                if (a.last_chunk)
-                    *a.out.n_hits = all;
-                else
-                    *a.hits_base = all;         // read by the next launch of this call
-            }
+            if (tile == n_tiles - 1 && threadIdx.x == 0)
+                *a.hits_total_out = base + (int64_t)s_excl + total;
         }
     }
     if (kCompact && threadIdx.x == 0) {
@@ -1449,28 +1448,41 @@ struct LaunchCfg {
     hipStream_t stream;
 };
 
+// Tables beyond ~110 interfaces need more than the 64 KiB of dynamic LDS a kernel may
+// use by default (gfx950 has 160 KiB per CU): the limit of the instance is raised once.
+constexpr size_t kDefaultDynLds = 64 * 1024;
+template <class K>
+inline void launch_with_lds(K kernel, const dim3 &grid, const dim3 &block, size_t lds,
+                            hipStream_t st, const TraceArgs &a)
+{
+    if (lds > kDefaultDynLds)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, a);
+}
+
 template <int GEN, bool PRW, int FEAT>
 inline void launch_mode(const LaunchCfg &k, const TraceArgs &a)
 {
     const dim3 block(block_of(k.out_mode));
     switch (k.out_mode) {
     case ROX_OUT_FULL:
-        hipLaunchKernelGGL((trace_kernel<ROX_OUT_FULL, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        launch_with_lds(trace_kernel<ROX_OUT_FULL, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
         break;
     case ROX_OUT_LAST:
-        hipLaunchKernelGGL((trace_kernel<ROX_OUT_LAST, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        launch_with_lds(trace_kernel<ROX_OUT_LAST, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
         break;
     case ROX_OUT_OPD:
-        hipLaunchKernelGGL((trace_kernel<ROX_OUT_OPD, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        launch_with_lds(trace_kernel<ROX_OUT_OPD, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
         break;
     case ROX_OUT_HITS_COMPACT:
-        hipLaunchKernelGGL((trace_kernel<ROX_OUT_HITS_COMPACT, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        launch_with_lds(trace_kernel<ROX_OUT_HITS_COMPACT, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
         break;
     case ROX_OUT_FAN:
-        hipLaunchKernelGGL((trace_kernel<ROX_OUT_FAN, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        launch_with_lds(trace_kernel<ROX_OUT_FAN, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
         break;
     default:
-        hipLaunchKernelGGL((trace_kernel<ROX_OUT_HITS, GEN, PRW, FEAT>), k.grid, block, k.lds, k.stream, a);
+        launch_with_lds(trace_kernel<ROX_OUT_HITS, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
         break;
     }
 }

@@ -191,13 +191,14 @@ struct StreamCtx {
     uint64_t *d_tiles = nullptr;
     int64_t tiles_cap = 0;
     uint32_t *d_ticket = nullptr;       // [0] ticket, [1] workgroups done
-    int64_t *d_hits_base = nullptr;
+    int64_t *d_hits_base = nullptr;     // [2] running totals between launches (ping-pong)
     uint32_t epoch = 0;
     // ROX_HOST_POINTERS staging: HBM arena for big batches, device-mapped pinned
     // block for small ones (grow-only)
     char *d_stage = nullptr, *h_stage = nullptr;
     size_t d_stage_cap = 0, h_stage_cap = 0;
     std::mutex stage_mu;                // one ROX_HOST_POINTERS call at a time per stream
+    std::mutex compact_mu;              // epoch / ticket state: one HITS_COMPACT enqueue at a time
 };
 
 }  // namespace
@@ -289,6 +290,8 @@ int check_opts(const rox_system *sys, const rox_opts *o, const rox_out *out, int
                                    "memory directly: do not set ROX_HOST_POINTERS");
     } else if (out->ld < n_rays) {
         return fail(ROX_E_ARG, "out.ld (%lld) < n_rays (%lld)", (long long)out->ld, (long long)n_rays);
+    } else if (o->flags & ROX_HITS_APPEND) {
+        return fail(ROX_E_ARG, "ROX_HITS_APPEND goes with ROX_OUT_HITS_COMPACT only");
     }
     if (!out->seg && n_rays > 0)
         return fail(ROX_E_ARG, "out.seg is null");
@@ -338,13 +341,15 @@ void launch_feat(int inst, const LaunchCfg &k, const TraceArgs &a)
     fns[inst](k, a);
 }
 
-int ensure_compact(StreamCtx *cx, int64_t tiles)
+// (initialisations are enqueued on the launch stream itself: a stream created with
+// hipStreamNonBlocking is not ordered after NULL-stream memsets)
+int ensure_compact(StreamCtx *cx, int64_t tiles, hipStream_t st)
 {
     if (!cx->d_ticket) {
         HIP_TRY(hipMalloc(&cx->d_ticket, 2 * sizeof(uint32_t)));
-        HIP_TRY(hipMemset(cx->d_ticket, 0, 2 * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&cx->d_hits_base, sizeof(int64_t)));
-        HIP_TRY(hipMemset(cx->d_hits_base, 0, sizeof(int64_t)));
+        HIP_TRY(hipMemsetAsync(cx->d_ticket, 0, 2 * sizeof(uint32_t), st));
+        HIP_TRY(hipMalloc(&cx->d_hits_base, 2 * sizeof(int64_t)));
+        HIP_TRY(hipMemsetAsync(cx->d_hits_base, 0, 2 * sizeof(int64_t), st));
     }
     if (tiles > cx->tiles_cap) {
         if (cx->d_tiles)
@@ -352,7 +357,7 @@ int ensure_compact(StreamCtx *cx, int64_t tiles)
         cx->d_tiles = nullptr;
         cx->tiles_cap = 0;
         HIP_TRY(hipMalloc(&cx->d_tiles, sizeof(uint64_t) * (size_t)tiles));
-        HIP_TRY(hipMemset(cx->d_tiles, 0, sizeof(uint64_t) * (size_t)tiles));
+        HIP_TRY(hipMemsetAsync(cx->d_tiles, 0, sizeof(uint64_t) * (size_t)tiles, st));
         cx->tiles_cap = tiles;
         cx->epoch = 0;
     }
@@ -362,8 +367,9 @@ int ensure_compact(StreamCtx *cx, int64_t tiles)
 int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
 {
     if (a.opts.out_mode == ROX_OUT_HITS_COMPACT && a.n_rays == 0) {
-        // nothing to trace: the count is still owed
-        HIP_TRY(hipMemsetAsync(a.out.n_hits, 0, sizeof(int64_t), st));
+        // nothing to trace: the count is still owed (appending nothing leaves it as it is)
+        if (!(a.opts.flags & ROX_HITS_APPEND))
+            HIP_TRY(hipMemsetAsync(a.out.n_hits, 0, sizeof(int64_t), st));
         return 0;
     }
     if (a.n_rays == 0)
@@ -394,28 +400,38 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
     const int64_t total = a.n_rays, chunk_max = rays_per_launch();
     const bool compact = a.opts.out_mode == ROX_OUT_HITS_COMPACT;
     StreamCtx *cx = nullptr;
+    // two host threads enqueueing HITS_COMPACT launches on one stream take turns with the
+    // stream's epoch / ticket / tile-state words (the launches themselves run in stream order)
+    std::unique_lock<std::mutex> compact_lock;
     if (compact) {
         cx = ctx_for(sys, st);
         if (!cx)
             return fail(ROX_E_NOMEM, "out of host memory");
+        compact_lock = std::unique_lock<std::mutex>(cx->compact_mu);
         const int64_t per = total < chunk_max ? total : chunk_max;
         const int tb = block_of(ROX_OUT_HITS_COMPACT);
-        int rc = ensure_compact(cx, (per + tb - 1) / tb);
+        int rc = ensure_compact(cx, (per + tb - 1) / tb, st);
         if (rc)
             return rc;
     }
     const rox_out out0 = a.out;
     a.in_ld = total;
-    for (int64_t base = 0; base < total; base += chunk_max) {
+    // HITS_COMPACT: launch c reads its base from slot[(c + 1) & 1] and leaves the running total
+    // in slot[c & 1]; the first launch starts from zero, or -- ROX_HITS_APPEND -- from the
+    // caller's count, copied into slot[1] first (device or device-mapped host memory)
+    const bool append = compact && (a.opts.flags & ROX_HITS_APPEND);
+    if (append)
+        HIP_TRY(hipMemcpyAsync(cx->d_hits_base + 1, out0.n_hits, sizeof(int64_t), hipMemcpyDefault, st));
+    int64_t n_launch = 0;
+    for (int64_t base = 0; base < total; base += chunk_max, ++n_launch) {
         a.ray_base = base;
         a.n_rays = total - base < chunk_max ? total - base : chunk_max;
         if (compact) {
             a.tile_state = cx->d_tiles;
             a.ticket = cx->d_ticket;
-            a.hits_base = cx->d_hits_base;
+            a.hits_base_in = (n_launch == 0 && !append) ? nullptr : cx->d_hits_base + ((n_launch + 1) & 1);
+            a.hits_total_out = (base + chunk_max >= total) ? out0.n_hits : cx->d_hits_base + (n_launch & 1);
             a.epoch = ++cx->epoch;
-            a.first_chunk = base == 0;
-            a.last_chunk = base + chunk_max >= total;
             a.out.status = out0.status ? out0.status + base : nullptr;
         } else {
             a.out.seg = out0.seg + base;
@@ -726,6 +742,27 @@ int rox_device_count(int *count)
 int rox_set_device(int device)
 {
     HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+int rox_pin_host_memory(void *p, size_t bytes, void **device_ptr)
+{
+    if (!p || !bytes || !device_ptr)
+        return fail(ROX_E_ARG, "rox_pin_host_memory: bad argument");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    hipError_t e = hipHostGetDevicePointer(device_ptr, p, 0);
+    if (e != hipSuccess) {
+        (void)hipHostUnregister(p);
+        return fail(ROX_E_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+
+int rox_unpin_host_memory(void *p)
+{
+    if (!p)
+        return fail(ROX_E_ARG, "rox_unpin_host_memory: null pointer");
+    HIP_TRY(hipHostUnregister(p));
     return 0;
 }
 

@@ -266,6 +266,32 @@ class DeviceResult:
         return h
 
 
+class HitsPack:
+    """A buffer that ROX_OUT_HITS_COMPACT | ROX_HITS_APPEND launches pack their
+    surviving (x, y) pairs into, one launch behind the other, with the running
+    count on the device: ``xy`` [cap, 2] f64 in HBM -- or ``dest`` = (pointer,
+    capacity) of other device-visible memory, e.g. a slice of a pinned shared host
+    segment -- ``count`` [1] i64, and the cumulative count after each launch."""
+
+    def __init__(self, torch, device, cap, max_launches, dest=None):
+        self._torch, self.device = torch, device
+        if dest is None:
+            self.xy = torch.empty((int(cap), 2), dtype=torch.float64, device=device)
+            self.seg_ptr, self.cap = self.xy.data_ptr(), int(cap)
+        else:
+            self.xy = None
+            self.seg_ptr, self.cap = int(dest[0]), int(dest[1])
+        self.count = torch.zeros(1, dtype=torch.int64, device=device)
+        self.cum = torch.zeros(max(int(max_launches), 1), dtype=torch.int64, device=device)
+        self.n_launches = 0
+        self.rays = 0
+
+    def counts(self):
+        """survivors per launch (synchronises the launch stream)"""
+        c = self.cum[:self.n_launches].cpu().numpy()
+        return np.diff(np.concatenate([[0], c])).astype(np.int64)
+
+
 class TraceEngine:
     """one immutable surface table on one GPU.
 
@@ -406,6 +432,44 @@ class TraceEngine:
                                                  int(wvl_idx), C.byref(opts), C.byref(o),
                                                  self._stream()), 'rox_trace_pupil_grid')
         return self._hits_finish(lease, R)
+
+    def hits_pack(self, cap, max_launches, dest=None):
+        return HitsPack(self.torch, self.device, cap, max_launches, dest)
+
+    def trace_pupil_grid_hits_append(self, fld, grid, wvl_idx, opts, pack):
+        """enqueue one ROX_OUT_HITS_COMPACT | ROX_HITS_APPEND launch behind the pairs
+        ``pack`` already holds; nothing is synchronised"""
+        R = grid_rays(grid)
+        if pack.rays + R > pack.cap or pack.n_launches >= pack.cum.numel():
+            raise EngineError(f'HitsPack full: {pack.rays} + {R} rays into a capacity of {pack.cap}')
+        if not (opts.flags & abi.HITS_APPEND) or opts.out_mode != abi.OUT_HITS_COMPACT:
+            raise EngineError('trace_pupil_grid_hits_append needs OUT_HITS_COMPACT | HITS_APPEND')
+        o = abi.Out()
+        o.seg = pack.seg_ptr
+        o.n_hits = pack.count.data_ptr()
+        o.ld = pack.cap
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_trace_pupil_grid(self._handle, C.byref(fld), C.byref(grid),
+                                                 int(wvl_idx), C.byref(opts), C.byref(o),
+                                                 self._stream()), 'rox_trace_pupil_grid')
+            k = pack.n_launches
+            pack.cum[k:k + 1].copy_(pack.count, non_blocking=True)      # same stream: ordered
+        pack.n_launches += 1
+        pack.rays += R
+        return pack
+
+    # -- host memory other processes share (dist.HostSegment) ------------------------
+    def pin_host_memory(self, ptr, nbytes):
+        """register [ptr, ptr+nbytes) with the HIP runtime; returns the pointer kernels
+        on this device write it through"""
+        dev = C.c_void_p()
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_pin_host_memory(C.c_void_p(ptr), C.c_size_t(nbytes), C.byref(dev)),
+                   'rox_pin_host_memory')
+        return dev.value
+
+    def unpin_host_memory(self, ptr):
+        _check(self.lib.rox_unpin_host_memory(C.c_void_p(ptr)), 'rox_unpin_host_memory')
 
     def trace_pupil_list_hits(self, fld, px, py, wvl_idx, opts):
         t = self.torch

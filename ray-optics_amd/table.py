@@ -380,6 +380,11 @@ def field_from_model(opt_model, fld, pupil_type='rel pupil'):
     z_enp = fod.enp_dist
     vig = (fld.vlx, fld.vux, fld.vly, fld.vuy)
     z_dir0 = opt_model['seq_model'].z_dir[0]
+    if osp['fov'].is_wide_angle:
+        # trace.py:302-308: a wide-angle model never flips dir0 and never intersects the
+        # object surface, whatever the pupil specification -- z_dir0 = 0 encodes "never flip"
+        # (include/roxtrace.h, rox_field.z_dir0)
+        z_dir0 = 0.0
     if pupil_value_key == 'epd':
         if pupil_type == 'aim pt':                     # :334-337
             return field_struct(p0, (0., 0.), 0.0, fod.obj_dist + z_enp, vig, z_dir0,

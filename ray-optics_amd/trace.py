@@ -146,8 +146,8 @@ def _launch_setup(opt_model, fld, wvl, kwargs, out_mode, foc=0.0, image_pt=(0., 
     f = field_from_model(opt_model, fld, pupil_type)
     if pupil_type != 'rel pupil':
         opts.flags &= ~abi.APPLY_VIGNETTING             # trace.py:291-295
-    if f.kind == abi.FLD_EPD_WIDE:
-        opts.flags &= ~abi.INTERSECT_OBJ                # trace.py:302-303
+    if f.kind == abi.FLD_EPD_WIDE or f.z_dir0 == 0.0:
+        opts.flags &= ~abi.INTERSECT_OBJ                # trace.py:302-303 (any wide-angle field)
     return eng, f, tbl.wvl_index(wvl), opts
 
 

@@ -338,7 +338,7 @@ def workload_file(opm, name, desc):
         # aim point it converged to, recomputed here from a clean start
         pt0, _d0 = osp.obj_coords(fld)
         aim_ref = trace.aim_chief_ray(opm, fld, wvl)
-        if pt0[0] == 0.0 and sm.stop_surface is not None:
+        if pt0[0] == 0.0 and sm.stop_surface is not None and not osp['fov'].is_wide_angle:
             aim.append(dict(pt0=[float(v) for v in pt0],
                             z_enp=float(fod.obj_dist + fod.enp_dist),
                             z_dir0=float(sm.z_dir[0]), wvl_idx=table.wvl_index(wvl),
@@ -434,6 +434,12 @@ def psf_cases():
     print(f'psf.npz: {os.path.getsize(path) / 1024:.0f} KiB, {sorted(set(k.split("/")[0] for k in out))}')
 
 
+C3_ZMX_DESC = ('BASELINE.json configs[2]: Zemax .zmx import -- rayoptics/zemax/tests/US08427765-1.ZMX, '
+               '13 interfaces incl. one EVENASPH, 3 real-image-height fields x 3 wavelengths, image '
+               "f/2.1 -- read by the reference's own zmxread; the five catalogue glasses carry their "
+               'nominal (nd, vd)')
+
+
 def main():
     rng = np.random.default_rng(SEED)
     if '--only-psf' in sys.argv:
@@ -449,6 +455,9 @@ def main():
             'opd_f0': case_opd(opm, 0, 550.0, 11),
             'opd_f2': case_opd(opm, 2, 486.1, 10),
         })
+        return
+    if '--only-c3-zmx' in sys.argv:
+        workload_file(rm.zmx_evenasph_c3(), 'zmx_evenasph_c3', C3_ZMX_DESC)
         return
     if '--workloads-only' not in sys.argv:
         kat_dblgauss_seq()
@@ -469,6 +478,7 @@ def main():
     workload_file(rm.nikkor(), 'nikkor_c3',
                   'BASELINE.json configs[2] stand-in: 29-interface zoom with 4 '
                   'even aspheres (rayoptics/optical/tests/Nikon Nikkor Z 14-30mm f-4 S.roa)')
+    workload_file(rm.zmx_evenasph_c3(), 'zmx_evenasph_c3', C3_ZMX_DESC)
     workload_file(rm.litho_c5(), 'litho_c5',
                   'BASELINE.json configs[4] stand-in: the largest prescription in the reference '
                   'tree, rayoptics/zemax/tests/US05831776-1.zmx (44 interfaces, K=43, 248 nm '

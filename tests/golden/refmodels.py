@@ -283,6 +283,27 @@ def litho_c5():
     return finish(opm, do_apertures=False)
 
 
+def zmx_evenasph_c3():
+    """BASELINE.json configs[2]: "Zemax .zmx import, 12-surface even-asphere zoom, 3 fields
+    x 3 wvls" -- rayoptics/zemax/tests/US08427765-1.ZMX (13 interfaces, one EVENASPH, three
+    'real height' image fields, F/d/C lines, image f/2.1) through the reference's own Zemax
+    importer.  Its five glasses (J-LAK14, L-TIM28, SF11, TAF3, TAFD30) are unknown to the
+    stubbed catalogue; they get their nominal catalogue (nd, vd) through the test ModelGlass
+    so that the system is the lens the file describes and the wavelengths differ."""
+    import pathlib
+    from rayoptics.zemax import zmxread
+    path = pathlib.Path(REF_SRC) / 'rayoptics' / 'zemax' / 'tests' / 'US08427765-1.ZMX'
+    opm, _info = zmxread.read_lens(None, path.open(encoding='utf-8').read(), do_update=False)
+    nominal = {'J-LAK14': (1.69680, 55.46), 'L-TIM28_MOLD': (1.68893, 31.08),
+               'SF11': (1.78472, 25.76), 'TAF3': (1.80420, 46.50), 'TAFD30': (1.88300, 40.80)}
+    for g in opm['seq_model'].gaps:
+        name = g.medium.name()
+        if name.startswith('not '):
+            nd, vd = nominal[name[4:]]
+            g.medium = ModelGlass(nd, vd, name[4:])
+    return finish(opm, do_apertures=False)
+
+
 def telecentric():
     """image-space telecentric singlet (stop at the front focal plane): the
     reference sphere of the axial field is 'kinda big' (waveabr.py:213-216), so the

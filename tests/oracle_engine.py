@@ -30,9 +30,54 @@ class _Res:
         return torch.from_numpy(self._h.status)
 
 
+class _Pack:
+    """engine.HitsPack look-alike on host memory"""
+
+    def __init__(self, cap, max_launches, dest=None):
+        import ctypes as C
+        import torch
+        if dest is None:
+            self.cap = int(cap)
+            self.xy = torch.empty((self.cap, 2), dtype=torch.float64)
+            self._np = self.xy.numpy()
+        else:
+            self.cap = int(dest[1])
+            self.xy = None
+            self._np = np.ctypeslib.as_array(
+                (C.c_double * (2 * max(self.cap, 1))).from_address(int(dest[0]))).reshape(-1, 2)
+        self._cum, self.n, self.rays, self.max_launches = [], 0, 0, max_launches
+
+    def counts(self):
+        return np.diff(np.concatenate([[0], self._cum])).astype(np.int64)
+
+
 class OracleEngine:
     def __init__(self, table, device=None):
         self.table = table
+        self.device = 'cpu'
+
+    def hits_pack(self, cap, max_launches, dest=None):
+        return _Pack(cap, max_launches, dest)
+
+    def trace_pupil_grid_hits_append(self, fld, grid, wvl_idx, opts, pack):
+        assert opts.flags & abi.HITS_APPEND and opts.out_mode == abi.OUT_HITS_COMPACT
+        assert len(pack._cum) < pack.max_launches
+        o = oracle.make_opts(flags=opts.flags & ~abi.HITS_APPEND, out_mode=opts.out_mode,
+                             first_surf=opts.first_surf, last_surf=opts.last_surf, eps=opts.eps,
+                             fuzz=opts.fuzz, foc=opts.foc, image_pt=tuple(opts.image_pt))
+        hits = oracle.trace_pupil_grid(self.table, fld, grid, wvl_idx, o).hits
+        pack.rays += (grid.row_count or grid.num) * grid.num
+        assert pack.rays <= pack.cap
+        pack._np[pack.n:pack.n + len(hits)] = hits
+        pack.n += len(hits)
+        pack._cum.append(pack.n)
+        return pack
+
+    def pin_host_memory(self, ptr, nbytes):
+        return ptr
+
+    def unpin_host_memory(self, ptr):
+        pass
 
     def close(self):
         pass

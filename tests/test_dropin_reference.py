@@ -396,7 +396,8 @@ def test_raylist_refocus_fused(ref, installed):
     assert not np.array_equal(ours[0], ours[1])
 
 
-@pytest.mark.parametrize('spec', ['obj_NA', 'img_fno', 'img_NA', 'aim_pt', 'aim_dir', 'wide'])
+@pytest.mark.parametrize('spec', ['obj_NA', 'img_fno', 'img_NA', 'aim_pt', 'aim_dir', 'wide',
+                                  'wide_NA', 'wide_aim_pt', 'wide_aim_dir'])
 def test_every_ray_start_branch_on_device(ref, installed, spec):
     """every branch of OpticalSpecs.ray_start_from_osp (opticalspec.py:289-400)
     -- angular pupils ('NA', 'f/#', image-space forms), 'aim pt' / 'aim dir'
@@ -411,18 +412,18 @@ def test_every_ray_start_branch_on_device(ref, installed, spec):
     kw = {}
     want_kind = abi.FLD_EPD
     start, stop = np.array([-1., -1.]), np.array([1., 1.])
-    if spec == 'obj_NA':
+    if spec in ('obj_NA', 'wide_NA'):
         osp['pupil'] = PupilSpec(osp, key=['object', 'NA'], value=0.04)
         want_kind = abi.FLD_NA
     elif spec == 'img_fno':
         osp['pupil'] = PupilSpec(osp, key=['image', 'f/#'], value=6.0)
     elif spec == 'img_NA':
         osp['pupil'] = PupilSpec(osp, key=['image', 'NA'], value=0.05)
-    elif spec == 'aim_pt':
+    elif spec in ('aim_pt', 'wide_aim_pt'):
         kw['pupil_type'] = 'aim pt'
         want_kind = abi.FLD_AIM_PT
         start, stop = np.array([-4., -4.]), np.array([4., 4.])
-    elif spec == 'aim_dir':
+    elif spec in ('aim_dir', 'wide_aim_dir'):
         osp['pupil'] = PupilSpec(osp, key=['object', 'NA'], value=0.04)
         kw['pupil_type'] = 'aim dir'
         want_kind = abi.FLD_AIM_DIR
@@ -433,17 +434,24 @@ def test_every_ray_start_branch_on_device(ref, installed, spec):
         for f in osp['fov'].fields:     # (z_enp from the paraxial model; the wide-angle
             f.aim_info = None           #  pupil search is host control plane, wideangle.py)
         want_kind = abi.FLD_EPD_WIDE
+    elif spec.startswith('wide_'):
+        # trace_base keys on fov.is_wide_angle alone (trace.py:302-308): with an angular pupil
+        # or an 'aim pt' / 'aim dir' pupil type the object surface is still skipped and dir0
+        # is never flipped -- ray[0].p is then pt0 itself
+        osp['fov'].is_wide_angle = True
     fld = osp['fov'].fields[1]
     wvl = opm['seq_model'].central_wavelength()
-    assert field_from_model(opm, fld, kw.get('pupil_type', 'rel pupil')).kind == want_kind
+    f_c = field_from_model(opm, fld, kw.get('pupil_type', 'rel pupil'))
+    assert f_c.kind == want_kind
+    assert (f_c.z_dir0 == 0.0) == spec.startswith('wide')
 
     def run():
         return trace.trace_grid(opm, [start.copy(), stop.copy(), 7], fld, wvl, 0.0,
-                                img_filter=lambda p, pkg: np.full(8, np.nan) if pkg is None else
-                                np.concatenate([p, pkg[0][0][1], pkg[0][-1][0]]),
+                                img_filter=lambda p, pkg: np.full(11, np.nan) if pkg is None else
+                                np.concatenate([p, pkg[0][0][1], pkg[0][-1][0], pkg[0][0][0]]),
                                 form='grid', append_if_none=True, **kw)
     go, gt = both(installed, run)
-    assert go.shape == gt.shape == (7, 7, 8)
+    assert go.shape == gt.shape == (7, 7, 11)
     np.testing.assert_array_equal(go, gt)
     assert np.isfinite(go[:, :, 2]).sum() > 10
 

@@ -254,17 +254,19 @@ def test_sharded_spot_single_rank(engines):
     from rayoptics_amd.engine import TraceEngine
     wl = workloads.load('rc_telescope_c4')
     eng = TraceEngine(wl.table)
-    out = trace_spot_sharded(eng, wl.fields, wl.image_pts, 1, 24, wl.foc)
-    assert len(out) == 5
     N = wl.n_ifcs
-    for (fi, wi), (xy, st) in out.items():
-        opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING,
-                                out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
-                                foc=wl.foc, image_pt=wl.image_pts[fi])
-        ref = oracle.trace_pupil_grid(wl.table, wl.fields[fi],
-                                      oracle.make_grid((-1., -1.), (1., 1.), 24), wi, opts)
-        np.testing.assert_array_equal(st, ref.status)
-        bit_equal(xy, ref.seg.T, f'field {fi}')
+    for by in ('rows', 'field'):
+        tm = {}
+        out = trace_spot_sharded(eng, wl.fields, wl.image_pts, 1, 24, wl.foc, by=by, timings=tm)
+        assert len(out) == 5
+        for (fi, wi), xy in out.items():
+            opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING,
+                                    out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                                    foc=wl.foc, image_pt=wl.image_pts[fi])
+            ref = oracle.trace_pupil_grid(wl.table, wl.fields[fi],
+                                          oracle.make_grid((-1., -1.), (1., 1.), 24), wi, opts)
+            bit_equal(xy, ref.hits, f'field {fi}')
+        assert tm['pairs_total'] == sum(len(v) for v in out.values()) < 5 * 24 * 24
     eng.close()
 
 

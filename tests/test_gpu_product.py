@@ -241,43 +241,51 @@ def test_trace_raw_on_an_explicit_path_list():
 
 def test_config5_full_size_on_one_gpu():
     """BASELINE configs[4] in full: 9 fields x 5 wavelengths x 2048 x 2048 pupil
-    grids (188.7 M rays, HITS, 3.2 GB) of the 44-interface lithography lens
-    imported from rayoptics/zemax/tests/US05831776-1.zmx, traced on ONE GPU through
-    the multi-GPU path's own code (dist.partition / trace_blocks); a 64-row block of
-    every (field, wavelength) grid bit-exact vs the oracle, and the whole-job
-    invariants (every ray accounted for, survivors finite, vignetted fraction sane)"""
+    grids (188.7 M rays) of the 44-interface lithography lens imported from
+    rayoptics/zemax/tests/US05831776-1.zmx, traced on ONE GPU through the multi-GPU
+    path's own code (dist.partition / trace_blocks: 45 packed-hit launches appended
+    into one buffer, counts kept on the device).  Per grid: a 64-row block of the
+    unpacked HITS trace bit-exact vs the oracle, the packed block identical to the
+    survivors of that HITS trace in ray order; and the whole-job invariants (every
+    ray accounted for, survivors finite, vignetted fraction sane)"""
     import torch
     from oracle import oracle
     from rayoptics_amd import workloads, dist as rdist
-    from rayoptics_amd.engine import TraceEngine
+    from rayoptics_amd.engine import TraceEngine, DeviceResult, make_opts, make_grid
     wl = workloads.load('litho_c5')
     assert wl.n_ifcs == 44 and len(wl.fields) == 9 and len(wl.table.wvls) == 5
     eng = TraceEngine(wl.table)
     num = 2048
     plan = rdist.partition(9, 5, num, 1)
-    cap = sum(b.row_count for b in plan[0]) * num
-    assert cap == 45 * num * num
-    xy, st, n = rdist.trace_blocks(eng, plan[0], cap, wl.fields, wl.image_pts, num, wl.foc)
-    torch.cuda.synchronize()
-    assert n == cap
-    ok = st == 0
-    n_ok = int(ok.sum().item())
-    assert int((st == 255).sum().item()) == 0              # every ray was traced
+    cap = rdist.rays_of(plan[0], num)
+    assert cap == 45 * num * num and len(plan[0]) == 45
+    pack = rdist.trace_blocks(eng, plan[0], num, wl.fields, wl.image_pts, wl.foc)
+    counts = pack.counts()
+    assert pack.rays == cap and len(counts) == 45
+    n_ok = int(counts.sum())
+    assert int(pack.count.item()) == n_ok
     assert 0.55 * cap < n_ok < 0.85 * cap                   # the circular pupil in the square grid
-    assert bool(torch.isfinite(xy[:, ok]).all().item())
+    assert bool(torch.isfinite(pack.xy[:n_ok]).all().item())
     N = wl.n_ifcs
     rng = np.random.default_rng(5)
+    hits = DeviceResult(torch, eng.device, 0, num * num, abi.OUT_HITS, want_pupil=False, nan_fill=True)
+    offs = np.concatenate([[0], np.cumsum(counts)])
     for g, b in enumerate(plan[0]):
+        opts = make_opts(flags=FLAGS, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
+                         foc=wl.foc, image_pt=wl.image_pts[b.fi])
+        eng.trace_pupil_grid(wl.fields[b.fi], make_grid((-1., -1.), (1., 1.), num), b.wi, opts,
+                             want_pupil=False, out=hits)
+        ok = hits.status == 0
+        assert int((hits.status == 255).sum().item()) == 0      # every ray was traced
+        assert int(ok.sum().item()) == counts[g]
+        assert torch.equal(hits.seg[:, ok].T.contiguous(), pack.xy[offs[g]:offs[g + 1]]), b
         i0 = int(rng.integers(0, num - 64))
-        opts = oracle.make_opts(flags=FLAGS, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
-                                foc=wl.foc, image_pt=wl.image_pts[b.fi])
         grid = oracle.make_grid((-1., -1.), (1., 1.), num, row_begin=i0, row_count=64)
         orc = oracle.trace_pupil_grid(wl.table, wl.fields[b.fi], grid, b.wi, opts)
-        lo = g * num * num + i0 * num
-        hi = lo + 64 * num
-        np.testing.assert_array_equal(st[lo:hi].cpu().numpy(), orc.status)
-        got = xy[:, lo:hi].cpu().numpy()
-        same = (got == orc.seg) | (np.isnan(got) & np.isnan(orc.seg))
+        lo, hi = i0 * num, (i0 + 64) * num
+        np.testing.assert_array_equal(hits.status[lo:hi].cpu().numpy(), orc.status)
+        got = hits.seg[:, lo:hi].cpu().numpy()
+        same = (got == orc.seg) | (~(orc.status == 0))[None, :]
         assert same.all(), (b, int((~same).sum()))
     eng.close()
 

@@ -1,0 +1,252 @@
+"""-m gpu, round 3: packed hits appended over several launches (ROX_HITS_APPEND) into HBM
+and into pinned / shared host memory, the sharded spot diagram through both exchanges on
+one rank, tables beyond 64 KiB of LDS, BASELINE configs[2] from the .zmx import at full
+size, and bench.py launching its own ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from rayoptics_amd import abi, SurfaceTable, field_struct
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+SPOT = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_hits(wl, fi, wi, grid_kw, flags=SPOT):
+    from oracle import oracle
+    N = wl.n_ifcs
+    o = oracle.make_opts(flags=flags, out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                         foc=wl.foc, image_pt=wl.image_pts[fi])
+    return oracle.trace_pupil_grid(wl.table, wl.fields[fi], oracle.make_grid((-1., -1.), (1., 1.), **grid_kw),
+                                   wi, o).hits
+
+
+def test_hits_append_packs_several_grids_without_a_host_round_trip():
+    """three (field, wavelength) grids and two row blocks appended into one buffer: the
+    buffer equals the concatenation of the oracle's packed hits, the per-launch counts come
+    back in one read; the same into a pinned host destination"""
+    import torch
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid, _pool
+    wl = workloads.load('dblgauss_c2')
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    jobs = [(0, 0, dict(num=96)), (2, 1, dict(num=96)), (1, 2, dict(num=96, row_begin=10, row_count=37)),
+            (2, 0, dict(num=96, row_begin=47, row_count=49)), (1, 1, dict(num=5))]
+    want = [oracle_hits(wl, fi, wi, kw) for fi, wi, kw in jobs]
+    cap = sum((kw.get('row_count') or kw['num']) * kw['num'] for _f, _w, kw in jobs)
+    for where in ('hbm', 'pinned'):
+        lease = None
+        dest = None
+        if where == 'pinned':
+            lease = _pool.take(torch, 16 * cap)
+            dest = (lease.ptr, cap)
+        pack = eng.hits_pack(cap, len(jobs), dest=dest)
+        for fi, wi, kw in jobs:
+            o = make_opts(flags=SPOT | abi.HITS_APPEND, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                          last_surf=N - 2, foc=wl.foc, image_pt=wl.image_pts[fi])
+            eng.trace_pupil_grid_hits_append(wl.fields[fi], make_grid((-1., -1.), (1., 1.), **kw), wi, o, pack)
+        counts = pack.counts()
+        np.testing.assert_array_equal(counts, [len(w) for w in want])
+        total = int(counts.sum())
+        got = pack.xy[:total].cpu().numpy() if where == 'hbm' else lease.array((total, 2), np.float64)
+        assert np.array_equal(got, np.concatenate(want)), where
+        assert int(pack.count.item()) == total
+        with pytest.raises(Exception, match='full'):
+            o = make_opts(flags=SPOT | abi.HITS_APPEND, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                          last_surf=N - 2, foc=wl.foc, image_pt=wl.image_pts[0])
+            eng.trace_pupil_grid_hits_append(wl.fields[0], make_grid((-1., -1.), (1., 1.), 96), 0, o, pack)
+    # appending is refused in the other output modes
+    from rayoptics_amd.engine import EngineError
+    with pytest.raises(EngineError, match='HITS_APPEND'):
+        eng.trace_pupil_grid(wl.fields[0], make_grid((-1., -1.), (1., 1.), 8), 0,
+                             make_opts(flags=SPOT | abi.HITS_APPEND, out_mode=abi.OUT_HITS, first_surf=1,
+                                       last_surf=N - 2))
+    eng.close()
+
+
+def test_hits_append_over_chunked_launches():
+    """ROX_RAYS_PER_LAUNCH=4096: every appended grid is several launches whose running
+    total ping-pongs between two device slots (subprocess: the limit is read once)"""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import rayoptics_amd
+from rayoptics_amd import abi, workloads
+from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+from oracle import oracle
+wl = workloads.load('rc_telescope_c4'); N = wl.n_ifcs
+eng = TraceEngine(wl.table)
+SPOT = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+pack = eng.hits_pack(5 * 150 * 150, 5)
+want = []
+for fi in range(5):
+    o = make_opts(flags=SPOT | abi.HITS_APPEND, out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                  foc=wl.foc, image_pt=wl.image_pts[fi])
+    eng.trace_pupil_grid_hits_append(wl.fields[fi], make_grid((-1., -1.), (1., 1.), 150), 0, o, pack)
+    oo = oracle.make_opts(flags=SPOT, out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                          foc=wl.foc, image_pt=wl.image_pts[fi])
+    want.append(oracle.trace_pupil_grid(wl.table, wl.fields[fi], oracle.make_grid((-1., -1.), (1., 1.), 150), 0, oo).hits)
+c = pack.counts()
+assert list(c) == [len(w) for w in want], (c, [len(w) for w in want])
+assert np.array_equal(pack.xy[:int(c.sum())].cpu().numpy(), np.concatenate(want))
+print('chunked append ok', int(c.sum()))
+''' % (ROOT, os.path.join(ROOT, 'tests'))
+    env = dict(os.environ, ROX_RAYS_PER_LAUNCH='4096')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'chunked append ok' in r.stdout
+
+
+@pytest.mark.parametrize('exchange', ['rccl', 'host'])
+def test_sharded_spot_one_rank_both_exchanges(exchange):
+    """dist.trace_spot_sharded without a process group: the packed pairs reach host memory
+    through the D2H copy ('rccl') or are written by the kernels straight into a registered
+    MAP_SHARED segment ('host'); both equal the oracle's survivors per grid"""
+    from rayoptics_amd import workloads, dist as rdist
+    from rayoptics_amd.engine import TraceEngine
+    wl = workloads.load('dblgauss_c2')
+    eng = TraceEngine(wl.table)
+    num, nw = 160, len(wl.table.wvls)
+    seg = None
+    if exchange == 'host':
+        plan = rdist.partition(len(wl.fields), nw, num, 1)
+        seg = rdist.HostSegment(eng, f'rox_test_seg_{os.getpid()}', [rdist.rays_of(plan[0], num)], 0,
+                                create=True)
+    try:
+        tm = {}
+        out = rdist.trace_spot_sharded(eng, wl.fields, wl.image_pts, nw, num, wl.foc, exchange=exchange,
+                                       segment=seg, timings=tm)
+        assert len(out) == len(wl.fields) * nw
+        for (fi, wi), xy in out.items():
+            want = oracle_hits(wl, fi, wi, dict(num=num))
+            assert np.array_equal(xy, want), (exchange, fi, wi)
+        assert tm['pairs_total'] == sum(len(v) for v in out.values())
+    finally:
+        if seg is not None:
+            seg.close(unlink=True)
+    eng.close()
+
+
+def lens_chain(n_lenses):
+    surfs = [dict(cv=0.0, thi=1.0e10, n=1.0, max_aperture=1e12)]
+    for _ in range(n_lenses):
+        surfs.append(dict(cv=1 / 103.0, thi=4.0, n=[1.5168, 1.5200, 1.5140], max_aperture=14.0))
+        surfs.append(dict(cv=-1 / 103.0, thi=46.0, n=1.0, max_aperture=14.0))
+    surfs.append(dict(cv=0.0, thi=0.0, n=1.0, max_aperture=50.0))
+    return SurfaceTable.from_prescription(surfs, wvls=(587.6, 486.1, 656.3), stop_idx=1)
+
+
+def test_tables_beyond_64_kib_of_lds():
+    """122 and 202 interfaces: 90 and 150 KB of dynamic LDS per workgroup (the default
+    limit is 64 KiB; the instance's limit is raised on first use), FULL packets and hits
+    bit-exact vs the oracle; explicit rays with per-ray wavelengths stage all three index
+    rows; the aiming kernel stages the same table"""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    for n_lenses in (60, 100):
+        tbl = lens_chain(n_lenses)
+        N = tbl.n_ifcs
+        assert N == 2 * n_lenses + 2
+        eng = TraceEngine(tbl)
+        theta = np.deg2rad(0.4)
+        fld = field_struct([0.0, -1.0e10 * np.tan(theta), 0.0], (0., 0.), 9.0, 1.0e10)
+        grid = make_grid((-1., -1.), (1., 1.), 48)
+        for mode in (abi.OUT_FULL, abi.OUT_HITS):
+            opts = make_opts(flags=SPOT, out_mode=mode, first_surf=1, last_surf=N - 2)
+            dev = eng.trace_pupil_grid(fld, grid, 1, opts, nan_fill=True).to_host()
+            orc = oracle.trace_pupil_grid(tbl, fld, oracle.make_grid((-1., -1.), (1., 1.), 48), 1, opts)
+            np.testing.assert_array_equal(dev.status, orc.status)
+            assert np.array_equal(dev.seg, orc.seg, equal_nan=True), (N, mode)
+            assert np.array_equal(dev.op, orc.op, equal_nan=True)
+            assert (dev.status == 0).sum() > 500
+        rng = np.random.default_rng(N)
+        R = 700
+        pt0 = np.stack([rng.uniform(-8, 8, R), rng.uniform(-8, 8, R), np.full(R, -50.0)])
+        d = np.stack([rng.uniform(-.01, .01, R), rng.uniform(-.01, .01, R), np.ones(R)])
+        d /= np.linalg.norm(d, axis=0)
+        wi = rng.integers(0, 3, R).astype(np.int32)
+        opts = make_opts(flags=abi.CHECK_APERTURES, out_mode=abi.OUT_LAST, first_surf=1, last_surf=N - 2)
+        dev = eng.trace_rays(pt0, d, wi, opts, nan_fill=True).to_host()
+        orc = oracle.trace_rays(tbl, pt0, d, wi, opts)
+        np.testing.assert_array_equal(dev.status, orc.status)
+        assert np.array_equal(dev.seg, orc.seg, equal_nan=True)
+        a = abi.Aim()
+        a.pt0[1] = -1.0e10 * np.tan(theta)
+        a.z_enp, a.y_target, a.z_dir0, a.wvl_idx, a.surf, a.flip = 1.0e10, 0.0, 1.0, 1, 1, 1
+        y_dev, r_dev = eng.aim_chief_rays([a])
+        y_orc, r_orc = oracle.aim_chief_rays(tbl, [a], 1e-12)
+        assert r_dev[0] == r_orc[0] and y_dev[0] == y_orc[0]
+        eng.close()
+
+
+def test_c3_zmx_import_3fields_3wvls_512():
+    """BASELINE configs[2] from the .zmx import (US08427765-1.ZMX: 13 interfaces, one
+    EVENASPH, wide-angle 'real height' fields): 3 fields x 3 wavelengths x 512x512 hits
+    bit-exact vs the oracle, FULL packets on a 192x192 grid"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    wl = workloads.load('zmx_evenasph_c3')
+    N = wl.n_ifcs
+    assert N == 13 and len(wl.fields) == 3 and len(wl.table.wvls) == 3
+    assert all(f.kind == abi.FLD_EPD_WIDE for f in wl.fields)
+    flags = abi.CHECK_APERTURES | abi.APPLY_VIGNETTING       # wide angle: the object is not intersected
+    eng = TraceEngine(wl.table)
+    grid = make_grid((-1., -1.), (1., 1.), 512)
+    through = 0
+    for fi in range(3):
+        for wi in range(3):
+            opts = make_opts(flags=flags, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
+                             foc=wl.foc, image_pt=wl.image_pts[fi])
+            dev = eng.trace_pupil_grid(wl.fields[fi], grid, wi, opts, nan_fill=True).to_host()
+            orc = oracle.trace_pupil_grid(wl.table, wl.fields[fi], oracle.make_grid((-1., -1.), (1., 1.), 512),
+                                          wi, opts)
+            np.testing.assert_array_equal(dev.status, orc.status)
+            np.testing.assert_array_equal(dev.fail_surf, orc.fail_surf)
+            assert np.array_equal(dev.seg, orc.seg, equal_nan=True), (fi, wi)
+            through += int((dev.status == 0).sum())
+    assert 0.3 * 9 * 512 * 512 < through < 0.9 * 9 * 512 * 512
+    opts = make_opts(flags=flags, out_mode=abi.OUT_FULL, first_surf=1, last_surf=N - 2)
+    g = make_grid((-1., -1.), (1., 1.), 192)
+    dev = eng.trace_pupil_grid(wl.fields[2], g, 0, opts, nan_fill=True).to_host()
+    orc = oracle.trace_pupil_grid(wl.table, wl.fields[2], oracle.make_grid((-1., -1.), (1., 1.), 192), 0, opts)
+    np.testing.assert_array_equal(dev.status, orc.status)
+    assert np.array_equal(dev.seg, orc.seg, equal_nan=True) and np.array_equal(dev.op, orc.op, equal_nan=True)
+    eng.close()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the script re-executes itself
+    under torch.distributed.run (here two ranks sharing device 0, gloo carrying the
+    collectives) and rank 0 prints exactly one JSON line with the multi-rank fields"""
+    env = dict(os.environ, ROX_BENCH_BACKEND='gloo', ROX_BENCH_SHARE_GPU='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5',
+                        '--warmup', '2', '--strong-num', '192', '--no-cpu-baseline', '--no-configs'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b['n_gpus'] == 2 and b['ranks_seen_by_backend'] == 2
+    s = b['strong_scaling']
+    assert s['ranks'] == 2 and s['ranks_seen_by_backend'] == 2
+    for prob in ('c5', 'c4'):
+        for ex in ('rccl', 'host'):
+            rec = s[prob][ex]
+            assert 'error' not in rec, (prob, ex, rec)
+            for k in ('kernel_ms_max_over_ranks', 'counts_exchange_ms', 'gather_ms', 'd2h_ms',
+                      'reassembly_ms', 'end_to_end_ms', 'pairs'):
+                assert rec[k] is not None and rec[k] >= 0, (prob, ex, k)
+            assert rec['end_to_end_ms'] >= rec['kernel_ms_max_over_ranks'] * 0.5
+        assert s[prob]['rccl']['pairs'] == s[prob]['host']['pairs'] < s[prob]['rays']
+    assert s['c5']['rccl']['grids_delivered'] == 45 and s['c4']['rccl']['grids_delivered'] == 5

@@ -37,6 +37,8 @@ def main():
     fld = wl.fields[args.field]
     wi = wl.ref_wvl_idx
     flags = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+    if fld.kind == abi.FLD_EPD_WIDE or fld.z_dir0 == 0.0:
+        flags &= ~abi.INTERSECT_OBJ             # wide-angle fields (trace.py:302-303)
     grid = make_grid((-1., -1.), (1., 1.), args.num)
     R = args.num ** 2
     res = {'lib': os.path.basename(engine.LIB_PATH)}
@@ -74,6 +76,13 @@ def main():
     for k, v in times.items():
         res[k + '_us'] = round(float(np.median(v)) * 1e3, 2)
         res[k + '_min_us'] = round(float(np.min(v)) * 1e3, 2)
+    # work of one launch (for per-intersection counter figures, tools/make_valu.py)
+    st = outs['hits'][1].status
+    fs = outs['hits'][1].fail_surf.to(torch.int64)
+    ok = st == abi.OK
+    res.update(workload=args.workload, field=args.field, num=args.num, rays=R,
+               rays_through=int(ok.sum().item()),
+               intersections=int(ok.sum().item()) * (N - 1) + int(fs[~ok].sum().item()))
     print(json.dumps(res))
 
 

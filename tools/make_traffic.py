@@ -7,6 +7,16 @@ import subprocess
 import sys
 
 
+def lib_hash():
+    """digest of the library build the counters were taken with (bench.py withholds the
+    figure when the kernels have changed since)"""
+    try:
+        with open('ray-optics_amd/libroxtrace.so.srchash') as f:
+            return f.read().strip()[:16]
+    except OSError:
+        return None
+
+
 def main(pmc_dir, out, tag):
     j = json.loads(subprocess.check_output([sys.executable, 'tools/pmc_summary.py', pmc_dir]))
     full = j['FULL']
@@ -14,6 +24,7 @@ def main(pmc_dir, out, tag):
     d = {'workload': 'dblgauss_c2', 'num': 1024, 'kernel': 'trace_kernel<FULL,PUPIL>',
          'hbm_bytes_per_launch': hbm, 'WRITE_SIZE_KiB': full['WRITE_SIZE'],
          'FETCH_SIZE_KiB_uncorrected': full['FETCH_SIZE'], 'source': tag,
+         'library_source_hash': lib_hash(),
          'note': 'separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), means over the '
                  'FULL-kernel dispatches of tools/ab_bench.py'}
     with open(out, 'w') as f:

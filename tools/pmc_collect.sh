@@ -2,15 +2,17 @@
 # Collects rocprofv3 PMC counters for the trace kernels on the GPU box, one
 # counter group per pass (TCC slots: FETCH_SIZE and WRITE_SIZE cannot share a
 # pass; PMC is never combined with sys/hip/hsa tracing on this pool).
-#   usage: tools/pmc_collect.sh <tag> [workload]   (outputs under gpurun_out/pmc_<tag>/)
+#   usage: tools/pmc_collect.sh <tag> [workload [num [field]]]   (outputs under gpurun_out/pmc_<tag>/)
 set -u
 TAG=${1:-r01}
 WL=${2:-dblgauss_c2}
+NUM=${3:-1024}
+FLD=${4:-0}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-CMD="python $R/tools/ab_bench.py --reps 1 --launches 3 --workload $WL"
+CMD="python $R/tools/ab_bench.py --reps 1 --launches 3 --workload $WL --num $NUM --field $FLD"
 pass() {   # name counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o $name -- $CMD > $OUT/$name.log 2>&1

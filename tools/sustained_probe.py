@@ -33,21 +33,26 @@ def main():
     ap.add_argument('--mode', default='full')
     ap.add_argument('--seconds', type=float, default=3.0)
     ap.add_argument('--batch', type=int, default=10)
+    ap.add_argument('--workload', default='dblgauss_c2')
+    ap.add_argument('--field', type=int, default=0)
+    ap.add_argument('--num', type=int, default=1024)
     args = ap.parse_args()
     import torch
     import rayoptics_amd  # noqa: F401
     from rayoptics_amd import abi, workloads, engine
     from rayoptics_amd.engine import TraceEngine, make_opts, make_grid, DeviceResult
-    wl = workloads.load('dblgauss_c2')
+    wl = workloads.load(args.workload)
     N = wl.n_ifcs
     eng = TraceEngine(wl.table)
-    fld = wl.fields[0]
+    fld = wl.fields[args.field]
     flags = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+    if fld.kind == abi.FLD_EPD_WIDE or fld.z_dir0 == 0.0:
+        flags &= ~abi.INTERSECT_OBJ
     mode = abi.OUT_FULL if args.mode == 'full' else abi.OUT_HITS
     o = make_opts(flags=flags, out_mode=mode, first_surf=1, last_surf=N - 2, foc=wl.foc,
-                  image_pt=wl.image_pts[0])
-    R = 1024 * 1024
-    grid = make_grid((-1., -1.), (1., 1.), 1024)
+                  image_pt=wl.image_pts[args.field])
+    R = args.num * args.num
+    grid = make_grid((-1., -1.), (1., 1.), args.num)
     out = DeviceResult(torch, eng.device, eng.num_segments(flags), R, mode,
                        want_pupil=(mode == abi.OUT_FULL), nan_fill=False)
     samples = []
@@ -72,6 +77,7 @@ def main():
     th.join()
     n = len(series)
     print(json.dumps({'lib': os.path.basename(engine.LIB_PATH), 'mode': args.mode,
+                      'workload': args.workload, 'field': args.field, 'num': args.num,
                       'first_batches_us': [s[1] for s in series[:12]],
                       'every_50th_batch_us': [s[1] for s in series[::max(n // 40, 1)]],
                       'mean_us': sum(s[1] for s in series) / n,
