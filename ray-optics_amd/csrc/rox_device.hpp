@@ -70,16 +70,39 @@
 #ifndef ROX_WG_SYNC          // 1: FULL mode: a workgroup barrier per surface keeps the waves of a
 #define ROX_WG_SYNC 1         //    workgroup on the same packet rows (218 -> 202 us)
 #endif
+// FULL mode of the instances that carry Newton code (aspheres, toroids): the iteration counts
+// differ per wave, so a 1024-thread workgroup (the only one its CU holds at 99-125 VGPRs) waits
+// at every surface for its slowest wave with nothing else to run.  Smaller workgroups -- four
+// per CU, out of step with each other -- win there (phone lens 319 -> 290 us, Nikkor 485 -> 452,
+// .zmx zoom 210 -> 196; 512 threads: 292 / 463 / 204; 128: 299 / 465 / 201).
+#ifndef ROX_BLOCK_FULL_POLY
+#define ROX_BLOCK_FULL_POLY 256
+#endif
+#ifndef ROX_WG_SYNC_POLY     // barrier per surface also there (off: 286 / 483 / 195 -- within the noise)
+#define ROX_WG_SYNC_POLY 1
+#endif
+#ifndef ROX_MIN_WAVES_FULL_POLY  // 5 caps the VGPRs at 96 (five workgroups per CU) at the price of 12-28 B
+#define ROX_MIN_WAVES_FULL_POLY ROX_MIN_WAVES  // of scratch per lane: phone lens 273, but the .zmx zoom 386 us
+#endif
+#ifndef ROX_IDENT_RT_FULL_POLY   // 1: the identity-rotation short cut also in the FULL mode of those
+#define ROX_IDENT_RT_FULL_POLY 1 //    instances, which are closer to their VALU bound (283 / 473 / 187 us)
+#endif
 
 namespace rox {
 
 constexpr int kBlock = ROX_BLOCK;
 constexpr int kWaves = kBlock / 64;
-// threads per workgroup (= rays per tile) of an output mode
-constexpr int block_of(int out_mode)
+// threads per workgroup (= rays per tile) of an output mode of a feature instance
+// (feat & kFeatNewton: the instance carries Newton code -- F_EVEN | F_RADIAL | F_TOROID)
+constexpr int kFeatNewton = 1 | 2 | 4;
+constexpr int block_of(int out_mode, int feat)
 {
-    return out_mode == ROX_OUT_FULL ? ROX_BLOCK_FULL
+    return out_mode == ROX_OUT_FULL ? ((feat & kFeatNewton) ? ROX_BLOCK_FULL_POLY : ROX_BLOCK_FULL)
          : out_mode == ROX_OUT_HITS_COMPACT ? ROX_BLOCK_COMPACT : ROX_BLOCK;
+}
+constexpr int min_waves_of(int out_mode, int feat)
+{
+    return (out_mode == ROX_OUT_FULL && (feat & kFeatNewton)) ? ROX_MIN_WAVES_FULL_POLY : ROX_MIN_WAVES;
 }
 static_assert(sizeof(rox_aperture) == 40, "rox_aperture layout");
 static_assert(sizeof(rox_phase) == 168, "rox_phase layout");
@@ -899,7 +922,8 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
                   O_ZDIR = offsetof(rox_surface, z_dir) / 8,
                   O_PH = offsetof(rox_surface, ph) / 8;
     constexpr bool kPoly = (FEAT & F_POLY) != 0;
-    constexpr bool kSync = ROX_WG_SYNC && OUT_MODE == ROX_OUT_FULL;
+    constexpr bool kSync = OUT_MODE == ROX_OUT_FULL && (kPoly ? ROX_WG_SYNC_POLY : ROX_WG_SYNC);
+    constexpr bool kIdentRt = ROX_IDENT_RT && (OUT_MODE != ROX_OUT_FULL || (kPoly && ROX_IDENT_RT_FULL_POLY));
     const int N = c.N;
     tblp tbl = c.tbl;
     tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
@@ -973,7 +997,6 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         const int rt_order = ((tbli)prow)[4];
         const v3 dp{bp.x - prow[O_T], bp.y - prow[O_T + 1], bp.z - prow[O_T + 2]};
         v3 b4p, b4d;
-#if ROX_IDENT_RT
         // rt exactly the identity (flagged on the device row when the system is created): each
         // dgemv chain fma(0, z, fma(0, y, fma(1, x, 0.0))) is x + 0.0 for finite operands in
         // either column order (-0 becomes +0 as in the chain).  A non-finite component would
@@ -981,13 +1004,11 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         // every active lane's six components are finite (their sum is: a conservative test).
         // (reduced-output modes only: in FULL mode, which is bound by its packet stores, the
         // extra branch measured 2 % slower)
-        if (OUT_MODE != ROX_OUT_FULL && ((tbli)prow)[5] != 0 &&
+        if (kIdentRt && ((tbli)prow)[5] != 0 &&
             __all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((bd.x + bd.y) + bd.z)))) {
             b4p = v3{dp.x + 0.0, dp.y + 0.0, dp.z + 0.0};
             b4d = v3{bd.x + 0.0, bd.y + 0.0, bd.z + 0.0};
-        } else
-#endif
-        {
+        } else {
             b4p = rotate(prow + O_RT, rt_order, dp);
             b4d = rotate(prow + O_RT, rt_order, bd);
         }
@@ -1188,11 +1209,11 @@ __device__ __forceinline__ uint64_t ts_pack(uint32_t epoch, uint64_t flag, uint3
 
 // ------------------------------------------------------------------ the kernel
 template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT>
-__global__ void __launch_bounds__(block_of(OUT_MODE), ROX_MIN_WAVES)
+__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT), min_waves_of(OUT_MODE, FEAT))
 trace_kernel(const TraceArgs a)
 {
     constexpr bool kCompact = (OUT_MODE == ROX_OUT_HITS_COMPACT);
-    constexpr int kB = block_of(OUT_MODE);      // threads per workgroup = rays per tile
+    constexpr int kB = block_of(OUT_MODE, FEAT);    // threads per workgroup = rays per tile
 
     const int N = a.n_ifcs;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1464,7 +1485,7 @@ inline void launch_with_lds(K kernel, const dim3 &grid, const dim3 &block, size_
 template <int GEN, bool PRW, int FEAT>
 inline void launch_mode(const LaunchCfg &k, const TraceArgs &a)
 {
-    const dim3 block(block_of(k.out_mode));
+    const dim3 block(block_of(k.out_mode, FEAT));
     switch (k.out_mode) {
     case ROX_OUT_FULL:
         launch_with_lds(trace_kernel<ROX_OUT_FULL, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);

@@ -394,6 +394,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
     const int inst = pick_instance(need);
     // (an instance compiled with F_PHASE stages the phase constants, needed or not)
     k.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0);
+
     if (k.lds > 160 * 1024 - 64)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS (max 163776)", k.lds);
     // lane byte offsets are 32-bit: at most 2^28 rays per launch
@@ -409,7 +410,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
             return fail(ROX_E_NOMEM, "out of host memory");
         compact_lock = std::unique_lock<std::mutex>(cx->compact_mu);
         const int64_t per = total < chunk_max ? total : chunk_max;
-        const int tb = block_of(ROX_OUT_HITS_COMPACT);
+        const int tb = block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]);
         int rc = ensure_compact(cx, (per + tb - 1) / tb, st);
         if (rc)
             return rc;
@@ -441,7 +442,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
             a.out.pupil = out0.pupil ? out0.pupil + base : nullptr;
         }
         // enough workgroups to fill 256 CUs several times over, grid-stride the rest
-        const int bs = block_of(a.opts.out_mode);
+        const int bs = block_of(a.opts.out_mode, kInstances[inst]);
         int64_t blocks = (a.n_rays + bs - 1) / bs;
         const int64_t cap = (int64_t)sys->num_cus * blocks_per_cu(bs);
         if (blocks > cap)
