@@ -64,6 +64,12 @@
 #ifndef ROX_BLOCK_COMPACT    // workgroup = tile size of HITS_COMPACT: fewer, larger tiles make the
 #define ROX_BLOCK_COMPACT 1024 // look-back cheaper (into pinned memory 128 -> 501, 256 -> 371,
 #endif                        // 512 -> 337, 1024 -> 316 us)
+#ifndef ROX_COMPACT_DEFER    // 1: HITS_COMPACT tiles after a workgroup's first look back and copy one tile
+#define ROX_COMPACT_DEFER 0   //    late (measured: nothing at 1024-ray tiles -- 156 vs 159 us into HBM -- and the
+#endif                        //    output leaves later: 332 vs 301 us into pinned memory)
+#ifndef ROX_MIN_WAVES_COMPACT_LEAN   // waves per SIMD the lean / aplist HITS_COMPACT instances are compiled for
+#define ROX_MIN_WAVES_COMPACT_LEAN ROX_MIN_WAVES
+#endif
 #ifndef ROX_BLOCK_FULL       // workgroup size of FULL mode: with the per-surface barrier the whole
 #define ROX_BLOCK_FULL 1024   // workgroup writes its packet rows together (sustained 256 -> 215 us,
 #endif                        // 512 -> 198 us, 1024 -> 192.5 us; without the barrier 217 us)
@@ -102,7 +108,9 @@ constexpr int block_of(int out_mode, int feat)
 }
 constexpr int min_waves_of(int out_mode, int feat)
 {
-    return (out_mode == ROX_OUT_FULL && (feat & kFeatNewton)) ? ROX_MIN_WAVES_FULL_POLY : ROX_MIN_WAVES;
+    return (out_mode == ROX_OUT_FULL && (feat & kFeatNewton)) ? ROX_MIN_WAVES_FULL_POLY
+         : (out_mode == ROX_OUT_HITS_COMPACT && !(feat & ~8)) ? ROX_MIN_WAVES_COMPACT_LEAN
+         : ROX_MIN_WAVES;
 }
 static_assert(sizeof(rox_aperture) == 40, "rox_aperture layout");
 static_assert(sizeof(rox_phase) == 168, "rox_phase layout");
@@ -179,6 +187,8 @@ struct TraceArgs {
     const int64_t *hits_base_in;
     int64_t *hits_total_out;
     uint32_t epoch;
+    // the first `small_tiles` tickets are tiles of kSmallTile rays (see compact_tiles())
+    int32_t small_tiles;
     rox_field fld;
     rox_opts opts;
     rox_out out;
@@ -1207,6 +1217,93 @@ __device__ __forceinline__ uint64_t ts_pack(uint32_t epoch, uint64_t flag, uint3
     return ((uint64_t)epoch << 32) | (flag << 30) | count;
 }
 
+// A tile's survivors (packed in `stash`, `total` of them) go to their final place: wave 0 finds
+// the number of survivors of all earlier tiles by decoupled look-back over the predecessors'
+// published counts, then every thread copies pairs (consecutive threads, consecutive pairs).
+// Called by all threads of the workgroup.
+template <int kB>
+__device__ __forceinline__ void finish_tile(const TraceArgs &a, int64_t tile, int total,
+                                            const d2 *stash, int64_t n_tiles, uint32_t *s_excl)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        uint32_t excl = 0;
+        uint64_t *st = a.tile_state;
+        if (tile != 0) {
+            // Look back over the predecessors, nearest first, 512 states per round trip (8
+            // independent loads per lane): sum counts until a tile that already knows its
+            // inclusive prefix is met; a tile that has published nothing yet is waited for,
+            // keeping the partial sum.
+            int64_t look = tile - 1;
+            for (bool done = false; !done;) {
+                uint64_t w[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int64_t idx = look - (k * 64 + lane);
+                    w[k] = ts_pack(a.epoch, TS_PREFIX, 0);      // before tile 0
+                    if (idx >= 0)
+                        w[k] = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                int consumed = 512;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t flag = (uint32_t)(w[k] >> 30) & 3u;
+                    const bool ready = (uint32_t)(w[k] >> 32) == a.epoch && flag != 0;
+                    const uint64_t rmask = __ballot(ready);
+                    const uint64_t pmask = __ballot(ready && flag == TS_PREFIX);
+                    const int first_not = (~rmask) ? __builtin_ctzll(~rmask) : 64;
+                    const int first_pref = pmask ? __builtin_ctzll(pmask) : 64;
+                    const int take = first_pref < first_not ? first_pref + 1 : first_not;
+                    uint32_t v = lane < take ? (uint32_t)(w[k] & 0x3fffffffu) : 0u;
+                    for (int o = 32; o > 0; o >>= 1)
+                        v += __shfl_xor(v, o);
+                    excl += v;
+                    if (first_pref < first_not) {
+                        done = true;
+                        break;
+                    }
+                    if (first_not < 64) {       // wait for that tile, resume from it
+                        consumed = k * 64 + first_not;
+                        __builtin_amdgcn_s_sleep(1);
+                        break;
+                    }
+                }
+                look -= consumed;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&st[tile], ts_pack(a.epoch, TS_PREFIX, excl + (uint32_t)total),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0)
+            *s_excl = excl;
+    }
+    __syncthreads();
+    const int64_t base = a.hits_base_in ? *a.hits_base_in : 0;
+    const uint32_t excl = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_excl);
+    d2 *dst = reinterpret_cast<d2 *>(a.out.seg) + base + (int64_t)excl;
+    for (int j = threadIdx.x; j < total; j += kB)
+        __builtin_nontemporal_store(stash[j], dst + j);
+    if (tile == n_tiles - 1 && threadIdx.x == 0)
+        *a.hits_total_out = base + (int64_t)excl + total;
+}
+
+// HITS_COMPACT tile geometry.  The first `want` tickets of a launch take tiles of kSmallTile
+// rays: a 1024-thread workgroup then runs four waves, one per SIMD, and is through its
+// surfaces in a third of the time sixteen take.  The host asks for them when the whole launch
+// fits one small tile per CU (a 256 x 256 grid spreads over 256 CUs instead of 64); later
+// tickets take full tiles.
+constexpr int kSmallTile = 256;
+__host__ __device__ inline int64_t compact_small_tiles(int64_t n_rays, int32_t want)
+{
+    const int64_t fit = n_rays / kSmallTile;
+    return want < fit ? (want < 0 ? 0 : want) : fit;
+}
+__host__ __device__ inline int64_t compact_tiles(int64_t n_rays, int32_t want_small, int kB)
+{
+    const int64_t s = compact_small_tiles(n_rays, want_small);
+    return s + (n_rays - s * kSmallTile + kB - 1) / kB;
+}
+
 // ------------------------------------------------------------------ the kernel
 template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT>
 __global__ void __launch_bounds__(block_of(OUT_MODE, FEAT), min_waves_of(OUT_MODE, FEAT))
@@ -1224,6 +1321,9 @@ trace_kernel(const TraceArgs a)
     double *wvls_w = phc_w + ((FEAT & F_PHASE) ? (size_t)nw_rows * N * kPhaseConsts : 0);
     double *apthr_w = wvls_w + a.n_wvls;                // [N]
     int32_t *slot_w = reinterpret_cast<int32_t *>(apthr_w + N);
+    // HITS_COMPACT: two tiles' worth of packed (x, y) pairs behind the slot map
+    d2 *stash_w = reinterpret_cast<d2 *>(
+        (reinterpret_cast<uintptr_t>(slot_w + 2 * N) + 15) & ~uintptr_t(15));
 
     // stage the surface table once per workgroup
     for (int i = threadIdx.x; i < N * kRowDoubles; i += kB)
@@ -1258,7 +1358,8 @@ trace_kernel(const TraceArgs a)
     c.eps = a.opts.eps; c.fuzz = a.opts.fuzz;
     c.probe_surf = -1;
     const int64_t ld = a.out.ld;
-    const int64_t n_tiles = (a.n_rays + kB - 1) / kB;
+    const int64_t n_small = kCompact ? compact_small_tiles(a.n_rays, a.small_tiles) : 0;
+    const int64_t n_tiles = kCompact ? compact_tiles(a.n_rays, a.small_tiles, kB) : (a.n_rays + kB - 1) / kB;
 
     // HITS_COMPACT: tiles are handed out by ticket, so that the tile a workgroup
     // waits for in the look-back is always held by a running workgroup
@@ -1266,6 +1367,9 @@ trace_kernel(const TraceArgs a)
     __shared__ int32_t s_wcnt[kB / 64];
     __shared__ uint32_t s_excl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr bool kDefer = kCompact && ROX_COMPACT_DEFER;
+    int64_t pend_tile = -1, pend_it = 0;    // HITS_COMPACT: the tile whose finish is deferred
+    int pend_total = 0;
 
     for (int64_t it = 0;; ++it) {
         int64_t tile;
@@ -1273,14 +1377,20 @@ trace_kernel(const TraceArgs a)
             if (threadIdx.x == 0)
                 s_tile = (int64_t)atomicAdd(&a.ticket[0], 1u);
             __syncthreads();
-            tile = s_tile;
+            // (wave-uniform by construction: keep it in scalar registers across the trace)
+            tile = (int64_t)__builtin_amdgcn_readfirstlane((int)s_tile);
         } else {
             tile = (int64_t)blockIdx.x + it * gridDim.x;
         }
         if (tile >= n_tiles)
             break;
-        const int64_t r = tile * kB + threadIdx.x;
-        const bool active = r < a.n_rays;
+        int64_t r = tile * kB + threadIdx.x;
+        bool active = r < a.n_rays;
+        if (kCompact) {
+            const bool small = tile < n_small;
+            r = (small ? tile * kSmallTile : n_small * kSmallTile + (tile - n_small) * kB) + threadIdx.x;
+            active = r < a.n_rays && (!small || threadIdx.x < kSmallTile);
+        }
         RayEnd e;
         SegOut so;
         so.base = reinterpret_cast<char *>(a.out.seg);
@@ -1360,8 +1470,9 @@ trace_kernel(const TraceArgs a)
         }
 
         if (kCompact) {
-            // ---- stable compaction of the hits: ballot ranks within the wave,
-            // wave counts through LDS, tile prefix by decoupled look-back ---------
+            // ---- stable compaction of the hits: ballot ranks within the wave, wave counts
+            // through LDS, the tile's survivors packed into an LDS stash; finish_tile() then
+            // finds the tile's place by decoupled look-back and copies the stash there.
             const bool ok = active && e.status == ROX_OK;
             const uint64_t mask = __ballot(ok);
             const int lrank = __popcll(mask & ((1ull << lane) - 1ull));
@@ -1376,79 +1487,39 @@ trace_kernel(const TraceArgs a)
                     woff += cnt;
                 total += cnt;
             }
-            if (wave == 0) {
-                uint32_t excl = 0;
-                uint64_t *st = a.tile_state;
-                if (tile == 0) {
-                    if (lane == 0)
-                        __hip_atomic_store(&st[0], ts_pack(a.epoch, TS_PREFIX, (uint32_t)total),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    if (lane == 0)
-                        __hip_atomic_store(&st[tile], ts_pack(a.epoch, TS_AGG, (uint32_t)total),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // Look back over the predecessors, nearest first, 512 states per
-                    // round trip (8 independent loads per lane): sum aggregates until a
-                    // tile that already knows its inclusive prefix is met; a tile that
-                    // has published nothing yet is waited for, keeping the partial sum.
-                    int64_t look = tile - 1;
-                    for (bool done = false; !done;) {
-                        uint64_t w[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int64_t idx = look - (k * 64 + lane);
-                            w[k] = ts_pack(a.epoch, TS_PREFIX, 0);      // before tile 0
-                            if (idx >= 0)
-                                w[k] = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        int consumed = 512;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const uint32_t flag = (uint32_t)(w[k] >> 30) & 3u;
-                            const bool ready = (uint32_t)(w[k] >> 32) == a.epoch && flag != 0;
-                            const uint64_t rmask = __ballot(ready);
-                            const uint64_t pmask = __ballot(ready && flag == TS_PREFIX);
-                            const int first_not = (~rmask) ? __builtin_ctzll(~rmask) : 64;
-                            const int first_pref = pmask ? __builtin_ctzll(pmask) : 64;
-                            const int take = first_pref < first_not ? first_pref + 1 : first_not;
-                            uint32_t v = lane < take ? (uint32_t)(w[k] & 0x3fffffffu) : 0u;
-                            for (int o = 32; o > 0; o >>= 1)
-                                v += __shfl_xor(v, o);
-                            excl += v;
-                            if (first_pref < first_not) {
-                                done = true;
-                                break;
-                            }
-                            if (first_not < 64) {       // wait for that tile, resume from it
-                                consumed = k * 64 + first_not;
-                                __builtin_amdgcn_s_sleep(1);
-                                break;
-                            }
-                        }
-                        look -= consumed;
-                    }
-                    if (lane == 0)
-                        __hip_atomic_store(&st[tile], ts_pack(a.epoch, TS_PREFIX, excl + (uint32_t)total),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (lane == 0)
-                    s_excl = excl;
-            }
-            __syncthreads();
-            const int64_t base = a.hits_base_in ? *a.hits_base_in : 0;
-            const int64_t at = base + (int64_t)s_excl + woff + lrank;
+            woff = __builtin_amdgcn_readfirstlane(woff);        // per-wave / per-workgroup values
+            total = __builtin_amdgcn_readfirstlane(total);
+            d2 *stash = stash_w + (size_t)(it & 1) * kB;
             if (ok) {
                 const double dist = a.opts.foc / e.ad.z;
                 d2 xy;
                 xy.x = (e.inc.x + dist * e.ad.x) - a.opts.image_pt[0];
                 xy.y = (e.inc.y + dist * e.ad.y) - a.opts.image_pt[1];
-                __builtin_nontemporal_store(xy, reinterpret_cast<d2 *>(a.out.seg) + at);
+                stash[woff + lrank] = xy;
             }
-            if (tile == n_tiles - 1 && threadIdx.x == 0)
-                *a.hits_total_out = base + (int64_t)s_excl + total;
+            if (threadIdx.x == 0)       // the count is published at once; tile 0's is its prefix
+                __hip_atomic_store(&a.tile_state[tile],
+                                   ts_pack(a.epoch, tile == 0 ? TS_PREFIX : TS_AGG, (uint32_t)total),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();            // the stash is complete
+            // Deferred finish: a tile looks back and copies only after the workgroup has traced
+            // its *next* tile -- by then every predecessor has long published its count, so no
+            // wave sits in a look-back while the SIMDs have nothing else to run.  A workgroup's
+            // first tile finishes at once (early output for a destination behind PCIe).
+            if (!kDefer || it == 0) {
+                finish_tile<kB>(a, tile, total, stash, n_tiles, &s_excl);
+            } else {
+                if (pend_tile >= 0)
+                    finish_tile<kB>(a, pend_tile, pend_total, stash_w + (size_t)((it - 1) & 1) * kB,
+                                    n_tiles, &s_excl);
+                pend_tile = tile;
+                pend_total = total;
+                pend_it = it;
+            }
         }
     }
+    if (kCompact && kDefer && pend_tile >= 0)
+        finish_tile<kB>(a, pend_tile, pend_total, stash_w + (size_t)(pend_it & 1) * kB, n_tiles, &s_excl);
     if (kCompact && threadIdx.x == 0) {
         // the last workgroup out re-arms the ticket for the next launch of this
         // stream context (every workgroup leaves exactly once, after its last draw)

@@ -313,6 +313,24 @@ int blocks_per_cu(int bs)
 
 // rays per kernel launch (lane byte offsets are 32-bit: at most 2^28).
 // ROX_RAYS_PER_LAUNCH overrides it (tests exercise the chunked path with it).
+// HITS_COMPACT: how many first tickets take small tiles (rox_device.hpp compact_tiles).
+// A launch that small tiles spread over no more workgroups than the chip has CUs (a
+// 256 x 256 grid: 256 tiles of 256 rays instead of 64 of 1024) runs all of it that way:
+// 30 vs 40 us into HBM, 41 vs 53 us into pinned memory.  Larger launches take full tiles
+// throughout: small first tiles measured slower there (1024 x 1024: 178 vs 158 us into HBM,
+// 319 vs 301 us into pinned memory; 45 x 1M rays of config 5: 26.3 vs 23.1 ms).
+// ROX_COMPACT_SMALL_TILES overrides the count for experiments.
+int32_t compact_small_want(const rox_system *sys, int64_t n_rays)
+{
+    static const int v = [] {
+        const char *e = getenv("ROX_COMPACT_SMALL_TILES");
+        return e ? atoi(e) : -1;
+    }();
+    if (v >= 0)
+        return v;
+    return n_rays <= (int64_t)sys->num_cus * kSmallTile ? sys->num_cus : 0;
+}
+
 int64_t rays_per_launch()
 {
     static const int64_t v = [] {
@@ -394,6 +412,8 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
     const int inst = pick_instance(need);
     // (an instance compiled with F_PHASE stages the phase constants, needed or not)
     k.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0);
+    if (a.opts.out_mode == ROX_OUT_HITS_COMPACT)    // two tiles of packed pairs (rox_device.hpp)
+        k.lds += 16 + 2 * 16 * (size_t)block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]);
 
     if (k.lds > 160 * 1024 - 64)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS (max 163776)", k.lds);
@@ -411,7 +431,8 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
         compact_lock = std::unique_lock<std::mutex>(cx->compact_mu);
         const int64_t per = total < chunk_max ? total : chunk_max;
         const int tb = block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]);
-        int rc = ensure_compact(cx, (per + tb - 1) / tb, st);
+        a.small_tiles = compact_small_want(sys, per);
+        int rc = ensure_compact(cx, compact_tiles(per, a.small_tiles, tb), st);
         if (rc)
             return rc;
     }
@@ -443,7 +464,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
         }
         // enough workgroups to fill 256 CUs several times over, grid-stride the rest
         const int bs = block_of(a.opts.out_mode, kInstances[inst]);
-        int64_t blocks = (a.n_rays + bs - 1) / bs;
+        int64_t blocks = compact ? compact_tiles(a.n_rays, a.small_tiles, bs) : (a.n_rays + bs - 1) / bs;
         const int64_t cap = (int64_t)sys->num_cus * blocks_per_cu(bs);
         if (blocks > cap)
             blocks = cap;

@@ -14,6 +14,8 @@
 #   pmc:<workload>[:num]           tools/pmc_collect.sh passes for a workload -> pmc_<tag>_<workload>/
 #   probe:<mode>:<workload>[:field[:lib]]   tools/sustained_probe.py (steady-state kernel time)
 #   py:<script and args>           python <script...> > <tag>/<script>.out
+#   lib:<variant.so>               export ROX_LIB for the following steps ("lib:" resets)
+#   env:NAME=VALUE                 export for the following steps ("env:NAME=" unsets)
 #   smoke                          __graft_entry__.smoke()
 set -u
 cd "${GRAFT_REPO_ROOT:-$PWD}"
@@ -85,7 +87,12 @@ PY
       unset ROX_LIB ;;
     py)
       name=$(echo "$rest" | awk '{print $1}' | xargs basename)
-      timeout 1800 python $rest > "$OUT/$name.out" 2> "$OUT/$name.err"; echo "rc=$?"; tail -15 "$OUT/$name.out"; tail -3 "$OUT/$name.err" ;;
+      timeout 1800 python $rest >> "$OUT/$name.out" 2> "$OUT/$name.err"; echo "rc=$?"; tail -1 "$OUT/$name.out" | cut -c1-1500; tail -3 "$OUT/$name.err" ;;
+    lib)      # ROX_LIB for the following steps ("lib:" alone: back to the product library)
+      if [ -n "$rest" ]; then export ROX_LIB="$PWD/$rest"; else unset ROX_LIB; fi
+      echo "ROX_LIB=${ROX_LIB:-}" ;;
+    env)      # env:NAME=VALUE exports, env:NAME= unsets, for the following steps
+      if [ -n "${rest#*=}" ]; then export "$rest"; else unset "${rest%%=*}"; fi; echo "$rest" ;;
     smoke)
       timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3 ;;
     *) echo "unknown step $step" ;;
