@@ -16,7 +16,7 @@
  *                             trace_safe -> trace.py:253-310 trace_base ->
  *                             opticalspec.py:289-400 ray_start_from_osp,
  *                             opticalspec.py:1339-1353 apply_vignetting)
- *   rox_aim_chief_rays     <- rayoptics/raytr/trace.py:313-415    iterate_ray() (1-D branch)
+ *   rox_aim_chief_rays     <- rayoptics/raytr/trace.py:313-415    iterate_ray() (both branches)
  *                             rayoptics/raytr/trace.py:627-640    aim_chief_ray()
  *   rox_calc_vignetting    <- rayoptics/raytr/vigcalc.py:233-340, 396-461
  *                             calc_vignetting_for_field() / calc_vignetted_ray() /
@@ -394,19 +394,26 @@ int rox_trace_pupil_list(rox_system *sys, const rox_field *fld,
                          const rox_out *out, void *stream);
 
 /* chief-ray aiming ------------------------------------------------------- */
-/* One problem per (field, wavelength): the 1-D branch of trace.iterate_ray
+/* One problem per (field, wavelength): trace.iterate_ray
  * (rayoptics/raytr/trace.py:313-415) as trace.aim_chief_ray calls it
  * (trace.py:627-640, from OpticalSpecs.update_optical_properties,
- * opticalspec.py:263-281): find y1 such that the ray from pt0 towards
- * (0, y1, z_enp) meets interface `surf` at y_target, by the secant iteration
- * of scipy.optimize.newton (x0 = 0, tol 1.48e-8, maxiter 50), every trial ray
- * traced through the whole system (raytrace.trace defaults).  All problems run
- * in one launch, one lane each.  Fields or targets off the y axis take
- * iterate_ray's 2-D (MINPACK) branch, which stays on the host:
- * ROX_E_UNSUPPORTED.  probs / aim_y / result are host memory; synchronous. */
-enum { ROX_AIM_CONVERGED = 0,   /* aim_y = root                                 */
-       ROX_AIM_NOT_CONVERGED = 1,/* aim_y = results.root as iterate_ray keeps it */
-       ROX_AIM_TRACE_ERROR = 2 };/* a trial ray failed before `surf`: aim_y = 0  */
+ * opticalspec.py:263-281): find the aim point (x1, y1) on the paraxial entrance
+ * pupil plane such that the ray from pt0 towards (x1, y1, z_enp) meets interface
+ * `surf` at (x_target, y_target), every trial ray traced through the whole
+ * system (raytrace.trace defaults).  Both branches of the reference run on the
+ * device, one lane per problem, all problems in one launch:
+ *   two_d = 0  field and target on the y axis (trace.py:376-392): x1 = 0 and y1 by
+ *              the secant iteration of scipy.optimize.newton (x0 = 0, tol 1.48e-8,
+ *              maxiter 50)
+ *   two_d = 1  any other field (trace.py:394-410): scipy.optimize.fsolve from (0, 0)
+ *              with epsfcn = 0.0001 * fod.enp_radius -- MINPACK's hybrd (Powell's
+ *              hybrid method: forward-difference Jacobian, dog-leg steps, Broyden
+ *              updates; xtol 1.49012e-8, maxfev 600, factor 100, internal scaling)
+ * probs / aim_xy / result are host memory; synchronous. */
+enum { ROX_AIM_CONVERGED = 0,   /* aim = root                                   */
+       ROX_AIM_NOT_CONVERGED = 1,/* aim = the last iterate, as iterate_ray keeps it
+                                    (results.root; fsolve's x with ier != 1)      */
+       ROX_AIM_TRACE_ERROR = 2 };/* a trial ray failed before `surf`: aim = (0, 0) */
 typedef struct rox_aim {
     double pt0[3];           /* osp.obj_coords(fld)[0]                         */
     double z_enp;            /* fod.obj_dist + fod.enp_dist                    */
@@ -415,10 +422,13 @@ typedef struct rox_aim {
     int32_t wvl_idx;
     int32_t surf;            /* ifcx (the stop surface)                        */
     int32_t flip;            /* not wide angle: dir0 = -dir0 if dir0.z*z_dir0 < 0 */
-    int32_t reserved;
-} rox_aim;                   /* 64 bytes */
+    int32_t two_d;           /* which branch of iterate_ray (see above)        */
+    double x_target;         /* xy_target[0]                                   */
+    double epsfcn;           /* two_d: 0.0001 * fod.enp_radius                 */
+} rox_aim;                   /* 80 bytes */
+/* aim_xy: [n][2] = (x1, y1) per problem */
 int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs,
-                       double eps, double *aim_y, int32_t *result, void *stream);
+                       double eps, double *aim_xy, int32_t *result, void *stream);
 
 #ifdef __cplusplus
 }

@@ -181,17 +181,17 @@ def make_grid(start, stop, num, kind=abi.GRID_PRODUCT, row_begin=0, row_count=0)
 
 
 def aim_chief_rays(table, probs, eps=1.0e-12):
-    """probs: sequence of abi.Aim -> (aim_y float64[n], result int32[n])"""
+    """probs: sequence of abi.Aim -> (aim float64[n, 2] = (x1, y1), result int32[n])"""
     n = len(probs)
     arr = (abi.Aim * n)(*probs)
-    aim_y = np.zeros(n)
+    aim = np.zeros((n, 2))
     result = np.zeros(n, dtype=np.int32)
     rc = lib().rox_oracle_aim_chief_rays(table.rows, table.n_ifcs, table.n_table.ctypes.data,
                                          _wvls(table).ctypes.data, len(table.wvls), n, arr,
-                                         eps, aim_y.ctypes.data, result.ctypes.data)
+                                         eps, aim.ctypes.data, result.ctypes.data)
     if rc:
         raise RuntimeError(f'oracle error {rc}')
-    return aim_y, result
+    return aim, result
 
 
 def calc_vignetting(table, probs, eps=1.0e-12):
@@ -220,3 +220,41 @@ def calc_psf(opd, ndim, maxdim):
     if rc:
         raise ValueError(f'oracle calc_psf: shapes rejected ({rc})')
     return out
+
+
+HYBRD_FCN = C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+
+def hybrd(func, x0, xtol=1.49012e-8, maxfev=0, epsfcn=None, factor=100.0):
+    """oracle/minpack_hybrd.c through a Python callback: what scipy.optimize.fsolve(func, x0,
+    full_output=True) runs (minus fsolve's own extra func(x0) call).  func may raise
+    StopIteration to abort (MINPACK's iflag < 0).  Returns (x, infodict, info)."""
+    x = np.array(x0, dtype=np.float64).ravel().copy()
+    n = len(x)
+    if maxfev == 0:
+        maxfev = 200 * (n + 1)
+    if epsfcn is None:
+        epsfcn = np.finfo(np.float64).eps
+
+    def cb(n_, xp, fp, _ctx):
+        try:
+            f = np.asarray(func(np.array([xp[i] for i in range(n_)])), dtype=np.float64).ravel()
+        except StopIteration:
+            return -1
+        for i in range(n_):
+            fp[i] = f[i]
+        return 0
+    fvec = np.zeros(n)
+    fjac = np.zeros(n * n)
+    r = np.zeros(n * (n + 1) // 2)
+    qtf = np.zeros(n)
+    nfev = C.c_int(0)
+    f = lib().rox_oracle_hybrd
+    f.restype = C.c_int
+    f.argtypes = [HYBRD_FCN, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                  C.c_double, C.c_double, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p]
+    info = f(HYBRD_FCN(cb), None, n, x.ctypes.data, fvec.ctypes.data, float(xtol), int(maxfev),
+             float(epsfcn), float(factor), C.byref(nfev), fjac.ctypes.data, r.ctypes.data,
+             qtf.ctypes.data)
+    # scipy hands fjac back as the C-ordered view of MINPACK's column-major array
+    return x, dict(nfev=nfev.value, fvec=fvec, fjac=fjac.reshape(n, n), r=r, qtf=qtf), info

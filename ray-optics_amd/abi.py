@@ -125,7 +125,8 @@ class Aim(C.Structure):
     _fields_ = [('pt0', C.c_double * 3), ('z_enp', C.c_double),
                 ('y_target', C.c_double), ('z_dir0', C.c_double),
                 ('wvl_idx', C.c_int32), ('surf', C.c_int32),
-                ('flip', C.c_int32), ('reserved', C.c_int32)]
+                ('flip', C.c_int32), ('two_d', C.c_int32),
+                ('x_target', C.c_double), ('epsfcn', C.c_double)]
 
 
 class Vig(C.Structure):
@@ -143,7 +144,7 @@ assert C.sizeof(Opts) == 568
 assert C.sizeof(Field) == 192
 assert C.sizeof(Grid) == 48
 assert C.sizeof(Out) == 56
-assert C.sizeof(Aim) == 64
+assert C.sizeof(Aim) == 80
 
 # every symbol include/roxtrace.h declares (checked by tests/test_abi.py) ...
 EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',

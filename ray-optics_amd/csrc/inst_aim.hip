@@ -5,6 +5,7 @@
 // lane = one (field, wavelength) problem, every trial ray traced through the
 // whole system with raytrace.trace's defaults (raytrace.py:51-80).
 #include "rox_device.hpp"
+#include "rox_hybrd.hpp"
 
 namespace rox {
 namespace {
@@ -66,6 +67,41 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
         return y_ray - pb.y_target;
     };
 
+    if (pb.two_d) {
+        // trace.py:351-372 surface_coordinate under fsolve (MINPACK hybrd, rox_hybrd.hpp);
+        // fsolve evaluates f(x0) itself before MINPACK does
+        auto f2 = [&](const double *coord, double *fv) -> bool {
+            const v3 pt1{coord[0], coord[1], pb.z_enp};
+            v3 dir0 = unit(v3{pt1.x - pt0.x, pt1.y - pt0.y, pt1.z - pt0.z});
+            if (pb.flip && dir0.z * pb.z_dir0 < 0)
+                dir0 = v3{-dir0.x, -dir0.y, -dir0.z};
+            RayEnd e;
+            trace_ray<MODE_PROBE, true, F_ALL>(c, so, pt0, dir0, pb.wvl_idx, true, e);
+            double xr = 0., yr = 0.;
+            if (e.status != ROX_OK) {
+                if (e.fail_surf < pb.surf)
+                    return false;                       // raise ray_error
+            } else {
+                xr = e.probe_p.x;
+                yr = e.probe_p.y;
+            }
+            fv[0] = xr - pb.x_target;
+            fv[1] = yr - pb.y_target;
+            return true;
+        };
+        double x[2] = {0., 0.}, fv0[2];
+        int nfev = 0;
+        int info = f2(x, fv0) ? hybrd::solve<2>(f2, x, 1.49012e-8, 600, pb.epsfcn, 100.0, nfev) : -1;
+        if (info < 0) {                                 // except TraceError: start_coords = [0, 0]
+            x[0] = x[1] = 0.0;
+            a.result[i] = ROX_AIM_TRACE_ERROR;
+        } else {
+            a.result[i] = info == 1 ? ROX_AIM_CONVERGED : ROX_AIM_NOT_CONVERGED;
+        }
+        a.aim_xy[2 * i] = x[0];
+        a.aim_xy[2 * i + 1] = x[1];
+        return;
+    }
     const double tol = 1.48e-8;
     double p0 = 0.0, p = 0.0;
     int result = ROX_AIM_NOT_CONVERGED;
@@ -105,7 +141,8 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
         p = 0.0;
         result = ROX_AIM_TRACE_ERROR;
     }
-    a.aim_y[i] = p;
+    a.aim_xy[2 * i] = 0.0;
+    a.aim_xy[2 * i + 1] = p;
     a.result[i] = result;
 }
 

@@ -1608,7 +1608,7 @@ struct AimArgs {
     int32_t n_ifcs, n_wvls, n;
     const rox_aim *probs;      // device
     double eps;
-    double *aim_y;             // device [n]
+    double *aim_xy;            // device [n][2]
     int32_t *result;           // device [n]
 };
 void launch_aim(const AimArgs &, size_t lds, hipStream_t);

@@ -1030,9 +1030,9 @@ int rox_trace_pupil_list(rox_system *sys, const rox_field *fld, int64_t n_rays, 
 }
 
 int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs, double eps,
-                       double *aim_y, int32_t *result, void *stream)
+                       double *aim_xy, int32_t *result, void *stream)
 {
-    if (!sys || n < 0 || (n > 0 && (!probs || !aim_y || !result)))
+    if (!sys || n < 0 || (n > 0 && (!probs || !aim_xy || !result)))
         return fail(ROX_E_ARG, "rox_aim_chief_rays: bad argument");
     if (n == 0)
         return 0;
@@ -1041,9 +1041,8 @@ int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs, double 
             return fail(ROX_E_ARG, "probs[%d].wvl_idx %d out of range", i, probs[i].wvl_idx);
         if (probs[i].surf < 0 || probs[i].surf >= sys->n_ifcs)
             return fail(ROX_E_ARG, "probs[%d].surf %d out of range", i, probs[i].surf);
-        if (probs[i].pt0[0] != 0.0)
-            return fail(ROX_E_UNSUPPORTED, "probs[%d]: field off the y axis takes iterate_ray's "
-                                           "2-D branch (host)", i);
+        if (probs[i].two_d && !(probs[i].epsfcn >= 0.0))
+            return fail(ROX_E_ARG, "probs[%d].epsfcn %g", i, probs[i].epsfcn);
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t N = sys->n_ifcs, W = sys->n_wvls;
@@ -1052,14 +1051,14 @@ int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs, double 
     if (lds > 160 * 1024 - 64)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
     void *d = nullptr;
-    const size_t pb = sizeof(rox_aim) * n, yb = sizeof(double) * n, rb = sizeof(int32_t) * n;
+    const size_t pb = sizeof(rox_aim) * n, yb = sizeof(double) * 2 * n, rb = sizeof(int32_t) * n;
     HIP_TRY(hipMalloc(&d, pb + yb + rb));
     AimArgs a{};
     a.rows = sys->d_rows; a.n_table = sys->d_ntab; a.ph_consts = sys->d_phc; a.wvls = sys->d_wvls;
     a.slots = sys->d_slots[0];
     a.n_ifcs = sys->n_ifcs; a.n_wvls = sys->n_wvls; a.n = n;
     a.probs = (const rox_aim *)d;
-    a.aim_y = (double *)((char *)d + pb);
+    a.aim_xy = (double *)((char *)d + pb);
     a.result = (int32_t *)((char *)d + pb + yb);
     a.eps = eps;
     hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
@@ -1068,7 +1067,7 @@ int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs, double 
         e = hipGetLastError();
     }
     if (e == hipSuccess)
-        e = hipMemcpyAsync(aim_y, a.aim_y, yb, hipMemcpyDeviceToHost, st);
+        e = hipMemcpyAsync(aim_xy, a.aim_xy, yb, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess)
         e = hipMemcpyAsync(result, a.result, rb, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess)

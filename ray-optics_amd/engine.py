@@ -544,16 +544,16 @@ class TraceEngine:
 
     # -- chief-ray aiming ---------------------------------------------------------
     def aim_chief_rays(self, probs, eps=1.0e-12):
-        """probs: sequence of abi.Aim -> (aim_y float64[n], result int32[n])"""
+        """probs: sequence of abi.Aim -> (aim float64[n, 2] = (x1, y1), result int32[n])"""
         n = len(probs)
         arr = (abi.Aim * n)(*probs)
-        aim_y = np.zeros(n)
+        aim = np.zeros((n, 2))
         result = np.zeros(n, dtype=np.int32)
         with self.torch.cuda.device(self.device):
             _check(self.lib.rox_aim_chief_rays(self._handle, n, arr, float(eps),
-                                               aim_y.ctypes.data, result.ctypes.data,
+                                               aim.ctypes.data, result.ctypes.data,
                                                self._stream()), 'rox_aim_chief_rays')
-        return aim_y, result
+        return aim, result
 
     def calc_vignetting(self, probs, eps=1.0e-12):
         """probs: sequence of abi.Vig -> (vig float64[n], clip_surf int32[n])"""

@@ -286,33 +286,35 @@ def seq_trace_grid(self, fct, fi, wl=None, num_rays=21, form='grid',
 
 # ---- chief-ray aiming --------------------------------------------------------
 def _aim_problem(opt_model, fld, wvl, tbl, stop):
-    """rox_aim for the 1-D branch of iterate_ray (trace.py:376-392), or None when
-    the field takes another branch (2-D MINPACK iteration, wide-angle search)"""
+    """rox_aim for iterate_ray (trace.py:313-415) aiming at the centre of the stop: the 1-D
+    branch for a field on the y axis (:376-392), the 2-D branch otherwise (:394-410, fsolve
+    with epsfcn = 0.0001 * fod.enp_radius).  None for wide-angle models, whose pupil search
+    is wideangle.find_real_enp (trace.py:634-635)."""
     osp = opt_model['optical_spec']
     if osp['fov'].is_wide_angle:
         return None
     fod = opt_model['analysis_results']['parax_data'].fod
     pt0, _d0 = osp.obj_coords(fld)
-    if pt0[0] != 0.0:
-        return None
     a = abi.Aim()
     for i in range(3):
         a.pt0[i] = float(pt0[i])
     a.z_enp = float(fod.obj_dist + fod.enp_dist)
-    a.y_target = 0.0
+    a.x_target = a.y_target = 0.0
     a.z_dir0 = float(opt_model['seq_model'].z_dir[0])
     a.wvl_idx = tbl.wvl_index(wvl)
     a.surf = int(stop)
     a.flip = 1
+    a.two_d = 0 if pt0[0] == 0.0 else 1
+    a.epsfcn = float(0.0001 * fod.enp_radius)
     return a
 
 
 def aim_chief_rays(opt_model, flds, wvl=None):
-    """aim_info for every field in ``flds``: the fields on iterate_ray's 1-D
-    branch are solved together in one launch (one lane each, secant iteration
-    restated from scipy.optimize.newton); the others -- off-axis-in-x fields
-    (2-D MINPACK iteration) and wide-angle pupil searches -- keep the reference's
-    own host code (rayoptics/raytr/trace.py:313-415, wideangle.py:86-427)."""
+    """aim_info for every field in ``flds``, all solved together in one launch (one lane
+    each): fields on the y axis by the secant iteration of scipy.optimize.newton, the others
+    by MINPACK's hybrd as scipy.optimize.fsolve runs it -- both restated on the device
+    (rayoptics/raytr/trace.py:313-415).  Wide-angle models keep the reference's own pupil
+    search (wideangle.py:86-427), whose trial rays go through the rebound raytrace.trace."""
     from rayoptics.raytr import trace as ref_trace
     sm = opt_model['seq_model']
     if wvl is None:
@@ -331,9 +333,9 @@ def aim_chief_rays(opt_model, flds, wvl=None):
             probs.append(a)
             where.append(k)
     if probs:
-        aim_y, _result = eng.aim_chief_rays(probs)
-        for k, y in zip(where, aim_y):
-            out[k] = np.array([0., float(y)])
+        aim, _result = eng.aim_chief_rays(probs)
+        for k, xy in zip(where, aim):
+            out[k] = np.array([float(xy[0]), float(xy[1])])
     return out
 
 

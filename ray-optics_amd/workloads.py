@@ -20,6 +20,7 @@ class Workload:
         self.foc = d['foc']
         self.ref_wvl_idx = d['ref_wvl_idx']
         self.aim = d.get('aim')     # chief-ray aiming problems + the reference's answers
+        self.aim2d = d.get('aim2d')     # the same for fields off the y axis (fsolve branch)
         self.vig = d.get('vig')     # vignetting searches + the reference's answers
         self.fields = []
         self.image_pts = []

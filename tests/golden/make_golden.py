@@ -343,6 +343,24 @@ def workload_file(opm, name, desc):
                             z_enp=float(fod.obj_dist + fod.enp_dist),
                             z_dir0=float(sm.z_dir[0]), wvl_idx=table.wvl_index(wvl),
                             surf=int(sm.stop_surface), aim_y=float(aim_ref[1])))
+    # the 2-D branch of iterate_ray (fields off the y axis: scipy.optimize.fsolve = MINPACK
+    # hybrd, trace.py:394-410): the same fields moved off axis in x, solved by the reference
+    aim2d = []
+    if sm.stop_surface is not None and not osp['fov'].is_wide_angle:
+        rng2 = np.random.default_rng(2025)
+        for fld in osp['fov'].fields:
+            keep_xy = (fld.x, fld.y)
+            for _trial in range(3):
+                fld.x = float(rng2.uniform(-0.8, 0.8))
+                fld.y = float(rng2.uniform(-0.8, 0.8))
+                pt0, _d0 = osp.obj_coords(fld)
+                aim_ref = trace.aim_chief_ray(opm, fld, wvl)
+                aim2d.append(dict(pt0=[float(v) for v in pt0],
+                                  z_enp=float(fod.obj_dist + fod.enp_dist),
+                                  z_dir0=float(sm.z_dir[0]), wvl_idx=table.wvl_index(wvl),
+                                  surf=int(sm.stop_surface), epsfcn=float(0.0001 * fod.enp_radius),
+                                  aim=[float(aim_ref[0]), float(aim_ref[1])]))
+            fld.x, fld.y = keep_xy
     # the vignetting search the reference runs per field (vigcalc.calc_vignetting_for_field,
     # vigcalc.py:233-340) and its answers; the field's own factors are restored afterwards
     import rayoptics.raytr.vigcalc as vigcalc
@@ -356,7 +374,7 @@ def workload_file(opm, name, desc):
                         vig=[float(fld.vux), float(fld.vlx), float(fld.vuy), float(fld.vly)]))
         fld.vux, fld.vlx, fld.vuy, fld.vly = keep
     d = dict(description=desc, table=table.to_dict(), fields=flds, foc=float(foc),
-             ref_wvl_idx=int(osp['wvls'].reference_wvl), aim=aim, vig=vig)
+             ref_wvl_idx=int(osp['wvls'].reference_wvl), aim=aim, aim2d=aim2d, vig=vig)
     path = os.path.join(HERE, '..', '..', 'ray-optics_amd', 'data', name + '.json')
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, 'w') as f:

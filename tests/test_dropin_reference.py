@@ -664,10 +664,39 @@ def test_single_ray_trace_seam(ref, installed):
         assert n_err >= 1 or build is ref.rc_telescope
 
 
-def test_two_dimensional_aiming_runs_on_the_device_trace(ref, installed):
-    """a field off the y axis takes iterate_ray's fsolve branch (trace.py:393-410):
-    scipy's MINPACK drives the rebound single-ray trace and lands on the
-    reference's aim point bit for bit"""
+def test_two_dimensional_aiming_restated(ref, installed):
+    """fields off the y axis take iterate_ray's fsolve branch (trace.py:393-410).  The
+    drop-in solves them in the batched aiming launch with MINPACK's hybrd restated
+    (rox_aim.two_d); the aim points equal the reference's own fsolve results bit for bit
+    on every fixture model, for fields all over the field of view"""
+    import rayoptics.raytr.trace as trace
+    from rayoptics_amd import trace as rox_trace
+    rng = np.random.default_rng(11)
+    n_2d = 0
+    for build in (ref.dblgauss, ref.singlet, ref.rc_telescope, ref.nikkor, ref.cell_phone):
+        opm = build()
+        osp = opm['osp']
+        flds = osp['fov'].fields
+        for trial in range(4):
+            for f in flds:
+                f.x, f.y = float(rng.uniform(-1, 1)) * 0.7, float(rng.uniform(-1, 1)) * 0.7
+            flds[0].x = 0.0                         # one field stays on the 1-D branch
+            installed.uninstall()
+            theirs = [np.array(trace.aim_chief_ray(opm, f), dtype=float) for f in flds]
+            installed.install()
+            sm = opm['seq_model']
+            eng_probs = [rox_trace._aim_problem(opm, f, sm.central_wavelength(),
+                                                rox_trace.session.engine_for(opm).table,
+                                                sm.stop_surface) for f in flds]
+            n_2d += sum(p.two_d for p in eng_probs)
+            ours = rox_trace.aim_chief_rays(opm, flds)          # one launch, both branches
+            for a, b in zip(ours, theirs):
+                np.testing.assert_array_equal(a, b)
+    assert n_2d >= 30
+
+
+def test_two_dimensional_aiming_through_the_seam(ref, installed):
+    """a field off the y axis through trace.aim_chief_ray, and the chief ray it aims"""
     import rayoptics.raytr.trace as trace
     opm = ref.dblgauss()
     osp = opm['osp']

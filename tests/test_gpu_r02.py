@@ -300,10 +300,11 @@ def test_chief_ray_aiming():
         y_orc, r_orc = oracle.aim_chief_rays(wl.table, allp)
         np.testing.assert_array_equal(r_dev, r_orc)
         np.testing.assert_array_equal(y_dev, y_orc)
+        assert (y_dev[:, 0] == 0.0).all()
         for m, a in zip(meta, probs):
             y, r = eng.aim_chief_rays([a])
-            assert abs(y[0] - m['aim_y']) <= 1e-10, (name, y[0], m['aim_y'])
-            assert y[0] == m['aim_y']
+            assert abs(y[0, 1] - m['aim_y']) <= 1e-10, (name, y[0], m['aim_y'])
+            assert y[0, 1] == m['aim_y']
         eng.close()
 
 

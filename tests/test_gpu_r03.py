@@ -186,7 +186,7 @@ def test_tables_beyond_64_kib_of_lds():
         a.z_enp, a.y_target, a.z_dir0, a.wvl_idx, a.surf, a.flip = 1.0e10, 0.0, 1.0, 1, 1, 1
         y_dev, r_dev = eng.aim_chief_rays([a])
         y_orc, r_orc = oracle.aim_chief_rays(tbl, [a], 1e-12)
-        assert r_dev[0] == r_orc[0] and y_dev[0] == y_orc[0]
+        assert r_dev[0] == r_orc[0] and np.array_equal(y_dev, y_orc)
         eng.close()
 
 
@@ -253,3 +253,61 @@ def test_bench_launches_its_own_ranks():
             assert rec['end_to_end_ms'] >= rec['kernel_ms_max_over_ranks'] * 0.5
         assert s[prob]['rccl']['pairs'] == s[prob]['host']['pairs'] < s[prob]['rays']
     assert s['c5']['rccl']['grids_delivered'] == 45 and s['c4']['rccl']['grids_delivered'] == 5
+
+
+def aim2d_problem(m, wvl_idx=None):
+    a = abi.Aim()
+    for i in range(3):
+        a.pt0[i] = m['pt0'][i]
+    a.z_enp, a.x_target, a.y_target, a.z_dir0 = m['z_enp'], 0.0, 0.0, m['z_dir0']
+    a.wvl_idx, a.surf, a.flip = (m['wvl_idx'] if wvl_idx is None else wvl_idx), m['surf'], 1
+    a.two_d, a.epsfcn = 1, m['epsfcn']
+    return a
+
+
+def test_two_dimensional_chief_ray_aiming():
+    """iterate_ray's fsolve branch (fields off the y axis) in the batched aiming launch:
+    MINPACK's hybrd per lane == the CPU restatement (itself bit-identical to SciPy's fsolve)
+    bit for bit, == the aim points the reference itself found (stored with the workloads);
+    mixed with 1-D problems in one launch; perturbed problems incl. ones whose trial rays fail"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine
+    rng = np.random.default_rng(4)
+    n_err = n_conv = 0
+    for name in ('dblgauss_c2', 'nikkor_c3', 'cell_phone', 'singlet_c1', 'rc_telescope_c4', 'litho_c5'):
+        wl = workloads.load(name)
+        assert wl.aim2d, name
+        eng = TraceEngine(wl.table)
+        probs = [aim2d_problem(m) for m in wl.aim2d]
+        aim, res = eng.aim_chief_rays(probs)
+        for m, xy, r in zip(wl.aim2d, aim, res):
+            assert r != abi.AIM_TRACE_ERROR     # (ier is not consulted by iterate_ray)
+            assert np.array_equal(xy, m['aim']), (name, xy, m['aim'])
+        # every wavelength, the 1-D problems of the workload in between, perturbed copies
+        allp = []
+        for w in range(len(wl.table.wvls)):
+            for m in wl.aim2d:
+                allp.append(aim2d_problem(m, w))
+                p = aim2d_problem(m, w)
+                p.pt0[0] *= rng.uniform(0.2, 3.0)
+                p.pt0[1] *= rng.uniform(0.2, 3.0)
+                p.z_enp *= rng.uniform(0.7, 1.3)
+                p.epsfcn *= 10.0 ** rng.uniform(-3, 1)
+                p.x_target, p.y_target = rng.normal(size=2) * 0.05
+                allp.append(p)
+            for m in wl.aim or []:
+                a = abi.Aim()
+                for i in range(3):
+                    a.pt0[i] = m['pt0'][i]
+                a.z_enp, a.y_target, a.z_dir0 = m['z_enp'], 0.0, m['z_dir0']
+                a.wvl_idx, a.surf, a.flip = w, m['surf'], 1
+                allp.append(a)
+        a_dev, r_dev = eng.aim_chief_rays(allp)
+        a_orc, r_orc = oracle.aim_chief_rays(wl.table, allp)
+        np.testing.assert_array_equal(r_dev, r_orc)
+        assert np.array_equal(a_dev, a_orc, equal_nan=True), name
+        n_err += int((r_dev == abi.AIM_TRACE_ERROR).sum())
+        n_conv += int((r_dev == abi.AIM_CONVERGED).sum())
+        eng.close()
+    assert n_conv > 100

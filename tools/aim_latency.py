@@ -32,6 +32,15 @@ def main():
             a.z_enp, a.y_target, a.z_dir0 = m['z_enp'], 0.0, m['z_dir0']
             a.wvl_idx, a.surf, a.flip = m['wvl_idx'], m['surf'], 1
             probs.append(a)
+        n_1d = len(probs)
+        for m in wl.aim2d or []:            # fields off the y axis: the fsolve (hybrd) branch
+            a = abi.Aim()
+            for i in range(3):
+                a.pt0[i] = m['pt0'][i]
+            a.z_enp, a.y_target, a.z_dir0 = m['z_enp'], 0.0, m['z_dir0']
+            a.wvl_idx, a.surf, a.flip = m['wvl_idx'], m['surf'], 1
+            a.two_d, a.epsfcn = 1, m['epsfcn']
+            probs.append(a)
         for _ in range(5):
             eng.aim_chief_rays(probs)
         t = []
@@ -40,6 +49,7 @@ def main():
             eng.aim_chief_rays(probs)
             t.append(time.perf_counter() - t0)
         print(json.dumps({'workload': name, 'interfaces': wl.n_ifcs, 'fields_aimed': len(probs),
+                          'on_the_y_axis': n_1d, 'off_axis_2d': len(probs) - n_1d,
                           'ms_median': float(np.median(t) * 1e3), 'ms_min': float(np.min(t) * 1e3)}))
         eng.close()
 

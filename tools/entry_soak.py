@@ -77,11 +77,21 @@ def main():
                 a.y_target, a.z_dir0 = 0.0, m['z_dir0']
                 a.wvl_idx, a.surf, a.flip = int(rng.integers(0, len(wl.table.wvls))), m['surf'], 1
                 probs.append(a)
+            for m in wl.aim2d or []:            # the fsolve branch: fields off the y axis
+                a = abi.Aim()
+                a.pt0[0] = m['pt0'][0] * rng.uniform(0.3, 1.5)
+                a.pt0[1], a.pt0[2] = m['pt0'][1] * rng.uniform(0.3, 1.5), m['pt0'][2]
+                a.z_enp = m['z_enp'] * rng.uniform(0.95, 1.05)
+                a.x_target = a.y_target = 0.0
+                a.z_dir0 = m['z_dir0']
+                a.wvl_idx, a.surf, a.flip = int(rng.integers(0, len(wl.table.wvls))), m['surf'], 1
+                a.two_d, a.epsfcn = 1, m['epsfcn']
+                probs.append(a)
         if probs:
             yd, rd = eng.aim_chief_rays(probs)
             yo, ro = oracle.aim_chief_rays(wl.table, probs)
             n_aim += len(probs)
-            bad_aim += int((~((yd == yo) | (np.isnan(yd) & np.isnan(yo)))).sum() + (rd != ro).sum())
+            bad_aim += int((~((yd == yo) | (np.isnan(yd) & np.isnan(yo))).all(axis=1)).sum() + (rd != ro).sum())
         vp = []
         for trial in range(20):
             for v in wl.vig or []:
