@@ -20,6 +20,13 @@ model files), on BASELINE.json configs[1]:
            time_trace.py does
   fanned   ``raw`` over ``--procs`` processes (the reference has no parallelism
            of its own; rays are independent)
+  port     oracle/rox_oracle.c (the C restatement bench.py times on the GPU box
+           as ``cpu_baseline``), one thread, on the SAME num x num grid on THIS
+           host -> ``port_same_host`` with the port : reference ratio, which is
+           the bridge between the two hosts (bench.py divides the GPU host's
+           port rate by it)
+  config1  BASELINE.json configs[0]: singlet, 1 field, 1 wvl, 64 x 64 grid through
+           the reference's ``trace.trace_grid`` (plumbing case, CPU only)
 """
 import argparse
 import json
@@ -106,6 +113,81 @@ def raw_loop(args):
     return time.perf_counter() - t0, len(rays), inters
 
 
+def port_same_host(num, ref_inters_per_s, ref_rays_per_s, ref_inters):
+    """oracle/rox_oracle.c, single thread, FULL packets, on the same grid of the
+    same model (the stored dblgauss_c2 table is the table of rm.dblgauss())."""
+    import rayoptics_amd  # noqa: F401
+    from rayoptics_amd import abi, workloads
+    from rayoptics_amd.engine import make_opts
+    from oracle import oracle
+    oracle.build()
+    wl = workloads.load('dblgauss_c2')
+    N = wl.n_ifcs
+    fld = wl.fields[0]
+    opts = make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING,
+                     out_mode=abi.OUT_FULL, first_surf=1, last_surf=N - 2)
+    xs = np.empty(num)
+    v, step = -1.0, 2.0 / (num - 1)
+    for k in range(num):
+        xs[k] = v
+        v += step
+    px = np.repeat(xs, num)
+    py = np.tile(xs, num)
+    res = oracle.HostResult(N, num * num, opts.out_mode, want_pupil=True)
+    oracle.trace_pupil_list(wl.table, fld, px, py, wl.ref_wvl_idx, opts, res=res)   # warm
+    passes, dt = 0, 0.0
+    while dt < 5.0:
+        t0 = time.perf_counter()
+        oracle.trace_pupil_list(wl.table, fld, px, py, wl.ref_wvl_idx, opts, res=res)
+        dt += time.perf_counter() - t0
+        passes += 1
+    ok = res.status == abi.OK
+    inters = int(ok.sum()) * (N - 1) + int(res.fail_surf[~ok].astype(np.int64).sum())
+    rate = inters * passes / dt
+    return {'what': 'oracle/rox_oracle.c -O2, 1 thread, FULL packets, the same grid on the same host',
+            'passes': passes, 'seconds': dt, 'rays': num * num, 'rays_through': int(ok.sum()),
+            'intersections_per_pass': inters, 'reference_intersections': ref_inters,
+            'rays_per_s': num * num * passes / dt, 'intersections_per_s': rate,
+            'port_over_reference': rate / ref_inters_per_s,
+            'port_over_reference_by_rays': (num * num * passes / dt) / ref_rays_per_s,
+            'ratio_of': 'port intersections/s : reference raw rt.trace intersections/s, one core each'}
+
+
+def config1_singlet(num=64):
+    """BASELINE.json configs[0] on the reference itself"""
+    import refmodels as rm
+    import rayoptics.raytr.trace as trace
+    opm = rm.singlet()
+    sm, osp = opm['seq_model'], opm['optical_spec']
+    fld = osp['fov'].fields[0]
+    wvl = sm.central_wavelength()
+    foc = osp['focus'].focus_shift
+    rs, cr = trace.setup_pupil_coords(opm, fld, wvl, foc)
+    fld.chief_ray, fld.ref_sphere = cr, rs
+    image_pt = rs[0]
+
+    def spot(p, ray_pkg):                      # axisarrayfigure.py:229-238
+        if ray_pkg is not None:
+            seg = ray_pkg[0][-1]
+            dist = foc / seg[1][2]
+            t_abr = (seg[0] + dist * seg[1]) - image_pt
+            return np.array([t_abr[0], t_abr[1]])
+        return None
+
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        grid = trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), num], fld, wvl, foc,
+                                img_filter=spot, form='list', append_if_none=False)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    K = len(sm.ifcs) - 1
+    return {'workload': f'BASELINE.json configs[0]: singlet, {len(sm.ifcs)} interfaces, 1 field, 1 wvl, '
+                        f'{num}x{num} grid, reference trace.trace_grid',
+            'seconds_best_of_3': best, 'rays': num * num, 'rays_through': len(grid),
+            'rays_per_s': num * num / best, 'intersections_per_s_nominal': num * num * K / best}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--num', type=int, default=256, help='pupil grid is num x num (>= 65536 rays)')
@@ -169,6 +251,8 @@ def main():
                                 'rays_per_s': R / t_fan_loop,
                                 'intersections_per_s': sum(p[2] for p in parts) / t_fan_loop},
     }
+    rec['port_same_host'] = port_same_host(num, inters / t_raw, n_raw / t_raw, inters)
+    rec['config1_singlet_64'] = config1_singlet(64)
     with open(args.out, 'w') as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec, indent=1))
