@@ -190,8 +190,10 @@ def test_chunked_launches():
 def test_phase_elements(kind):
     """raytrace.py:205-210 on the device.  Holograms / thin lenses are bit-exact;
     gratings and DOEs evaluate `x**2`, `r_sqr**k` where the reference calls libm
-    pow() (not correctly rounded for ~1e-3 of its arguments): there the bound is
-    the north star's 1e-10 and >= 99 % of the values are still bit-identical."""
+    pow() (not correctly rounded for ~1e-3 of its arguments): there the assertion
+    is what the 800-system soak observed (profiles/r02_phase_soak.json) -- every
+    ray's status and failing surface identical, values within 1e-12 (observed
+    <= 8.4e-14; the north star allows 1e-10), >= 99.9 % of them bit-identical."""
     from oracle import oracle
     from rayoptics_amd.engine import TraceEngine
     n_ok = n_evan = 0
@@ -216,12 +218,11 @@ def test_phase_elements(kind):
                 bit_equal(dev.seg, orc.seg, f'{kind} seg')
                 bit_equal(dev.op, orc.op, f'{kind} op')
             else:
-                agree = dev.status == orc.status
-                assert agree.mean() > 0.999      # a 1-ulp radicand may flip a borderline ray
-                m = agree
-                f1 = H.assert_soa_close(orc.seg[..., m], dev.seg[..., m], f'{kind} seg')
-                f2 = H.assert_soa_close(orc.op[m], dev.op[m], f'{kind} op')
-                assert min(f1, f2) > 0.99, (kind, f1, f2)
+                np.testing.assert_array_equal(dev.status, orc.status)
+                np.testing.assert_array_equal(dev.fail_surf, orc.fail_surf)
+                f1 = H.assert_soa_close(orc.seg, dev.seg, f'{kind} seg', atol=1e-12)
+                f2 = H.assert_soa_close(orc.op, dev.op, f'{kind} op', atol=1e-12)
+                assert min(f1, f2) > 0.999, (kind, f1, f2)
         n_ok += int((orc.status == abi.OK).sum())
         n_evan += int((orc.status == abi.EVANESCENT).sum())
         eng.close()
