@@ -463,7 +463,8 @@ def roofline_hits(inters, R, kern_ms, workload='dblgauss_c2'):
 
 def configs_leg(torch, abi, workloads):
     """Every BASELINE.json configuration at its own shape on this GPU: one pass = every
-    (field, wavelength) grid of the configuration launched back to back; steady-state ms
+    (field, wavelength) grid of the configuration, in ONE launch (rox_trace_pupil_grids; the
+    figure for one launch per grid, back to back, is kept beside it); steady-state ms
     per pass from events on the launch stream (median of 5 timed batches after >= 100 ms of
     untimed passes).  FULL packets where they fit HBM (config 5's 666 GB do not)."""
     from rayoptics_amd.engine import TraceEngine, make_opts, make_grid, DeviceResult
@@ -499,43 +500,60 @@ def configs_leg(torch, abi, workloads):
         for mode, label in ((abi.OUT_HITS, 'hits'), (abi.OUT_FULL, 'full')):
             if mode == abi.OUT_FULL and not do_full:
                 continue
-            res = DeviceResult(torch, eng.device, eng.num_segments(0), R, mode,
-                               want_pupil=(mode == abi.OUT_FULL), nan_fill=False)
+            # every grid of the configuration has its own output buffers (a pass leaves the
+            # whole configuration's result in HBM)
+            ress = [DeviceResult(torch, eng.device, eng.num_segments(0), R, mode,
+                                 want_pupil=(mode == abi.OUT_FULL), nan_fill=False) for _ in pairs]
+            optl = [make_opts(flags=(SPOT_FLAGS & ~abi.INTERSECT_OBJ) | wide[f], out_mode=mode,
+                              first_surf=1, last_surf=N - 2, foc=wl.foc, image_pt=wl.image_pts[f])
+                    for f, _w in pairs]
+            fldl = [wl.fields[f] for f, _w in pairs]
+            wvll = [w for _f, w in pairs]
 
-            def one_pass(count=False):
+            def looped_pass(count=False):       # one launch per (field, wavelength)
                 inters = nbytes = 0
-                for f, w in pairs:
-                    o = make_opts(flags=(SPOT_FLAGS & ~abi.INTERSECT_OBJ) | wide[f], out_mode=mode,
-                                  first_surf=1, last_surf=N - 2, foc=wl.foc, image_pt=wl.image_pts[f])
-                    eng.trace_pupil_grid(wl.fields[f], grid, w, o, out=res)
+                for fl, w, o, res in zip(fldl, wvll, optl, ress):
+                    eng.trace_pupil_grid(fl, grid, w, o, out=res)
                     if count:
                         i, b = work_of(res.status, res.fail_surf, N, abi, full=(mode == abi.OUT_FULL))
                         inters += i
                         nbytes += b
                 return inters, nbytes
-            inters, nbytes = one_pass(count=True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n_warm = 0
-            while (time.perf_counter() - t0) < 0.1 or n_warm < 2:
-                one_pass()
-                n_warm += 1
-                if n_warm % 16 == 0:
-                    torch.cuda.synchronize()
-            torch.cuda.synchronize()
-            per = max(1, min(50, int(0.02 / max((time.perf_counter() - t0) / n_warm, 1e-6))))
-            ts = []
-            for _ in range(5):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(per):
-                    one_pass()
-                e1.record()
+
+            def batched_pass():                 # rox_trace_pupil_grids: the configuration in one launch
+                eng.trace_pupil_grids(fldl, wvll, grid, optl, outs=ress)
+
+            def steady_ms(one_pass):
                 torch.cuda.synchronize()
-                ts.append(e0.elapsed_time(e1) / per)
-            ms = sorted(ts)[len(ts) // 2]
-            r = {'kernel_ms_per_pass': ms, 'rays_per_s': R * len(pairs) / (ms * 1e-3),
-                 'intersections': inters, 'intersections_per_s': inters / (ms * 1e-3)}
+                t0 = time.perf_counter()
+                n_warm = 0
+                while (time.perf_counter() - t0) < 0.1 or n_warm < 2:
+                    one_pass()
+                    n_warm += 1
+                    if n_warm % 16 == 0:
+                        torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                per = max(1, min(50, int(0.02 / max((time.perf_counter() - t0) / n_warm, 1e-6))))
+                ts = []
+                for _ in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(per):
+                        one_pass()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) / per)
+                return sorted(ts)[len(ts) // 2]
+            inters, nbytes = looped_pass(count=True)
+            ms_loop = steady_ms(looped_pass)
+            ms = ms_loop
+            r = {}
+            if len(pairs) > 1:
+                ms = steady_ms(batched_pass)
+                r['launches_per_pass'] = 1
+                r['kernel_ms_per_pass_one_launch_per_grid'] = ms_loop
+            r.update({'kernel_ms_per_pass': ms, 'rays_per_s': R * len(pairs) / (ms * 1e-3),
+                      'intersections': inters, 'intersections_per_s': inters / (ms * 1e-3)})
             if mode == abi.OUT_FULL:
                 gbps = nbytes / (ms * 1e-3) / 1e9
                 r.update({'bound': 'hbm', 'algorithmic_bytes': nbytes, 'GBps': gbps,
@@ -548,7 +566,7 @@ def configs_leg(torch, abi, workloads):
                                             (256 * 4 * 2.4e9 * ms * 1e-3))
                     r['valu_source'] = pmc.get('source')
             rec[label] = r
-            del res
+            del ress
         out[key] = rec
         eng.close()
         torch.cuda.empty_cache()

@@ -11,6 +11,8 @@
  *                             rayoptics/raytr/trace.py:537-560    trace_fan()
  *                             rayoptics/raytr/analyses.py:666-696 trace_ray_grid()
  *                             rayoptics/raytr/analyses.py:212-230 trace_ray_fan()
+ *   rox_trace_pupil_grids  <- rayoptics/seq/sequential.py:1058-1114 SequentialModel.trace_grid /
+ *                             trace_wavefront (the loop over wavelengths), one launch
  *   rox_trace_pupil_list   <- rayoptics/raytr/analyses.py:437-455 trace_ray_list()
  *                             (each of the above through trace.py:160-221
  *                             trace_safe -> trace.py:253-310 trace_base ->
@@ -47,7 +49,7 @@
 extern "C" {
 #endif
 
-#define ROX_ABI_VERSION 4
+#define ROX_ABI_VERSION 5
 #define ROX_MAX_COEF 10   /* EvenPolynomial r^2..r^20 / RadialPolynomial r^1..r^10 */
 #define ROX_MAX_AP 4      /* clear apertures per surface carried in the table */
 #define ROX_SEG_DOUBLES 10 /* p[3], d[3], dst, nrml[3]  (model_constants.py:31) */
@@ -386,6 +388,19 @@ int rox_trace_pupil_grid(rox_system *sys, const rox_field *fld,
                          const rox_grid *grid, int32_t wvl_idx,
                          const rox_opts *opts, const rox_out *out,
                          void *stream);
+
+/* the same grid for n_grids (field, wavelength) pairs in ONE launch: item i traces
+ * flds[i] at wvl_idx[i] with opts[i] into outs[i] -- the per-wavelength loop of
+ * SequentialModel.trace_grid / trace_wavefront (rayoptics/seq/sequential.py:1058-1114)
+ * and the per-field loops of the figures that call them
+ * (rayoptics/mpl/axisarrayfigure.py:213-262).  Every item behaves exactly as the
+ * rox_trace_pupil_grid call with the same arguments.  out_mode and
+ * ROX_FILTER_PHANTOMS must be the same for all items; device pointers only
+ * (no ROX_HOST_POINTERS), no ROX_HITS_APPEND; with ROX_OUT_HITS_COMPACT every item
+ * has its own outs[i].seg and outs[i].n_hits. */
+int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *flds,
+                          const int32_t *wvl_idx, const rox_grid *grid,
+                          const rox_opts *opts, const rox_out *outs, void *stream);
 
 /* rays generated on the device from explicit pupil coordinates px,py[n_rays] */
 int rox_trace_pupil_list(rox_system *sys, const rox_field *fld,

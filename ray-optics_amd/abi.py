@@ -5,7 +5,7 @@ by :mod:`rayoptics_amd.engine`, which fails loudly when it is missing.
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_COEF = 10
 MAX_AP = 4
 SEG_DOUBLES = 10
@@ -150,7 +150,7 @@ assert C.sizeof(Aim) == 80
 EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_last_error', 'rox_system_create', 'rox_system_destroy',
            'rox_system_num_segments', 'rox_trace_rays',
-           'rox_trace_pupil_grid', 'rox_trace_pupil_list',
+           'rox_trace_pupil_grid', 'rox_trace_pupil_grids', 'rox_trace_pupil_list',
            'rox_aim_chief_rays', 'rox_calc_vignetting', 'rox_calc_psf',
            'rox_pin_host_memory', 'rox_unpin_host_memory')
 # ... and the measurement / self-test helpers of include/roxtrace_diag.h
@@ -180,6 +180,9 @@ def declare(lib):
     lib.rox_trace_pupil_grid.restype = C.c_int
     lib.rox_trace_pupil_grid.argtypes = [vp, P(Field), P(Grid), i32, P(Opts),
                                          P(Out), vp]
+    lib.rox_trace_pupil_grids.restype = C.c_int
+    lib.rox_trace_pupil_grids.argtypes = [vp, i32, P(Field), P(i32), P(Grid), P(Opts),
+                                          P(Out), vp]
     lib.rox_trace_pupil_list.restype = C.c_int
     lib.rox_trace_pupil_list.argtypes = [vp, P(Field), i64, vp, vp, i32,
                                          P(Opts), P(Out), vp]

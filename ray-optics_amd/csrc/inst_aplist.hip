@@ -4,4 +4,5 @@
 
 namespace rox {
 void launch_aplist(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_APLIST>(k, a); }
+void launch_aplist_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<F_APLIST>(k, items); }
 }  // namespace rox

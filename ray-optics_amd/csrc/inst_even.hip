@@ -4,4 +4,5 @@
 
 namespace rox {
 void launch_even(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_EVEN>(k, a); }
+void launch_even_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<F_EVEN>(k, items); }
 }  // namespace rox

@@ -4,4 +4,5 @@
 
 namespace rox {
 void launch_general(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_ALL>(k, a); }
+void launch_general_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<F_ALL>(k, items); }
 }  // namespace rox

@@ -4,4 +4,5 @@
 
 namespace rox {
 void launch_lean(const LaunchCfg &k, const TraceArgs &a) { launch_instance<0>(k, a); }
+void launch_lean_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<0>(k, items); }
 }  // namespace rox

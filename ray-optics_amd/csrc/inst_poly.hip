@@ -4,4 +4,5 @@
 
 namespace rox {
 void launch_poly(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_POLY>(k, a); }
+void launch_poly_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<F_POLY>(k, items); }
 }  // namespace rox

@@ -4,4 +4,5 @@
 
 namespace rox {
 void launch_radial(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_RADIAL>(k, a); }
+void launch_radial_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<F_RADIAL>(k, items); }
 }  // namespace rox

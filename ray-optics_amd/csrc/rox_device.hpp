@@ -771,8 +771,8 @@ __device__ __forceinline__ int apply_phase(tblp ph, tblp pc, const v3 &pt, const
 
 // ------------------------------------------------------------------ OPD
 // waveabr.py:117-132 eic_distance
-__device__ __forceinline__ double eic_distance(const v3 &p, const v3 &d, const double *p0,
-                                               const double *d0)
+template <class P3>
+__device__ __forceinline__ double eic_distance(const v3 &p, const v3 &d, P3 p0, P3 d0)
 {
     const v3 sd{d.x + d0[0], d.y + d0[1], d.z + d0[2]};
     const v3 dp{p.x - p0[0], p.y - p0[1], p.z - p0[2]};
@@ -780,7 +780,8 @@ __device__ __forceinline__ double eic_distance(const v3 &p, const v3 &d, const d
 }
 
 // waveabr.py:256-307 wave_abr_full_calc_finite_pup (+ transform.py:234-258)
-__device__ __forceinline__ double wave_abr_finite_pup(const rox_wavefront &w, const v3 &ray1_p,
+template <class WF>      // rox_wavefront, in whatever address space the launch arguments live
+__device__ __forceinline__ double wave_abr_finite_pup(WF &w, const v3 &ray1_p,
                                                       const v3 &ray0_d, const v3 &rayk_p,
                                                       const v3 &rayk_d, double ray_op)
 {
@@ -811,7 +812,8 @@ __device__ __forceinline__ double wave_abr_finite_pup(const rox_wavefront &w, co
 // waveabr.py:356-424 wave_abr_full_calc_inf_ref (ROX_WF_INF_FULL) and its pre-calc /
 // calc split :427-488 (ROX_WF_INF_SPLIT); dist_to_shortest_join :178-196,
 // ray_dist_to_perp_from_origin :166-175.  Chief-ray-only terms come from the host.
-__device__ __forceinline__ double wave_abr_inf_ref(const rox_wavefront &w, const v3 &ray1_p,
+template <class WF>
+__device__ __forceinline__ double wave_abr_inf_ref(WF &w, const v3 &ray1_p,
                                                    const v3 &ray0_d, const v3 &rayk_p,
                                                    const v3 &rayk_d, const v3 &rayl_p,
                                                    const v3 &rayl_d, double ray_op)
@@ -1161,7 +1163,8 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
 // ------------------------------------------------------------------ ray start
 // opticalspec.py:1339-1353 apply_vignetting + :289-400 ray_start_from_osp +
 // trace.py:302-308.  pupil (px, py) is updated in place (the reference's quirk).
-__device__ __forceinline__ void ray_start(const rox_field &f, uint32_t flags, double &px,
+template <class FLD>     // rox_field (kernel argument, batch item in constant memory, aim problem)
+__device__ __forceinline__ void ray_start(FLD &f, uint32_t flags, double &px,
                                           double &py, v3 &pt0, v3 &dir0)
 {
     if (flags & ROX_APPLY_VIGNETTING) {         // opticalspec.py:1339-1353
@@ -1221,8 +1224,8 @@ __device__ __forceinline__ uint64_t ts_pack(uint32_t epoch, uint64_t flag, uint3
 // the number of survivors of all earlier tiles by decoupled look-back over the predecessors'
 // published counts, then every thread copies pairs (consecutive threads, consecutive pairs).
 // Called by all threads of the workgroup.
-template <int kB>
-__device__ __forceinline__ void finish_tile(const TraceArgs &a, int64_t tile, int total,
+template <int kB, class ARGS>
+__device__ __forceinline__ void finish_tile(ARGS &a, int64_t tile, int total,
                                             const d2 *stash, int64_t n_tiles, uint32_t *s_excl)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1305,9 +1308,9 @@ __host__ __device__ inline int64_t compact_tiles(int64_t n_rays, int32_t want_sm
 }
 
 // ------------------------------------------------------------------ the kernel
-template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT>
-__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT), min_waves_of(OUT_MODE, FEAT))
-trace_kernel(const TraceArgs a)
+// the work of one workgroup on one launch item: its share of the item's ray tiles
+template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT, class ARGS>
+__device__ __forceinline__ void trace_tiles(ARGS &a)
 {
     constexpr bool kCompact = (OUT_MODE == ROX_OUT_HITS_COMPACT);
     constexpr int kB = block_of(OUT_MODE, FEAT);    // threads per workgroup = rays per tile
@@ -1530,6 +1533,26 @@ trace_kernel(const TraceArgs a)
     }
 }
 
+template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT>
+__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT), min_waves_of(OUT_MODE, FEAT))
+trace_kernel(const TraceArgs a)
+{
+    trace_tiles<OUT_MODE, GEN, PER_RAY_WVL, FEAT>(a);
+}
+
+// One launch for several pupil grids of one system -- the (field x wavelength) loops of
+// SequentialModel.trace_grid / trace_wavefront (rayoptics/seq/sequential.py:1058-1114) and of
+// the figures that call them per field: blockIdx.y picks the item, blockIdx.x strides over
+// that item's tiles.  The items sit in device memory and are read through the constant
+// address space, i.e. with the same scalar loads that read a kernel argument.
+typedef const __attribute__((address_space(4))) TraceArgs *ConstTraceArgs;
+template <int OUT_MODE, int FEAT>
+__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT), min_waves_of(OUT_MODE, FEAT))
+trace_kernel_batch(const TraceArgs *items)
+{
+    trace_tiles<OUT_MODE, GEN_PUPIL, false, FEAT>(*(ConstTraceArgs)(items + blockIdx.y));
+}
+
 // ------------------------------------------------------------------ launching
 struct LaunchCfg {
     int gen;            // GEN_*
@@ -1591,6 +1614,43 @@ inline void launch_instance(const LaunchCfg &k, const TraceArgs &a)
         launch_mode<GEN_RAYS, false, FEAT>(k, a);
 }
 
+// the batched form (trace_kernel_batch): pupil grids, one wavelength per item
+template <class K>
+inline void launch_batch_with_lds(K kernel, const dim3 &grid, const dim3 &block, size_t lds,
+                                  hipStream_t st, const TraceArgs *items)
+{
+    if (lds > kDefaultDynLds)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, items);
+}
+
+template <int FEAT>
+inline void launch_instance_batch(const LaunchCfg &k, const TraceArgs *items)
+{
+    const dim3 block(block_of(k.out_mode, FEAT));
+    switch (k.out_mode) {
+    case ROX_OUT_FULL:
+        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_FULL, FEAT>, k.grid, block, k.lds, k.stream, items);
+        break;
+    case ROX_OUT_LAST:
+        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_LAST, FEAT>, k.grid, block, k.lds, k.stream, items);
+        break;
+    case ROX_OUT_OPD:
+        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_OPD, FEAT>, k.grid, block, k.lds, k.stream, items);
+        break;
+    case ROX_OUT_HITS_COMPACT:
+        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_HITS_COMPACT, FEAT>, k.grid, block, k.lds, k.stream, items);
+        break;
+    case ROX_OUT_FAN:
+        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_FAN, FEAT>, k.grid, block, k.lds, k.stream, items);
+        break;
+    default:
+        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_HITS, FEAT>, k.grid, block, k.lds, k.stream, items);
+        break;
+    }
+}
+
 // the feature instances that are compiled (one translation unit each,
 // csrc/inst_*.hip); the host launches the first one that covers the need
 constexpr int kInstances[] = {0, F_EVEN, F_RADIAL, F_POLY, F_APLIST, F_ALL};
@@ -1600,6 +1660,12 @@ void launch_radial(const LaunchCfg &, const TraceArgs &);
 void launch_poly(const LaunchCfg &, const TraceArgs &);
 void launch_aplist(const LaunchCfg &, const TraceArgs &);
 void launch_general(const LaunchCfg &, const TraceArgs &);
+void launch_lean_batch(const LaunchCfg &, const TraceArgs *);
+void launch_even_batch(const LaunchCfg &, const TraceArgs *);
+void launch_radial_batch(const LaunchCfg &, const TraceArgs *);
+void launch_poly_batch(const LaunchCfg &, const TraceArgs *);
+void launch_aplist_batch(const LaunchCfg &, const TraceArgs *);
+void launch_general_batch(const LaunchCfg &, const TraceArgs *);
 
 // chief-ray aiming (csrc/inst_aim.hip)
 struct AimArgs {

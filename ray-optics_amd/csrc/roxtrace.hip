@@ -197,6 +197,20 @@ struct StreamCtx {
     // block for small ones (grow-only)
     char *d_stage = nullptr, *h_stage = nullptr;
     size_t d_stage_cap = 0, h_stage_cap = 0;
+    // rox_trace_pupil_grids: the launch items of a batch.  Written into one of kItemSlots
+    // pinned slots (a slot is reused only after the copy that read it has completed),
+    // copied to d_items in stream order, read by the kernel through scalar loads.
+    static constexpr int kItemSlots = 4;
+    rox::TraceArgs *d_items = nullptr, *h_items = nullptr;
+    int32_t items_cap = 0;
+    hipEvent_t item_ev[kItemSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool item_ev_live[kItemSlots] = {false, false, false, false};
+    uint32_t item_slot = 0;
+    uint32_t *d_btickets = nullptr;     // HITS_COMPACT in a batch: [items][2] tickets
+    uint64_t *d_btiles = nullptr;       // ... and [items][tiles] look-back states
+    int64_t btickets_cap = 0, btiles_cap = 0;
+    uint32_t bepoch = 0;
+    std::mutex batch_mu;                // one batch enqueue at a time per stream
     std::mutex stage_mu;                // one ROX_HOST_POINTERS call at a time per stream
     std::mutex compact_mu;              // epoch / ticket state: one HITS_COMPACT enqueue at a time
 };
@@ -359,6 +373,14 @@ void launch_feat(int inst, const LaunchCfg &k, const TraceArgs &a)
     fns[inst](k, a);
 }
 
+void launch_feat_batch(int inst, const LaunchCfg &k, const TraceArgs *items)
+{
+    typedef void (*fn)(const LaunchCfg &, const TraceArgs *);
+    static const fn fns[] = {launch_lean_batch, launch_even_batch, launch_radial_batch,
+                             launch_poly_batch, launch_aplist_batch, launch_general_batch};
+    fns[inst](k, items);
+}
+
 // (initialisations are enqueued on the launch stream itself: a stream created with
 // hipStreamNonBlocking is not ordered after NULL-stream memsets)
 int ensure_compact(StreamCtx *cx, int64_t tiles, hipStream_t st)
@@ -382,6 +404,35 @@ int ensure_compact(StreamCtx *cx, int64_t tiles, hipStream_t st)
     return 0;
 }
 
+// the table pointers of a launch, the leanest kernel instance that covers this system and
+// these options, and its LDS need
+int launch_setup(rox_system *sys, TraceArgs &a, int gen, bool prw, hipStream_t st, LaunchCfg &k,
+                 int &inst)
+{
+    a.rows = sys->d_rows;
+    a.n_table = sys->d_ntab;
+    a.ph_consts = sys->d_phc;
+    a.wvls = sys->d_wvls;
+    a.slots = sys->d_slots[(a.opts.flags & ROX_FILTER_PHANTOMS) ? 1 : 0];
+    a.n_ifcs = sys->n_ifcs;
+    a.n_wvls = sys->n_wvls;
+    int need = sys->features;
+    if ((a.opts.flags & ROX_FILTER_PHANTOMS) && sys->n_seg[1] != sys->n_seg[0])
+        need |= F_PHFILT;
+    k.gen = gen;
+    k.per_ray_wvl = prw;
+    k.out_mode = a.opts.out_mode;
+    k.stream = st;
+    inst = pick_instance(need);
+    // (an instance compiled with F_PHASE stages the phase constants, needed or not)
+    k.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0);
+    if (a.opts.out_mode == ROX_OUT_HITS_COMPACT)    // two tiles of packed pairs (rox_device.hpp)
+        k.lds += 16 + 2 * 16 * (size_t)block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]);
+    if (k.lds > 160 * 1024 - 64)
+        return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS (max 163776)", k.lds);
+    return 0;
+}
+
 int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
 {
     if (a.opts.out_mode == ROX_OUT_HITS_COMPACT && a.n_rays == 0) {
@@ -393,30 +444,11 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
     if (a.n_rays == 0)
         return 0;
     const bool prw = a.wvl_idx != nullptr;
-    a.rows = sys->d_rows;
-    a.n_table = sys->d_ntab;
-    a.ph_consts = sys->d_phc;
-    a.wvls = sys->d_wvls;
-    a.slots = sys->d_slots[(a.opts.flags & ROX_FILTER_PHANTOMS) ? 1 : 0];
-    a.n_ifcs = sys->n_ifcs;
-    a.n_wvls = sys->n_wvls;
-    // the leanest kernel instance that covers this system and these options
-    int need = sys->features;
-    if ((a.opts.flags & ROX_FILTER_PHANTOMS) && sys->n_seg[1] != sys->n_seg[0])
-        need |= F_PHFILT;
     LaunchCfg k;
-    k.gen = gen;
-    k.per_ray_wvl = prw;
-    k.out_mode = a.opts.out_mode;
-    k.stream = st;
-    const int inst = pick_instance(need);
-    // (an instance compiled with F_PHASE stages the phase constants, needed or not)
-    k.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0);
-    if (a.opts.out_mode == ROX_OUT_HITS_COMPACT)    // two tiles of packed pairs (rox_device.hpp)
-        k.lds += 16 + 2 * 16 * (size_t)block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]);
-
-    if (k.lds > 160 * 1024 - 64)
-        return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS (max 163776)", k.lds);
+    int inst;
+    int rc0 = launch_setup(sys, a, gen, prw, st, k, inst);
+    if (rc0)
+        return rc0;
     // lane byte offsets are 32-bit: at most 2^28 rays per launch
     const int64_t total = a.n_rays, chunk_max = rays_per_launch();
     const bool compact = a.opts.out_mode == ROX_OUT_HITS_COMPACT;
@@ -906,6 +938,13 @@ int rox_system_destroy(rox_system *sys)
         (void)hipFree(c->d_hits_base);
         (void)hipFree(c->d_stage);
         (void)hipHostFree(c->h_stage);
+        (void)hipFree(c->d_items);
+        (void)hipHostFree(c->h_items);
+        (void)hipFree(c->d_btickets);
+        (void)hipFree(c->d_btiles);
+        for (hipEvent_t ev : c->item_ev)
+            if (ev)
+                (void)hipEventDestroy(ev);
         delete c;
     }
     delete sys;
@@ -985,6 +1024,135 @@ int rox_trace_pupil_grid(rox_system *sys, const rox_field *fld, const rox_grid *
     a.out = s.dev;
     rc = launch(sys, a, GEN_PUPIL, st);
     return rc ? rc : unstage_out(s, st);
+}
+
+// Several pupil grids of one system in ONE launch: item i traces `grid` for field flds[i]
+// at wavelength wvl_idx[i] with opts[i] into outs[i].  blockIdx.y = item, so a spot diagram's
+// 3 fields x 3 wavelengths x 64^2 rays fills the chip as one launch instead of idling on
+// nine small ones, and nine 512^2 grids lose eight launch tails.
+int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *flds,
+                          const int32_t *wvl_idx, const rox_grid *grid, const rox_opts *opts,
+                          const rox_out *outs, void *stream)
+{
+    if (!sys)
+        return fail(ROX_E_ARG, "null system");
+    if (n_grids < 0 || (n_grids > 0 && (!flds || !wvl_idx || !opts || !outs)))
+        return fail(ROX_E_ARG, "null argument");
+    if (n_grids == 0)
+        return 0;
+    hipStream_t st = (hipStream_t)stream;
+    for (int32_t i = 0; i < n_grids; ++i) {
+        if (opts[i].flags & (ROX_HOST_POINTERS | ROX_HITS_APPEND))
+            return fail(ROX_E_UNSUPPORTED, "rox_trace_pupil_grids: device pointers only, no ROX_HITS_APPEND "
+                                           "(item %d)", i);
+        if (opts[i].out_mode != opts[0].out_mode ||
+            ((opts[i].flags ^ opts[0].flags) & ROX_FILTER_PHANTOMS))
+            return fail(ROX_E_ARG, "rox_trace_pupil_grids: out_mode and ROX_FILTER_PHANTOMS must be the "
+                                   "same for every item (item %d)", i);
+    }
+    // the items, validated one by one exactly as single launches are
+    std::vector<TraceArgs> items((size_t)n_grids);
+    int rc;
+    for (int32_t i = 0; i < n_grids; ++i)
+        if ((rc = prepare_grid(sys, &flds[i], grid, wvl_idx[i], &opts[i], &outs[i], st, items[i])))
+            return rc;
+    const int64_t R = items[0].n_rays;
+    const bool compact = opts[0].out_mode == ROX_OUT_HITS_COMPACT;
+    if (n_grids == 1 || n_grids > 65535 || R > rays_per_launch() || R == 0) {
+        // nothing to batch (or more than one launch each): the plain path, item by item
+        for (int32_t i = 0; i < n_grids; ++i)
+            if ((rc = launch(sys, items[i], GEN_PUPIL, st)))
+                return rc;
+        return 0;
+    }
+    LaunchCfg k;
+    int inst = 0;
+    for (int32_t i = 0; i < n_grids; ++i) {
+        if ((rc = launch_setup(sys, items[i], GEN_PUPIL, false, st, k, inst)))
+            return rc;
+        items[i].in_ld = R;
+        items[i].ray_base = 0;
+    }
+    StreamCtx *cx = ctx_for(sys, st);
+    if (!cx)
+        return fail(ROX_E_NOMEM, "out of host memory");
+    std::lock_guard<std::mutex> lock(cx->batch_mu);
+    const int bs = block_of(opts[0].out_mode, kInstances[inst]);
+    int64_t blocks = (R + bs - 1) / bs;
+    if (compact) {
+        // per-item tickets and look-back states; small tiles when the whole batch is small
+        const int32_t small = ((int64_t)n_grids * R <= (int64_t)sys->num_cus * kSmallTile)
+                                  ? compact_small_want(sys, R) : 0;
+        const int64_t tiles = compact_tiles(R, small, bs);
+        blocks = tiles;
+        if ((int64_t)n_grids > cx->btickets_cap) {
+            if (cx->d_btickets)
+                HIP_TRY(hipFree(cx->d_btickets));
+            cx->d_btickets = nullptr;
+            cx->btickets_cap = 0;
+            HIP_TRY(hipMalloc(&cx->d_btickets, sizeof(uint32_t) * 2 * (size_t)n_grids));
+            HIP_TRY(hipMemsetAsync(cx->d_btickets, 0, sizeof(uint32_t) * 2 * (size_t)n_grids, st));
+            cx->btickets_cap = n_grids;
+        }
+        if ((int64_t)n_grids * tiles > cx->btiles_cap) {
+            if (cx->d_btiles)
+                HIP_TRY(hipFree(cx->d_btiles));
+            cx->d_btiles = nullptr;
+            cx->btiles_cap = 0;
+            HIP_TRY(hipMalloc(&cx->d_btiles, sizeof(uint64_t) * (size_t)(n_grids * tiles)));
+            HIP_TRY(hipMemsetAsync(cx->d_btiles, 0, sizeof(uint64_t) * (size_t)(n_grids * tiles), st));
+            cx->btiles_cap = n_grids * tiles;
+            cx->bepoch = 0;
+        }
+        ++cx->bepoch;
+        for (int32_t i = 0; i < n_grids; ++i) {
+            items[i].small_tiles = small;
+            items[i].tile_state = cx->d_btiles + (size_t)i * tiles;
+            items[i].ticket = cx->d_btickets + 2 * (size_t)i;
+            items[i].hits_base_in = nullptr;
+            items[i].hits_total_out = outs[i].n_hits;
+            items[i].epoch = cx->bepoch;
+        }
+    }
+    // Per item as many workgroups as a launch of its own would get: items differ in work
+    // (vignetting, Newton counts), and it is the hardware dispatcher handing out many more
+    // workgroups than fit that evens them out.  (Splitting one launch's worth between the
+    // items -- all resident at once, each striding over its item -- measured 6 % slower on
+    // config 5's 45 grids of 2048 x 2048.)  HITS_COMPACT draws tiles by ticket: any number
+    // of workgroups per item will do.
+    const int64_t cap = (int64_t)sys->num_cus * blocks_per_cu(bs);
+    if (blocks > cap)
+        blocks = cap;
+    // items -> pinned slot -> device, in stream order
+    if (n_grids > cx->items_cap) {
+        if (cx->d_items)
+            HIP_TRY(hipFree(cx->d_items));      // synchronises with the launches reading it
+        if (cx->h_items)
+            HIP_TRY(hipHostFree(cx->h_items));
+        cx->d_items = cx->h_items = nullptr;
+        cx->items_cap = 0;
+        const int32_t want = n_grids < 64 ? 64 : n_grids;
+        HIP_TRY(hipMalloc(&cx->d_items, sizeof(TraceArgs) * (size_t)want));
+        HIP_TRY(hipHostMalloc(&cx->h_items, sizeof(TraceArgs) * (size_t)want * StreamCtx::kItemSlots,
+                              hipHostMallocDefault));
+        cx->items_cap = want;
+        for (bool &live : cx->item_ev_live)
+            live = false;
+    }
+    const uint32_t slot = cx->item_slot++ % StreamCtx::kItemSlots;
+    if (!cx->item_ev[slot])
+        HIP_TRY(hipEventCreateWithFlags(&cx->item_ev[slot], hipEventDisableTiming));
+    if (cx->item_ev_live[slot])
+        HIP_TRY(hipEventSynchronize(cx->item_ev[slot]));
+    TraceArgs *h = cx->h_items + (size_t)slot * cx->items_cap;
+    memcpy(h, items.data(), sizeof(TraceArgs) * (size_t)n_grids);
+    HIP_TRY(hipMemcpyAsync(cx->d_items, h, sizeof(TraceArgs) * (size_t)n_grids, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(cx->item_ev[slot], st));
+    cx->item_ev_live[slot] = true;
+    k.grid = dim3((unsigned)blocks, (unsigned)n_grids);
+    launch_feat_batch(inst, k, cx->d_items);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int rox_trace_pupil_list(rox_system *sys, const rox_field *fld, int64_t n_rays, const double *px,

@@ -385,6 +385,53 @@ class TraceEngine:
                                                  self._stream()), 'rox_trace_pupil_grid')
         return res
 
+    def _batch_args(self, flds, wvl_idxs, opts_list, outs):
+        n = len(flds)
+        if not (len(wvl_idxs) == len(opts_list) == len(outs) == n):
+            raise EngineError('trace_pupil_grids: flds, wvl_idxs, opts and outs differ in length')
+        f_arr = (abi.Field * n)(*flds)
+        w_arr = (C.c_int32 * n)(*[int(w) for w in wvl_idxs])
+        o_arr = (abi.Opts * n)(*opts_list)
+        out_arr = (abi.Out * n)(*outs)
+        return n, f_arr, w_arr, o_arr, out_arr
+
+    def trace_pupil_grids(self, flds, wvl_idxs, grid, opts_list, want_pupil=True,
+                          nan_fill=False, outs=None):
+        """``grid`` traced for every (flds[i], wvl_idxs[i], opts_list[i]) in ONE launch
+        (rox_trace_pupil_grids): the (field x wavelength) loops of a spot diagram, a set of
+        ray fans or a wavefront map.  Returns one DeviceResult per item; each is what
+        trace_pupil_grid would have returned for it."""
+        R = grid_rays(grid)
+        n = len(flds)
+        res = [self._result(R, opts_list[i], want_pupil, nan_fill, outs[i] if outs else None)
+               for i in range(n)]
+        n, f_arr, w_arr, o_arr, out_arr = self._batch_args(flds, wvl_idxs, opts_list,
+                                                           [r.out_struct() for r in res])
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_trace_pupil_grids(self._handle, n, f_arr, w_arr, C.byref(grid),
+                                                  o_arr, out_arr, self._stream()),
+                   'rox_trace_pupil_grids')
+        return res
+
+    def trace_pupil_grids_hits(self, flds, wvl_idxs, grid, opts_list):
+        """ROX_OUT_HITS_COMPACT for several (field, wavelength) pairs in one launch: a list of
+        (R_ok, 2) arrays, each a view of the pinned block the kernel packed that item's
+        survivors into (one synchronise for all of them)."""
+        R = grid_rays(grid)
+        leases, outs = [], []
+        for _ in flds:
+            lease, o, _st = self._hits_out(R)
+            leases.append(lease)
+            outs.append(o)
+        n, f_arr, w_arr, o_arr, out_arr = self._batch_args(flds, wvl_idxs, opts_list, outs)
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_trace_pupil_grids(self._handle, n, f_arr, w_arr, C.byref(grid),
+                                                  o_arr, out_arr, self._stream()),
+                   'rox_trace_pupil_grids')
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return [lease.array((C.c_int64.from_address(lease.ptr + 16 * R).value, 2), np.float64)
+                for lease in leases]
+
     def trace_pupil_list(self, fld, px, py, wvl_idx=0, opts=None, want_pupil=True,
                          nan_fill=False, out=None):
         t = self.torch

@@ -73,6 +73,15 @@ def assert_soa_close(exp_seg, got_seg, what='seg', atol=ATOL, require_exact=Fals
     return exact
 
 
+def bit_equal(a, b, what):
+    """same shape, same bits (NaN where NaN)"""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), (f'{what}: {np.count_nonzero(~same)} of {same.size} differ, '
+                        f'first {np.argwhere(~same)[:3].tolist()}')
+
+
 def assert_result_matches(case, res, atol=ATOL, require_exact=False, seg_key='seg'):
     """compare an oracle/device result object (seg, op, status, fail_surf) with
     the reference outputs stored in a golden case"""

@@ -48,8 +48,9 @@ print('value %.4g  ms/step %.4f  cold %.4f  frac %.3f  hits_ms %.4f  spot_ms %.3
     b['roofline_hits']['kernel_ms'], b['spot_diagram']['wallclock_ms']))
 for k, c in (b.get('configs') or {}).items():
     if isinstance(c, dict) and 'hits' in c:
-        print(k, 'hits %.3f ms' % c['hits']['kernel_ms_per_pass'],
-              ('full %.3f ms %.3f of 8 TB/s' % (c['full']['kernel_ms_per_pass'], c['full']['frac_of_8000'])) if 'full' in c else '')
+        loop = lambda d: (' (per-grid launches %.3f)' % d['kernel_ms_per_pass_one_launch_per_grid']) if 'kernel_ms_per_pass_one_launch_per_grid' in d else ''
+        print(k, 'hits %.3f ms%s' % (c['hits']['kernel_ms_per_pass'], loop(c['hits'])),
+              ('full %.3f ms%s %.3f of 8 TB/s' % (c['full']['kernel_ms_per_pass'], loop(c['full']), c['full']['frac_of_8000'])) if 'full' in c else '')
     else:
         print(k, c)
 s = b.get('strong_scaling') or {}
