@@ -20,6 +20,9 @@
  *                             opticalspec.py:1339-1353 apply_vignetting)
  *   rox_aim_chief_rays     <- rayoptics/raytr/trace.py:313-415    iterate_ray() (both branches)
  *                             rayoptics/raytr/trace.py:627-640    aim_chief_ray()
+ *   rox_find_real_enp      <- rayoptics/raytr/wideangle.py:86-427 find_real_enp() /
+ *                             find_edge() / find_z_enp_on_interval(), :46-83
+ *                             enp_z_coordinate()
  *   rox_calc_vignetting    <- rayoptics/raytr/vigcalc.py:233-340, 396-461
  *                             calc_vignetting_for_field() / calc_vignetted_ray() /
  *                             iterate_pupil_ray()
@@ -444,6 +447,37 @@ typedef struct rox_aim {
 /* aim_xy: [n][2] = (x1, y1) per problem */
 int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs,
                        double eps, double *aim_xy, int32_t *result, void *stream);
+
+/* rayoptics/raytr/wideangle.py:86-427 find_real_enp (vselector 'rev1') +
+ * find_z_enp_on_interval: the z of the real entrance pupil of a wide-angle
+ * field, measured from the first interface -- what trace.aim_chief_ray
+ * (trace.py:634-635) stores as fld.aim_info of a wide-angle model.  One lane
+ * per (field, wavelength) runs the reference's whole search: the sampled walk
+ * from the paraxial pupil, find_edge's bisections, scipy.optimize.newton's
+ * secant iteration (tol 1.48e-8, rtol 1e-7) and the brentq fall-back (xtol
+ * 2e-12, rtol 1e-7, 100 iterations), every trial ray traced by
+ * enp_z_coordinate (wideangle.py:46-83; intersect_obj = False). */
+enum { ROX_ENP_FOUND = 0,        /* z_enp as find_real_enp returns it               */
+       ROX_ENP_NO_CHIEF_RAY = 1, /* "chief ray trace failed": no ray reaches the stop
+                                    centre; z_enp = the last good sample (:283-291) */
+       ROX_ENP_REFERENCE_RAISES = 3 }; /* the reference itself raises here (no sample
+                                    got through: unpacking None; brentq without a sign
+                                    change; a failed last ray indexed at the stop)  */
+typedef struct rox_enp {
+    double dir0[3];          /* osp.obj_coords(fld)[1]                          */
+    double rot[9];           /* rot_v1_into_v2([0,0,1], dir0), row-major         */
+    double obj_dist;         /* fod.obj_dist                                    */
+    double z_enp_0;          /* fod.enp_dist (the paraxial entrance pupil)      */
+    double aim_info;         /* fld.aim_info, NaN if None                       */
+    int32_t wvl_idx;
+    int32_t surf;            /* stop_idx (1 when the model has no stop surface) */
+    int32_t rot_order;       /* ROX_RT_* of rot (np.matmul -> dgemv)            */
+    int32_t check_direction; /* find_real_enp_rev1's keyword (True)             */
+} rox_enp;                   /* 136 bytes */
+/* z_out: [n][2] = (z_enp, z of the last trial ray traced: the `rr` the
+ * reference returns beside z_enp is that ray) */
+int rox_find_real_enp(rox_system *sys, int32_t n, const rox_enp *probs,
+                      double eps, double *z_out, int32_t *result, void *stream);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,9 @@ def lib():
         L.rox_oracle_aim_chief_rays.restype = C.c_int
         L.rox_oracle_aim_chief_rays.argtypes = [P(abi.Surface), i32, vp, vp, i32, i32,
                                                 P(abi.Aim), C.c_double, vp, vp]
+        L.rox_oracle_find_real_enp.restype = C.c_int
+        L.rox_oracle_find_real_enp.argtypes = [P(abi.Surface), i32, vp, vp, i32, i32,
+                                               P(abi.Enp), C.c_double, vp, vp]
         L.rox_oracle_calc_vignetting.restype = C.c_int
         L.rox_oracle_calc_vignetting.argtypes = [P(abi.Surface), i32, vp, vp, i32, i32,
                                                  P(abi.Vig), C.c_double, vp, vp]
@@ -192,6 +195,52 @@ def aim_chief_rays(table, probs, eps=1.0e-12):
     if rc:
         raise RuntimeError(f'oracle error {rc}')
     return aim, result
+
+
+def find_real_enp(table, probs, eps=1.0e-12):
+    """probs: sequence of abi.Enp -> (z float64[n, 2] = (z_enp, z of the last trial ray),
+    result int32[n] = abi.ENP_*): wideangle.find_real_enp restated (rox_oracle.c)"""
+    n = len(probs)
+    arr = (abi.Enp * n)(*probs)
+    z = np.zeros((n, 2))
+    result = np.zeros(n, dtype=np.int32)
+    rc = lib().rox_oracle_find_real_enp(table.rows, table.n_ifcs, table.n_table.ctypes.data,
+                                        _wvls(table).ctypes.data, len(table.wvls), n, arr,
+                                        C.c_double(eps), z.ctypes.data, result.ctypes.data)
+    if rc:
+        raise RuntimeError(f'oracle error {rc}')
+    return z, result
+
+
+SCALAR_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
+
+
+def brentq(f, a, b, xtol=2e-12, rtol=8.881784197001252e-16, maxiter=100):
+    """scipy.optimize.brentq's core as restated in rox_oracle.c, around a Python callable:
+    (root, funcalls, iterations, err) -- the pin against scipy itself"""
+    L = lib()
+    L.rox_oracle_brentq.restype = C.c_double
+    L.rox_oracle_brentq.argtypes = [SCALAR_FN, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int)]
+    fc, it, err = C.c_int(), C.c_int(), C.c_int()
+    cb = SCALAR_FN(lambda x, _ctx: float(f(x)))
+    root = L.rox_oracle_brentq(cb, None, a, b, xtol, rtol, maxiter, C.byref(fc), C.byref(it),
+                               C.byref(err))
+    return root, fc.value, it.value, err.value
+
+
+def secant(f, x0, tol=1.48e-8, rtol=0.0, maxiter=50):
+    """scipy.optimize.newton's secant branch (disp=False) as restated in rox_oracle.c:
+    (root, converged, funcalls)"""
+    L = lib()
+    L.rox_oracle_secant.restype = C.c_double
+    L.rox_oracle_secant.argtypes = [SCALAR_FN, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                    C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    conv, fc = C.c_int(), C.c_int()
+    cb = SCALAR_FN(lambda x, _ctx: float(f(x)))
+    root = L.rox_oracle_secant(cb, None, x0, tol, rtol, maxiter, C.byref(conv), C.byref(fc))
+    return root, bool(conv.value), fc.value
 
 
 def calc_vignetting(table, probs, eps=1.0e-12):

@@ -129,6 +129,17 @@ class Aim(C.Structure):
                 ('x_target', C.c_double), ('epsfcn', C.c_double)]
 
 
+class Enp(C.Structure):
+    """rox_enp: one wide-angle pupil search (wideangle.find_real_enp)"""
+    _fields_ = [('dir0', C.c_double * 3), ('rot', C.c_double * 9),
+                ('obj_dist', C.c_double), ('z_enp_0', C.c_double), ('aim_info', C.c_double),
+                ('wvl_idx', C.c_int32), ('surf', C.c_int32),
+                ('rot_order', C.c_int32), ('check_direction', C.c_int32)]
+
+
+ENP_FOUND, ENP_NO_CHIEF_RAY, ENP_REFERENCE_RAISES = 0, 1, 3
+
+
 class Vig(C.Structure):
     _fields_ = [('fld', Field), ('start_dir', C.c_double * 2), ('unit_dir', C.c_double * 2),
                 ('xy', C.c_int32), ('wvl_idx', C.c_int32), ('stop_surf', C.c_int32),
@@ -145,13 +156,14 @@ assert C.sizeof(Field) == 192
 assert C.sizeof(Grid) == 48
 assert C.sizeof(Out) == 56
 assert C.sizeof(Aim) == 80
+assert C.sizeof(Enp) == 136
 
 # every symbol include/roxtrace.h declares (checked by tests/test_abi.py) ...
 EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_last_error', 'rox_system_create', 'rox_system_destroy',
            'rox_system_num_segments', 'rox_trace_rays',
            'rox_trace_pupil_grid', 'rox_trace_pupil_grids', 'rox_trace_pupil_list',
-           'rox_aim_chief_rays', 'rox_calc_vignetting', 'rox_calc_psf',
+           'rox_aim_chief_rays', 'rox_find_real_enp', 'rox_calc_vignetting', 'rox_calc_psf',
            'rox_pin_host_memory', 'rox_unpin_host_memory')
 # ... and the measurement / self-test helpers of include/roxtrace_diag.h
 DIAG_EXPORTS = ('rox_time_pupil_grid', 'rox_selftest_fp64')
@@ -188,6 +200,8 @@ def declare(lib):
                                          P(Opts), P(Out), vp]
     lib.rox_aim_chief_rays.restype = C.c_int
     lib.rox_aim_chief_rays.argtypes = [vp, i32, P(Aim), dbl, vp, vp, vp]
+    lib.rox_find_real_enp.restype = C.c_int
+    lib.rox_find_real_enp.argtypes = [vp, i32, P(Enp), dbl, vp, vp, vp]
     lib.rox_calc_vignetting.restype = C.c_int
     lib.rox_calc_vignetting.argtypes = [vp, i32, P(Vig), dbl, vp, vp, vp]
     lib.rox_calc_psf.restype = C.c_int

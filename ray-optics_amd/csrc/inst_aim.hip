@@ -311,7 +311,359 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     a.clip[i] = clip;
 }
 
+// scipy.optimize.newton's secant branch with rtol (disp = False); see secant() above for
+// the rtol = 0 form the vignetting search uses.  `f` never raises here.
+template <class F>
+__device__ __forceinline__ double secant_rtol(F &f, double x0, double tol, double rtol, bool &converged)
+{
+    converged = false;
+    double p0 = x0, p = x0;
+    const double eps = 1e-4;
+    double p1 = x0 * (1 + eps);
+    p1 += (p1 >= 0 ? eps : -eps);
+    double q0 = f(p0);
+    double q1 = f(p1);
+    if (fabs(q1) < fabs(q0)) {
+        double t = p0; p0 = p1; p1 = t;
+        t = q0; q0 = q1; q1 = t;
+    }
+    for (int itr = 0; itr < 50; ++itr) {
+        if (q1 == q0)
+            return (p1 + p0) / 2.0;
+        if (fabs(q1) > fabs(q0))
+            p = (-q0 / q1 * p1 + p0) / (1 - q0 / q1);
+        else
+            p = (-q1 / q0 * p0 + p1) / (1 - q1 / q0);
+        const bool close = (isfinite(p) && isfinite(p1)) ? (fabs(p - p1) <= tol + rtol * fabs(p1))
+                                                         : (p == p1);
+        if (close) {
+            converged = true;
+            return p;
+        }
+        p0 = p1; q0 = q1;
+        p1 = p;
+        q1 = f(p1);
+    }
+    return p;
+}
+
+// scipy.optimize.brentq's core (scipy/optimize/Zeros/brentq.c): err = -1 when f(a) and f(b)
+// have the same sign (scipy raises ValueError)
+template <class F>
+__device__ __forceinline__ double brentq(F &f, double xa, double xb, double xtol, double rtol,
+                                         int iter, int &err)
+{
+    double xpre = xa, xcur = xb;
+    double xblk = 0., fpre, fcur, fblk = 0., spre = 0., scur = 0., sbis;
+    double delta, stry, dpre, dblk;
+    fpre = f(xpre);
+    fcur = f(xcur);
+    err = 0;
+    if (fpre == 0)
+        return xpre;
+    if (fcur == 0)
+        return xcur;
+    if (signbit(fpre) == signbit(fcur)) {
+        err = -1;
+        return 0.;
+    }
+    for (int i = 0; i < iter; ++i) {
+        if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
+            xblk = xpre;
+            fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur; xcur = xblk; xblk = xpre;
+            fpre = fcur; fcur = fblk; fblk = fpre;
+        }
+        delta = (xtol + rtol * fabs(xcur)) / 2;
+        sbis = (xblk - xcur) / 2;
+        if (fcur == 0 || fabs(sbis) < delta)
+            return xcur;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                dpre = (fpre - fcur) / (xpre - xcur);
+                dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            const double lim = fmin(fabs(spre), 3 * fabs(sbis) - delta);
+            if (2 * fabs(stry) < lim) {
+                spre = scur; scur = stry;
+            } else {
+                spre = sbis; scur = sbis;
+            }
+        } else {
+            spre = sbis; scur = sbis;
+        }
+        xpre = xcur; fpre = fcur;
+        if (fabs(scur) > delta)
+            xcur += scur;
+        else
+            xcur += (sbis > 0 ? delta : -delta);
+        fcur = f(xcur);
+    }
+    err = -2;
+    return xcur;
+}
+
+// rayoptics/raytr/wideangle.py:96-292 find_real_enp_rev1 + :295-315 find_edge + :317-427
+// find_z_enp_on_interval, one lane per (field, wavelength); every trial ray is
+// enp_z_coordinate (:46-83).  tuples-or-None of the reference are (value, have_*) pairs here.
+__global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
+{
+    const int N = a.n_ifcs, W = a.n_wvls;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *tbl_w = lds;
+    double *ntab_w = tbl_w + (size_t)N * kRowDoubles;
+    double *phc_w = ntab_w + (size_t)W * N;
+    double *wvls_w = phc_w + (size_t)W * N * kPhaseConsts;
+    int32_t *slot_w = reinterpret_cast<int32_t *>(wvls_w + W);
+    for (int i = threadIdx.x; i < N * kRowDoubles; i += 64)
+        tbl_w[i] = a.rows[i];
+    for (int i = threadIdx.x; i < W * N; i += 64)
+        ntab_w[i] = a.n_table[i];
+    for (int i = threadIdx.x; i < W * N * kPhaseConsts; i += 64)
+        phc_w[i] = a.ph_consts[i];
+    for (int i = threadIdx.x; i < W; i += 64)
+        wvls_w[i] = a.wvls[i];
+    for (int i = threadIdx.x; i < 2 * N; i += 64)
+        slot_w[i] = a.slots[i];
+    __syncthreads();
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n)
+        return;
+    const rox_enp pb = a.probs[i];
+
+    Ctx c;
+    c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
+    c.slot = slot_w; c.nslots_before = slot_w + N;
+    c.apthr = nullptr;
+    c.N = N;
+    c.check_ap = false; c.intersect_obj = false; c.filter_ph = false;   // intersect_obj=False
+    c.first_surf = 1; c.last_surf = N - 2;
+    c.eps = a.eps; c.fuzz = 1e-5;
+    c.probe_surf = pb.surf;
+    SegOut so{nullptr, 0, 0};
+    const v3 dir0{pb.dir0[0], pb.dir0[1], pb.dir0[2]};
+
+    // the last trial ray (the reference's `rr`)
+    double z_last = 0.;
+    RayEnd last;
+    last.status = ROX_OK;
+    last.fail_surf = -1;
+    // enp_z_coordinate: true if the ray got through; ht = final_coord[1]
+    auto trial = [&](double z_enp, double &ht) -> bool {
+        const double obj2enp_dist = (pb.obj_dist + z_enp);
+        const v3 pt1{0., 0., obj2enp_dist};
+        const v3 m = rotate(pb.rot, pb.rot_order, v3{-pt1.x, -pt1.y, -pt1.z});
+        const v3 pt0{m.x + pt1.x, m.y + pt1.y, m.z + pt1.z};
+        trace_ray<MODE_PROBE, true, F_ALL>(c, so, pt0, dir0, pb.wvl_idx, true, last);
+        z_last = z_enp;
+        if (last.status != ROX_OK) {
+            ht = 0.;
+            return false;
+        }
+        ht = last.probe_p.y;
+        return true;
+    };
+    auto eval = [&](double z) -> double {
+        double ht;
+        (void)trial(z, ht);
+        return ht - 0.;
+    };
+    // rr.pkg.ray[stop_idx][mc.p][mc.y]: a failed ray's partial packet reaches the stop only if
+    // it failed behind it, or at it with an incident point (anything but a missed surface)
+    auto last_ht = [&](bool &raises) -> double {
+        if (last.status == ROX_OK || last.fail_surf > pb.surf)
+            return last.probe_p.y;
+        if (last.fail_surf == pb.surf && last.status != ROX_MISSED_SURFACE)
+            return last.inc.y;
+        raises = true;
+        return 0.;
+    };
+    auto find_edge = [&](double ea, double eb, int max_iter, double &z_edge, double &h_edge) {
+        double fa, fb, fc;
+        (void)trial(ea, fa);
+        bool okb = trial(eb, fb);
+        for (int k = 0; k < max_iter; ++k) {
+            const double cc = ea + (eb - ea) / 2;
+            if (!trial(cc, fc)) {
+                eb = cc; okb = false; fb = fc;
+            } else {
+                ea = cc; fa = fc;
+            }
+        }
+        if (!okb) {
+            z_edge = ea; h_edge = fa;
+        } else {
+            z_edge = eb; h_edge = fb;
+        }
+    };
+    auto fuzzy_zero = [](double x) { return fabs(x) < 1e-14; };
+
+    double z_out = 0.;
+    int code = ROX_ENP_FOUND;
+    double ht;
+    bool done = false;
+    if (!isnan(pb.aim_info)) {                      // :128-134
+        (void)trial(pb.aim_info, ht);
+        if (fabs(ht) < 1.48e-08) {
+            z_out = pb.aim_info;
+            done = true;
+        }
+    }
+    const double z_enp_0 = pb.z_enp_0;
+    if (!done && pb.dir0[2] == 1) {                 // :138-141
+        (void)trial(z_enp_0, ht);
+        z_out = z_enp_0;
+        done = true;
+    }
+    if (!done) {
+        bool have_start = false, have_prev = false, have_end = false;
+        double start_z = 0, start_h = 0, prev_z = 0, prev_h = 0, end_z = 0, end_h = 0;
+        double del_z = -z_enp_0 / 16;
+        double z_enp = z_enp_0;
+        bool keep_going = true, first = true;
+        int first_surf_misses = 0, trials = 0, successes = 0;
+        while (keep_going && trials < 64 && first_surf_misses < 2) {
+            if (trial(z_enp, ht)) {
+                ++successes;
+                if (!have_start) {
+                    have_start = true; start_z = z_enp; start_h = ht;
+                }
+                have_prev = have_end; prev_z = end_z; prev_h = end_h;
+                have_end = true; end_z = z_enp; end_h = ht;
+                if (successes > 1 && prev_h * end_h < 0)
+                    keep_going = false;
+                if (successes == 2 && pb.check_direction) {
+                    if (fabs(start_h) < fabs(end_h) && first) {
+                        del_z = -del_z;
+                        z_enp = z_enp_0;
+                        first = false;
+                        double t = end_z; end_z = start_z; start_z = t;
+                        t = end_h; end_h = start_h; start_h = t;
+                    }
+                }
+            } else {
+                if (last.status == ROX_MISSED_SURFACE && last.fail_surf == 1) {
+                    del_z = -del_z;
+                    z_enp = z_enp_0;
+                    ++first_surf_misses;
+                }
+                if (have_start) {
+                    if (first) {
+                        del_z = -del_z;
+                        z_enp = z_enp_0;
+                        first = false;
+                        double t = end_z; end_z = start_z; start_z = t;
+                        t = end_h; end_h = start_h; start_h = t;
+                    } else {
+                        keep_going = false;
+                    }
+                }
+            }
+            z_enp += del_z;
+            if (fuzzy_zero(z_enp))
+                z_enp = del_z / 10;
+            ++trials;
+        }
+        double ia = 0., ib = 0.;
+        if (!have_start) {
+            code = ROX_ENP_REFERENCE_RAISES;
+            done = true;
+        } else {
+            const double z_a = start_z, h_a = start_h, z_b = end_z, h_b = end_h;
+            if (z_a == z_b) {                       // :208-223
+                const double start_new = z_a - del_z, end_new = z_b + del_z;
+                have_start = have_end = false;
+                const double step = (end_new - start_new) / 7;      // np.linspace(num=8)
+                for (int k = 0; k < 8; ++k) {
+                    double z = (double)k * step + start_new;
+                    if (k == 7)
+                        z = end_new;
+                    if (trial(z, ht)) {
+                        if (!have_start) {
+                            have_start = true; start_z = z; start_h = ht;
+                        }
+                        have_end = true; end_z = z; end_h = ht;
+                    }
+                }
+                if (!have_start) {
+                    code = ROX_ENP_REFERENCE_RAISES;
+                    done = true;
+                }
+                ia = start_z; ib = end_z;
+            } else if (h_a * h_b < 0) {
+                ia = z_a; ib = z_b;
+                if (have_prev && prev_h * h_b < 0) {
+                    start_z = prev_z; start_h = prev_h;
+                    ia = prev_z; ib = z_b;
+                }
+            } else {
+                double z_eb, h_eb, z_ea, h_ea;
+                find_edge(z_b, z_b + del_z, 6, z_eb, h_eb);
+                if (h_eb * h_b < 0) {
+                    start_z = z_b; start_h = h_b;
+                    end_z = z_eb; end_h = h_eb;
+                    ia = z_b; ib = z_eb;
+                } else {
+                    find_edge(z_a, z_a - del_z, 6, z_ea, h_ea);
+                    if (h_ea * h_a < 0) {
+                        start_z = z_a; start_h = h_a;
+                        end_z = z_ea; end_h = h_ea;
+                        ia = z_a; ib = z_ea;
+                    } else {
+                        const double z_cntr = z_ea + (z_eb - z_ea) / 2;
+                        (void)trial(z_cntr, ht);
+                        z_out = z_b;
+                        code = ROX_ENP_NO_CHIEF_RAY;
+                        done = true;
+                    }
+                }
+            }
+        }
+        if (!done) {
+            double z_estimate;
+            if (fuzzy_zero(end_h - start_h))
+                z_estimate = start_z;
+            else
+                z_estimate = start_z - ((end_z - start_z) / (end_h - start_h)) * start_h;
+            bool converged, raises = false;
+            double z = secant_rtol(eval, z_estimate, 1.48e-8, 1e-7, converged);
+            const double ht_at_stop = last_ht(raises);
+            if (!raises && fabs(ht_at_stop - 0.) < 1e-6)
+                converged = true;
+            if (!raises && !converged) {
+                int err;
+                z = brentq(eval, ia, ib, 2e-12, 1e-7, 100, err);
+                if (err == -1)
+                    raises = true;
+            }
+            if (!raises)
+                (void)last_ht(raises);
+            if (raises)
+                code = ROX_ENP_REFERENCE_RAISES;
+            else
+                z_out = z;
+        }
+    }
+    a.z_out[2 * i] = z_out;
+    a.z_out[2 * i + 1] = z_last;
+    a.result[i] = code;
+}
+
 }  // namespace
+
+void launch_enp(const EnpArgs &a, size_t lds, hipStream_t st)
+{
+    if (lds > kDefaultDynLds)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(enp_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(enp_kernel, dim3((a.n + 63) / 64), dim3(64), lds, st, a);
+}
 
 void launch_vig(const VigArgs &a, size_t lds, hipStream_t st)
 {

@@ -116,6 +116,7 @@ static_assert(sizeof(rox_aperture) == 40, "rox_aperture layout");
 static_assert(sizeof(rox_phase) == 168, "rox_phase layout");
 static_assert(sizeof(rox_surface) == 576, "rox_surface layout");
 static_assert(sizeof(rox_field) == 192, "rox_field layout");
+static_assert(sizeof(rox_enp) == 136, "rox_enp layout");
 
 // Device-side row = the public rox_surface + per-surface values that are the
 // same for every ray and are therefore computed once at rox_system_create:
@@ -1678,6 +1679,18 @@ struct AimArgs {
     int32_t *result;           // device [n]
 };
 void launch_aim(const AimArgs &, size_t lds, hipStream_t);
+
+// wide-angle pupil search (csrc/inst_aim.hip)
+struct EnpArgs {
+    const double *rows, *n_table, *ph_consts, *wvls;
+    const int32_t *slots;
+    int32_t n_ifcs, n_wvls, n;
+    const rox_enp *probs;      // device
+    double eps;
+    double *z_out;             // device [n][2]
+    int32_t *result;           // device [n]
+};
+void launch_enp(const EnpArgs &, size_t lds, hipStream_t);
 
 // vignetting search (csrc/inst_aim.hip)
 struct VigArgs {

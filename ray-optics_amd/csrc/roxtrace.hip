@@ -1246,6 +1246,53 @@ int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs, double 
     return 0;
 }
 
+int rox_find_real_enp(rox_system *sys, int32_t n, const rox_enp *probs, double eps,
+                      double *z_out, int32_t *result, void *stream)
+{
+    if (!sys || n < 0 || (n > 0 && (!probs || !z_out || !result)))
+        return fail(ROX_E_ARG, "rox_find_real_enp: bad argument");
+    if (n == 0)
+        return 0;
+    for (int i = 0; i < n; ++i) {
+        if (probs[i].wvl_idx < 0 || probs[i].wvl_idx >= sys->n_wvls)
+            return fail(ROX_E_ARG, "probs[%d].wvl_idx %d out of range", i, probs[i].wvl_idx);
+        if (probs[i].surf < 0 || probs[i].surf >= sys->n_ifcs)
+            return fail(ROX_E_ARG, "probs[%d].surf %d out of range", i, probs[i].surf);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = sys->n_ifcs, W = sys->n_wvls;
+    const size_t lds = (N * sizeof(dev_surface) + W * N * sizeof(double) * (1 + kPhaseConsts) +
+                        W * sizeof(double) + 2 * N * sizeof(int32_t) + 15) & ~size_t(15);
+    if (lds > 160 * 1024 - 64)
+        return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
+    void *d = nullptr;
+    const size_t pb = sizeof(rox_enp) * n, zb = sizeof(double) * 2 * n, rb = sizeof(int32_t) * n;
+    HIP_TRY(hipMalloc(&d, pb + zb + rb));
+    EnpArgs a{};
+    a.rows = sys->d_rows; a.n_table = sys->d_ntab; a.ph_consts = sys->d_phc; a.wvls = sys->d_wvls;
+    a.slots = sys->d_slots[0];
+    a.n_ifcs = sys->n_ifcs; a.n_wvls = sys->n_wvls; a.n = n;
+    a.probs = (const rox_enp *)d;
+    a.z_out = (double *)((char *)d + pb);
+    a.result = (int32_t *)((char *)d + pb + zb);
+    a.eps = eps;
+    hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        launch_enp(a, lds, st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(z_out, a.z_out, zb, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(result, a.result, rb, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess)
+        return fail(ROX_E_HIP, "rox_find_real_enp: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs, double eps,
                         double *vig, int32_t *clip_surf, void *stream)
 {

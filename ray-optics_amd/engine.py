@@ -602,6 +602,19 @@ class TraceEngine:
                                                self._stream()), 'rox_aim_chief_rays')
         return aim, result
 
+    def find_real_enp(self, probs, eps=1.0e-12):
+        """probs: sequence of abi.Enp -> (z float64[n, 2] = (z_enp, z of the last trial ray),
+        result int32[n] = abi.ENP_*)"""
+        n = len(probs)
+        arr = (abi.Enp * n)(*probs)
+        z = np.zeros((n, 2))
+        result = np.zeros(n, dtype=np.int32)
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_find_real_enp(self._handle, n, arr, float(eps),
+                                              z.ctypes.data, result.ctypes.data,
+                                              self._stream()), 'rox_find_real_enp')
+        return z, result
+
     def calc_vignetting(self, probs, eps=1.0e-12):
         """probs: sequence of abi.Vig -> (vig float64[n], clip_surf int32[n])"""
         n = len(probs)

@@ -38,6 +38,7 @@ def install(fallback='raise'):
     import rayoptics.raytr.analyses as ranalyses
     import rayoptics.raytr.opticalspec as ropticalspec
     import rayoptics.raytr.vigcalc as rvigcalc
+    import rayoptics.raytr.wideangle as rwideangle
     from rayoptics.seq.sequential import SequentialModel
     if _saved:
         uninstall()
@@ -66,6 +67,10 @@ def install(fallback='raise'):
              # update_optical_properties aims all fields in one launch
              (rtrace, 'aim_chief_ray', _t.aim_chief_ray),
              (ropticalspec, 'aim_chief_ray', _t.aim_chief_ray),
+             # the wide-angle pupil search behind aim_chief_ray (trace.py:634-635) and
+             # eval_z_enp_curve; trace.py imports it by name (trace.py:29)
+             (rwideangle, 'find_real_enp', _t.find_real_enp),
+             (rtrace, 'find_real_enp', _t.find_real_enp),
              (ropticalspec.OpticalSpecs, 'update_optical_properties',
               _t.osp_update_optical_properties),
              # vignetting search and the boundary rays behind set_clear_apertures

@@ -240,6 +240,23 @@ def trace_grid_spot(opt_model, grid_rng, fld, wvl, foc, image_pt, **kwargs):
                                      wi, opts)
 
 
+def trace_grid_spots(opt_model, grid_rng, fld, wvls, foc, image_pt, **kwargs):
+    """``trace_grid_spot`` for every wavelength of ``wvls`` in ONE launch
+    (rox_trace_pupil_grids): the per-wavelength loop of SequentialModel.trace_grid
+    (sequential.py:1073-1084) -- a list of (R_ok, 2) arrays, one per wavelength."""
+    kwargs['check_apertures'] = True
+    kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', True)
+    flds, wis, optl = [], [], []
+    eng = None
+    for wvl in wvls:
+        eng, f, wi, opts = _launch_setup(opt_model, fld, wvl, dict(kwargs), abi.OUT_HITS_COMPACT,
+                                         foc, image_pt[:2])
+        flds.append(f)
+        wis.append(wi)
+        optl.append(opts)
+    return eng.trace_pupil_grids_hits(flds, wis, make_grid(grid_rng[0], grid_rng[1], grid_rng[2]), optl)
+
+
 def _is_spot_filter(fct):
     """SpotDiagramFigure's own callback (rayoptics/mpl/axisarrayfigure.py:229-238):
     a closure, so it can only be recognised by where it was defined -- module and
@@ -270,6 +287,10 @@ def seq_trace_grid(self, fct, fi, wl=None, num_rays=21, form='grid',
     grids = []
     grid_def = [np.array([-1., -1.]), np.array([1., 1.]), num_rays]
     fused = _is_spot_filter(fct) and form == 'list' and not append_if_none
+    if fused and len(wv_list) > 1:
+        # every wavelength of the field in one launch
+        return (trace_grid_spots(self.opt_model, grid_def, fld, list(wv_list), foc,
+                                 fld.ref_sphere[0], **dict(kwargs)), wvls.render_colors)
     for wi, wvl in enumerate(wv_list):
         if fused:
             grid = trace_grid_spot(self.opt_model, grid_def, fld, wvl, foc,
@@ -309,12 +330,71 @@ def _aim_problem(opt_model, fld, wvl, tbl, stop):
     return a
 
 
+def _enp_problem(opt_model, fld, wvl, tbl, stop):
+    """rox_enp for wideangle.find_real_enp (wideangle.py:96-134): the field's object-space
+    direction, the rotation enp_z_coordinate applies to the pupil point, the paraxial pupil"""
+    from rayoptics.util.misc_math import rot_v1_into_v2
+    osp = opt_model['optical_spec']
+    fod = opt_model['analysis_results']['parax_data'].fod
+    _pt0, dir0 = osp.obj_coords(fld)
+    rot = rot_v1_into_v2(np.array([0., 0., 1.]), dir0)
+    e = abi.Enp()
+    for i in range(3):
+        e.dir0[i] = float(dir0[i])
+        for j in range(3):
+            e.rot[3 * i + j] = float(rot[i][j])
+    from .table import rt_order_of
+    e.rot_order = rt_order_of(rot)
+    e.obj_dist = float(fod.obj_dist)
+    e.z_enp_0 = float(fod.enp_dist)
+    e.aim_info = float('nan') if fld.aim_info is None else float(fld.aim_info)
+    e.wvl_idx = tbl.wvl_index(wvl)
+    e.surf = 1 if stop is None else int(stop)
+    e.check_direction = 1
+    return e
+
+
+def find_real_enps(opt_model, stop_idx, flds, wvl):
+    """wideangle.find_real_enp for every field of ``flds`` in one launch (one lane each):
+    [(z_enp, z of the last trial ray, abi.ENP_*)]"""
+    eng = session.engine_for(opt_model)
+    out = [(0.0, 0.0, abi.ENP_REFERENCE_RAISES)] * len(flds)
+    # (an aim_info that is not a scalar -- left over from a non-wide-angle aim -- is the
+    # reference's own business: those fields are routed to its function)
+    where = [k for k, fld in enumerate(flds) if np.ndim(fld.aim_info) == 0]
+    if where:
+        probs = [_enp_problem(opt_model, flds[k], wvl, eng.table, stop_idx) for k in where]
+        z, result = eng.find_real_enp(probs)
+        for j, k in enumerate(where):
+            out[k] = (float(z[j, 0]), float(z[j, 1]), int(result[j]))
+    return out
+
+
+def find_real_enp(opm, stop_idx, fld, wvl, vselector='rev1'):
+    """rayoptics/raytr/wideangle.py:86-94 (the 'rev1' search, :96-292): (z_enp, rr) with
+    the whole search -- sampled walk, find_edge, newton, brentq -- run by one device lane;
+    ``rr`` is the reference's RayResult of the last trial ray, retraced once."""
+    import rayoptics.raytr.wideangle as wa
+    ref_fn = getattr(wa.find_real_enp, '__wrapped__', wa.find_real_enp)
+    if vselector != 'rev1':
+        return ref_fn(opm, stop_idx, fld, wvl, vselector=vselector)
+    (z_enp, z_last, code), = find_real_enps(opm, stop_idx, [fld], wvl)
+    if code == abi.ENP_REFERENCE_RAISES:
+        return ref_fn(opm, stop_idx, fld, wvl)      # raises what the reference raises
+    osp = opm['optical_spec']
+    fod = opm['analysis_results']['parax_data'].fod
+    _pt0, dir0 = osp.obj_coords(fld)
+    _coord, rr = wa.enp_z_coordinate(z_last, opm['seq_model'], 1 if stop_idx is None else stop_idx,
+                                     dir0, fod.obj_dist, wvl)
+    return z_enp, rr
+
+
 def aim_chief_rays(opt_model, flds, wvl=None):
     """aim_info for every field in ``flds``, all solved together in one launch (one lane
     each): fields on the y axis by the secant iteration of scipy.optimize.newton, the others
     by MINPACK's hybrd as scipy.optimize.fsolve runs it -- both restated on the device
-    (rayoptics/raytr/trace.py:313-415).  Wide-angle models keep the reference's own pupil
-    search (wideangle.py:86-427), whose trial rays go through the rebound raytrace.trace."""
+    (rayoptics/raytr/trace.py:313-415).  Wide-angle models: the pupil search of
+    wideangle.find_real_enp (wideangle.py:86-427), one lane per field (rox_find_real_enp)."""
     from rayoptics.raytr import trace as ref_trace
     sm = opt_model['seq_model']
     if wvl is None:
@@ -323,6 +403,13 @@ def aim_chief_rays(opt_model, flds, wvl=None):
     out = [None] * len(flds)
     if stop is None and not opt_model['optical_spec']['fov'].is_wide_angle:
         return [np.array([0., 0.]) + np.array([0., 0.]) for _ in flds]      # floating stop, :412-413
+    if opt_model['optical_spec']['fov'].is_wide_angle:          # trace.py:634-635
+        for k, (z_enp, _z_last, code) in enumerate(find_real_enps(opt_model, stop, flds, wvl)):
+            if code == abi.ENP_REFERENCE_RAISES:
+                out[k] = _ref_aim_chief_ray(ref_trace)(opt_model, flds[k], wvl)
+            else:
+                out[k] = z_enp
+        return out
     eng = session.engine_for(opt_model)
     probs, where = [], []
     for k, fld in enumerate(flds):

@@ -452,6 +452,61 @@ def psf_cases():
     print(f'psf.npz: {os.path.getsize(path) / 1024:.0f} KiB, {sorted(set(k.split("/")[0] for k in out))}')
 
 
+def wideangle_cases():
+    """tests/golden/wideangle.npz: wide-angle pupil searches (wideangle.find_real_enp,
+    wideangle.py:86-427) of two models over random field angles -- the rox_enp problem of
+    every case (as the product's trace._enp_problem builds it) and what the reference
+    returned: z_enp, or the fact that it raised."""
+    import ctypes
+    import logging
+    import warnings
+    import rayoptics.raytr.wideangle as wa
+    from rayoptics_amd import trace as T, abi
+    logging.disable(logging.CRITICAL)
+    rng = np.random.default_rng(SEED + 9)
+    nik = os.path.join(rm.REF_SRC, 'rayoptics', 'optical', 'tests', 'Nikon Nikkor Z 14-30mm f-4 S.roa')
+    models = [('dblgauss', rm.dblgauss(), np.concatenate([[0., 14.], rng.uniform(0., 45., 38), rng.uniform(45., 89., 10)])),
+              ('nikkor', rm.load_roa(nik, fov=(('object', 'angle'), 57.7), flds=[0., 30., 57.7],
+                                     is_relative=False),
+               np.concatenate([[0., 57.7], rng.uniform(0., 62., 38), rng.uniform(62., 89., 10)]))]
+    out = {}
+    for name, opm, angles in models:
+        sm, osp = opm['seq_model'], opm['osp']
+        fov = osp['fov']
+        fov.is_wide_angle = True
+        tbl = ra.SurfaceTable.from_seq_model(sm)
+        stop = sm.stop_surface
+        probs, z_ref, raised = [], [], []
+        for k, ang in enumerate(angles):
+            fld = fov.fields[-1]
+            fld.x, fld.y = 0., float(ang) / (fov.value if fov.is_relative else 1.0)
+            wvl = osp['wvls'].wavelengths[k % len(osp['wvls'].wavelengths)]
+            # every fifth case starts from a (slightly wrong) previous answer, :128-134
+            fld.aim_info = None if (k % 5 or not z_ref or raised[-1]) else z_ref[-1] * (1 + 1e-9)
+            pb = T._enp_problem(opm, fld, wvl, tbl, stop)
+            probs.append(np.frombuffer(ctypes.string_at(ctypes.addressof(pb), ctypes.sizeof(pb)),
+                                       dtype=np.uint8).copy())
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                try:
+                    z, _rr = wa.find_real_enp(opm, stop, fld, wvl)
+                    z_ref.append(float(z))
+                    raised.append(False)
+                except Exception:
+                    z_ref.append(np.nan)
+                    raised.append(True)
+        out[f'{name}/table_json'] = np.array(json.dumps(tbl.to_dict()))
+        out[f'{name}/probs'] = np.stack(probs)
+        out[f'{name}/z_enp'] = np.array(z_ref)
+        out[f'{name}/raised'] = np.array(raised)
+        out[f'{name}/angles'] = np.asarray(angles, dtype=float)
+        print(name, len(angles), 'cases,', int(np.sum(raised)), 'where the reference raises')
+    logging.disable(logging.NOTSET)
+    path = os.path.join(HERE, 'wideangle.npz')
+    np.savez_compressed(path, **out)
+    print(f'wideangle.npz: {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 C3_ZMX_DESC = ('BASELINE.json configs[2]: Zemax .zmx import -- rayoptics/zemax/tests/US08427765-1.ZMX, '
                '13 interfaces incl. one EVENASPH, 3 real-image-height fields x 3 wavelengths, image '
                "f/2.1 -- read by the reference's own zmxread; the five catalogue glasses carry their "
@@ -473,6 +528,9 @@ def main():
             'opd_f0': case_opd(opm, 0, 550.0, 11),
             'opd_f2': case_opd(opm, 2, 486.1, 10),
         })
+        return
+    if '--only-wideangle' in sys.argv:
+        wideangle_cases()
         return
     if '--only-c3-zmx' in sys.argv:
         workload_file(rm.zmx_evenasph_c3(), 'zmx_evenasph_c3', C3_ZMX_DESC)
@@ -577,6 +635,7 @@ def main():
     })
 
     psf_cases()
+    wideangle_cases()
 
     # aspheric toroids (Newton path, anamorphic)
     opm = rm.toroid_lens()

@@ -114,6 +114,12 @@ class OracleEngine:
     def trace_pupil_grid_hits(self, fld, grid, wvl_idx, opts):
         return oracle.trace_pupil_grid(self.table, fld, grid, wvl_idx, opts).hits.copy()
 
+    def trace_pupil_grids_hits(self, flds, wvl_idxs, grid, opts_list):
+        return [self.trace_pupil_grid_hits(f, grid, w, o) for f, w, o in zip(flds, wvl_idxs, opts_list)]
+
+    def trace_pupil_grids(self, flds, wvl_idxs, grid, opts_list, **kw):
+        return [self.trace_pupil_grid(f, grid, w, o) for f, w, o in zip(flds, wvl_idxs, opts_list)]
+
     def trace_pupil_list_hits(self, fld, px, py, wvl_idx, opts):
         return oracle.trace_pupil_list(self.table, fld, px, py, wvl_idx, opts).hits.copy()
 
@@ -123,6 +129,9 @@ class OracleEngine:
 
     def aim_chief_rays(self, probs, eps=1.0e-12):
         return oracle.aim_chief_rays(self.table, probs, eps)
+
+    def find_real_enp(self, probs, eps=1.0e-12):
+        return oracle.find_real_enp(self.table, probs, eps)
 
     def calc_vignetting(self, probs, eps=1.0e-12):
         return oracle.calc_vignetting(self.table, probs, eps)

@@ -715,10 +715,56 @@ def test_two_dimensional_aiming_through_the_seam(ref, installed):
     same_pkg(pkg_o, pkg_t)
 
 
-def test_wide_angle_pupil_search_runs_on_the_device_trace(ref, installed):
+def test_wide_angle_find_real_enp_drop_in(ref, installed):
+    """wideangle.find_real_enp rebound (one engine call runs the whole search): the same
+    (z_enp, rr) -- rr being the last trial ray -- and the same exception where the
+    reference raises; eval_z_enp_curve (wideangle.py:667-703) on top of it unchanged"""
+    import logging
+    import warnings
+    import rayoptics.raytr.wideangle as wa
+    opm = ref.dblgauss()
+    sm, osp = opm['seq_model'], opm['osp']
+    osp['fov'].is_wide_angle = True
+    fld = osp['fov'].fields[-1]
+    wvl = sm.central_wavelength()
+
+    def run():
+        out = []
+        logging.disable(logging.CRITICAL)
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                for ang in (0.0, 3.0, 9.5, 14.0, 21.0, 33.0, 85.0):
+                    fld.x, fld.y, fld.aim_info = 0., ang / 14.0, None
+                    try:
+                        z, rr = wa.find_real_enp(opm, sm.stop_surface, fld, wvl)
+                        out.append((float(z), rr.pkg.ray, rr.pkg.op, type(rr.err).__name__))
+                    except Exception as e:
+                        out.append(type(e).__name__)
+                fld.x, fld.y, fld.aim_info = 0., 1.0, None
+                curve = wa.eval_z_enp_curve(opm, printout=False)
+        finally:
+            logging.disable(logging.NOTSET)
+        return out, curve[1:]
+    (ours, curve_o), (theirs, curve_t) = both(installed, run)
+    assert len(ours) == len(theirs) == 7
+    n_found = 0
+    for a, b in zip(ours, theirs):
+        if isinstance(b, str):
+            assert a == b
+            continue
+        n_found += 1
+        assert a[0] == b[0] and a[3] == b[3]
+        same_pkg((a[1], a[2], 0), (b[1], b[2], 0))
+    assert n_found >= 4
+    for a, b in zip(curve_o, curve_t):
+        np.testing.assert_array_equal(np.asarray(a, dtype=float), np.asarray(b, dtype=float))
+
+
+def test_wide_angle_aim_chief_ray_drop_in(ref, installed):
     """with is_wide_angle the reference aims through wideangle.find_real_enp
-    (wideangle.py:86-427, scipy newton / brentq around rt.trace); with the seam
-    rebound that search traces on the device and finds the same z_enp"""
+    (wideangle.py:86-427, scipy newton / brentq around rt.trace); the drop-in runs that
+    search for every field in one engine call and finds the same z_enp"""
     import rayoptics.raytr.trace as trace
     opm = ref.dblgauss()
     osp = opm['osp']

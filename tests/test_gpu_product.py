@@ -49,6 +49,33 @@ def test_trace_grid_spot_product_function(name):
     session.clear()
 
 
+@pytest.mark.parametrize('name', ['dblgauss', 'nikkor'])
+def test_trace_grid_spots_every_wavelength_in_one_launch(name):
+    """trace.trace_grid_spots (the per-wavelength loop of SequentialModel.trace_grid as one
+    rox_trace_pupil_grids launch) == the reference's SpotDiagramFigure data per wavelength"""
+    from rayoptics_amd import trace, session
+    fx = H.fixture(name)
+    c = fx['spot']
+    num = int(c['num'])
+    by_field = {}
+    for key in [k for k in c if k.endswith('_hits')]:
+        fi, wi = key.split('_')[0], int(key.split('_')[1][1:])
+        by_field.setdefault(fi, []).append(wi)
+    n_multi = 0
+    for fi, wis in by_field.items():
+        wis = sorted(wis)
+        m = model_of(fx, [H.field_from_arr(c[f'{fi}_field'])], [tuple(c[f'{fi}_image_pt'])],
+                     foc=float(c['foc']))
+        got = trace.trace_grid_spots(m, [np.array([-1., -1.]), np.array([1., 1.]), num], m.fields[0],
+                                     [fx.table.wvls[w] for w in wis], float(c['foc']), c[f'{fi}_image_pt'])
+        assert len(got) == len(wis)
+        for w, xy in zip(wis, got):
+            np.testing.assert_array_equal(xy, c[f'{fi}_w{w}_hits'])
+        n_multi += len(wis) > 1
+    assert n_multi >= 1
+    session.clear()
+
+
 from test_oracle_golden import OPD_CASES  # noqa: E402
 
 

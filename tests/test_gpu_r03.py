@@ -311,3 +311,29 @@ def test_two_dimensional_chief_ray_aiming():
         n_conv += int((r_dev == abi.AIM_CONVERGED).sum())
         eng.close()
     assert n_conv > 100
+
+
+# ---------------------------------------------------------------- wide-angle pupil search
+@pytest.mark.parametrize('name', ['dblgauss', 'nikkor'])
+def test_wide_angle_pupil_search_on_the_device(name):
+    """rox_find_real_enp (wideangle.find_real_enp: sampled walk, find_edge, newton, brentq;
+    one lane per problem): z_enp, the last trial ray's z and the result code identical to the
+    oracle's, z_enp identical to what the reference itself returned (tests/golden/
+    wideangle.npz), ROX_ENP_REFERENCE_RAISES exactly where the reference raised"""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine
+    from test_oracle_wideangle import golden_model
+    tbl, probs, z_ref, raised = golden_model(name)
+    eng = TraceEngine(tbl)
+    z_d, res_d = eng.find_real_enp(probs)
+    z_o, res_o = oracle.find_real_enp(tbl, probs)
+    np.testing.assert_array_equal(res_d, res_o)
+    np.testing.assert_array_equal(z_d, z_o)
+    np.testing.assert_array_equal(res_d == abi.ENP_REFERENCE_RAISES, raised)
+    ok = ~raised
+    np.testing.assert_array_equal(z_d[ok, 0], z_ref[ok])
+    # one problem at a time gives the same answers (no cross-lane state)
+    for k in (0, 7, len(probs) - 1):
+        z1, r1 = eng.find_real_enp(probs[k:k + 1])
+        assert r1[0] == res_d[k] and np.array_equal(z1[0], z_d[k])
+    eng.close()

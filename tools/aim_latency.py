@@ -54,5 +54,33 @@ def main():
         eng.close()
 
 
+def wide_angle():
+    """rox_find_real_enp on the stored wide-angle problems (tests/golden/wideangle.npz): all
+    of a model's problems in one call, and nine of them (a typical field list)"""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_oracle_wideangle import golden_model
+    from rayoptics_amd import abi
+    from rayoptics_amd.engine import TraceEngine
+    for name in ('dblgauss', 'nikkor'):
+        tbl, probs, _z, raised = golden_model(name)
+        eng = TraceEngine(tbl)
+        for n in (9, len(probs)):
+            sel = [p for p, r in zip(probs, raised) if not r][:n]
+            for _ in range(5):
+                eng.find_real_enp(sel)
+            t = []
+            for _ in range(40):
+                t0 = time.perf_counter()
+                _zz, res = eng.find_real_enp(sel)
+                t.append(time.perf_counter() - t0)
+            print(json.dumps({'wide_angle_search': name, 'interfaces': tbl.n_ifcs, 'problems': len(sel),
+                              'found': int((res == abi.ENP_FOUND).sum()),
+                              'ms_median': float(np.median(t) * 1e3), 'ms_min': float(np.min(t) * 1e3)}))
+        eng.close()
+
+
 if __name__ == '__main__':
+    if '--wide-angle' in sys.argv:
+        wide_angle()
+        sys.exit(0)
     main()
