@@ -10,7 +10,7 @@
 #   testfile:<path>[:k-expr]       one test file
 #   bench[:extra args]             python bench.py --steps 20 --warmup 5 (driver's shape) -> bench.json
 #   benchN:<n>[:extra args]        plain `python bench.py --gpus n` (self-launch; gloo + shared GPU rehearsal)
-#   prof                           rocprofv3 --kernel-trace --stats of bench.py (no cpu baseline) -> prof/
+#   prof[:tag[:extra args]]        rocprofv3 --kernel-trace --stats of bench.py (no cpu baseline) -> prof[_tag]/
 #   pmc:<workload>[:num]           tools/pmc_collect.sh passes for a workload -> pmc_<tag>_<workload>/
 #   probe:<mode>:<workload>[:field[:lib]]   tools/sustained_probe.py (steady-state kernel time)
 #   py:<script and args>           python <script...> > <tag>/<script>.out
@@ -73,10 +73,13 @@ for p in ('c5', 'c4'):
         print(p, ex, s[p].get(ex))
 PY
       ;;
-    prof)
+    prof)     # prof[:tag[:extra bench args]]  e.g. prof:main:--no-configs --no-strong
       R=$PWD
-      (cd /tmp; export TMPDIR=/tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o bench -- python "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$R/$OUT/prof_bench.json" 2> "$R/$OUT/prof.err")
-      echo "rc=$?"; find "$OUT/prof" -name "*kernel_stats.csv" | head -1 | xargs -r head -30 | cut -c1-220 ;;
+      ptag=${rest%%:*}; pextra=""; [ "$rest" != "$ptag" ] && pextra=${rest#*:}
+      pdir="prof${ptag:+_$ptag}"
+      (cd /tmp; export TMPDIR=/tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/$pdir" -o bench -- python "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline $pextra > "$R/$OUT/${pdir}_bench.json" 2> "$R/$OUT/$pdir.err")
+      echo "rc=$?"; find "$OUT/$pdir" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-220
+      find "$OUT/$pdir" -name "*kernel_trace.csv" -size +8M -delete ;;
     pmc)
       wl=${rest%%:*}
       bash tools/pmc_collect.sh "${TAG}_$wl" $(echo "$rest" | tr ':' ' ') ;;

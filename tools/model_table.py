@@ -24,7 +24,7 @@ def main():
     num = 1024
     R = num * num
     rows = []
-    for name in ('singlet_c1', 'dblgauss_c2', 'rc_telescope_c4', 'cell_phone', 'nikkor_c3'):
+    for name in ('singlet_c1', 'dblgauss_c2', 'rc_telescope_c4', 'cell_phone', 'nikkor_c3', 'zmx_evenasph_c3'):
         wl = workloads.load(name)
         N = wl.n_ifcs
         eng = TraceEngine(wl.table)
@@ -47,7 +47,7 @@ def main():
             rec[key + '_rays_per_s'] = R / (ms * 1e-3)
             rec[key + '_intersections_per_s'] = inters / (ms * 1e-3)
             rec['rays_through'] = int(ok.sum())
-        ref = REFERENCE_RAYS_PER_S[name]
+        ref = REFERENCE_RAYS_PER_S.get(name)
         rec['reference_rays_per_s_published'] = ref
         if ref:
             rec['full_speedup_vs_published'] = rec['full_rays_per_s'] / ref
