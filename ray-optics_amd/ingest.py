@@ -47,6 +47,7 @@ catalogue glasses to dispersive indices: hand such a lookup in as ``index_of``.
 """
 import json
 import math
+import os
 import re
 
 import numpy as np
@@ -254,6 +255,7 @@ class Prescription:
         self.ref_wvl = 0
         self.title = ''
         self.private_glasses = {}   # name -> (wavelengths nm, indices): CODE V PRV ... END
+        self.unmodelled_types = []  # [(surface index, Zemax TYPE)] imported as their base conic
 
     # rayoptics/seq/sequential.py:611-668 + rayoptics/elem/transform.py:86-118
     def to_table(self, wvls=None, index_of=None):
@@ -410,8 +412,17 @@ def _read_text(path):
     raise UnsupportedModelError(f'cannot decode {path}')
 
 
-def read_zmx(path):
-    """Zemax .zmx -> Prescription (rayoptics/zemax/zmxread.py:118-456)"""
+def read_zmx(path, unknown_types='reference'):
+    """Zemax .zmx -> Prescription (rayoptics/zemax/zmxread.py:118-456).
+
+    ``unknown_types``: what to do with a surface TYPE this reader has no model for (the one
+    in the reference tree: QED_TYPE, a Forbes Q-type asphere).  'reference' (default) does what
+    the reference's importer does -- zmxread.handle_types_and_params (zmxread.py:295-333)
+    remembers the type name and otherwise ignores it, so the surface keeps its base conic and
+    the XDAT terms are dropped -- but says so: a warning, and ``Prescription.unmodelled_types``
+    = [(surface index, type)].  'raise' refuses the file (UnsupportedModelError)."""
+    if unknown_types not in ('reference', 'raise'):
+        raise ValueError(f'unknown_types={unknown_types!r}')
     p = Prescription()
     cur = -1
     n_clear_ap = 0
@@ -478,7 +489,13 @@ def read_zmx(path):
                 s.cR = 0.0
                 s.coefs = []
             elif typ != 'STANDARD':
-                raise UnsupportedModelError(f'Zemax surface type {typ}')
+                if unknown_types == 'raise':
+                    raise UnsupportedModelError(f'Zemax surface type {typ}')
+                import warnings
+                warnings.warn(f'{os.path.basename(str(path))}: surface {cur} is a {typ}, which is not '
+                              'modelled: imported as its base conic, as the reference\'s zmxread does '
+                              '(the extra terms are dropped)', stacklevel=2)
+                p.unmodelled_types.append((cur, typ))
         elif cmd == 'CONI':
             s = p.ifcs[cur]
             if s.profile == 'Spherical':
@@ -744,6 +761,33 @@ def _roa_medium(m):
     return ('glass', name)
 
 
+def _roa_vec(v, n=3):
+    """a NumPy vector as json_tricks writes it: a plain list, or {"__ndarray__": [...], ...}"""
+    if isinstance(v, dict):
+        v = v.get('__ndarray__', v.get('data'))
+    if v is None:
+        return [0.0] * n
+    out = [float(x) for x in v]
+    if len(out) != n:
+        raise UnsupportedModelError(f'.roa vector of {len(out)} components where {n} are expected')
+    return out
+
+
+def _roa_decenter(rec):
+    """DecenterData of a .roa surface (rayoptics/elem/surface.py:274-337; json_tricks writes
+    the instance's __dict__: _dtype (older files: dtype), dec, euler, rot_pt, rot_mat).  Only
+    dtype, dec and euler define the transform: rot_mat is derived from euler on update()
+    (:312-316) and rot_pt is not read anywhere in the reference."""
+    at = rec.get('attributes', rec)
+    dtype = at.get('_dtype', at.get('dtype'))
+    if dtype not in ('decenter', 'reverse', 'dec and return', 'bend'):
+        raise UnsupportedModelError(f'.roa decenter type {dtype!r}')
+    d = new_decenter(dtype)
+    d['dec'] = _roa_vec(at.get('dec'))
+    d['euler'] = _roa_vec(at.get('euler'))
+    return d
+
+
 def read_roa(path):
     """ray-optics .roa (json_tricks dump of the OpticalModel; nesting per SURVEY 8c)"""
     with open(path) as f:
@@ -759,7 +803,7 @@ def read_roa(path):
         s.mode = at.get('interact_mode', 'transmit')
         s.max_aperture = at.get('max_aperture', 1.0)
         if at.get('decenter') is not None:
-            raise UnsupportedModelError('decentered .roa surfaces are not ingested')
+            s.decenter = _roa_decenter(at['decenter'])
         if cls == 'ThinLens':
             s.thinlens_power = at.get('_power', at.get('optical_power', 0.0))
         else:
@@ -798,11 +842,11 @@ def read_roa(path):
     return p
 
 
-def read(path):
-    """dispatch on the file extension"""
+def read(path, **kwargs):
+    """dispatch on the file extension (keywords go to the format's reader)"""
     ext = str(path).rsplit('.', 1)[-1].lower()
     if ext == 'zmx':
-        return read_zmx(path)
+        return read_zmx(path, **kwargs)
     if ext == 'seq':
         return read_seq(path)
     if ext == 'roa':

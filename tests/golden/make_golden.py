@@ -507,6 +507,116 @@ def wideangle_cases():
     print(f'wideangle.npz: {os.path.getsize(path) / 1024:.0f} KiB')
 
 
+def _jt(obj_cls_module, obj_cls_name, attributes):
+    """a class instance as json_tricks writes it (json_tricks/encoders.py class_instance_encode:
+    {"__instance_type__": [module, name], "attributes": obj.__dict__})"""
+    return {'__instance_type__': [obj_cls_module, obj_cls_name], 'attributes': attributes}
+
+
+def _jt_array(a):
+    """a NumPy array as json_tricks writes it in its default (non-compressed) mode"""
+    a = np.asarray(a)
+    return {'__ndarray__': a.tolist(), 'dtype': str(a.dtype), 'shape': list(a.shape), 'Corder': True}
+
+
+def dump_roa(opm, path):
+    """Writes the part of a .roa that the trace path reads -- seq_model (interfaces with
+    inline profiles, DecenterData, clear apertures; gaps; stop; z_dir) and the optical spec --
+    in json_tricks' layout, from a LIVE reference model.  json_tricks itself is absent here
+    (oracle/refshim.py), so the layout is restated from its encoder: every object is its
+    class path + __dict__, arrays are {"__ndarray__": ...}.  Used for the one thing no .roa
+    of the reference tree carries: a non-null `decenter` record."""
+    sm, osp = opm['seq_model'], opm['optical_spec']
+
+    def profile(pf):
+        at = {'cv': float(pf.cv)}
+        for k in ('cc', 'ec'):
+            if hasattr(pf, k):
+                at[k] = float(getattr(pf, k))
+        if hasattr(pf, 'coefs'):
+            at['coefs'] = [float(c) for c in pf.coefs]
+        return _jt(type(pf).__module__, type(pf).__name__, at)
+
+    def decenter(d):
+        if d is None:
+            return None
+        return _jt('rayoptics.elem.surface', 'DecenterData', {
+            '_dtype': d.dtype, 'dec': _jt_array(d.dec), 'euler': _jt_array(d.euler),
+            'rot_pt': _jt_array(d.rot_pt),
+            'rot_mat': None if d.rot_mat is None else _jt_array(d.rot_mat)})
+
+    def aperture(ca):
+        at = {'x_offset': float(ca.x_offset), 'y_offset': float(ca.y_offset), 'rotation': 0.0,
+              'is_obscuration': bool(ca.is_obscuration)}
+        if type(ca).__name__ == 'Circular':
+            at['radius'] = float(ca.radius)
+        else:
+            at['x_half_width'], at['y_half_width'] = float(ca.x_half_width), float(ca.y_half_width)
+        return _jt('rayoptics.elem.surface', type(ca).__name__, at)
+
+    def medium(m):
+        name = type(m).__name__
+        if name == 'Air':
+            return _jt('opticalglass.opticalmedium', 'Air', {})
+        if name == 'ModelGlass':
+            return _jt('opticalglass.modelglass', 'ModelGlass',
+                       {'n': float(m.n), 'v': float(m.vd), 'label': m.name() if callable(getattr(m, 'name', None)) else str(m.label)})
+        return _jt('opticalglass.opticalmedium', 'ConstantIndex',
+                   {'n': float(m.rindex(550.0)), 'label': ''})
+    ifcs = []
+    for ifc in sm.ifcs:
+        ifcs.append(_jt('rayoptics.elem.surface', 'Surface', {
+            'interact_mode': ifc.interact_mode, 'delta_n': float(getattr(ifc, 'delta_n', 0.0)),
+            'decenter': decenter(ifc.decenter), 'max_aperture': float(ifc.max_aperture),
+            'label': getattr(ifc, 'label', ''),
+            'clear_apertures': [aperture(ca) for ca in ifc.clear_apertures], 'edge_apertures': [],
+            'profile': profile(ifc.profile)}))
+    gaps = [_jt('rayoptics.seq.gap', 'Gap', {'thi': float(g.thi), 'medium': medium(g.medium)})
+            for g in sm.gaps]
+    wv = osp['wvls']
+    fov, pup = osp['fov'], osp['pupil']
+    spec = _jt('rayoptics.raytr.opticalspec', 'OpticalSpecs', {
+        'spectral_region': _jt('rayoptics.raytr.opticalspec', 'WvlSpec', {
+            'wavelengths': [float(w) for w in wv.wavelengths],
+            'spectral_wts': [float(w) for w in wv.spectral_wts], 'reference_wvl': int(wv.reference_wvl)}),
+        'pupil': _jt('rayoptics.raytr.opticalspec', 'PupilSpec',
+                     {'key': ['aperture'] + list(pup.key), 'value': float(pup.value)}),
+        'field_of_view': _jt('rayoptics.raytr.opticalspec', 'FieldSpec', {
+            'key': ['field'] + list(fov.key), 'value': float(fov.value),
+            'is_relative': bool(fov.is_relative),
+            'fields': [_jt('rayoptics.raytr.opticalspec', 'Field', {'x': float(f.x), 'y': float(f.y)})
+                       for f in fov.fields]})})
+    doc = {'optical_model': _jt('rayoptics.optical.opticalmodel', 'OpticalModel', {
+        'ro_version': 'written by tests/golden/make_golden.py dump_roa',
+        'seq_model': _jt('rayoptics.seq.sequential', 'SequentialModel', {
+            'ifcs': ifcs, 'gaps': gaps, 'stop_surface': sm.stop_surface,
+            'cur_surface': sm.cur_surface, 'z_dir': [int(z) for z in sm.z_dir],
+            'do_apertures': False}),
+        'optical_spec': spec, 'profile_dict': {}})}
+    with open(path, 'w') as f:
+        json.dump(doc, f, indent=1)
+
+
+def roa_decenter_fixture():
+    """tests/golden/decentered.roa + decentered_roa_table.json: refmodels.tilted_singlet()
+    (DecenterData 'dec and return' on a lens surface, a 'decenter' coordinate break, apertures)
+    written as a .roa, and the table the reference's own transforms give for that model."""
+    opm = rm.tilted_singlet()
+    path = os.path.join(HERE, 'decentered.roa')
+    dump_roa(opm, path)
+    tbl = ra.SurfaceTable.from_seq_model(opm['seq_model'])
+    with open(os.path.join(HERE, 'decentered_roa_table.json'), 'w') as f:
+        json.dump(tbl.to_dict(), f)
+    # the file read back through the reference's classes gives the same table
+    back = rm.load_roa(path)
+    t2 = ra.SurfaceTable.from_seq_model(back['seq_model'])
+    for t in (tbl, t2):         # (load_roa gives the object / image surfaces the class default)
+        t.rows[0].max_aperture = t.rows[-1].max_aperture = 1.0
+    same = all(bytes(a) == bytes(b) for a, b in zip(tbl.rows, t2.rows))
+    print(f'decentered.roa: {os.path.getsize(path) / 1024:.0f} KiB; read back through the '
+          f'reference classes: rows identical = {same}')
+
+
 C3_ZMX_DESC = ('BASELINE.json configs[2]: Zemax .zmx import -- rayoptics/zemax/tests/US08427765-1.ZMX, '
                '13 interfaces incl. one EVENASPH, 3 real-image-height fields x 3 wavelengths, image '
                "f/2.1 -- read by the reference's own zmxread; the five catalogue glasses carry their "
@@ -528,6 +638,9 @@ def main():
             'opd_f0': case_opd(opm, 0, 550.0, 11),
             'opd_f2': case_opd(opm, 2, 486.1, 10),
         })
+        return
+    if '--only-roa-decenter' in sys.argv:
+        roa_decenter_fixture()
         return
     if '--only-wideangle' in sys.argv:
         wideangle_cases()
@@ -636,6 +749,7 @@ def main():
 
     psf_cases()
     wideangle_cases()
+    roa_decenter_fixture()
 
     # aspheric toroids (Newton path, anamorphic)
     opm = rm.toroid_lens()

@@ -127,6 +127,9 @@ def _medium_from_json(m):
         return Air()
     if kind == 'ModelGlass':
         return ModelGlass(a['n'], a['v'], a.get('label', ''))
+    if kind == 'ConstantIndex':
+        from opticalglass.opticalmedium import ConstantIndex
+        return ConstantIndex(a['n'], a.get('label', ''))
     raise ValueError(f'medium {kind} needs a glass catalog')
 
 
@@ -178,6 +181,24 @@ def load_roa(path, pupil=None, fov=None, flds=None, wvls=None, ref_wl=None,
         s = surface.Surface(profile=_profile_from_json(pj_),
                             interact_mode=a['interact_mode'],
                             max_ap=a['max_aperture'])
+        dj = a.get('decenter')
+        if dj is not None:          # DecenterData as json_tricks writes it (the instance's __dict__)
+            da = dj['attributes']
+            vec = lambda v: v['__ndarray__'] if isinstance(v, dict) else v   # noqa: E731
+            dec, eul = vec(da['dec']), vec(da['euler'])
+            s.decenter = surface.DecenterData(da.get('_dtype', da.get('dtype')), x=dec[0], y=dec[1],
+                                              alpha=eul[0], beta=eul[1], gamma=eul[2])
+            s.decenter.dec[2] = dec[2]
+        for cj in a.get('clear_apertures') or []:
+            ca = cj['attributes']
+            kind = cj['__instance_type__'][1]
+            kw = dict(x_offset=ca.get('x_offset', 0.0), y_offset=ca.get('y_offset', 0.0),
+                      is_obscuration=ca.get('is_obscuration', False))
+            if kind == 'Circular':
+                s.clear_apertures.append(surface.Circular(radius=ca['radius'], **kw))
+            else:
+                s.clear_apertures.append(getattr(surface, kind)(
+                    x_half_width=ca['x_half_width'], y_half_width=ca['y_half_width'], **kw))
         g = gap.Gap(thi[k], _medium_from_json(sm_j['gaps'][k]['attributes']['medium']))
         sm.insert(s, g, z_dir=sm_j['z_dir'][k] if 'z_dir' in sm_j else 1)
         if k == sm_j['stop_surface']:

@@ -364,3 +364,32 @@ def test_ingested_prescriptions_trace_like_the_oracle():
             assert np.array_equal(dev.op, orc.op, equal_nan=True), key
         assert (orc.status == abi.OK).sum() > 20, (key, int((orc.status == abi.OK).sum()))
         eng.close()
+
+
+def test_decentered_roa_parsed_here_traces_like_the_oracle():
+    """tests/golden/decentered.roa (DecenterData records, a coordinate break, aperture lists)
+    parsed on this box by rayoptics_amd.ingest -- no reference involved -- gives the table of
+    the `tilted_singlet` golden fixture, and the device traces it like the oracle"""
+    import os
+    from oracle import oracle
+    from rayoptics_amd import ingest
+    from rayoptics_amd.engine import TraceEngine
+    fx = H.fixture('tilted_singlet')
+    pres = ingest.read_roa(os.path.join(H.GOLDEN, 'decentered.roa'))
+    tbl = pres.to_table(wvls=fx.table.wvls, index_of=ingest.reference_fallback_index)
+    tbl.n_table[:] = fx.table.n_table
+    for a, b in zip(tbl.rows, fx.table.rows):
+        assert bytes(a) == bytes(b)
+    rng = np.random.default_rng(5)
+    R = 4096 + 33
+    pt0, d = H.random_rays(rng, R, tbl.rows[0].t[2], spread=7.0)
+    wi = (np.arange(R) % len(tbl.wvls)).astype(np.int32)
+    eng = TraceEngine(tbl)
+    opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES, out_mode=abi.OUT_FULL,
+                            first_surf=1, last_surf=tbl.n_ifcs - 2)
+    orc = oracle.trace_rays(tbl, pt0, d, wi, opts)
+    dev = eng.trace_rays(pt0, d, wi, opts, nan_fill=True).to_host()
+    np.testing.assert_array_equal(dev.status, orc.status)
+    H.bit_equal(dev.seg, orc.seg, 'decentered.roa')
+    assert 100 < int((orc.status == 0).sum()) < R
+    eng.close()

@@ -421,3 +421,40 @@ def test_synthetic_seq_with_every_command(tmp_path):
     rows_equal(ours, theirs, 'synthetic.seq')
     assert ours.rows[5].profile == abi.PROFILE_NAMES['YToroid'] and ours.rows[6].ph.kind == abi.PH_DOE_RADIAL
     assert ours.rows[1].n_ap == 1 and ours.rows[2].n_ap == 1 and ours.rows[4].ap[0].kind == abi.AP_ALWAYS_BLOCK
+
+
+def test_roa_decenter_records_ingested():
+    """a .roa whose surfaces carry DecenterData ('dec and return' on a lens surface, a
+    'decenter' coordinate break) -- tests/golden/decentered.roa, written in json_tricks'
+    layout from a live reference model by make_golden.dump_roa -- gives, field by field, the
+    table the reference's own transforms gave for that model (stored beside it)"""
+    import json
+    from rayoptics_amd import SurfaceTable, ingest
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    theirs = SurfaceTable.from_dict(json.load(open(os.path.join(here, 'decentered_roa_table.json'))))
+    pres = ingest.read_roa(os.path.join(here, 'decentered.roa'))
+    assert sum(s.decenter is not None for s in pres.ifcs) == 2
+    ours = pres.to_table(wvls=theirs.wvls, index_of=ingest.reference_fallback_index)
+    ours.n_table[:] = theirs.n_table            # (ModelGlass dispersion is the reference's)
+    rows_equal(ours, theirs, 'decentered.roa')
+    # the rotations are real ones
+    assert any(abs(r.rt[1]) > 1e-3 for r in ours.rows)
+
+
+@pytest.mark.needs_reference
+def test_roa_decenter_fixture_reads_back_through_the_reference_classes():
+    """the same file through the reference's own Surface / DecenterData / transform code
+    (refmodels.load_roa) gives that table too: the fixture is a faithful .roa"""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    import refmodels as rm
+    from rayoptics_amd import SurfaceTable
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    stored = SurfaceTable.from_dict(json.load(open(os.path.join(here, 'decentered_roa_table.json'))))
+    back = SurfaceTable.from_seq_model(rm.load_roa(os.path.join(here, 'decentered.roa'))['seq_model'])
+    live = SurfaceTable.from_seq_model(rm.tilted_singlet()['seq_model'])
+    for t in (stored, back, live):
+        t.rows[0].max_aperture = t.rows[-1].max_aperture = 1.0
+    rows_equal(back, stored, 'read back')
+    rows_equal(live, stored, 'live model')
