@@ -175,3 +175,4 @@ def test_psf_calls_from_several_threads():
     for t in ths:
         t.join()
     assert not errs, errs
+

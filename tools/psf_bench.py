@@ -25,6 +25,8 @@ def main():
     sizes = ((64, 256), (128, 512), (256, 1024), (512, 2048), (1024, 4096))
     if os.environ.get('PSF_ONLY_LARGE'):           # PMC passes: one size, few launches
         sizes = ((1024, 4096),)
+    if os.environ.get('PSF_SIZES'):                # e.g. PSF_SIZES=64x256,128x512
+        sizes = tuple(tuple(int(v) for v in t.split('x')) for t in os.environ['PSF_SIZES'].split(','))
     for ndim, maxdim in sizes:
         y, x = np.mgrid[-1:1:ndim * 1j, -1:1:ndim * 1j]
         opd = 1.5 * (x * x + y * y) + 0.4 * x * y * y
