@@ -61,6 +61,7 @@ def install(fallback='raise'):
              (ranalyses, 'calc_psf', _a.calc_psf),
              (ranalyses, 'update_psf_data', _a.update_psf_data),
              (SequentialModel, 'trace_grid', _t.seq_trace_grid),
+             (SequentialModel, 'trace_fan', _t.seq_trace_fan),
              (SequentialModel, 'trace_wavefront', _a.seq_trace_wavefront),
              # chief-ray aiming: trace.aim_chief_ray is imported by name into
              # opticalspec (opticalspec.py:19), so both bindings are replaced, and

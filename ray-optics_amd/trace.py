@@ -305,6 +305,111 @@ def seq_trace_grid(self, fct, fi, wl=None, num_rays=21, form='grid',
     return grids, wvls.render_colors
 
 
+_FAN_FIGURE_CALLBACKS = {'RayFanFigure.__init__.<locals>.ray_abr': 'ray',
+                         'RayFanFigure.__init__.<locals>.opd': 'opd'}
+
+
+def _fan_figure_callback(fct):
+    """RayFanFigure's own two callbacks (rayoptics/mpl/axisarrayfigure.py:110-129):
+    closures, recognised -- like SpotDiagramFigure's `spot` -- by module and qualified name"""
+    if getattr(fct, '__module__', '') != 'rayoptics.mpl.axisarrayfigure':
+        return None
+    return _FAN_FIGURE_CALLBACKS.get(getattr(fct, '__qualname__', ''))
+
+
+def seq_trace_fan(self, fct, fi, xy, num_rays=21, **kwargs):
+    """rayoptics/seq/sequential.py:1006-1056, as a replacement *method* of SequentialModel:
+    the x or y fan of field ``fi`` at every wavelength.  Chief ray and reference sphere per
+    wavelength stay the reference's; for RayFanFigure's own callbacks (transverse aberration,
+    OPD) the fans of all wavelengths are ONE launch in ROX_OUT_FAN mode (per ray: dx, dy and
+    the OPD against that wavelength's reference sphere) instead of a packet per ray and a
+    Python callback on each."""
+    from rayoptics.raytr import trace as ref_trace
+    from .table import wavefront_from_model, UnsupportedModelError
+    opt_model = self.opt_model
+    osp = opt_model.optical_spec
+    fld = osp.field_of_view.fields[fi]
+    wvl = self.central_wavelength()
+    foc = osp.defocus.get_focus()
+
+    rs_pkg, cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, wvl, foc)
+    fld.chief_ray = cr_pkg
+    fld.ref_sphere = rs_pkg
+    # the central wavelength's image point is the reference for every wavelength (:1019-1020)
+    ref_img_pt = rs_pkg[0]
+
+    wvls = osp.spectral_region
+    fan_start = np.array([0., 0.])
+    fan_stop = np.array([0., 0.])
+    fan_start[xy] = -1.0
+    fan_stop[xy] = 1.0
+    fan_def = [fan_start, fan_stop, num_rays]
+    kind = _fan_figure_callback(fct)
+    fusable = (kind is not None and kwargs.get('output_filter') is None
+               and kwargs.get('rayerr_filter') is None and not kwargs.get('filter_out_phantoms', False))
+    rc, setups = [], []
+    for wi, w in enumerate(wvls.wavelengths):
+        rc.append(wvls.render_colors[wi])
+        rs_pkg, cr_pkg = ref_trace.setup_pupil_coords(opt_model, fld, w, foc, image_pt=ref_img_pt)
+        fld.chief_ray = cr_pkg
+        fld.ref_sphere = rs_pkg
+        wf = None
+        if fusable:
+            try:
+                wf = wavefront_from_model(opt_model, fld, cr_pkg, rs_pkg)
+            except UnsupportedModelError:
+                fusable = False
+        setups.append((w, rs_pkg, cr_pkg, wf))
+
+    fans = []                      # per wavelength: [(pupil[xy], value)]
+    if fusable:
+        kw = dict(kwargs)
+        kw['apply_vignetting'] = kw.get('apply_vignetting', True)
+        flds, wis, optl = [], [], []
+        eng = None
+        for w, rs_pkg, _cr, wf in setups:
+            eng, f, widx, opts = _launch_setup(opt_model, fld, w, dict(kw), abi.OUT_FAN, foc,
+                                               rs_pkg[0][:2], wf)
+            flds.append(f)
+            wis.append(widx)
+            optl.append(opts)
+        res = eng.trace_pupil_grids(flds, wis, make_grid(fan_def[0], fan_def[1], num_rays, abi.GRID_FAN),
+                                    optl)
+        for (w, _rs, _cr, _wf), r in zip(setups, res):
+            h = r.to_host(want=('seg', 'status', 'pupil'))
+            seg = h.seg if h.seg.ndim == 2 else h.seg[0]       # [3][num_rays]: dx, dy, OPD
+            if kind == 'opd':
+                # convert_to_waves = 1/self.wvl_to_sys_units(wvl) of the figure (:126)
+                val = (1 / opt_model.nm_to_sys_units(w)) * seg[2]
+            else:
+                val = seg[xy]
+            fans.append([(h.pupil[xy, k], val[k]) for k in range(num_rays) if h.status[k] == abi.OK])
+    else:
+        for w, rs_pkg, cr_pkg, _wf in setups:
+            fld.chief_ray = cr_pkg
+            fld.ref_sphere = rs_pkg
+            fan = trace_fan(opt_model, fan_def, fld, w, foc,
+                            img_filter=lambda p, ray_pkg, w=w: fct(p, xy, ray_pkg, fld, w, foc),
+                            **dict(kwargs))
+            fans.append([(p[xy], y_val) for p, y_val in fan])
+    # (the field is left with the last wavelength's chief ray and sphere, as in the reference)
+    fans_x, fans_y = [], []
+    max_rho_val = 0.0
+    max_y_val = 0.0
+    for fan in fans:
+        f_x, f_y = [], []
+        for x_val, y_val in fan:
+            f_x.append(x_val)
+            f_y.append(y_val)
+            if abs(x_val) > max_rho_val:
+                max_rho_val = abs(x_val)
+            if abs(y_val) > max_y_val:
+                max_y_val = abs(y_val)
+        fans_x.append(f_x)
+        fans_y.append(f_y)
+    return np.array(fans_x), np.array(fans_y), (max_rho_val, max_y_val), rc
+
+
 # ---- chief-ray aiming --------------------------------------------------------
 def _aim_problem(opt_model, fld, wvl, tbl, stop):
     """rox_aim for iterate_ray (trace.py:313-415) aiming at the centre of the stop: the 1-D

@@ -73,6 +73,57 @@ def test_spot_diagram_figure_unchanged(ref, installed):
             np.testing.assert_array_equal(go, gt)
 
 
+@pytest.mark.parametrize('model', ['dblgauss', 'telecentric'])
+@pytest.mark.parametrize('data_type', ['Ray', 'OPD'])
+def test_ray_fan_figure_unchanged(ref, installed, model, data_type):
+    """RayFanFigure (rayoptics/mpl/axisarrayfigure.py:100-174) drives
+    SequentialModel.trace_fan with its own `ray_abr` / `opd` callbacks: the rebound method
+    recognises them and fuses each field's fans over all wavelengths into one ROX_OUT_FAN
+    launch -- the figure's data (pupil coordinate, aberration, axis maxima) is unchanged;
+    finite and infinite reference spheres"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    from rayoptics.mpl.axisarrayfigure import RayFanFigure
+    opm = getattr(ref, model)()
+
+    def run():
+        fig = plt.figure(FigureClass=RayFanFigure, opt_model=opm, data_type=data_type,
+                         do_smoothing=False, num_rays=15)
+        fig.update_data()
+        data = [[(np.array(cell[0]), np.array(cell[1]), cell[2]) for cell in row]
+                for row in fig.axis_data_array]
+        plt.close(fig)
+        return data
+    ours, theirs = both(installed, run)
+    assert len(ours) == len(theirs) == len(opm['osp']['fov'].fields)
+    n_values = 0
+    for ro, rt_ in zip(ours, theirs):
+        for (xo, yo, mo), (xt, yt, mt) in zip(ro, rt_):
+            np.testing.assert_array_equal(xo, xt)
+            np.testing.assert_array_equal(yo, yt)
+            assert mo == mt
+            n_values += yo.size
+    assert n_values > 100
+
+
+def test_seq_trace_fan_generic_callback(ref, installed):
+    """any other callback through SequentialModel.trace_fan: packets per ray, the caller's
+    function on each (sequential.py:1040-1042)"""
+    opm = ref.dblgauss()
+    sm = opm['seq_model']
+
+    def fct(p, xy, ray_pkg, fld, wvl, foc):
+        return ray_pkg[0][-1][0][xy] + 1e-3 * ray_pkg[1]
+
+    def run():
+        return sm.trace_fan(fct, 2, 1, num_rays=11)
+    (xo, yo, mo, co), (xt, yt, mt, ct) = both(installed, run)
+    np.testing.assert_array_equal(xo, xt)
+    np.testing.assert_array_equal(yo, yt)
+    assert mo == mt and co == ct
+
+
 def test_trace_grid_callback_forms(ref, installed):
     import rayoptics.raytr.trace as trace
     opm = ref.dblgauss()

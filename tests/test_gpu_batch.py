@@ -127,6 +127,43 @@ def test_batched_wavefront_maps():
     assert done >= 4
 
 
+def test_batched_fans_all_wavelengths_in_one_launch():
+    """ROX_OUT_FAN over a GRID_FAN grid, one item per wavelength with its own reference sphere,
+    focus and image point -- what the rebound SequentialModel.trace_fan launches for
+    RayFanFigure -- item by item equal to the oracle"""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine
+    from test_oracle_golden import OPD_CASES, opd_opts
+    done = 0
+    for name in ('dblgauss', 'telecentric'):
+        fx = H.fixture(name)
+        cs = [fx[case] for n, case in OPD_CASES if n == name]
+        eng = TraceEngine(fx.table)
+        for xy in (0, 1):
+            start, stop = np.zeros(2), np.zeros(2)
+            start[xy], stop[xy] = -1.0, 1.0
+            grid = oracle.make_grid(start, stop, 21, abi.GRID_FAN)
+            flds, wis, opts = [], [], []
+            for k, c in enumerate(cs):
+                o = opd_opts(c)
+                o.out_mode = abi.OUT_FAN
+                o.flags |= abi.APPLY_VIGNETTING
+                o.foc, o.image_pt[0], o.image_pt[1] = 0.01 * k, 0.01, -0.02 * k
+                flds.append(H.field_from_arr(c['field']))
+                wis.append(int(c['wvl_idx']))
+                opts.append(o)
+            res = eng.trace_pupil_grids(flds, wis, grid, opts, nan_fill=True)
+            for f, w, o, r in zip(flds, wis, opts, res):
+                orc = oracle.trace_pupil_grid(fx.table, f, grid, w, o)
+                dev = r.to_host()
+                np.testing.assert_array_equal(dev.status, orc.status)
+                H.bit_equal(dev.seg, orc.seg, f'{name} fan xy={xy}')
+                H.bit_equal(dev.pupil, orc.pupil, 'pupil')
+                done += 1
+        eng.close()
+    assert done >= 8
+
+
 def test_batch_argument_checks():
     from rayoptics_amd import workloads
     from rayoptics_amd.engine import TraceEngine, make_grid, EngineError
