@@ -67,7 +67,8 @@ def test_struct_layouts_match_header(tmp_path):
     import subprocess
     structs = {'rox_aperture': abi.Aperture, 'rox_phase': abi.Phase, 'rox_surface': abi.Surface,
                'rox_wavefront': abi.Wavefront, 'rox_opts': abi.Opts, 'rox_field': abi.Field,
-               'rox_grid': abi.Grid, 'rox_out': abi.Out, 'rox_aim': abi.Aim, 'rox_vig': abi.Vig}
+               'rox_grid': abi.Grid, 'rox_out': abi.Out, 'rox_aim': abi.Aim, 'rox_vig': abi.Vig,
+               'rox_enp': abi.Enp}
     lines = ['#include <stdio.h>', '#include <stddef.h>',
              f'#include "{ROOT}/include/roxtrace.h"', 'int main(void) {']
     for cname, st in structs.items():
