@@ -2,7 +2,8 @@
 """Soak of the small entries, device vs oracle: every ray-start branch with random field
 constants (bit for bit), chief-ray aiming on perturbed problems (bit for bit), the vignetting
 search on perturbed fields (<= 1e-12: the objective squares a coordinate, libm pow in the
-reference and the oracle, an exact product in the kernel).
+reference and the oracle, an exact product in the kernel), the wide-angle pupil search on
+random directions / pupil guesses / starting points (bit for bit, result codes included).
 
     python tools/entry_soak.py"""
 import json
@@ -114,6 +115,44 @@ def main():
             ok = np.isfinite(vd) & np.isfinite(vo)
             worst_vig = max(worst_vig, float(np.abs(vd[ok] - vo[ok]).max()) if ok.any() else 0.0)
         eng.close()
+    # ---- the wide-angle pupil search: random field directions, pupil guesses and starting
+    # points on three tables (problems need no reference: any direction / rotation pair is a
+    # valid input to the search)
+    n_enp = bad_enp = 0
+    codes = {}
+    for name in ('dblgauss_c2', 'nikkor_c3', 'cell_phone'):
+        wl = workloads.load(name)
+        eng = TraceEngine(wl.table)
+        stop = wl.table.stop_idx if getattr(wl.table, 'stop_idx', None) is not None else 1
+        z0 = float(wl.table.rows[0].t[2])
+        probs = []
+        for trial in range(600):
+            ang = np.deg2rad(rng.uniform(0., 88.) if trial % 4 else rng.uniform(0., 20.))
+            e = abi.Enp()
+            d = np.array([0., np.sin(ang), np.cos(ang)])
+            # rot_v1_into_v2([0, 0, 1], d) for a direction in the y-z plane: a rotation about x
+            rot = np.array([[1., 0., 0.], [0., np.cos(ang), np.sin(ang)], [0., -np.sin(ang), np.cos(ang)]])
+            for i in range(3):
+                e.dir0[i] = d[i]
+                for j in range(3):
+                    e.rot[3 * i + j] = rot[i, j]
+            e.rot_order = abi.RT_C_ORDER
+            e.obj_dist = z0
+            e.z_enp_0 = float(rng.uniform(2., 80.)) * (1 if trial % 7 else -1)
+            e.aim_info = float('nan') if trial % 5 else e.z_enp_0 * rng.uniform(0.5, 1.5)
+            e.wvl_idx = int(rng.integers(0, len(wl.table.wvls)))
+            e.surf = int(stop) if trial % 11 else max(1, int(stop) - 1)
+            e.check_direction = 1 if trial % 13 else 0
+            probs.append(e)
+        zd, rd = eng.find_real_enp(probs)
+        zo, ro = oracle.find_real_enp(wl.table, probs)
+        n_enp += len(probs)
+        bad_enp += int(((rd != ro) | ~((zd == zo) | (np.isnan(zd) & np.isnan(zo))).all(axis=1)).sum())
+        for c in ro.tolist():
+            codes[c] = codes.get(c, 0) + 1
+        eng.close()
+    out['wide_angle_search'] = {'problems': n_enp, 'mismatching': bad_enp,
+                                'oracle_result_codes': {str(k): v for k, v in sorted(codes.items())}}
     out['aiming'] = {'problems': n_aim, 'mismatching': bad_aim}
     out['vignetting'] = {'problems': n_vig, 'clip_surface_mismatches': bad_clip, 'max_abs_diff': worst_vig}
     out['seconds'] = round(time.time() - t0, 1)
