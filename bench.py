@@ -58,6 +58,7 @@ import json
 import os
 import socket
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -81,6 +82,8 @@ def parse():
     ap.add_argument('--cpu-sample-rows', type=int, default=0,
                     help='pupil rows traced by the CPU baseline (0 = auto, ~10 s)')
     ap.add_argument('--no-strong', action='store_true', help='skip the strong-scaling leg')
+    ap.add_argument('--strong-timeout', type=float, default=300.0,
+                    help='multi-rank runs: seconds after which the strong-scaling leg is given up')
     ap.add_argument('--no-configs', action='store_true', help='skip the per-config leg')
     ap.add_argument('--strong-num', type=int, default=2048,
                     help='pupil grid of the strong-scaling leg is num x num per (field, wvl)')
@@ -277,20 +280,7 @@ def main():
             configs = {'error': repr(e)}
     torch.cuda.empty_cache()
 
-    # every run: the fixed-size problems with the path's one exchange step
-    strong = None
-    if not args.no_strong:
-        try:
-            strong = strong_scaling(args, torch, dist, multi, world, rank, fence, ranks_seen)
-        except Exception as e:      # never lose the main line to the extra leg
-            import traceback
-            traceback.print_exc(file=sys.stderr)
-            strong = {'error': repr(e)}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(wl, fld, wi, opts, num, args.cpu_sample_rows)
-
+    line = None
     if rank == 0:
         traffic, traffic_source = committed_traffic(num, wl.name)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -332,18 +322,57 @@ def main():
                                      'is the floor)'},
             'configs': configs,
             'psf': psf,
-            'cpu_baseline': cpu,
-            'strong_scaling': strong,
+            'cpu_baseline': None,
+            'strong_scaling': None,
             'library': library_id(),
         }
-        # the one JSON line goes to the real stdout (fd 1 was pointed at stderr while the
-        # communicator was being built and the collectives ran)
+
+    emitted = threading.Event()
+
+    def emit():
+        """the one JSON line goes to the real stdout (fd 1 was pointed at stderr while the
+        communicator was being built and the collectives ran)"""
+        nonlocal saved_stdout
+        if rank != 0 or emitted.is_set():
+            return
+        emitted.set()
         sys.stdout.flush()
         if saved_stdout is not None:
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
             saved_stdout = None
         print(json.dumps(line), flush=True)
+
+    # every run: the fixed-size problems with the path's one exchange step.  The main line is
+    # complete at this point and must not be lost to this extra leg: an exception is recorded,
+    # and a rank that hangs in an exchange (a divergent failure would leave the others waiting
+    # in a collective until the backend's own timeout kills the job) trips a watchdog that
+    # prints the line without the leg and ends every rank with status 0.
+    if not args.no_strong:
+        def give_up():
+            if rank == 0:
+                line['strong_scaling'] = {'error': f'timed out after {args.strong_timeout} s: a rank hung in '
+                                                   'an exchange; the main line above is unaffected'}
+                emit()
+            os._exit(0)
+        dog = threading.Timer(args.strong_timeout, give_up) if multi else None
+        if dog:
+            dog.daemon = True
+            dog.start()
+        try:
+            strong = strong_scaling(args, torch, dist, multi, world, rank, fence, ranks_seen)
+        except Exception as e:
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            strong = {'error': repr(e)}
+        if dog:
+            dog.cancel()
+        if rank == 0:
+            line['strong_scaling'] = strong
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(wl, fld, wi, opts, num, args.cpu_sample_rows)
+    emit()
     if multi:
         if saved_stdout is not None:            # other ranks: keep their fd 1 on stderr
             os.close(saved_stdout)

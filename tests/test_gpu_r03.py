@@ -255,6 +255,24 @@ def test_bench_launches_its_own_ranks():
     assert s['c5']['rccl']['grids_delivered'] == 45 and s['c4']['rccl']['grids_delivered'] == 5
 
 
+def test_bench_main_line_survives_a_hung_strong_scaling_leg():
+    """the watchdog of the strong-scaling leg: with a timeout the leg cannot meet, rank 0 still
+    prints exactly one JSON line -- the complete main line, the leg recorded as timed out --
+    and every rank ends with status 0"""
+    env = dict(os.environ, ROX_BENCH_BACKEND='gloo', ROX_BENCH_SHARE_GPU='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5',
+                        '--warmup', '2', '--no-cpu-baseline', '--no-configs', '--strong-timeout', '0.02'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b['n_gpus'] == 2 and b['value'] > 1e9 and b['roofline']['frac'] > 0.1
+    assert 'timed out' in b['strong_scaling']['error']
+
+
 def aim2d_problem(m, wvl_idx=None):
     a = abi.Aim()
     for i in range(3):
