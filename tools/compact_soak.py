@@ -25,7 +25,7 @@ def main():
     rng = np.random.default_rng(21)
     t0 = time.time()
     flags = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
-    n = bad = n_hp = bad_hp = 0
+    n = bad = n_hp = bad_hp = n_b = bad_b = 0
     for name in ('dblgauss_c2', 'rc_telescope_c4', 'nikkor_c3'):
         wl = workloads.load(name)
         eng = TraceEngine(wl.table)
@@ -66,9 +66,41 @@ def main():
             bad_hp += not (rc == 0 and np.array_equal(res.status, orc.status)
                            and np.array_equal(res.seg, orc.seg, equal_nan=True)
                            and np.array_equal(res.op, orc.op, equal_nan=True))
+        # rox_trace_pupil_grids: random item counts and grid sizes, packed hits and FULL packets,
+        # every item against the single-grid entry on the device (itself soaked against the
+        # oracle above) -- the per-item tickets / look-back states and the item slots re-armed
+        # between back-to-back batches of different shapes
+        for trial in range(trials // 6):
+            k = int(rng.integers(1, 24))
+            num = int(rng.integers(1, 200)) if trial % 4 else int(rng.integers(200, 700))
+            pairs = [(int(rng.integers(0, len(wl.fields))), int(rng.integers(0, len(wl.table.wvls))))
+                     for _ in range(k)]
+            grid = oracle.make_grid(rng.uniform(-1.3, -0.5, 2), rng.uniform(0.5, 1.3, 2), num)
+            mode = abi.OUT_HITS_COMPACT if trial % 3 else abi.OUT_FULL
+            optl = [oracle.make_opts(flags=flags, out_mode=mode, first_surf=1, last_surf=N - 2,
+                                     foc=float(rng.uniform(-0.05, 0.05)), image_pt=wl.image_pts[fi])
+                    for fi, _wi in pairs]
+            flds = [wl.fields[fi] for fi, _wi in pairs]
+            wis = [wi_ for _fi, wi_ in pairs]
+            if mode == abi.OUT_HITS_COMPACT:
+                got = eng.trace_pupil_grids_hits(flds, wis, grid, optl)
+                got = [g.copy() for g in got]
+                for f, w_, o, g in zip(flds, wis, optl, got):
+                    one = eng.trace_pupil_grid_hits(f, grid, w_, o)
+                    n_b += 1
+                    bad_b += not (one.shape == g.shape and np.array_equal(one, g))
+            else:
+                res = eng.trace_pupil_grids(flds, wis, grid, optl, nan_fill=True)
+                for f, w_, o, r in zip(flds, wis, optl, res):
+                    a = r.to_host()
+                    b = eng.trace_pupil_grid(f, grid, w_, o, nan_fill=True).to_host()
+                    n_b += 1
+                    bad_b += not (np.array_equal(a.status, b.status) and np.array_equal(a.seg, b.seg, equal_nan=True)
+                                  and np.array_equal(a.op, b.op, equal_nan=True))
         eng.close()
     print(json.dumps({'compact_launches': n, 'compact_mismatching': bad, 'host_pointer_calls': n_hp,
-                      'host_pointer_mismatching': bad_hp, 'seconds': round(time.time() - t0, 1)}))
+                      'host_pointer_mismatching': bad_hp, 'batched_items': n_b, 'batched_mismatching': bad_b,
+                      'seconds': round(time.time() - t0, 1)}))
 
 
 if __name__ == '__main__':
