@@ -12,7 +12,7 @@
 #   benchN:<n>[:extra args]        plain `python bench.py --gpus n` (self-launch; gloo + shared GPU rehearsal)
 #   prof[:tag[:extra args]]        rocprofv3 --kernel-trace --stats of bench.py (no cpu baseline) -> prof[_tag]/
 #   pmc:<workload>[:num]           tools/pmc_collect.sh passes for a workload -> pmc_<tag>_<workload>/
-#   probe:<mode>:<workload>[:field[:lib]]   tools/sustained_probe.py (steady-state kernel time)
+#   probe:<mode>:<workload>[:field[:lib[:uncached]]]   tools/sustained_probe.py (steady-state kernel time)
 #   py:<script and args>           python <script...> > <tag>/<script>.out
 #   lib:<variant.so>               export ROX_LIB for the following steps ("lib:" resets)
 #   env:NAME=VALUE                 export for the following steps ("env:NAME=" unsets)
@@ -84,9 +84,9 @@ PY
       wl=${rest%%:*}
       bash tools/pmc_collect.sh "${TAG}_$wl" $(echo "$rest" | tr ':' ' ') ;;
     probe)
-      IFS=: read -r mode wl field lib <<< "$rest"
+      IFS=: read -r mode wl field lib unc <<< "$rest"
       [ -n "${lib:-}" ] && export ROX_LIB="$PWD/$lib"
-      timeout 300 python tools/sustained_probe.py --mode "$mode" --workload "${wl:-dblgauss_c2}" --field "${field:-0}" --seconds 2 2>/dev/null \
+      timeout 300 python tools/sustained_probe.py --mode "$mode" --workload "${wl:-dblgauss_c2}" --field "${field:-0}" --seconds 2 ${unc:+--uncached} 2>/dev/null \
         | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$rest', d['lib'], 'mean_us', round(d['mean_us'],1), 'last_quarter', round(d['last_quarter_mean_us'],1))" | tee -a "$OUT/probe.txt"
       unset ROX_LIB ;;
     py)

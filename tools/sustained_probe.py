@@ -36,6 +36,8 @@ def main():
     ap.add_argument('--workload', default='dblgauss_c2')
     ap.add_argument('--field', type=int, default=0)
     ap.add_argument('--num', type=int, default=1024)
+    ap.add_argument('--uncached', action='store_true',
+                    help='packet buffer from hipExtMallocWithFlags(hipDeviceMallocUncached) instead of torch')
     args = ap.parse_args()
     import torch
     import rayoptics_amd  # noqa: F401
@@ -55,6 +57,21 @@ def main():
     grid = make_grid((-1., -1.), (1., 1.), args.num)
     out = DeviceResult(torch, eng.device, eng.num_segments(flags), R, mode,
                        want_pupil=(mode == abi.OUT_FULL), nan_fill=False)
+    if args.uncached:
+        import ctypes as C
+        hip = C.CDLL('libamdhip64.so')
+        ptr = C.c_void_p()
+        nbytes = out._seg.numel() * 8
+        rc = hip.hipExtMallocWithFlags(C.byref(ptr), C.c_size_t(nbytes), C.c_uint(3))   # hipDeviceMallocUncached
+        if rc != 0:
+            raise SystemExit(f'hipExtMallocWithFlags: {rc}')
+        inner = out.out_struct
+
+        def patched():
+            o_ = inner()
+            o_.seg = ptr.value
+            return o_
+        out.out_struct = patched
     samples = []
     stop = threading.Event()
 
@@ -76,7 +93,7 @@ def main():
     stop.set()
     th.join()
     n = len(series)
-    print(json.dumps({'lib': os.path.basename(engine.LIB_PATH), 'mode': args.mode,
+    print(json.dumps({'lib': os.path.basename(engine.LIB_PATH), 'mode': args.mode, 'uncached': args.uncached,
                       'workload': args.workload, 'field': args.field, 'num': args.num,
                       'first_batches_us': [s[1] for s in series[:12]],
                       'every_50th_batch_us': [s[1] for s in series[::max(n // 40, 1)]],
