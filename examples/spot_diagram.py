@@ -31,16 +31,18 @@ def main(num=1024):
     N = wl.n_ifcs
     flags = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
     grid = make_grid((-1., -1.), (1., 1.), num)
-    for fi, fld in enumerate(wl.fields):
-        for wi, wvl in enumerate(wl.table.wvls):
-            opts = make_opts(flags=flags, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
-                             foc=wl.foc, image_pt=wl.image_pts[fi])
-            res = eng.trace_pupil_grid(fld, grid, wi, opts, want_pupil=False)
-            ok = res.status == 0
-            xy = res.seg[:, ok]                  # transverse aberrations of the rays that get through
-            rms = float(xy.std(dim=1).norm())
-            print(f'field {fi}  {wvl:6.1f} nm  {int(ok.sum()):8d} of {num * num} rays   '
-                  f'rms spot radius {rms * 1e3:8.3f} um')
+    # every (field, wavelength) spot of the lens in ONE launch (rox_trace_pupil_grids): the rays
+    # that get through come back packed in ray order, one (R_ok, 2) host array per spot --
+    # what SequentialModel.trace_grid(spot, fi, wl, num_rays, form='list') returns
+    pairs = [(fi, wi) for fi in range(len(wl.fields)) for wi in range(len(wl.table.wvls))]
+    opts = [make_opts(flags=flags, out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                      foc=wl.foc, image_pt=wl.image_pts[fi]) for fi, _wi in pairs]
+    spots = eng.trace_pupil_grids_hits([wl.fields[fi] for fi, _wi in pairs], [wi for _fi, wi in pairs],
+                                       grid, opts)
+    for (fi, wi), xy in zip(pairs, spots):
+        rms = float(np.linalg.norm(xy.std(axis=0)))
+        print(f'field {fi}  {wl.table.wvls[wi]:6.1f} nm  {len(xy):8d} of {num * num} rays   '
+              f'rms spot radius {rms * 1e3:8.3f} um')
     eng.close()
 
 

@@ -393,3 +393,18 @@ def test_decentered_roa_parsed_here_traces_like_the_oracle():
     H.bit_equal(dev.seg, orc.seg, 'decentered.roa')
     assert 100 < int((orc.status == 0).sum()) < R
     eng.close()
+
+
+@pytest.mark.parametrize('script,args,expect', [('spot_diagram.py', ['96'], 'rms spot radius'),
+                                                 ('wavefront_psf.py', ['32', '128'], 'Strehl')])
+def test_examples_run(script, args, expect):
+    """the stand-alone examples run as written (subprocess, from the repo root)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'examples', script)] + args,
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if expect in ln]
+    assert len(lines) >= 2, r.stdout[-1000:]
