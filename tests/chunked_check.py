@@ -90,5 +90,25 @@ for name in ('dblgauss', 'tilted_singlet'):
         assert np.array_equal(dev.status, orc.status)
         same(dev.seg, orc.seg, 'rays seg')
         same(dev.op, orc.op, 'rays op')
+    # rox_trace_pupil_grids when an item needs more than one launch (num * num > the limit): the
+    # entry falls back to the plain path item by item; below the limit it is one batched launch
+    if name == 'dblgauss':
+        for num3, what in ((131, 'fallback'), (60, 'batched')):
+            g4 = oracle.make_grid((-1., -1.), (1., 1.), num3)
+            flds = [fld, H.field_from_arr(fx['grid_f2']['field']), fld]
+            wis = [0, 1, 2]
+            for mode in (abi.OUT_FULL, abi.OUT_HITS_COMPACT):
+                optl = [H.make_opts(c, out_mode=mode, foc=0.01 * k, image_pt=(0.1, 0.3)) for k in range(3)]
+                want = [oracle.trace_pupil_grid(fx.table, f, g4, w, o) for f, w, o in zip(flds, wis, optl)]
+                if mode == abi.OUT_HITS_COMPACT:
+                    got = eng.trace_pupil_grids_hits(flds, wis, g4, optl)
+                    for g, w in zip(got, want):
+                        same(g, w.hits, f'grids {what} compact')
+                else:
+                    got = eng.trace_pupil_grids(flds, wis, g4, optl, nan_fill=True)
+                    for g, w in zip(got, want):
+                        h = g.to_host()
+                        assert np.array_equal(h.status, w.status)
+                        same(h.seg, w.seg, f'grids {what} seg')
     eng.close()
 print('chunked ok')
