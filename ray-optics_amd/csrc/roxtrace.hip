@@ -325,6 +325,21 @@ int blocks_per_cu(int bs)
     return v > 0 ? v : 32 * 256 / bs;      // measured: FULL 238 us at 8/CU, 228 us at 32/CU (256 threads)
 }
 
+// HITS_COMPACT: workgroups per CU.  Tiles are drawn by ticket, so any number of workgroups
+// finishes the launch; a CU holds exactly one 1024-thread workgroup of these instances, and one
+// persistent workgroup per CU that draws its four tiles in turn (table staged once, no
+// workgroup start-up between tiles) measured 146 us per 2^20 rays into HBM against 159 us
+// for one workgroup per tile (nine appended grids: 1.36 vs 1.49 ms; two per CU 1.40).
+// ROX_COMPACT_BLOCKS_PER_CU overrides it for experiments.
+int compact_blocks_per_cu()
+{
+    static const int v = [] {
+        const char *e = getenv("ROX_COMPACT_BLOCKS_PER_CU");
+        return e ? atoi(e) : 0;
+    }();
+    return v > 0 ? v : 1;
+}
+
 // rays per kernel launch (lane byte offsets are 32-bit: at most 2^28).
 // ROX_RAYS_PER_LAUNCH overrides it (tests exercise the chunked path with it).
 // HITS_COMPACT: how many first tickets take small tiles (rox_device.hpp compact_tiles).
@@ -497,7 +512,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
         // enough workgroups to fill 256 CUs several times over, grid-stride the rest
         const int bs = block_of(a.opts.out_mode, kInstances[inst]);
         int64_t blocks = compact ? compact_tiles(a.n_rays, a.small_tiles, bs) : (a.n_rays + bs - 1) / bs;
-        const int64_t cap = (int64_t)sys->num_cus * blocks_per_cu(bs);
+        const int64_t cap = (int64_t)sys->num_cus * (compact ? compact_blocks_per_cu() : blocks_per_cu(bs));
         if (blocks > cap)
             blocks = cap;
         k.grid = dim3((unsigned)blocks);
@@ -1120,7 +1135,7 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
     // items -- all resident at once, each striding over its item -- measured 6 % slower on
     // config 5's 45 grids of 2048 x 2048.)  HITS_COMPACT draws tiles by ticket: any number
     // of workgroups per item will do.
-    const int64_t cap = (int64_t)sys->num_cus * blocks_per_cu(bs);
+    const int64_t cap = (int64_t)sys->num_cus * (compact ? compact_blocks_per_cu() : blocks_per_cu(bs));
     if (blocks > cap)
         blocks = cap;
     // items -> pinned slot -> device, in stream order
