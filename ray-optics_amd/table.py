@@ -350,7 +350,34 @@ def field_struct(pt0, aim, eprad, z_enp, vig=(0., 0., 0., 0.), z_dir0=1.0,
     return f
 
 
-def field_from_model(opt_model, fld, pupil_type='rel pupil'):
+def _obj_coords(opt_model, fld, cache):
+    """``osp.obj_coords(fld)`` (rayoptics/raytr/opticalspec.py:990-1091).  For fields given
+    as real image heights it runs ``wideangle.eval_real_image_ht`` -- a reverse chief-ray
+    iteration of several single rays -- on every call; the reference calls it once per
+    *ray* (trace_base -> ray_start_from_osp), the drop-ins once per launch, and a spot
+    diagram's launches for one field all get the same answer.  ``cache`` (a dict that lives
+    and dies with the engine handle, i.e. with the model state) memoises exactly that case,
+    keyed by everything the result depends on beside the model: the field's coordinates, the
+    field specification and the first-order data object; the side effect (``fld.aim_info``
+    set to the pupil aim the iteration found, :1019-1030) is replayed on a hit."""
+    osp = opt_model['optical_spec']
+    fov = osp['fov']
+    if cache is None or tuple(fov.key) != ('image', 'real height'):
+        return osp.obj_coords(fld)
+    key = (id(fld), float(fld.x), float(fld.y), float(fov.value), bool(fov.is_relative),
+           bool(fov.is_wide_angle), float(osp['wvls'].central_wvl),
+           id(opt_model['analysis_results']['parax_data']))
+    hit = cache.get(key)
+    if hit is None:
+        p0, d0 = osp.obj_coords(fld)
+        hit = cache[key] = (np.array(p0, dtype=float), np.array(d0, dtype=float),
+                            None if fld.aim_info is None else np.array(fld.aim_info, dtype=float))
+    p0, d0, aim = hit
+    fld.aim_info = None if aim is None else (float(aim) if aim.ndim == 0 else aim.copy())
+    return p0.copy(), d0.copy()
+
+
+def field_from_model(opt_model, fld, pupil_type='rel pupil', cache=None):
     """per-field constants of ``OpticalSpecs.ray_start_from_osp``
     (rayoptics/raytr/opticalspec.py:289-400), every branch: 'epd' pupils
     (plain, wide-angle, 'aim pt'), angular pupils ('NA', 'f/#', 'aim dir').
@@ -365,7 +392,7 @@ def field_from_model(opt_model, fld, pupil_type='rel pupil'):
     pupil_oi_key, pupil_value_key = osp['pupil'].key
     pupil_value = osp['pupil'].value
     n_obj, n_img = osp.obj_img_rindex()
-    p0, d0 = osp.obj_coords(fld)                       # :306
+    p0, d0 = _obj_coords(opt_model, fld, cache)       # :306
     if pupil_oi_key == 'image':                        # :311-325
         if abs(fod.m) < 1e-10:
             pupil_value_key, pupil_value = 'epd', 2 * fod.enp_radius

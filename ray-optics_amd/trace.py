@@ -143,7 +143,7 @@ def _launch_setup(opt_model, fld, wvl, kwargs, out_mode, foc=0.0, image_pt=(0., 
     eng = session.engine_for(opt_model)
     tbl = eng.table
     opts = opts_from_kwargs(tbl.n_ifcs, kwargs, out_mode, foc, image_pt, wf)
-    f = field_from_model(opt_model, fld, pupil_type)
+    f = field_from_model(opt_model, fld, pupil_type, cache=eng.__dict__.setdefault('_obj_coords_cache', {}))
     if pupil_type != 'rel pupil':
         opts.flags &= ~abi.APPLY_VIGNETTING             # trace.py:291-295
     if f.kind == abi.FLD_EPD_WIDE or f.z_dir0 == 0.0:

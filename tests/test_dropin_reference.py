@@ -124,6 +124,60 @@ def test_seq_trace_fan_generic_callback(ref, installed):
     assert mo == mt and co == ct
 
 
+def test_real_image_height_fields_memoised_obj_coords(ref, installed):
+    """fields given as real image heights (BASELINE configs[2]'s .zmx: ('image', 'real
+    height'), wide angle): osp.obj_coords runs a reverse chief-ray iteration on every call
+    (opticalspec.py:1019-1030, wideangle.eval_real_image_ht).  The drop-ins memoise it per
+    engine handle: the same grids as the reference on the first and on later launches, the
+    same fld.aim_info left behind, and a changed field coordinate is a miss"""
+    import rayoptics.raytr.trace as trace
+    import rayoptics.raytr.wideangle as wa
+    opm = ref.zmx_evenasph_c3()
+    osp = opm['osp']
+    assert tuple(osp['fov'].key) == ('image', 'real height')
+    fld = osp['fov'].fields[2]
+    wvl = opm['seq_model'].central_wavelength()
+    calls = []
+    real = wa.eval_real_image_ht
+
+    def counting(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    def spot(p, pkg):
+        return None if pkg is None else np.array([p[0], p[1], pkg[0][-1][0][0], pkg[0][-1][0][1]])
+
+    def run():
+        out = []
+        y0 = fld.y
+        for y in (y0, y0, 0.8 * y0, y0):
+            fld.y = y
+            fld.aim_info = None
+            g = trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 7], fld, wvl, 0.0,
+                                 img_filter=spot, form='list', append_if_none=False)
+            out.append((np.array(g), float(fld.aim_info)))
+        fld.y = y0
+        return out
+    import rayoptics.raytr.opticalspec as ropt
+    saved = ropt.eval_real_image_ht
+    ropt.eval_real_image_ht = counting
+    try:
+        ours = run()
+        n_ours = len(calls)
+        installed.uninstall()
+        calls.clear()
+        theirs = run()
+        n_theirs = len(calls)
+        installed.install()
+    finally:
+        ropt.eval_real_image_ht = saved
+    for (go, ao), (gt, at) in zip(ours, theirs):
+        np.testing.assert_array_equal(go, gt)
+        assert ao == at
+    # the reference iterates once per ray; the drop-ins once per distinct field state
+    assert n_theirs == 4 * 49 and n_ours == 2, (n_ours, n_theirs)
+
+
 def test_trace_grid_callback_forms(ref, installed):
     import rayoptics.raytr.trace as trace
     opm = ref.dblgauss()
