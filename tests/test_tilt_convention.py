@@ -35,13 +35,10 @@ def _angles(n, seed):
 
 
 def test_ingest_tilt_matrix_matches_scipy_intrinsic_xyz():
-    worst = 0.
     for e in _angles(2000, 11):
         ours = ingest._euler2rot3d(e)
         theirs = Rotation.from_euler('XYZ', [-e[0], -e[1], e[2]], degrees=True).as_matrix()
-        worst = max(worst, float(np.abs(ours - theirs).max()))
         assert np.abs(ours - theirs).max() <= 4 * ULP, (e, ours, theirs)
-    assert worst > 0. or True          # (exact agreement would be fine too)
 
 
 def test_refshim_euler2mat_matches_scipy_intrinsic_xyz():
