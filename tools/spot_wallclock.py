@@ -58,6 +58,20 @@ def main():
                         args.reps)
     res['A_product_pinned_ms'] = {'median': med, 'min': mn, 'rays_through': int(xy.shape[0])}
     ref_xy = xy.copy()
+    # A': every wavelength of the field -- one call per wavelength (SequentialModel.trace_grid's
+    # loop) against trace_grid_spots (one batched launch, one synchronise)
+    wvls = list(wl.table.wvls)
+    if len(wvls) > 1:
+        def looped():
+            return [trace.trace_grid_spot(model, grid_rng, fld, w, wl.foc, image_pt) for w in wvls]
+        trace.trace_grid_spots(model, grid_rng, fld, wvls, wl.foc, image_pt)            # warm
+        one, med1, mn1 = timed(looped, args.reps)
+        allw, med2, mn2 = timed(lambda: trace.trace_grid_spots(model, grid_rng, fld, wvls, wl.foc, image_pt),
+                                args.reps)
+        assert all(np.array_equal(a, b) for a, b in zip(one, allw))
+        res['A_all_wavelengths_ms'] = {'wavelengths': len(wvls), 'one_call_per_wavelength': {'median': med1, 'min': mn1},
+                                       'one_batched_launch': {'median': med2, 'min': mn2}}
+        del one, allw
 
     eng = session.engine_for(model)
     lib = load_library()
