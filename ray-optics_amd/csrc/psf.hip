@@ -12,10 +12,12 @@
 // cores (v_mfma_f64_16x16x4_f64), for any M -- no power-of-two restriction --
 // and costs 8 M n (n + M) flop instead of a full M x M FFT's passes over HBM.
 //
-//   psf_prepare   P^T (phase of the block, transposed) and F (twiddles)
+//   psf_prepare   P^T (phase of the block, transposed) and F (twiddles: once per shape)
 //   cgemm_nt<0>   T = F P            C[i][j] = sum_k A[i][k] B[j][k], complex
 //   cgemm_nt<1>   AP = |T F^T|^2 and its maximum (epilogue)
 //   psf_scale     AP / max
+// Up to maxdim 512 (the sizes figures use) the GEMMs take 32 x 32 workgroup tiles; the padded
+// planes are zeroed and F is formed once per shape, not per call.
 //
 // Matrices are kept as separate real / imaginary planes, row-major with the
 // reduction index contiguous and padded with zeros to a multiple of 16 (rows
@@ -48,29 +50,37 @@ __host__ __device__ inline int64_t round_up(int64_t v, int64_t m) { return (v + 
 //   block origin o = M/2 - (n/2 - 1)                       (analyses.py:861-863)
 //   fftshift = roll by h = M/2 on input and output          (numpy.fft.fftshift)
 //   F[u][a]  = exp(-2 pi i ((u - h) mod M) ((o + a + h) mod M) / M)
+// exp(i 2 pi W) of one OPD entry with the entries that equal 1 zeroed (analyses.py:864-870)
+__device__ __forceinline__ void pupil_phase(double w, double &c, double &s)
+{
+    if (w != w)                                     // np.nan_to_num
+        w = 0.0;
+    else if (w == __builtin_inf())
+        w = DBL_MAX;
+    else if (w == -__builtin_inf())
+        w = -DBL_MAX;
+    // 1j*2*np.pi*W: the imaginary part is the single product 2 pi W
+    const double x = 6.283185307179586 * w;
+    sincos(x, &s, &c);
+    if (c == 1.0 && s == 0.0)                       // phase[i][j] == 1 -> 0 (:867-870)
+        c = s = 0.0;
+}
+
+// P^T (per call) and, when `twiddles`, F (per shape: it depends on (n, M) only)
 __global__ void psf_prepare(const double *opd, int n, int M, int kp, double *ptr, double *pti,
-                            double *fr, double *fi)
+                            double *fr, double *fi, unsigned long long *maxbits, int phases, int twiddles)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (int64_t)n * n) {
+    if (idx == 0 && phases)
+        *maxbits = 0;               // this call's maximum starts from zero (the second GEMM folds into it)
+    if (phases && idx < (int64_t)n * n) {
         const int a = (int)(idx / n), b = (int)(idx % n);
-        double w = opd[idx];
-        if (w != w)                                 // np.nan_to_num
-            w = 0.0;
-        else if (w == __builtin_inf())
-            w = DBL_MAX;
-        else if (w == -__builtin_inf())
-            w = -DBL_MAX;
-        // 1j*2*np.pi*W: the imaginary part is the single product 2 pi W
-        const double x = 6.283185307179586 * w;
         double s, c;
-        sincos(x, &s, &c);
-        if (c == 1.0 && s == 0.0)                   // phase[i][j] == 1 -> 0 (:867-870)
-            c = s = 0.0;
+        pupil_phase(opd[idx], c, s);
         ptr[(int64_t)b * kp + a] = c;
         pti[(int64_t)b * kp + a] = s;
     }
-    if (idx < (int64_t)M * n) {
+    if (twiddles && idx < (int64_t)M * n) {
         const int u = (int)(idx / n), a = (int)(idx % n);
         const int h = M / 2, o = M / 2 - (n / 2 - 1);
         const int64_t uu = (u - h + M) % M, ii = (o + a + h) % M;
@@ -82,15 +92,7 @@ __global__ void psf_prepare(const double *opd, int n, int M, int kp, double *ptr
     }
 }
 
-// C[i][j] = sum_k A[i][k] B[j][k] (complex, planes, K contiguous, padded).
-// One wave owns a 32 x 32 tile = 2 x 2 MFMA tiles.  v_mfma_f64_16x16x4_f64:
-// lane l feeds A[row = l & 15][k = l >> 4] and B[k = l >> 4][col = l & 15] and
-// holds C[row = (l >> 4) + 4 q][col = l & 15], q = 0..3.  Each lane loads four
-// consecutive k of its row at once; MFMA number e of a 16-wide k block then
-// multiplies the k set {4 g + e} -- the same permutation on both operands.
-// EPI 0: store the complex product;  EPI 1: store |C|^2 (as abs()**2) and fold
-// the maximum into *maxbits (non-negative doubles order like their bit patterns).
-template <int EPI>
+template <int EPI, int TM>      // TM x TM MFMA tiles per wave: 2 (32 x 32, large problems) or 1 (figure sizes)
 __global__ __launch_bounds__(256) void cgemm_nt(const double *__restrict__ ar_, const double *__restrict__ ai_,
                                                 const double *__restrict__ br_, const double *__restrict__ bi_,
                                                 int kp, int I, int J, double *c0, double *c1, int ldc,
@@ -98,11 +100,12 @@ __global__ __launch_bounds__(256) void cgemm_nt(const double *__restrict__ ar_, 
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
-    const int i0 = blockIdx.y * kTile + (wave >> 1) * 32;
-    const int j0 = blockIdx.x * kTile + (wave & 1) * 32;
-    d4 cr[2][2], ci[2][2];
-    for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b)
+    constexpr int WT = 16 * TM;             // rows / columns of the wave's tile; the block's is 2 WT
+    const int i0 = blockIdx.y * (2 * WT) + (wave >> 1) * WT;
+    const int j0 = blockIdx.x * (2 * WT) + (wave & 1) * WT;
+    d4 cr[TM][TM], ci[TM][TM];
+    for (int a = 0; a < TM; ++a)
+        for (int b = 0; b < TM; ++b)
             cr[a][b] = ci[a][b] = d4{0., 0., 0., 0.};
     const double *pa_r = ar_ + (size_t)(i0 + r) * kp + 4 * g;
     const double *pa_i = ai_ + (size_t)(i0 + r) * kp + 4 * g;
@@ -111,17 +114,17 @@ __global__ __launch_bounds__(256) void cgemm_nt(const double *__restrict__ ar_, 
     const size_t t16 = (size_t)16 * kp;
     // software pipeline: the operands of k block i + 1 are in flight while the 64 MFMAs of
     // block i issue (a lone wave per SIMD has nobody else to hide the load latency behind)
-    d4 xr[2], xi[2], yr[2], yi[2];
-    for (int t = 0; t < 2; ++t) {
+    d4 xr[TM], xi[TM], yr[TM], yi[TM];
+    for (int t = 0; t < TM; ++t) {
         xr[t] = *(const d4 *)(pa_r + t * t16);
         xi[t] = *(const d4 *)(pa_i + t * t16);
         yr[t] = *(const d4 *)(pb_r + t * t16);
         yi[t] = *(const d4 *)(pb_i + t * t16);
     }
     for (int k0 = 0; k0 < kp; k0 += kKBlock) {
-        d4 nxr[2], nxi[2], nyr[2], nyi[2], xn[2];
+        d4 nxr[TM], nxi[TM], nyr[TM], nyi[TM], xn[TM];
         const int kn = (k0 + kKBlock < kp) ? k0 + kKBlock : k0;     // last block: a harmless reload
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < TM; ++t) {
             nxr[t] = *(const d4 *)(pa_r + t * t16 + kn);
             nxi[t] = *(const d4 *)(pa_i + t * t16 + kn);
             nyr[t] = *(const d4 *)(pb_r + t * t16 + kn);
@@ -131,21 +134,21 @@ __global__ __launch_bounds__(256) void cgemm_nt(const double *__restrict__ ar_, 
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < TM; ++b) {
                     cr[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[a][e], yr[b][e], cr[a][b], 0, 0, 0);
                     cr[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xn[a][e], yi[b][e], cr[a][b], 0, 0, 0);
                     ci[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[a][e], yi[b][e], ci[a][b], 0, 0, 0);
                     ci[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xi[a][e], yr[b][e], ci[a][b], 0, 0, 0);
                 }
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < TM; ++t) {
             xr[t] = nxr[t]; xi[t] = nxi[t]; yr[t] = nyr[t]; yi[t] = nyi[t];
         }
     }
     double vmax = 0.0;
-    for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b)
+    for (int a = 0; a < TM; ++a)
+        for (int b = 0; b < TM; ++b)
             for (int q = 0; q < 4; ++q) {
                 const int row = i0 + 16 * a + g + 4 * q, col = j0 + 16 * b + r;
                 if (row >= I || col >= J)
@@ -183,6 +186,7 @@ struct Workspace {
     hipStream_t stream = nullptr;
     char *buf = nullptr;
     size_t cap = 0;
+    int64_t zeroed_for[3] = {0, 0, 0};      // (n, M, bytes) the padded planes were last zeroed for
     std::mutex mu;          // one call at a time builds / enqueues on this workspace
 };
 std::mutex g_mu;
@@ -260,6 +264,7 @@ extern "C" int rox_calc_psf(const double *opd, int32_t ndim, int32_t maxdim, dou
         ws->cap = 0;
         PSF_TRY(hipMalloc((void **)&ws->buf, total));
         ws->cap = total;
+        ws->zeroed_for[0] = ws->zeroed_for[1] = ws->zeroed_for[2] = 0;
     }
     char *p = ws->buf;
     double *fr = (double *)p;               p += pl_f;
@@ -271,7 +276,18 @@ extern "C" int rox_calc_psf(const double *opd, int32_t ndim, int32_t maxdim, dou
     unsigned long long *maxbits = (unsigned long long *)p;  p += 64;
     double *d_opd = (double *)p;            p += (b_opd + 63) & ~size_t(63);
     double *d_psf = (double *)p;
-    PSF_TRY(hipMemsetAsync(ws->buf, 0, zeroed, st));
+    // The planes are zero-padded to the GEMM tiles.  Every element inside the (n, M) shape is
+    // rewritten by each call and the padding is never written, so the planes need zeroing only
+    // when the workspace is new or the shape changes; the twiddles F depend on the shape alone
+    // and are formed then too (at figure sizes a call is little but stream operations and
+    // sincospi).  Forming the phases inside the first product instead -- three launches --
+    // measured slower from (64, 256) up: every block row repeats the n^2 sincos.
+    const bool new_shape = ws->zeroed_for[0] != n || ws->zeroed_for[1] != M ||
+                           ws->zeroed_for[2] != (int64_t)zeroed;
+    if (new_shape) {
+        PSF_TRY(hipMemsetAsync(ws->buf, 0, zeroed, st));
+        ws->zeroed_for[0] = n; ws->zeroed_for[1] = M; ws->zeroed_for[2] = (int64_t)zeroed;
+    }
     const double *src = opd;
     double *dst = psf;
     if (host) {
@@ -280,14 +296,23 @@ extern "C" int rox_calc_psf(const double *opd, int32_t ndim, int32_t maxdim, dou
         dst = d_psf;
     }
     const int64_t work = (int64_t)M * n;        // >= n * n
-    hipLaunchKernelGGL(psf_prepare, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, src, n, M,
-                       (int)kp, ptr, pti, fr, fi);
-    // T[u][b] = sum_a F[u][a] P[a][b]
-    hipLaunchKernelGGL(cgemm_nt<0>, dim3((unsigned)(np_ / kTile), (unsigned)(mp / kTile)), dim3(256), 0, st,
-                       fr, fi, ptr, pti, (int)kp, M, n, tr, ti, (int)kp, maxbits);
-    // AP[u][v] = |sum_b T[u][b] F[v][b]|^2
-    hipLaunchKernelGGL(cgemm_nt<1>, dim3((unsigned)(mp / kTile), (unsigned)(mp / kTile)), dim3(256), 0, st,
-                       tr, ti, fr, fi, (int)kp, M, M, dst, (double *)nullptr, M, maxbits);
+    const bool small = M <= 512;
+    hipLaunchKernelGGL(psf_prepare, dim3((unsigned)(((new_shape ? work : (int64_t)n * n) + 255) / 256)), dim3(256), 0,
+                       st, src, n, M, (int)kp, ptr, pti, fr, fi, maxbits, 1, new_shape ? 1 : 0);
+    // T[u][b] = sum_a F[u][a] P[a][b];  AP[u][v] = |sum_b T[u][b] F[v][b]|^2.
+    // 64 x 64 workgroup tiles give a (64, 256) problem 4 and 16 workgroups on 256 CUs: up to
+    // maxdim 512 the 32 x 32 instance is used (one MFMA tile per wave, four times the workgroups)
+    if (small) {
+        hipLaunchKernelGGL((cgemm_nt<0, 1>), dim3((unsigned)(np_ / 32), (unsigned)(mp / 32)), dim3(256), 0, st,
+                           fr, fi, ptr, pti, (int)kp, M, n, tr, ti, (int)kp, maxbits);
+        hipLaunchKernelGGL((cgemm_nt<1, 1>), dim3((unsigned)(mp / 32), (unsigned)(mp / 32)), dim3(256), 0, st,
+                           tr, ti, fr, fi, (int)kp, M, M, dst, (double *)nullptr, M, maxbits);
+    } else {
+        hipLaunchKernelGGL((cgemm_nt<0, 2>), dim3((unsigned)(np_ / kTile), (unsigned)(mp / kTile)), dim3(256), 0, st,
+                           fr, fi, ptr, pti, (int)kp, M, n, tr, ti, (int)kp, maxbits);
+        hipLaunchKernelGGL((cgemm_nt<1, 2>), dim3((unsigned)(mp / kTile), (unsigned)(mp / kTile)), dim3(256), 0, st,
+                           tr, ti, fr, fi, (int)kp, M, M, dst, (double *)nullptr, M, maxbits);
+    }
     hipLaunchKernelGGL(psf_scale, dim3(1024), dim3(256), 0, st, dst, (int64_t)M * M, maxbits);
     PSF_TRY(hipGetLastError());
     if (host) {
