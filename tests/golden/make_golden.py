@@ -594,7 +594,7 @@ def dump_roa(opm, path):
             'do_apertures': False}),
         'optical_spec': spec, 'profile_dict': {}})}
     with open(path, 'w') as f:
-        json.dump(doc, f, indent=1)
+        json.dump(doc, f, separators=(',', ':'))
 
 
 def roa_decenter_fixture():
