@@ -164,6 +164,53 @@ def test_batched_fans_all_wavelengths_in_one_launch():
     assert done >= 8
 
 
+def test_batches_from_two_threads_on_two_streams():
+    """two host threads, each with its own HIP stream, enqueue batches of different shapes on
+    ONE handle at the same time (item slots, per-item tickets and look-back states live in the
+    per-stream context): every item still equals the oracle"""
+    import threading
+    import torch
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_grid
+    wl = workloads.load('dblgauss_c2')
+    eng = TraceEngine(wl.table)
+    W = len(wl.table.wvls)
+    jobs = {0: (37, [(fi, wi) for fi in range(3) for wi in range(W)]),
+            1: (120, [(2, 0), (0, 1), (1, 2), (2, 2), (0, 0)])}
+    want, got, errs = {}, {0: [], 1: []}, []
+    for k, (num, pairs) in jobs.items():
+        grid = make_grid((-1., -1.), (1., 1.), num)
+        opts = _items(wl, pairs, abi.OUT_HITS_COMPACT)
+        want[k] = [oracle.trace_pupil_grid(wl.table, wl.fields[fi], grid, wi, o).hits
+                   for (fi, wi), o in zip(pairs, opts)]
+
+    def work(k):
+        try:
+            num, pairs = jobs[k]
+            grid = make_grid((-1., -1.), (1., 1.), num)
+            opts = _items(wl, pairs, abi.OUT_HITS_COMPACT)
+            st = torch.cuda.Stream(device=eng.device)
+            with torch.cuda.stream(st):
+                for _ in range(12):
+                    got[k].append([g.copy() for g in eng.trace_pupil_grids_hits(
+                        [wl.fields[fi] for fi, _ in pairs], [wi for _, wi in pairs], grid, opts)])
+        except Exception as e:          # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(k,)) for k in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in jobs:
+        assert len(got[k]) == 12
+        for rep in got[k]:
+            for g, w in zip(rep, want[k]):
+                assert g.shape == w.shape and np.array_equal(g, w), k
+    eng.close()
+
+
 def test_batch_argument_checks():
     from rayoptics_amd import workloads
     from rayoptics_amd.engine import TraceEngine, make_grid, EngineError
