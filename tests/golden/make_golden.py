@@ -617,6 +617,19 @@ def roa_decenter_fixture():
           f'reference classes: rows identical = {same}')
 
 
+def time_trace_workloads():
+    """ray-optics_amd/data/tt_*.json: the models of the reference's own benchmark of this path
+    (rayoptics/raytr/tests/time_trace.py -> trace_results.txt) that are not BASELINE
+    configurations already, through the reference's importers (refmodels.time_trace_model)"""
+    import logging
+    logging.disable(logging.CRITICAL)
+    for name, rel, row, pub in rm.TIME_TRACE_MODELS:
+        workload_file(rm.time_trace_model(rel), name,
+                      f"reference benchmark model '{row}' (rayoptics/{rel}; "
+                      f'rayoptics/raytr/tests/trace_results.txt: {pub} rays/s on the author\'s machine)')
+    logging.disable(logging.NOTSET)
+
+
 C3_ZMX_DESC = ('BASELINE.json configs[2]: Zemax .zmx import -- rayoptics/zemax/tests/US08427765-1.ZMX, '
                '13 interfaces incl. one EVENASPH, 3 real-image-height fields x 3 wavelengths, image '
                "f/2.1 -- read by the reference's own zmxread; the five catalogue glasses carry their "
@@ -638,6 +651,9 @@ def main():
             'opd_f0': case_opd(opm, 0, 550.0, 11),
             'opd_f2': case_opd(opm, 2, 486.1, 10),
         })
+        return
+    if '--only-time-trace' in sys.argv:
+        time_trace_workloads()
         return
     if '--only-roa-decenter' in sys.argv:
         roa_decenter_fixture()
@@ -750,6 +766,7 @@ def main():
     psf_cases()
     wideangle_cases()
     roa_decenter_fixture()
+    time_trace_workloads()
 
     # aspheric toroids (Newton path, anamorphic)
     opm = rm.toroid_lens()

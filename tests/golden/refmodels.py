@@ -337,3 +337,72 @@ def telecentric():
     sm.add_surface([1 / 40.0, 5.0, 1.6, 50.0])
     sm.add_surface([-1 / 40.0, 30.0])
     return finish(opm)
+
+
+# ---- the models of the reference's own benchmark (rayoptics/raytr/tests/time_trace.py) ----------
+class NominalGlass(refshim.OpticalMedium):
+    """a named catalogue glass with the dispersion formula the product's ingest has on file
+    (rayoptics_amd.ingest.nominal_index); stands in for opticalglass, which is absent here"""
+
+    def __init__(self, name):
+        from rayoptics_amd import ingest
+        self._name = name
+        super().__init__(ingest.nominal_index(name, 587.6), name, 'nominal')
+
+    def rindex(self, w):
+        from rayoptics_amd import ingest
+        return ingest.nominal_index(self._name, refshim.get_wavelength(w))
+
+
+def _nominal_media(opm):
+    """glasses the (stubbed, empty) catalogue did not find -- ConstantIndex(1.5, 'not NAME'),
+    as the reference's importers leave them -- get their nominal dispersion"""
+    for g in opm['seq_model'].gaps:
+        nm = g.medium.name()
+        if nm.startswith('not '):
+            g.medium = NominalGlass(nm[4:].strip())
+    return opm
+
+
+def time_trace_model(rel):
+    """one of the ten models rayoptics/raytr/tests/time_trace.py times (paths relative to the
+    rayoptics package): .seq through the reference's CODE V importer, .roa through load_roa"""
+    import pathlib
+    path = pathlib.Path(REF_SRC) / 'rayoptics' / rel
+    if rel.endswith('.seq'):
+        from rayoptics.codev import cmdproc
+        from rayoptics.seq.sequential import SequentialModel
+        from rayoptics.optical.opticalmodel import OpticalModel
+        saved = SequentialModel.set_clear_apertures, OpticalModel.update_model
+        SequentialModel.set_clear_apertures = lambda self, **kw: None
+        OpticalModel.update_model = lambda self, **kw: None
+        try:
+            opm, _info = cmdproc.read_lens(path, do_update=False)
+        finally:
+            SequentialModel.set_clear_apertures, OpticalModel.update_model = saved
+        return finish(_nominal_media(opm), do_apertures=True)
+    global _medium_from_json
+    plain = _medium_from_json
+
+    def with_glasses(m):
+        try:
+            return plain(m)
+        except ValueError:
+            a = m.get('attributes', {})
+            return NominalGlass(a.get('gname') or a.get('label') or a.get('name'))
+    _medium_from_json = with_glasses
+    try:
+        return load_roa(str(path))
+    finally:
+        _medium_from_json = plain
+
+
+TIME_TRACE_MODELS = [       # (workload name, file, row of trace_results.txt, published rays/s)
+    ('tt_singlet_seq', 'codev/tests/singlet.seq', 'singlet', 7955),
+    ('tt_landscape', 'codev/tests/landscape_lens.seq', 'landscape lens', 6197),
+    ('tt_triplet', 'models/Sasian Triplet.roa', 'Sasian triplet', 3740),
+    ('tt_two_sph_mirrors', 'models/TwoSphericalMirror.roa', '2 spherical mirrors (spheres)', 8347),
+    ('tt_two_mirrors_conic', 'models/TwoMirror.roa', '2 spherical mirrors (conics)', 7994),
+    ('tt_paraboloid', 'codev/tests/paraboloid.seq', 'paraboloid', 7957),
+    ('tt_cassegrain', 'models/Cassegrain.roa', 'Cassegrain', 7973),
+]

@@ -118,3 +118,39 @@ def test_c5_40_surface_chain_2048_grid():
     assert np.abs(xy[0][ok] + xy[0][::-1][ok]).max() < 1e-9
     assert np.abs(xy[1][ok] - xy[1][::-1][ok]).max() < 1e-9
     eng.close()
+
+
+TT_MODELS = ['tt_singlet_seq', 'tt_landscape', 'tt_triplet', 'tt_two_sph_mirrors', 'tt_two_mirrors_conic',
+             'tt_paraboloid', 'tt_cassegrain']
+
+
+@pytest.mark.parametrize('name', TT_MODELS)
+def test_reference_benchmark_models(name):
+    """the models of the reference's own benchmark of this path (rayoptics/raytr/tests/
+    time_trace.py; workloads made from the files by the reference's importers): every field,
+    FULL packets and packed hits of a 96 x 96 grid, device == oracle"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    wl = workloads.load(name)
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    grid = make_grid((-1., -1.), (1., 1.), 96)
+    for fi, fld in enumerate(wl.fields):
+        flags = abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+        if not (fld.kind == abi.FLD_EPD_WIDE or fld.z_dir0 == 0.0):
+            flags |= abi.INTERSECT_OBJ
+        for mode in (abi.OUT_FULL, abi.OUT_HITS_COMPACT):
+            o = make_opts(flags=flags, out_mode=mode, first_surf=1, last_surf=N - 2, foc=wl.foc,
+                          image_pt=wl.image_pts[fi])
+            orc = oracle.trace_pupil_grid(wl.table, fld, grid, wl.ref_wvl_idx, o)
+            if mode == abi.OUT_FULL:
+                dev = eng.trace_pupil_grid(fld, grid, wl.ref_wvl_idx, o, nan_fill=True).to_host()
+                np.testing.assert_array_equal(dev.status, orc.status)
+                same = (dev.seg == orc.seg) | (np.isnan(dev.seg) & np.isnan(orc.seg))
+                assert same.all(), (name, fi)
+                assert 1000 < int((orc.status == 0).sum()) < 96 * 96
+            else:
+                got = eng.trace_pupil_grid_hits(fld, grid, wl.ref_wvl_idx, o)
+                assert np.array_equal(got, orc.hits), (name, fi)
+    eng.close()
