@@ -52,6 +52,10 @@
 extern "C" {
 #endif
 
+/* ABI history: 4 = packed hits appended over launches (ROX_HITS_APPEND), rox_pin_host_memory,
+ * rox_aim carries both branches of iterate_ray;  5 = rox_trace_pupil_grids (several grids, one
+ * launch), rox_find_real_enp / rox_enp (the wide-angle pupil search).  rox_abi_version() of the
+ * library must equal the header a binding was written against. */
 #define ROX_ABI_VERSION 5
 #define ROX_MAX_COEF 10   /* EvenPolynomial r^2..r^20 / RadialPolynomial r^1..r^10 */
 #define ROX_MAX_AP 4      /* clear apertures per surface carried in the table */
