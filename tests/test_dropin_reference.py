@@ -178,6 +178,35 @@ def test_real_image_height_fields_memoised_obj_coords(ref, installed):
     assert n_theirs == 4 * 49 and n_ours == 2, (n_ours, n_theirs)
 
 
+def test_spot_diagram_figure_on_the_zmx_import(ref, installed):
+    """BASELINE configs[2]'s model -- the .zmx import with an EVENASPH surface, real-image-height
+    fields, wide angle -- through the reference's SpotDiagramFigure: the rebound
+    SequentialModel.trace_grid batches each field's wavelengths into one launch and memoises
+    the fields' reverse chief-ray iteration; the figure's data is unchanged"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    from rayoptics.mpl.axisarrayfigure import SpotDiagramFigure
+    opm = ref.zmx_evenasph_c3()
+
+    def run():
+        fig = plt.figure(FigureClass=SpotDiagramFigure, opt_model=opm, num_rays=8)
+        fig.update_data()
+        data = [[np.array(g) for g in row[0][0]] for row in fig.axis_data_array]
+        plt.close(fig)
+        return data
+    ours, theirs = both(installed, run)
+    assert len(ours) == len(theirs) == 3
+    n = 0
+    for ro, rt_ in zip(ours, theirs):
+        assert len(ro) == len(rt_) == 3
+        for go, gt in zip(ro, rt_):
+            assert go.shape == gt.shape and go.shape[1] == 2
+            np.testing.assert_array_equal(go, gt)
+            n += len(go)
+    assert n > 200
+
+
 def test_trace_grid_callback_forms(ref, installed):
     import rayoptics.raytr.trace as trace
     opm = ref.dblgauss()
