@@ -73,7 +73,7 @@ def test_spot_diagram_figure_unchanged(ref, installed):
             np.testing.assert_array_equal(go, gt)
 
 
-@pytest.mark.parametrize('model', ['dblgauss', 'telecentric'])
+@pytest.mark.parametrize('model', ['dblgauss', 'telecentric', 'zmx_evenasph_c3', 'rc_telescope'])
 @pytest.mark.parametrize('data_type', ['Ray', 'OPD'])
 def test_ray_fan_figure_unchanged(ref, installed, model, data_type):
     """RayFanFigure (rayoptics/mpl/axisarrayfigure.py:100-174) drives
