@@ -134,6 +134,119 @@ def soak_dropins():
     session.ENGINE_FACTORY = None
 
 
+def soak_round3():
+    """round 3: the wide-angle pupil search restated in the oracle against the reference's
+    find_real_enp on random field angles of perturbed models (z_enp bit for bit; "the reference
+    raises" exactly where it does), 2-D chief-ray aiming (fsolve) through the drop-in on random
+    off-axis fields, SequentialModel.trace_fan with RayFanFigure's callbacks through the fused
+    batch"""
+    import warnings
+    import refmodels as ref
+    import rayoptics.raytr.wideangle as wa
+    import rayoptics.raytr.trace as rtrace
+    from rayoptics_amd import abi, session, install, SurfaceTable
+    from rayoptics_amd import trace as T
+    from oracle import oracle
+    from oracle_engine import OracleEngine
+    warnings.simplefilter('ignore')
+    rng = np.random.default_rng(303)
+    nik = os.path.join(ref.REF_SRC, 'rayoptics', 'optical', 'tests', 'Nikon Nikkor Z 14-30mm f-4 S.roa')
+    builders = [('dblgauss', ref.dblgauss, 75.),
+                ('nikkor', lambda: ref.load_roa(nik, fov=(('object', 'angle'), 57.7), flds=[0., 30., 57.7],
+                                                 is_relative=False), 80.)]
+    t0, n, bad, codes = time.time(), 0, [], {}
+    for name, build, top in builders:
+        for trial in range(12):
+            opm = build()
+            sm = opm['seq_model']
+            if trial:
+                for ifc in sm.ifcs[1:-1]:
+                    if hasattr(ifc, 'profile') and ifc.profile.cv != 0:
+                        ifc.profile.cv *= 1 + 0.1 * rng.normal()
+                ref.finish(opm, do_apertures=False)
+            fov = opm['osp']['fov']
+            fov.is_wide_angle = True
+            tbl = SurfaceTable.from_seq_model(sm)
+            for ang in rng.uniform(0., top, 40):
+                fld = fov.fields[-1]
+                fld.x, fld.y, fld.aim_info = 0., float(ang) / (fov.value if fov.is_relative else 1.0), None
+                wvl = sm.central_wavelength()
+                pb = T._enp_problem(opm, fld, wvl, tbl, sm.stop_surface)
+                z, res = oracle.find_real_enp(tbl, [pb])
+                codes[int(res[0])] = codes.get(int(res[0]), 0) + 1
+                try:
+                    z_ref, _rr = wa.find_real_enp(opm, sm.stop_surface, fld, wvl)
+                    ok = res[0] != abi.ENP_REFERENCE_RAISES and z[0, 0] == float(z_ref)
+                except Exception:
+                    ok = res[0] == abi.ENP_REFERENCE_RAISES
+                n += 1
+                if not ok:
+                    bad.append((name, trial, float(ang)))
+    print(json.dumps({'soak': 'wide-angle pupil search: oracle == reference find_real_enp', 'cases': n,
+                      'mismatches': bad[:5], 'result_codes': {str(k): v for k, v in sorted(codes.items())},
+                      'seconds': round(time.time() - t0, 1)}))
+    # 2-D aiming and the fan figure callbacks through the drop-ins (oracle as the engine)
+    session.ENGINE_FACTORY = OracleEngine
+    t0, n, bad = time.time(), 0, []
+    for build in (ref.dblgauss, ref.nikkor, ref.cell_phone):
+        for trial in range(25):
+            opm = perturbed(build, rng, 0.01)
+            fld = opm['osp']['fov'].fields[-1]
+            fld.x, fld.y = float(rng.uniform(-0.7, 0.7)), float(rng.uniform(-0.9, 0.9))
+
+            def run():
+                fld.aim_info = None
+                return np.array(rtrace.aim_chief_ray(opm, fld), dtype=float)
+            try:
+                theirs = run()
+            except Exception:
+                continue
+            install.install()
+            ours = run()
+            install.uninstall()
+            n += 1
+            if not np.array_equal(ours, theirs):
+                bad.append((build.__name__, trial))
+    print(json.dumps({'soak': '2-D chief-ray aiming (fsolve / hybrd) through the drop-in on perturbed models',
+                      'cases': n, 'mismatches': bad[:5], 'seconds': round(time.time() - t0, 1)}))
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    from rayoptics.mpl.axisarrayfigure import RayFanFigure
+    t0, n, bad = time.time(), 0, []
+    for build in (ref.dblgauss, ref.nikkor, ref.telecentric, ref.rc_telescope):
+        for trial in range(6):
+            try:
+                opm = perturbed(build, rng, 0.005)
+            except Exception:
+                continue
+            for data_type in ('Ray', 'OPD'):
+                def run():
+                    fig = plt.figure(FigureClass=RayFanFigure, opt_model=opm, data_type=data_type,
+                                     do_smoothing=False, num_rays=11)
+                    fig.update_data()
+                    d = [[(np.array(c[0]).tolist(), np.array(c[1]).tolist(), c[2]) for c in row]
+                         for row in fig.axis_data_array]
+                    plt.close(fig)
+                    return d
+                try:
+                    theirs = run()
+                except Exception:
+                    continue
+                install.install()
+                ours = run()
+                install.uninstall()
+                n += 1
+                if json.dumps(ours) != json.dumps(theirs):
+                    bad.append((build.__name__, trial, data_type))
+    print(json.dumps({'soak': 'RayFanFigure (Ray / OPD) through SequentialModel.trace_fan on perturbed models',
+                      'figures': n, 'mismatches': bad[:5], 'seconds': round(time.time() - t0, 1)}))
+    session.ENGINE_FACTORY = None
+
+
 if __name__ == '__main__':
+    if '--round3' in sys.argv:
+        soak_round3()
+        sys.exit(0)
     soak_tests()
     soak_dropins()
