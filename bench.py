@@ -34,11 +34,13 @@ configs       every BASELINE.json configuration at its own shape: kernel ms, ray
 spot_diagram  BASELINE's second metric at the PRODUCT boundary: wall-clock of
               rayoptics_amd.trace.trace_grid_spot from the Python call to the host
               (R_ok, 2) array, on a table-backed model
-cpu_baseline  the plain-C oracle (oracle/rox_oracle.c, "port"), 1 thread, on a
-              bounded sample of the same grid, timed on this host; next to it the
-              reference's own Python path AND the same port as timed together in the
-              build container (tools/time_reference.py) -- the same-host ratio bridges
-              the two hosts (the reference is not installed on the GPU box)
+cpu_baseline  kind "reference": the reference ITSELF (staged as sourceless byte code in
+              oracle/_ref by oracle/stage_reference.py), one core of this host: rt.trace over
+              64 rows x 1024 rays of the timed grid (the shape of its own time_trace.py) and
+              trace.trace_grid 256x256; every packet it returns is compared with the timed HIP
+              launch's (parity_vs_timed_launch).  Beside it the plain-C port
+              (oracle/rox_oracle.c), one thread and all cores.  Where no reference is staged:
+              kind "port" with the build container's reference figure bridged by a ratio
 strong_scaling  every run, any N: BASELINE configs[4]'s shape -- 9 fields x 5
               wavelengths x 2048^2 pupil grids of the 44-interface lithography
               lens (188.7 M rays) cut into pupil-row blocks over the ranks, packed
@@ -81,6 +83,9 @@ def parse():
                          'spot) even with one rank: a 1-GPU rehearsal of the N>1 run')
     ap.add_argument('--cpu-sample-rows', type=int, default=0,
                     help='pupil rows traced by the CPU baseline (0 = auto, ~10 s)')
+    ap.add_argument('--ref-sample-rows', type=int, default=64,
+                    help='pupil rows of the timed grid the reference itself (oracle/_ref) re-traces: '
+                         '64 x 1024 = 65 536 rays, ~15 s of its per-ray Python loop')
     ap.add_argument('--no-strong', action='store_true', help='skip the strong-scaling leg')
     ap.add_argument('--strong-timeout', type=float, default=300.0,
                     help='multi-rank runs: seconds after which the strong-scaling leg is given up')
@@ -259,6 +264,20 @@ def main():
         xy = rox_trace.trace_grid_spot(model, grid_rng, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
         spot_ms.append((time.perf_counter() - t1) * 1e3)
     n_through = int(xy.shape[0])
+    # the rows of the timed launch's packets the CPU legs re-trace (the reference itself, when
+    # it is staged on this host, is compared with them ray by ray)
+    dev_sample = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        rr = min(args.ref_sample_rows, num)
+        i0r = (num - rr) // 2
+        sl = slice(i0r * num, (i0r + rr) * num)
+        step()
+        torch.cuda.synchronize()
+        dev_sample = {'row0': i0r, 'rows': rr,
+                      'seg': out.seg[:, :, sl].cpu().numpy(), 'op': out.op[sl].cpu().numpy(),
+                      'status': out.status[sl].cpu().numpy(),
+                      'fail_surf': out.fail_surf[sl].cpu().numpy(),
+                      'pupil': out.pupil[:, sl].cpu().numpy()}
     del xy, out
 
     # the PSF of an OPD grid (analyses.calc_psf): the GEMM-shaped neighbour of the path,
@@ -371,7 +390,8 @@ def main():
             line['strong_scaling'] = strong
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line['cpu_baseline'] = cpu_baseline(wl, fld, wi, opts, num, args.cpu_sample_rows)
+        line['cpu_baseline'] = cpu_baseline(wl, fld, wi, opts, num, args.cpu_sample_rows,
+                                            fi, dev_sample)
     emit()
     if multi:
         if saved_stdout is not None:            # other ranks: keep their fd 1 on stderr
@@ -734,7 +754,191 @@ def reference_python():
     return out
 
 
-def cpu_baseline(wl, fld, wi, opts, num, rows):
+def cpu_baseline(wl, fld, wi, opts, num, rows, fi=0, dev_sample=None):
+    """the CPU beside the kernel, on this host.  When the reference itself is staged here
+    (oracle/_ref, built by oracle/stage_reference.py) the headline is ITS rate -- kind
+    "reference": rt.trace over a block of rows of the same grid, one core -- with the plain-C
+    port (oracle/rox_oracle.c) kept beside it; without it the port is the headline (kind
+    "port") and the reference's figure is the build container's, bridged by a same-host ratio."""
+    port = cpu_port(wl, fld, wi, opts, num, rows)
+    try:
+        live = cpu_reference_live(wl, fi, wi, num, dev_sample)
+    except Exception as e:                  # the bench line must not die with the baseline
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        live = {'error': repr(e)}
+    if not live or 'error' in live:
+        port['reference_on_this_host'] = live
+        return port
+    out = {'value': live['raw_rt_trace']['intersections_per_s'],
+           'unit': 'ray-surface intersections/s', 'cores': 1, 'kind': 'reference',
+           'sample': live['raw_rt_trace']['sample'],
+           'rays_per_s': live['raw_rt_trace']['rays_per_s'],
+           'host_cpu_count': os.cpu_count(), 'host': live['host'],
+           'driver_trace_grid': live['driver_trace_grid'],
+           'parity_vs_timed_launch': live['parity_vs_timed_launch'],
+           'reference_build': live['reference_build'],
+           'port': {k: port[k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'rays_per_s',
+                                         'all_cores')},
+           'port_over_reference_this_host': port['value'] / live['raw_rt_trace']['intersections_per_s'],
+           'reference_python_build_container': port.get('reference_python')}
+    return out
+
+
+def cpu_reference_live(wl, fi, wi, num, dev_sample):
+    """the reference's own Python path (mjhoptics/ray-optics, sourceless byte code staged in
+    oracle/_ref) timed on THIS host, one core, the shape of its own benchmark
+    (rayoptics/raytr/tests/time_trace.py:37-45: repeated rt.trace) on BASELINE configs[1]:
+
+      raw     rt.trace (raytrace.py:51-80) over `rows` x num rays of the timed num x num grid
+              -- the same pupil coordinates (accumulate-by-step), ray starts made by the
+              reference's own apply_vignetting / ray_start_from_osp, check_apertures=True
+      driver  trace.trace_grid (trace.py:563-605) with SpotDiagramFigure's spot filter over a
+              256 x 256 grid of the same field: what a user of the reference runs
+
+    and every packet the raw loop returns is compared with the packets of the timed HIP launch
+    (`dev_sample`: the same rows of the device result) -- segments, op_delta, failure kind and
+    surface.  None when no reference is importable on this host."""
+    from oracle import refshim
+    if not refshim.available():
+        return None
+    import platform
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    if gold not in sys.path:
+        sys.path.insert(0, gold)
+    import refmodels as rm                      # installs the import shim
+    import rayoptics.raytr.raytrace as rt
+    import rayoptics.raytr.trace as rtrace
+    from rayoptics.raytr.traceerror import (TraceError, TraceMissedSurfaceError, TraceTIRError,
+                                            TraceRayBlockedError)
+    from rayoptics_amd import abi
+    opm = rm.dblgauss()
+    sm, osp = opm['seq_model'], opm['optical_spec']
+    fld = osp['fov'].fields[fi]
+    wvl = osp['wvls'].wavelengths[wi]
+    N = len(sm.ifcs)
+    rows = dev_sample['rows'] if dev_sample else 64
+    row0 = dev_sample['row0'] if dev_sample else (num - rows) // 2
+    # pupil coordinates of the grid by repeated += (trace.py:563-605)
+    xs = np.empty(num)
+    step = 2.0 / (num - 1)
+    v = -1.0
+    for k in range(num):
+        xs[k] = v
+        v += step
+    starts = []
+    for i in range(row0, row0 + rows):
+        for j in range(num):
+            pupil = fld.apply_vignetting(np.array([xs[i], xs[j]]))
+            pt0, dir0 = osp.ray_start_from_osp(pupil, fld, 'rel pupil')
+            if dir0[2] * sm.z_dir[0] < 0:
+                dir0 = -dir0
+            starts.append((pt0, dir0))
+    R = len(starts)
+    pkgs = [None] * R
+    inters = 0
+    t0 = time.perf_counter()
+    for r, (pt0, dir0) in enumerate(starts):
+        try:
+            pkgs[r] = rt.trace(sm, pt0, dir0, wvl, check_apertures=True)
+            inters += N - 1
+        except TraceError as e:
+            pkgs[r] = e
+            inters += e.surf
+    dt_raw = time.perf_counter() - t0
+
+    # the driver a user calls: trace_grid with the spot filter, 256 x 256
+    foc = 0.0
+    rs_pkg, cr_pkg = rtrace.setup_pupil_coords(opm, fld, wvl, foc)
+    fld.chief_ray, fld.ref_sphere = cr_pkg, rs_pkg
+    img = rs_pkg[0]
+
+    def spot(p, ray_pkg):
+        if ray_pkg is None:
+            return None
+        pt = ray_pkg[0][-1][0]
+        return np.array([pt[0] - img[0], pt[1] - img[1]])
+    n_drv = 256
+    t0 = time.perf_counter()
+    g = rtrace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), n_drv], fld, wvl, foc,
+                          img_filter=spot, form='list', append_if_none=False)
+    dt_drv = time.perf_counter() - t0
+
+    parity = None
+    if dev_sample is not None:
+        kinds = {TraceMissedSurfaceError: abi.MISSED_SURFACE, TraceTIRError: abi.TIR,
+                 TraceRayBlockedError: abi.BLOCKED}
+        seg, op = dev_sample['seg'], dev_sample['op']
+        st, fs = dev_sample['status'], dev_sample['fail_surf']
+        worst, n_bits, n_vals, bad_status = 0.0, 0, 0, 0
+        for r, pk in enumerate(pkgs):
+            if isinstance(pk, TraceError):
+                k = next((c for t, c in kinds.items() if isinstance(pk, t)), -1)
+                bad_status += int(st[r] != k or fs[r] != pk.surf)
+                continue
+            bad_status += int(st[r] != abi.OK)
+            ref = np.array([np.concatenate([s_[0], s_[1], [s_[2]], s_[3]]) for s_ in pk[0]])
+            dev = seg[:, :, r]
+            same = ref == dev
+            n_bits += int(same.sum())
+            n_vals += ref.size + 1
+            n_bits += int(pk[1] == op[r])
+            err = np.abs(ref - dev) / np.maximum(1.0, np.abs(ref))
+            worst = max(worst, float(err.max()), abs(pk[1] - op[r]) / max(1.0, abs(pk[1])))
+        parity = {'rays': R, 'rows_of_the_timed_grid': [row0, row0 + rows],
+                  'status_or_surface_mismatches': bad_status,
+                  'values_compared': n_vals, 'values_bit_identical': n_bits,
+                  'max_scaled_abs_diff': worst, 'tolerance_north_star': 1e-10,
+                  'what': 'every packet rt.trace returned for these rays vs the same rays of the '
+                          'timed HIP launch: 13 segments x 10 doubles + op_delta per surviving ray; '
+                          'failure class and surface for the others'}
+    return {
+        'host': {'cpu': _cpu_model(), 'nproc': os.cpu_count(), 'python': platform.python_version(),
+                 'numpy': np.__version__, 'blas': _blas_info()},
+        'reference_build': {'where': 'oracle/_ref (sourceless byte code, oracle/stage_reference.py)'
+                            if refshim.is_staged() else refshim.REFERENCE_SRC,
+                            'stamp': _ref_stamp()},
+        'raw_rt_trace': {'seconds': dt_raw, 'rays': R, 'intersections': inters,
+                         'rays_per_s': R / dt_raw, 'intersections_per_s': inters / dt_raw,
+                         'sample': f'the reference\'s rt.trace (raytrace.py:51-80), one core, over pupil '
+                                   f'rows {row0}..{row0 + rows - 1} x {num} = {R} rays of the timed '
+                                   f'{num}x{num} grid (field {fi}, {wvl} nm, check_apertures), {dt_raw:.1f} s'},
+        'driver_trace_grid': {'seconds': dt_drv, 'rays': n_drv * n_drv, 'rays_through': len(g),
+                              'rays_per_s': n_drv * n_drv / dt_drv,
+                              'extrapolated_1M_ray_spot_s': dt_drv * (1024 * 1024) / (n_drv * n_drv),
+                              'what': 'trace.trace_grid (trace.py:563-605), spot filter, 256x256, one core'},
+        'parity_vs_timed_launch': parity}
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.startswith('model name'):
+                    return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _blas_info():
+    try:
+        b = np.show_config(mode='dicts').get('Build Dependencies', {}).get('blas', {})
+        return f"{b.get('name')} {b.get('version')}"
+    except Exception:
+        return 'unknown'
+
+
+def _ref_stamp():
+    try:
+        with open(os.path.join(ROOT, 'oracle', '_ref', 'stamp.json')) as f:
+            st = json.load(f)
+        return {k: st.get(k) for k in ('source_hash', 'python', 'modules')}
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_port(wl, fld, wi, opts, num, rows):
     """the oracle (plain-C port of the reference's algorithm), one thread, on a
     bounded sample of the same workload: the first `rows` pupil rows of the
     num x num grid (explicit pupil coordinates, same accumulate-by-step)."""

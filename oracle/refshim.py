@@ -17,20 +17,55 @@ The one piece of third-party arithmetic that *is* restated is
 product of three axis rotations and is flagged "tilt parity unpinned" in
 DESIGN.md.
 
-``/root/reference`` does not exist on the GPU box: only golden-vector
-generators (tests/golden/make_golden.py) and the ``needs_reference`` CPU tests
-may call :func:`install`.
+``/root/reference`` does not exist on the GPU box.  There the reference is
+importable only from ``oracle/_ref`` -- sourceless byte code built by
+``oracle/stage_reference.py`` (the Python analogue of a compiled reference
+``.so``; git-ignored, travels with the gpurun snapshot).  Callers of
+:func:`install`: the golden-vector generators, the ``needs_reference`` CPU
+tests, the live-reference ``-m gpu`` tests and ``bench.py``'s ``cpu_baseline``.
 """
 import os
 import sys
 import types
 import math
 
-REFERENCE_SRC = os.environ.get('ROX_REFERENCE_SRC', '/root/reference/src')
+STAGED = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref')
+
+
+def _staged_ok() -> bool:
+    """oracle/_ref holds the reference as sourceless byte code (oracle/stage_reference.py);
+    usable only by the interpreter version that compiled it"""
+    import importlib.util
+    import json
+    try:
+        with open(os.path.join(STAGED, 'stamp.json')) as f:
+            return json.load(f).get('magic') == importlib.util.MAGIC_NUMBER.hex()
+    except (OSError, ValueError):
+        return False
+
+
+def _resolve():
+    env = os.environ.get('ROX_REFERENCE_SRC')
+    if env == 'staged':
+        return STAGED
+    if env:
+        return env
+    if os.path.isdir('/root/reference/src/rayoptics'):
+        return '/root/reference/src'
+    return STAGED if _staged_ok() else '/root/reference/src'
+
+
+REFERENCE_SRC = _resolve()
 
 
 def available() -> bool:
-    return os.path.isdir(os.path.join(REFERENCE_SRC, 'rayoptics'))
+    d = os.path.join(REFERENCE_SRC, 'rayoptics')
+    return os.path.isfile(os.path.join(d, '__init__.py')) or (
+        os.path.isfile(os.path.join(d, '__init__.pyc')) and _staged_ok())
+
+
+def is_staged() -> bool:
+    return os.path.abspath(REFERENCE_SRC) == STAGED
 
 
 class _Permissive(types.ModuleType):

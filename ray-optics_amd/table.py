@@ -150,8 +150,12 @@ class SurfaceTable:
 
     def wvl_index(self, wvl):
         """rayoptics/seq/sequential.py:281-285 index_for_wavelength: the
-        wavelength must be an exact member of the spectral region."""
-        return self.wvls.index(float(wvl))
+        wavelength must be an exact member of the spectral region (a miss raises the
+        reference's own error -- ``list.index``'s ValueError naming the value as given)"""
+        try:
+            return self.wvls.index(float(wvl))
+        except (ValueError, TypeError):
+            raise ValueError(f'{wvl!r} is not in list') from None
 
     def has_phantoms(self):
         return any(r.mode == abi.PHANTOM for r in self.rows)

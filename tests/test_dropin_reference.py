@@ -1129,3 +1129,159 @@ def test_floating_stop_aiming(ref, installed):
     ours, theirs = both(installed, run)
     np.testing.assert_array_equal(ours, theirs)
     np.testing.assert_array_equal(theirs, [0., 0.])
+
+
+FIGURE_MODELS = ['dblgauss', 'nikkor', 'rc_telescope', 'zmx_evenasph_c3']
+
+
+def test_wavefront_figure_fails_as_in_the_reference(ref, installed):
+    """WavefrontFigure (rayoptics/mpl/axisarrayfigure.py:310-401) hands the wavelength *index*
+    to SequentialModel.trace_grid as `wl` (:331-333), which the reference then looks up as a
+    wavelength in nm (sequential.py:281-285): the figure raises ValueError as shipped.  "Consume
+    results unchanged" here means the same exception with the same text through the drop-ins;
+    the reference's working wavefront figures are `Wavefront` / `DiffractionPSF` below"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    from rayoptics.mpl.axisarrayfigure import WavefrontFigure
+    opm = ref.dblgauss()
+
+    def run():
+        try:
+            fig = plt.figure(FigureClass=WavefrontFigure, opt_model=opm, num_rays=9)
+            fig.update_data()
+        except ValueError as e:
+            return str(e)
+        finally:
+            plt.close('all')
+        return None
+    ours, theirs = both(installed, run)
+    assert theirs is not None and ours == theirs
+
+
+@pytest.mark.parametrize('model', FIGURE_MODELS)
+def test_wavefront_and_diffraction_psf_panels_unchanged(ref, installed, model):
+    """the reference's working wavefront figures (rayoptics/mpl/analysisfigure.py:295-360,
+    364-433): `Wavefront` draws RayGrid.grid -- (x, y, OPD in waves) through trace_wavefront /
+    focus_wavefront -- and `DiffractionPSF` draws analyses.calc_psf of it.  Grid and colour
+    scale identical; the PSF (a pruned DFT on the device, pocketfft in the reference) within
+    1e-12 of a peak-normalised 1, the image scale identical"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    from rayoptics.mpl.analysisfigure import Wavefront, DiffractionPSF
+    from rayoptics.raytr.analyses import RayGrid
+    import torch
+    have_gpu = torch.cuda.is_available()
+    opm = getattr(ref, model)()
+    osp = opm['osp']
+    fi = len(osp['fov'].fields) - 1
+
+    def run():
+        out = []
+        for f in (0, fi):
+            rg = RayGrid(opm, f=f, num_rays=16)
+            wf = Wavefront(rg, title='w')
+            fig, ax = plt.subplots()
+            wf.plot(ax)
+            clim = ax.images[0].get_clim()
+            plt.close(fig)
+            if not have_gpu:        # the PSF kernels have no CPU form: GPU box only
+                out.append((np.array(rg.grid), clim, None, None))
+                continue
+            dp = DiffractionPSF(rg, 64, title='p')
+            fig, ax = plt.subplots()
+            dp.init_axis(ax)
+            dp.plot(ax)
+            plt.close(fig)
+            out.append((np.array(rg.grid), clim, np.array(dp.AP), dp.image_scale))
+        return out
+    ours, theirs = both(installed, run)
+    for (go, co, po, so), (gt, ct, pt, st) in zip(ours, theirs):
+        assert go.shape == gt.shape == (3, 16, 16)
+        np.testing.assert_array_equal(go, gt)
+        assert np.isfinite(go[2]).sum() > 40
+        assert co == ct and so == st
+        if have_gpu:
+            assert po.shape == pt.shape == (64, 64)
+            np.testing.assert_allclose(po, pt, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('model', FIGURE_MODELS)
+@pytest.mark.parametrize('dsp_typ', ['hist2d', 'spot'])
+def test_ray_geo_psf_unchanged(ref, installed, model, dsp_typ):
+    """RayGeoPSF (rayoptics/mpl/analysisfigure.py:177-292) over a RayList: the data bounds it
+    scales by, the scatter data and the 2-D histogram it draws are the reference's, for the
+    outermost field at every wavelength"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    from rayoptics.mpl.analysisfigure import RayGeoPSF
+    from rayoptics.raytr.analyses import RayList
+    opm = getattr(ref, model)()
+    osp = opm['osp']
+    fi = len(osp['fov'].fields) - 1
+
+    def run():
+        out = []
+        for wl in osp['wvls'].wavelengths:
+            rl = RayList(opm, num_rays=12, f=fi, wl=wl)
+            psf = RayGeoPSF(rl, dsp_typ=dsp_typ, title='t')
+            fig, ax = plt.subplots()
+            psf.plot(ax)
+            bounds = psf.ray_data_bounds()
+            abr = np.array(rl.ray_abr)
+            h = psf.hist2d_data if dsp_typ == 'hist2d' else None
+            plt.close(fig)
+            out.append((bounds, abr, h))
+        return out
+    ours, theirs = both(installed, run)
+    assert len(ours) == len(theirs) > 0
+    for (bo, ao, ho), (bt, at, ht) in zip(ours, theirs):
+        assert bo == bt
+        np.testing.assert_array_equal(ao, at)
+        assert ao.shape[0] == 2 and np.isfinite(ao).sum() > 40
+        if ho is not None:
+            for a, b in zip(ho, ht):
+                np.testing.assert_array_equal(a, b)
+            assert ho[0].sum() > 20
+
+
+@pytest.mark.parametrize('model', ['nikkor', 'rc_telescope'])
+def test_spot_and_ray_fan_figures_on_the_other_config_models(ref, installed, model):
+    """SpotDiagramFigure and RayFanFigure (both data types) on the BASELINE configs[2] / [3]
+    stand-ins too (the double Gauss and the .zmx import have their own tests above)"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    from rayoptics.mpl.axisarrayfigure import SpotDiagramFigure, RayFanFigure
+    opm = getattr(ref, model)()
+
+    def run():
+        fig = plt.figure(FigureClass=SpotDiagramFigure, opt_model=opm, num_rays=10)
+        fig.update_data()
+        spots = [[np.array(g) for g in row[0][0]] for row in fig.axis_data_array]
+        plt.close(fig)
+        fans = {}
+        for dt in ('Ray', 'OPD'):
+            fig = plt.figure(FigureClass=RayFanFigure, opt_model=opm, data_type=dt,
+                             do_smoothing=False, num_rays=11)
+            fig.update_data()
+            fans[dt] = [[(np.array(c[0]), np.array(c[1]), c[2]) for c in row]
+                        for row in fig.axis_data_array]
+            plt.close(fig)
+        return spots, fans
+    (so, fo), (st, ft) = both(installed, run)
+    n = 0
+    for ro, rt_ in zip(so, st):
+        assert len(ro) == len(rt_)
+        for go, gt in zip(ro, rt_):
+            np.testing.assert_array_equal(go, gt)
+            n += len(go)
+    assert n > 100
+    for dt in ('Ray', 'OPD'):
+        for ro, rt_ in zip(fo[dt], ft[dt]):
+            for (xo, yo, mo), (xt, yt, mt) in zip(ro, rt_):
+                np.testing.assert_array_equal(xo, xt)
+                np.testing.assert_array_equal(yo, yt)
+                assert mo == mt
