@@ -173,6 +173,9 @@ def trace_grid(opt_model, grid_rng, fld, wvl, foc, img_filter=None,
     rayerr_filter = kwargs.pop('rayerr_filter', None)
     named = kwargs.get('use_named_tuples', False)
     num = grid_rng[2]
+    if 'check_apertures' in kwargs:     # the reference passes it itself (:581-583)
+        raise TypeError("rayoptics.raytr.trace.trace_safe() got multiple values for keyword "
+                        "argument 'check_apertures'")
     kwargs['check_apertures'] = True                                 # :583
     kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', True)   # trace_base default
     pk = _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter,

@@ -62,9 +62,12 @@ def test_trace_grid_packets_hip_vs_the_references_python_loop(ref, installed, mo
     n_ok = 0
     for wvl in osp['wvls'].wavelengths:
         def run():
-            return trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 48], fld, wvl,
-                                    0.0, img_filter=lambda p, pkg: (np.array(p), pkg),
-                                    form='list', append_if_none=True, check_apertures=True)
+            got = []        # (the filter keeps the packets: np.array() of ragged packets raises
+            #                 in the reference under NumPy >= 1.24, trace.py:605)
+            trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 48], fld, wvl, 0.0,
+                             img_filter=lambda p, pkg: got.append((np.array(p), pkg)),
+                             form='list', append_if_none=True)
+            return got
         ours, theirs = both(installed, run)
         assert len(ours) == len(theirs) == 48 * 48
         for (po, ko), (pt, kt) in zip(ours, theirs):
