@@ -28,6 +28,12 @@ int rox_time_pupil_grid(rox_system *sys, const rox_field *fld,
  * sets of the band-edge classes that took a guarded path. */
 int rox_selftest_fp64(uint64_t n, uint64_t seed, uint64_t counts[4]);
 
+/* how many ROX_OUT_HITS_COMPACT launches this process has issued in each form:
+ * counts[0] = fused (compaction inside the trace kernel), counts[1] = two-pass (plain HITS
+ * launch + pack kernel; deep tables / Newton instances writing device memory, or
+ * ROX_PACK_TWO_PASS=1).  Tests use it to see which form a call took. */
+int rox_diag_pack_launches(uint64_t counts[2]);
+
 #ifdef __cplusplus
 }
 #endif

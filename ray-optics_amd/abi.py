@@ -166,7 +166,7 @@ EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_aim_chief_rays', 'rox_find_real_enp', 'rox_calc_vignetting', 'rox_calc_psf',
            'rox_pin_host_memory', 'rox_unpin_host_memory')
 # ... and the measurement / self-test helpers of include/roxtrace_diag.h
-DIAG_EXPORTS = ('rox_time_pupil_grid', 'rox_selftest_fp64')
+DIAG_EXPORTS = ('rox_time_pupil_grid', 'rox_selftest_fp64', 'rox_diag_pack_launches')
 
 
 def declare(lib):
@@ -215,4 +215,6 @@ def declare(lib):
                                         P(Out), vp, i32, P(dbl)]
     lib.rox_selftest_fp64.restype = C.c_int
     lib.rox_selftest_fp64.argtypes = [C.c_uint64, C.c_uint64, P(C.c_uint64)]
+    lib.rox_diag_pack_launches.restype = C.c_int
+    lib.rox_diag_pack_launches.argtypes = [P(C.c_uint64)]
     return lib

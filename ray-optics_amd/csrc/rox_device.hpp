@@ -1221,74 +1221,102 @@ __device__ __forceinline__ uint64_t ts_pack(uint32_t epoch, uint64_t flag, uint3
     return ((uint64_t)epoch << 32) | (flag << 30) | count;
 }
 
+// Where a tile's `total` packed pairs go: dst[base + excl ...), base = the pairs already in the
+// buffer (earlier launches of a chunked call, earlier ROX_HITS_APPEND calls).  `cap` (rox_out.ld)
+// is the capacity of dst in pairs: nothing is ever stored at or beyond it, and a call that would
+// have needed more room leaves the NEGATED pair count it needed in *total_out (the last tile
+// writes it), which later appending launches keep negative -- the caller sees n_hits < 0.
+// Called by all kB threads of the workgroup.
+template <int kB>
+__device__ __forceinline__ void store_tile_pairs(d2 *dst, int64_t cap, const int64_t *base_in,
+                                                 int64_t excl, int total, const d2 *stash,
+                                                 int64_t *total_out)
+{
+    const int64_t base = base_in ? *base_in : 0;
+    const int64_t at = (base < 0 ? -base : base) + excl;
+    int64_t room = base < 0 ? 0 : cap - at;
+    if (room > total)
+        room = total;
+    for (int j = threadIdx.x; j < room; j += kB)
+        __builtin_nontemporal_store(stash[j], dst + at + j);
+    if (total_out && threadIdx.x == 0) {
+        const int64_t all = at + total;
+        *total_out = (base < 0 || all > cap) ? -all : all;
+    }
+}
+
+// Wave 0 of a workgroup (all 64 lanes): the number of survivors of all tiles before `tile`, by
+// decoupled look-back over the predecessors' published counts; publishes this tile's inclusive
+// prefix.  The tile's own count must already be published (TS_AGG; tile 0: TS_PREFIX).
+__device__ __forceinline__ uint32_t look_back(uint64_t *st, uint32_t epoch, int64_t tile, int total,
+                                              int lane)
+{
+    uint32_t excl = 0;
+    if (tile != 0) {
+        // Look back over the predecessors, nearest first, 512 states per round trip (8
+        // independent loads per lane): sum counts until a tile that already knows its
+        // inclusive prefix is met; a tile that has published nothing yet is waited for,
+        // keeping the partial sum.
+        int64_t look = tile - 1;
+        for (bool done = false; !done;) {
+            uint64_t w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t idx = look - (k * 64 + lane);
+                w[k] = ts_pack(epoch, TS_PREFIX, 0);      // before tile 0
+                if (idx >= 0)
+                    w[k] = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int consumed = 512;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t flag = (uint32_t)(w[k] >> 30) & 3u;
+                const bool ready = (uint32_t)(w[k] >> 32) == epoch && flag != 0;
+                const uint64_t rmask = __ballot(ready);
+                const uint64_t pmask = __ballot(ready && flag == TS_PREFIX);
+                const int first_not = (~rmask) ? __builtin_ctzll(~rmask) : 64;
+                const int first_pref = pmask ? __builtin_ctzll(pmask) : 64;
+                const int take = first_pref < first_not ? first_pref + 1 : first_not;
+                uint32_t v = lane < take ? (uint32_t)(w[k] & 0x3fffffffu) : 0u;
+                for (int o = 32; o > 0; o >>= 1)
+                    v += __shfl_xor(v, o);
+                excl += v;
+                if (first_pref < first_not) {
+                    done = true;
+                    break;
+                }
+                if (first_not < 64) {       // wait for that tile, resume from it
+                    consumed = k * 64 + first_not;
+                    __builtin_amdgcn_s_sleep(1);
+                    break;
+                }
+            }
+            look -= consumed;
+        }
+        if (lane == 0)
+            __hip_atomic_store(&st[tile], ts_pack(epoch, TS_PREFIX, excl + (uint32_t)total),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return excl;
+}
+
 // A tile's survivors (packed in `stash`, `total` of them) go to their final place: wave 0 finds
-// the number of survivors of all earlier tiles by decoupled look-back over the predecessors'
-// published counts, then every thread copies pairs (consecutive threads, consecutive pairs).
-// Called by all threads of the workgroup.
+// the number of survivors of all earlier tiles by look_back(), then every thread copies pairs
+// (consecutive threads, consecutive pairs).  Called by all threads of the workgroup.
 template <int kB, class ARGS>
 __device__ __forceinline__ void finish_tile(ARGS &a, int64_t tile, int total,
                                             const d2 *stash, int64_t n_tiles, uint32_t *s_excl)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave == 0) {
-        uint32_t excl = 0;
-        uint64_t *st = a.tile_state;
-        if (tile != 0) {
-            // Look back over the predecessors, nearest first, 512 states per round trip (8
-            // independent loads per lane): sum counts until a tile that already knows its
-            // inclusive prefix is met; a tile that has published nothing yet is waited for,
-            // keeping the partial sum.
-            int64_t look = tile - 1;
-            for (bool done = false; !done;) {
-                uint64_t w[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int64_t idx = look - (k * 64 + lane);
-                    w[k] = ts_pack(a.epoch, TS_PREFIX, 0);      // before tile 0
-                    if (idx >= 0)
-                        w[k] = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                int consumed = 512;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t flag = (uint32_t)(w[k] >> 30) & 3u;
-                    const bool ready = (uint32_t)(w[k] >> 32) == a.epoch && flag != 0;
-                    const uint64_t rmask = __ballot(ready);
-                    const uint64_t pmask = __ballot(ready && flag == TS_PREFIX);
-                    const int first_not = (~rmask) ? __builtin_ctzll(~rmask) : 64;
-                    const int first_pref = pmask ? __builtin_ctzll(pmask) : 64;
-                    const int take = first_pref < first_not ? first_pref + 1 : first_not;
-                    uint32_t v = lane < take ? (uint32_t)(w[k] & 0x3fffffffu) : 0u;
-                    for (int o = 32; o > 0; o >>= 1)
-                        v += __shfl_xor(v, o);
-                    excl += v;
-                    if (first_pref < first_not) {
-                        done = true;
-                        break;
-                    }
-                    if (first_not < 64) {       // wait for that tile, resume from it
-                        consumed = k * 64 + first_not;
-                        __builtin_amdgcn_s_sleep(1);
-                        break;
-                    }
-                }
-                look -= consumed;
-            }
-            if (lane == 0)
-                __hip_atomic_store(&st[tile], ts_pack(a.epoch, TS_PREFIX, excl + (uint32_t)total),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const uint32_t excl = look_back(a.tile_state, a.epoch, tile, total, lane);
         if (lane == 0)
             *s_excl = excl;
     }
     __syncthreads();
-    const int64_t base = a.hits_base_in ? *a.hits_base_in : 0;
     const uint32_t excl = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_excl);
-    d2 *dst = reinterpret_cast<d2 *>(a.out.seg) + base + (int64_t)excl;
-    for (int j = threadIdx.x; j < total; j += kB)
-        __builtin_nontemporal_store(stash[j], dst + j);
-    if (tile == n_tiles - 1 && threadIdx.x == 0)
-        *a.hits_total_out = base + (int64_t)excl + total;
+    store_tile_pairs<kB>(reinterpret_cast<d2 *>(a.out.seg), a.out.ld, a.hits_base_in, (int64_t)excl,
+                         total, stash, tile == n_tiles - 1 ? a.hits_total_out : nullptr);
 }
 
 // HITS_COMPACT tile geometry.  The first `want` tickets of a launch take tiles of kSmallTile
@@ -1667,6 +1695,24 @@ void launch_radial_batch(const LaunchCfg &, const TraceArgs *);
 void launch_poly_batch(const LaunchCfg &, const TraceArgs *);
 void launch_aplist_batch(const LaunchCfg &, const TraceArgs *);
 void launch_general_batch(const LaunchCfg &, const TraceArgs *);
+
+// the pack pass of two-pass packed hits (csrc/pack.hip): a plain ROX_OUT_HITS launch has left
+// (x, y)[2][ld] and status[n_rays]; survivors go to dst in ray order, exactly where the fused
+// HITS_COMPACT instance would have put them (same tile-state / ticket / base / total protocol)
+struct PackArgs {
+    const uint8_t *status;
+    const double *xy;          // [2][ld]
+    int64_t ld, n_rays;
+    uint64_t *tile_state;
+    uint32_t *ticket;          // [0] next tile, [1] workgroups done
+    const int64_t *hits_base_in;
+    int64_t *hits_total_out;
+    uint32_t epoch;
+    double *dst;               // rox_out.seg of the HITS_COMPACT call: (x, y) pairs
+    int64_t ld_dst;            // its capacity in pairs (rox_out.ld)
+};
+constexpr int kPackBlock = 1024, kPackSub = 4, kPackTile = kPackBlock * kPackSub;
+void launch_pack(const PackArgs &, unsigned blocks, hipStream_t);
 
 // chief-ray aiming (csrc/inst_aim.hip)
 struct AimArgs {

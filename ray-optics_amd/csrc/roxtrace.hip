@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -193,6 +194,11 @@ struct StreamCtx {
     uint32_t *d_ticket = nullptr;       // [0] ticket, [1] workgroups done
     int64_t *d_hits_base = nullptr;     // [2] running totals between launches (ping-pong)
     uint32_t epoch = 0;
+    // two-pass packed hits: the plain HITS launch's (x, y)[2][pack_cap] and status[pack_cap]
+    // (grow-only; launches on one stream run in order, so they share it)
+    double *d_pack_xy = nullptr;
+    uint8_t *d_pack_status = nullptr;
+    int64_t pack_cap = 0;
     // ROX_HOST_POINTERS staging: HBM arena for big batches, device-mapped pinned
     // block for small ones (grow-only)
     char *d_stage = nullptr, *h_stage = nullptr;
@@ -302,6 +308,13 @@ int check_opts(const rox_system *sys, const rox_opts *o, const rox_out *out, int
         if (o->flags & ROX_HOST_POINTERS)
             return fail(ROX_E_ARG, "HITS_COMPACT writes device or device-mapped pinned host "
                                    "memory directly: do not set ROX_HOST_POINTERS");
+        // rox_out.ld = capacity of seg in (x, y) pairs.  A call that does not append can need
+        // up to n_rays of them; an appending call is clamped by the kernel (n_hits < 0)
+        if (!(o->flags & ROX_HITS_APPEND) && out->ld < n_rays)
+            return fail(ROX_E_ARG, "HITS_COMPACT: out.ld (%lld pairs of room) < n_rays (%lld)",
+                        (long long)out->ld, (long long)n_rays);
+        if (out->ld < 0)
+            return fail(ROX_E_ARG, "HITS_COMPACT: negative out.ld");
     } else if (out->ld < n_rays) {
         return fail(ROX_E_ARG, "out.ld (%lld) < n_rays (%lld)", (long long)out->ld, (long long)n_rays);
     } else if (o->flags & ROX_HITS_APPEND) {
@@ -419,6 +432,54 @@ int ensure_compact(StreamCtx *cx, int64_t tiles, hipStream_t st)
     return 0;
 }
 
+// Packed hits in two passes -- the unsynchronised HITS instance into a scratch, then the
+// streaming pack kernel (csrc/pack.hip) -- instead of the fused tile-synchronous instance.
+// The fused instance pays three workgroup barriers and a look-back per 1024-ray tile with
+// one workgroup per CU; that is the cheaper form while a tile's waves finish together
+// (shallow spherical systems) and while the destination sits behind PCIe (the pairs cross
+// the link while later tiles are traced).  On deep tables and Newton instances the waves
+// finish far apart and the plain HITS launch + a ~17 B/ray pack pass wins: measured
+// crossover in profiles/r04_pack_crossover.jsonl (tools/pack_bench.py).
+// ROX_PACK_TWO_PASS=0 / 1 forces one form (experiments, tests).
+std::atomic<uint64_t> g_two_pass_launches{0}, g_fused_pack_launches{0};
+constexpr int64_t kTwoPassMinRays = 1 << 16;
+bool want_two_pass(const rox_system *sys, int inst, int64_t n_rays, const void *dst)
+{
+    const char *e = getenv("ROX_PACK_TWO_PASS");        // (read per call: tests flip it)
+    const int forced = (e && *e) ? atoi(e) : -1;
+    if (forced == 0 || forced == 1)
+        return forced == 1;
+    (void)sys;
+    (void)inst;
+    if (n_rays < kTwoPassMinRays)
+        return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dst) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
+
+int ensure_pack_scratch(StreamCtx *cx, int64_t rays, bool need_status)
+{
+    const int64_t want = (rays + 511) & ~int64_t(511);
+    if (want > cx->pack_cap) {
+        if (cx->d_pack_xy)
+            HIP_TRY(hipFree(cx->d_pack_xy));        // synchronises: no launch still uses it
+        if (cx->d_pack_status)
+            HIP_TRY(hipFree(cx->d_pack_status));
+        cx->d_pack_xy = nullptr;
+        cx->d_pack_status = nullptr;
+        cx->pack_cap = 0;
+        HIP_TRY(hipMalloc(&cx->d_pack_xy, sizeof(double) * 2 * (size_t)want));
+        cx->pack_cap = want;
+    }
+    if (need_status && !cx->d_pack_status)
+        HIP_TRY(hipMalloc(&cx->d_pack_status, (size_t)cx->pack_cap));
+    return 0;
+}
+
 // the table pointers of a launch, the leanest kernel instance that covers this system and
 // these options, and its LDS need
 int launch_setup(rox_system *sys, TraceArgs &a, int gen, bool prw, hipStream_t st, LaunchCfg &k,
@@ -468,6 +529,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
     const int64_t total = a.n_rays, chunk_max = rays_per_launch();
     const bool compact = a.opts.out_mode == ROX_OUT_HITS_COMPACT;
     StreamCtx *cx = nullptr;
+    bool two_pass = false;
     // two host threads enqueueing HITS_COMPACT launches on one stream take turns with the
     // stream's epoch / ticket / tile-state words (the launches themselves run in stream order)
     std::unique_lock<std::mutex> compact_lock;
@@ -478,8 +540,12 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
         compact_lock = std::unique_lock<std::mutex>(cx->compact_mu);
         const int64_t per = total < chunk_max ? total : chunk_max;
         const int tb = block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]);
-        a.small_tiles = compact_small_want(sys, per);
-        int rc = ensure_compact(cx, compact_tiles(per, a.small_tiles, tb), st);
+        two_pass = want_two_pass(sys, inst, total, a.out.seg);
+        a.small_tiles = two_pass ? 0 : compact_small_want(sys, per);
+        int rc = ensure_compact(cx, two_pass ? (per + kPackTile - 1) / kPackTile
+                                             : compact_tiles(per, a.small_tiles, tb), st);
+        if (!rc && two_pass)
+            rc = ensure_pack_scratch(cx, per, a.out.status == nullptr);
         if (rc)
             return rc;
     }
@@ -508,6 +574,46 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
             a.out.status = out0.status ? out0.status + base : nullptr;
             a.out.fail_surf = out0.fail_surf ? out0.fail_surf + base : nullptr;
             a.out.pupil = out0.pupil ? out0.pupil + base : nullptr;
+        }
+        if (compact)
+            (two_pass ? g_two_pass_launches : g_fused_pack_launches).fetch_add(1, std::memory_order_relaxed);
+        if (two_pass) {
+            // pass 1: the plain HITS instance of the same rays into the scratch rows
+            TraceArgs h = a;
+            h.opts.out_mode = ROX_OUT_HITS;
+            h.opts.flags &= ~(uint32_t)ROX_HITS_APPEND;
+            h.out.seg = cx->d_pack_xy;
+            h.out.ld = cx->pack_cap;
+            h.out.op = nullptr;
+            h.out.fail_surf = nullptr;
+            h.out.pupil = nullptr;
+            h.out.n_hits = nullptr;
+            h.out.status = out0.status ? out0.status + base : cx->d_pack_status;
+            LaunchCfg kh = k;
+            kh.out_mode = ROX_OUT_HITS;
+            kh.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0);
+            const int hb = block_of(ROX_OUT_HITS, kInstances[inst]);
+            int64_t hblocks = (a.n_rays + hb - 1) / hb;
+            const int64_t hcap = (int64_t)sys->num_cus * blocks_per_cu(hb);
+            kh.grid = dim3((unsigned)(hblocks > hcap ? hcap : hblocks));
+            launch_feat(inst, kh, h);
+            // pass 2: survivors to their final place, in ray order
+            PackArgs p;
+            p.status = h.out.status;
+            p.xy = cx->d_pack_xy;
+            p.ld = cx->pack_cap;
+            p.n_rays = a.n_rays;
+            p.tile_state = a.tile_state;
+            p.ticket = a.ticket;
+            p.hits_base_in = a.hits_base_in;
+            p.hits_total_out = a.hits_total_out;
+            p.epoch = a.epoch;
+            p.dst = out0.seg;
+            p.ld_dst = out0.ld;
+            int64_t pblocks = (a.n_rays + kPackTile - 1) / kPackTile;
+            const int64_t pcap = (int64_t)sys->num_cus * 2;
+            launch_pack(p, (unsigned)(pblocks > pcap ? pcap : pblocks), st);
+            continue;
         }
         // enough workgroups to fill 256 CUs several times over, grid-stride the rest
         const int bs = block_of(a.opts.out_mode, kInstances[inst]);
@@ -951,6 +1057,8 @@ int rox_system_destroy(rox_system *sys)
         (void)hipFree(c->d_tiles);
         (void)hipFree(c->d_ticket);
         (void)hipFree(c->d_hits_base);
+        (void)hipFree(c->d_pack_xy);
+        (void)hipFree(c->d_pack_status);
         (void)hipFree(c->d_stage);
         (void)hipHostFree(c->h_stage);
         (void)hipFree(c->d_items);
@@ -1360,6 +1468,15 @@ int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs, double
 }
 
 // ---- include/roxtrace_diag.h ------------------------------------------------
+int rox_diag_pack_launches(uint64_t counts[2])
+{
+    if (!counts)
+        return fail(ROX_E_ARG, "null argument");
+    counts[0] = g_fused_pack_launches.load();
+    counts[1] = g_two_pass_launches.load();
+    return 0;
+}
+
 int rox_selftest_fp64(uint64_t n, uint64_t seed, uint64_t counts[4])
 {
     if (!counts)

@@ -287,8 +287,14 @@ class HitsPack:
         self.rays = 0
 
     def counts(self):
-        """survivors per launch (synchronises the launch stream)"""
+        """survivors per launch (synchronises the launch stream).  The kernels never store
+        at or beyond the capacity handed to them (rox_out.ld); a launch that needed more
+        leaves a negative running count, reported here"""
         c = self.cum[:self.n_launches].cpu().numpy()
+        if (c < 0).any():
+            k = int(np.argmax(c < 0))
+            raise EngineError(f'HitsPack overflow: launch {k} needed {-int(c[k])} pairs of room, '
+                              f'the destination holds {self.cap}')
         return np.diff(np.concatenate([[0], c])).astype(np.int64)
 
 

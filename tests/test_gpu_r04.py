@@ -1,0 +1,192 @@
+"""-m gpu, round 4: packed hits in two passes (plain HITS launch + csrc/pack.hip) must be
+indistinguishable from the fused HITS_COMPACT instance; the capacity clamp of packed hits."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from rayoptics_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+SPOT = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pack_counts(lib):
+    c = (C.c_uint64 * 2)()
+    assert lib.rox_diag_pack_launches(c) == 0
+    return int(c[0]), int(c[1])
+
+
+def oracle_hits(wl, fi, wi, **grid_kw):
+    from oracle import oracle
+    N = wl.n_ifcs
+    o = oracle.make_opts(flags=SPOT, out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                         foc=wl.foc, image_pt=wl.image_pts[fi])
+    return oracle.trace_pupil_grid(wl.table, wl.fields[fi],
+                                   oracle.make_grid((-1., -1.), (1., 1.), **grid_kw), wi, o).hits
+
+
+@pytest.fixture()
+def form():
+    """sets ROX_PACK_TWO_PASS for the library (read per call) and restores it"""
+    saved = os.environ.get('ROX_PACK_TWO_PASS')
+
+    def set_(v):
+        os.environ['ROX_PACK_TWO_PASS'] = v
+    yield set_
+    if saved is None:
+        os.environ.pop('ROX_PACK_TWO_PASS', None)
+    else:
+        os.environ['ROX_PACK_TWO_PASS'] = saved
+
+
+@pytest.mark.parametrize('name,num', [('dblgauss_c2', 300), ('nikkor_c3', 257), ('litho_c5', 200),
+                                      ('cell_phone', 129), ('rc_telescope_c4', 64)])
+def test_two_pass_packed_hits_equal_fused_and_oracle(form, name, num):
+    """every field at two wavelengths, appended block after block (whole grids and ragged row
+    blocks, sizes that are no multiple of the 4 096-ray pack tile) into one HBM buffer: the two
+    forms give the same bytes and counts, which are the oracle's"""
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    wl = workloads.load(name)
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    nw = len(wl.table.wvls)
+    jobs = []
+    for fi in range(len(wl.fields)):
+        for wi in sorted({0, nw - 1}):
+            jobs.append((fi, wi, dict(num=num)))
+        jobs.append((fi, 0, dict(num=num, row_begin=3, row_count=num // 3)))
+        jobs.append((fi, 0, dict(num=num, row_begin=num - 1, row_count=1)))
+    cap = sum((kw.get('row_count') or kw['num']) * kw['num'] for _f, _w, kw in jobs)
+    got = {}
+    for mode in ('0', '1'):
+        form(mode)
+        before = pack_counts(eng.lib)
+        pack = eng.hits_pack(cap, len(jobs))
+        for fi, wi, kw in jobs:
+            o = make_opts(flags=SPOT | abi.HITS_APPEND, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                          last_surf=N - 2, foc=wl.foc, image_pt=wl.image_pts[fi])
+            eng.trace_pupil_grid_hits_append(wl.fields[fi], make_grid((-1., -1.), (1., 1.), **kw),
+                                             wi, o, pack)
+        counts = pack.counts()
+        after = pack_counts(eng.lib)
+        took = (after[0] - before[0], after[1] - before[1])
+        assert took == ((len(jobs), 0) if mode == '0' else (0, len(jobs))), took
+        got[mode] = (counts, pack.xy[:int(counts.sum())].cpu().numpy())
+    np.testing.assert_array_equal(got['0'][0], got['1'][0])
+    assert np.array_equal(got['0'][1], got['1'][1])
+    want = [oracle_hits(wl, fi, wi, **kw) for fi, wi, kw in jobs]
+    np.testing.assert_array_equal(got['1'][0], [len(w) for w in want])
+    assert np.array_equal(got['1'][1], np.concatenate(want))
+    eng.close()
+
+
+def test_the_rule_picks_two_pass_for_deep_tables_into_hbm_only(form):
+    """ROX_PACK_TWO_PASS unset: packed hits into device memory take two passes from 65 536
+    rays up (measured never slower there, profiles/r04_pack_crossover.jsonl); small launches
+    and pinned-host destinations (the pairs cross PCIe while later tiles are traced) keep
+    the fused instance"""
+    import torch
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid, _pool
+    form('')
+    for name, num, where, want_two in [('litho_c5', 300, 'hbm', True), ('nikkor_c3', 300, 'hbm', True),
+                                       ('litho_c5', 300, 'pinned', False), ('litho_c5', 100, 'hbm', False),
+                                       ('dblgauss_c2', 300, 'hbm', True), ('dblgauss_c2', 300, 'pinned', False)]:
+        wl = workloads.load(name)
+        N = wl.n_ifcs
+        eng = TraceEngine(wl.table)
+        R = num * num
+        dest = None
+        if where == 'pinned':
+            lease = _pool.take(torch, 16 * R)
+            dest = (lease.ptr, R)
+        pack = eng.hits_pack(R, 1, dest=dest)
+        o = make_opts(flags=SPOT | abi.HITS_APPEND, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                      last_surf=N - 2, foc=wl.foc, image_pt=wl.image_pts[1])
+        before = pack_counts(eng.lib)
+        eng.trace_pupil_grid_hits_append(wl.fields[1], make_grid((-1., -1.), (1., 1.), num), 0, o, pack)
+        n = int(pack.counts()[0])
+        after = pack_counts(eng.lib)
+        assert (after[1] - before[1] == 1) == want_two, (name, num, where)
+        assert (after[0] - before[0] == 1) == (not want_two), (name, num, where)
+        xy = pack.xy[:n].cpu().numpy() if dest is None else lease.array((n, 2), np.float64)
+        assert np.array_equal(xy, oracle_hits(wl, 1, 0, num=num)), (name, where)
+        eng.close()
+
+
+@pytest.mark.parametrize('mode', ['0', '1'])
+def test_packed_hits_never_write_beyond_the_capacity(form, mode):
+    """rox_out.ld is the capacity of seg in pairs: an appending call that needs
+    more room stores nothing at or beyond it and leaves the NEGATED pair count it needed in
+    n_hits; a call that does not append is refused when ld < n_rays"""
+    import torch
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid, EngineError
+    form(mode)
+    wl = workloads.load('dblgauss_c2')
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    num = 150
+    grid = make_grid((-1., -1.), (1., 1.), num)
+    want = oracle_hits(wl, 0, 1, num=num)
+    n_ok = len(want)
+    cap = n_ok + n_ok // 2                  # the second appended grid does not fit
+    buf = torch.full((cap + 4096, 2), -7.0, dtype=torch.float64, device=eng.device)
+    count = torch.zeros(1, dtype=torch.int64, device=eng.device)
+    o = abi.Out()
+    o.seg, o.n_hits, o.ld = buf.data_ptr(), count.data_ptr(), cap
+    opts = make_opts(flags=SPOT | abi.HITS_APPEND, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                     last_surf=N - 2, foc=wl.foc, image_pt=wl.image_pts[0])
+    st = C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
+    for k in range(3):
+        rc = eng.lib.rox_trace_pupil_grid(eng._handle, C.byref(wl.fields[0]), C.byref(grid), 1,
+                                          C.byref(opts), C.byref(o), st)
+        assert rc == 0, eng.lib.rox_last_error()
+        torch.cuda.synchronize()
+        n = int(count.item())
+        assert n == (n_ok if k == 0 else -(k + 1) * n_ok), (k, n)
+    got = buf.cpu().numpy()
+    assert np.array_equal(got[:n_ok], want)
+    assert np.array_equal(got[n_ok:cap], want[:cap - n_ok])         # what fitted of the second grid
+    assert (got[cap:] == -7.0).all()                                  # nothing beyond the capacity
+    # not appending: the capacity must cover every ray of the call
+    opts2 = make_opts(flags=SPOT, out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                      foc=wl.foc, image_pt=wl.image_pts[0])
+    o.ld = num * num - 1
+    rc = eng.lib.rox_trace_pupil_grid(eng._handle, C.byref(wl.fields[0]), C.byref(grid), 1,
+                                      C.byref(opts2), C.byref(o), st)
+    assert rc != 0 and b'ld' in eng.lib.rox_last_error()
+    # the Python wrapper reports an overflowing pack
+    pack = eng.hits_pack(2 * num * num, 4)
+    pack.cap = n_ok + 10                     # lie about the room: the kernel's clamp must hold
+    o3 = make_opts(flags=SPOT | abi.HITS_APPEND, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                   last_surf=N - 2, foc=wl.foc, image_pt=wl.image_pts[0])
+    pack.rays = -4 * num * num               # (and get past the wrapper's own ray-count check)
+    eng.trace_pupil_grid_hits_append(wl.fields[0], grid, 1, o3, pack)
+    eng.trace_pupil_grid_hits_append(wl.fields[0], grid, 1, o3, pack)
+    with pytest.raises(EngineError, match='overflow'):
+        pack.counts()
+    eng.close()
+
+
+def test_the_compaction_suites_pass_in_the_two_pass_form():
+    """the existing packed-hits tests -- compaction at 1 ... 10^6 rays on one and two streams,
+    appended and chunked launches, lists and explicit rays, the sharded spot diagram -- re-run
+    in a subprocess with ROX_PACK_TWO_PASS=1"""
+    env = dict(os.environ, ROX_PACK_TWO_PASS='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        os.path.join(ROOT, 'tests', 'test_gpu_r02.py'),
+                        os.path.join(ROOT, 'tests', 'test_gpu_r03.py'),
+                        os.path.join(ROOT, 'tests', 'test_gpu_parity.py'),
+                        '-k', 'compact or append or hits or sharded or chunked or spot or stream'],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    tail = r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.returncode == 0, tail
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, tail

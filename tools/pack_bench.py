@@ -4,8 +4,11 @@
     [ROX_LIB=variant.so] python tools/pack_bench.py [--workload litho_c5] [--num 1024]
 
 One pass = every (field, wavelength) grid: (a) HITS launches into one reused buffer,
-(b) dist.trace_blocks -- HITS_COMPACT | HITS_APPEND launches packing into one HBM buffer.
-Steady-state ms per pass from events on the launch stream."""
+(b) dist.trace_blocks -- HITS_COMPACT | HITS_APPEND launches packing into one HBM buffer --
+in both forms of the library: fused (compaction inside the trace kernel, ROX_PACK_TWO_PASS=0)
+and two-pass (plain HITS launch + csrc/pack.hip, ROX_PACK_TWO_PASS=1), and what the library's
+own rule picks.  Steady-state ms per pass from events on the launch stream.
+--all runs the crossover table (profiles/r04_pack_crossover.jsonl)."""
 import argparse
 import json
 import os
@@ -21,7 +24,20 @@ def main():
     ap.add_argument('--workload', default='litho_c5')
     ap.add_argument('--num', type=int, default=1024)
     ap.add_argument('--passes', type=int, default=5)
+    ap.add_argument('--all', action='store_true')
     args = ap.parse_args()
+    if args.all:
+        for name, num in (('dblgauss_c2', 64), ('dblgauss_c2', 128), ('dblgauss_c2', 256), ('dblgauss_c2', 512),
+                          ('litho_c5', 128), ('litho_c5', 256), ('singlet_c1', 1024), ('rc_telescope_c4', 1024), ('tt_triplet', 1024),
+                          ('dblgauss_c2', 1024), ('zmx_evenasph_c3', 1024), ('cell_phone', 1024),
+                          ('nikkor_c3', 1024), ('litho_c5', 1024), ('litho_c5', 2048)):
+            args.workload, args.num = name, num
+            one(args)
+        return
+    one(args)
+
+
+def one(args):
     import torch
     import rayoptics_amd  # noqa: F401
     from rayoptics_amd import abi, workloads, engine, dist as rdist
@@ -61,10 +77,27 @@ def main():
         return sorted(ts)[len(ts) // 2]
     res = {'lib': os.path.basename(engine.LIB_PATH), 'workload': args.workload, 'num': num,
            'grids': len(plan[0]), 'rays': rdist.rays_of(plan[0], num)}
+    res['interfaces'] = N
     res['hits_ms'] = timed(pass_hits)
-    res['pack_ms'] = timed(pass_pack)
-    res['pack_over_hits'] = res['pack_ms'] / res['hits_ms']
-    print(json.dumps(res))
+    os.environ['ROX_PACK_TWO_PASS'] = '0'
+    res['fused_ms'] = timed(pass_pack)
+    os.environ['ROX_PACK_TWO_PASS'] = '1'
+    res['two_pass_ms'] = timed(pass_pack)
+    os.environ['ROX_PACK_TWO_PASS'] = ''
+    import ctypes as C
+    c0 = (C.c_uint64 * 2)()
+    c1 = (C.c_uint64 * 2)()
+    eng.lib.rox_diag_pack_launches(c0)
+    res['auto_ms'] = timed(pass_pack)
+    eng.lib.rox_diag_pack_launches(c1)
+    res['auto_picks'] = 'two_pass' if c1[1] > c0[1] else 'fused'
+    res['two_pass_over_fused'] = res['two_pass_ms'] / res['fused_ms']
+    res['fused_over_hits'] = res['fused_ms'] / res['hits_ms']
+    res['two_pass_over_hits'] = res['two_pass_ms'] / res['hits_ms']
+    print(json.dumps(res), flush=True)
+    eng.close()
+    del hits
+    torch.cuda.empty_cache()
 
 
 if __name__ == '__main__':
