@@ -45,15 +45,20 @@ strong_scaling  every run, any N: BASELINE configs[4]'s shape -- 9 fields x 5
               wavelengths x 2048^2 pupil grids of the 44-interface lithography
               lens (188.7 M rays) cut into pupil-row blocks over the ranks, packed
               hits (no padding for blocked rays), brought to rank 0's host memory
-              (a) by the RCCL gather + one D2H copy and (b) by every rank's kernel
-              writing into a shared pinned host segment over its own PCIe link; kernel,
-              count exchange, gather, D2H, host reassembly and end-to-end, separately;
-              plus configs[3] sharded by field
+              (a) by the pipelined RCCL gather + copy-engine D2H per piece, (b) by every
+              rank's copy engine into a shared pinned host segment over its own PCIe
+              link, (c) left in rank 0's HBM, (d) round 3's un-pipelined form; each timed
+              as passes between fences with the exchange inside; plus configs[3]
+              sharded by field and configs[1]'s grid sharded by rows
 
-N > 1: one rank per GPU.  The main line is weak scaling (each rank traces its
-own (field, wavelength) grid of the same size, no data-path collective in the
-timed region; max-over-ranks time); strong_scaling carries the fixed-size
-problem with its one exchange step.
+N > 1: one rank per GPU.  The headline (`value`, `ms_per_step`, "scaling": "strong") is the
+path north_star describes: BASELINE configs[4]'s spot problem (188.7 M rays) cut by pupil rows
+over the ranks, packed hits gathered to rank 0 over RCCL and delivered to its host memory,
+pipelined per piece, K passes between two fences -- the exchange is INSIDE the timed region;
+`predicted_ms` holds DESIGN section 7's arithmetic per N.  The collective-free figure (one
+FULL grid per rank, weak scaling) is kept under `weak_full`.  `strong_scaling` carries every
+exchange variant incl. the N = 1 line's own grid cut by rows (`c2_sharded`).  A rank hanging
+in an exchange ends the run with "ok": false and exit status 3 (the line is still printed).
 """
 import argparse
 import json
@@ -344,6 +349,174 @@ def main():
             'cpu_baseline': None,
             'strong_scaling': None,
             'library': library_id(),
+            'ok': True,
+        }
+
+    emitted = threading.Event()
+
+    def emit():
+        """the one JSON line goes to the real stdout (fd 1 was pointed at stderr while the
+        communicator was being built and the collectives ran)"""
+        nonlocal saved_stdout
+        if rank != 0 or emitted.is_set():
+            return
+        emitted.set()
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
+            saved_stdout = None
+        print(json.dumps(line), flush=True)
+
+    # A rank that hangs in an exchange (a divergent failure leaves the others waiting in a
+    # collective until the backend's own timeout kills the job) trips a watchdog: rank 0 prints
+    # the line it has -- "ok": false, the leg that hung named -- and every rank ends with exit
+    # status 3, so that neither the numbers already measured nor the failure are lost.
+    hung_in = ['']
+
+    def give_up():
+        if rank == 0:
+            line['ok'] = False
+            line['hung_in'] = hung_in[0]
+            line.setdefault('strong_scaling', {'error': f'timed out after {args.strong_timeout} s in '
+                                               f'{hung_in[0]}: a rank hung in an exchange'})
+            emit()
+        os._exit(3)
+
+    def guarded(what, fn):
+        hung_in[0] = what
+        dog = threading.Timer(args.strong_timeout, give_up) if multi else None
+        if dog:
+            dog.daemon = True
+            dog.start()
+        try:
+            return fn()
+        except Exception as e:
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            return {'error': repr(e)}
+        finally:
+            if dog:
+                dog.cancel()
+
+    # N > 1: the headline is the path north_star describes -- the fixed-size spot problem cut
+    # over the ranks with the RCCL gather INSIDE the timed region -- and the collective-free
+    # one-grid-per-rank figure above moves to `weak_full`.  (--force-dist rehearses this with
+    # one rank.)  If the leg fails, the weak figure stays the headline and says so.
+    if multi and not args.no_strong:
+        head = guarded('strong_headline', lambda: strong_headline(args, torch, dist, multi, world, rank, fence))
+        if rank == 0:
+            line['weak_full'] = {k: line[k] for k in ('value', 'ms_per_step', 'cold_ms_per_step', 'rays_per_s',
+                                                      'config', 'scaling')}
+            if 'error' in head:
+                line['headline'] = 'weak_full (the strong-scaled leg failed: ' + head['error'] + ')'
+                line['ok'] = False
+            else:
+                line['headline'] = 'strong-scaled spot problem, exchange inside the timed region'
+                line['value'] = head['intersections_per_step'] / (head['ms_per_step'] * 1e-3)
+                line['ms_per_step'] = head['ms_per_step']
+                line['rays_per_s'] = head['rays_per_step'] / (head['ms_per_step'] * 1e-3)
+                line['scaling'] = 'strong'
+                line['cold_ms_per_step'] = None
+                line['config'] = {
+                    'workload': head['workload'] + ' (BASELINE.json configs[4]); each step = launches -> '
+                                'per-piece counts -> grouped send/recv of the packed pairs to rank 0 over '
+                                'RCCL -> copy-engine D2H -> rank 0 holds every (field, wvl) grid\'s (R_ok, 2) '
+                                'host array; pipelined per piece of <= 4 Mi rays',
+                    'rays_per_step': head['rays_per_step'],
+                    'intersections_per_step': head['intersections_per_step'],
+                    'out_mode': 'HITS_COMPACT (two-pass: HITS + pack)', 'exchange': 'rccl, pipelined',
+                    'sharding': f'pupil-row blocks over {world} ranks', 'pairs_to_host': head['pairs'],
+                    'pieces_per_rank': head['pieces_per_rank'], 'stages': head['stages']}
+                line['predicted_ms'] = head['predicted_ms']
+                line['strong_headline'] = {k: head[k] for k in ('last_pass_phases_ms_rank0', 'grids_delivered')}
+
+    # every run: the fixed-size problems in every exchange variant (extra; the line above is
+    # complete without it)
+    if not args.no_strong:
+        strong = guarded('strong_scaling', lambda: strong_scaling(args, torch, dist, multi, world, rank,
+                                                                   fence, ranks_seen))
+        if rank == 0:
+            line['strong_scaling'] = strong
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        rr = min(args.ref_sample_rows, num)
+        i0r = (num - rr) // 2
+        sl = slice(i0r * num, (i0r + rr) * num)
+        step()
+        torch.cuda.synchronize()
+        dev_sample = {'row0': i0r, 'rows': rr,
+                      'seg': out.seg[:, :, sl].cpu().numpy(), 'op': out.op[sl].cpu().numpy(),
+                      'status': out.status[sl].cpu().numpy(),
+                      'fail_surf': out.fail_surf[sl].cpu().numpy(),
+                      'pupil': out.pupil[:, sl].cpu().numpy()}
+    del xy, out
+
+    # the PSF of an OPD grid (analyses.calc_psf): the GEMM-shaped neighbour of the path,
+    # on the fp64 matrix cores; device-resident, mean of back-to-back calls
+    psf = None
+    if rank == 0:
+        try:
+            psf = psf_leg(torch)
+        except Exception as e:
+            psf = {'error': repr(e)}
+
+    # every BASELINE configuration at its own shape (rank 0's GPU; the others wait at the
+    # next fence)
+    configs = None
+    if rank == 0 and not args.no_configs:
+        try:
+            configs = configs_leg(torch, abi, workloads)
+        except Exception as e:
+            configs = {'error': repr(e)}
+    torch.cuda.empty_cache()
+
+    line = None
+    if rank == 0:
+        traffic, traffic_source = committed_traffic(num, wl.name)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        line = {
+            'metric': 'ray-surface intersections/sec',
+            'value': inters_all / dt * args.steps,
+            'unit': 'ray-surface intersections/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_steps_run': n_w,
+            'ms_per_step': dt / args.steps * 1e3,
+            'cold_ms_per_step': cold_dt / args.steps * 1e3,
+            'fence_ms': fence_ms,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'ranks_seen_by_backend': ranks_seen,
+            'config': {'workload': 'double-Gauss 13 interfaces (K=12), 1 field, 1 wvl, '
+                                   f'{num}x{num} pupil grid per GPU, FULL ray packets, '
+                                   'device-generated rays (BASELINE.json configs[1])',
+                       'rays_per_step': int(rays_all), 'interfaces': N,
+                       'intersections_per_step': int(inters_all),
+                       'nominal_R_times_K': int(rays_all) * K,
+                       'out_mode': 'FULL', 'field_index': fi, 'wvl_nm': wl.table.wvls[wi],
+                       'sharding': 'one (field,wvl) grid per rank' if world > 1 else 'single GPU'},
+            'rays_per_s': rays_all / dt * args.steps,
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': achieved / 8000.0, 'traffic': traffic,
+                         'traffic_source': traffic_source,
+                         'kernel': 'trace_kernel<FULL,PUPIL>', 'kernel_ms': kern_ms,
+                         'algorithmic_bytes_per_launch': alg_bytes,
+                         'frac_of_measured_copy_peak_6290': achieved / 6290.0},
+            'roofline_hits': roofline_hits(inters, R, hits_kern_ms),
+            'spot_diagram': {'wallclock_ms': float(np.median(spot_ms)),
+                             'wallclock_min_ms': float(np.min(spot_ms)), 'rays': R,
+                             'rays_through': n_through, 'kernel_hits_ms': hits_kern_ms,
+                             'pcie_floor_ms': n_through * 16 / 54.7e9 * 1e3,
+                             'what': 'rayoptics_amd.trace.trace_grid_spot(model, grid_rng, fld, wvl, '
+                                     'foc, image_pt): Python call -> host (R_ok, 2) float64 array '
+                                     '(survivors packed in ray order by the trace launch, written '
+                                     'straight into pinned host memory; 13 MB over PCIe at ~55 GB/s '
+                                     'is the floor)'},
+            'configs': configs,
+            'psf': psf,
+            'cpu_baseline': None,
+            'strong_scaling': None,
+            'library': library_id(),
+            'ok': True,
         }
 
     emitted = threading.Event()
@@ -622,111 +795,239 @@ def configs_leg(torch, abi, workloads):
     return out
 
 
-def strong_scaling(args, torch, dist, multi, world, rank, fence, ranks_seen):
-    """BASELINE configs[4]'s shape on the 44-interface lithography lens (9 fields x 5
-    wavelengths x num^2 pupil grids, pupil-row blocks over the ranks) and configs[3]
-    (Ritchey-Chretien, 5 fields x 256^2, whole fields per rank): packed hits brought to
-    rank 0's host memory by both exchanges of rayoptics_amd.dist, every phase timed."""
-    from rayoptics_amd import workloads
-    from rayoptics_amd import dist as rdist
-    from rayoptics_amd.engine import TraceEngine
+# measured on one MI355X (profiles/r04_pack_crossover.jsonl, profiles/r02_pcie_store.jsonl) and
+# the link rates DESIGN section 7 prices the exchanges with
+PRED = {'c5_kernels_ms_one_gpu': 75.2, 'pcie_GBps': 55.0, 'xgmi_link_GBps': 153.0,
+        'piece_tail_ms': 0.9, 'stage_sync_ms_per_stage': 0.06}
 
-    def problem(name, num, by):
-        wl = workloads.load(name)
-        eng = TraceEngine(wl.table)
-        nf, nw = len(wl.fields), len(wl.table.wvls)
-        plan = rdist.partition(nf, nw, num, world, by)
-        caps = [rdist.rays_of(b, num) for b in plan]
-        K = wl.n_ifcs - 1
-        res = {'workload': f'{name} ({wl.n_ifcs} interfaces, K={K}), {nf} fields x {nw} wvls x '
-                           f'{num}x{num} pupil grids, packed hits (HITS_COMPACT | HITS_APPEND), '
-                           f"partition by {by}",
-               'rays': sum(caps), 'rays_per_rank_max': max(caps), 'blocks_per_rank': [len(b) for b in plan]}
-        for exchange in ('rccl', 'host'):
+
+def predicted_ms(pairs_bytes, kernels_ms_one_gpu, stages_of):
+    """DESIGN section 7's arithmetic for the pipelined exchanges, per N: the kernels split N
+    ways; rccl = 1/N of the pairs per peer over its own xGMI link, all of them over rank 0's
+    one PCIe link; host = every rank's share over its own PCIe link; a pipelined run ends
+    max(kernels, transfers) + the last piece's copy + one host sync per stage"""
+    out = {'assumptions': dict(PRED, pairs_bytes=pairs_bytes, kernels_ms_one_gpu=kernels_ms_one_gpu),
+           'rccl_to_host': {}, 'host_segment': {}, 'rccl_device_resident': {}}
+    for n in (1, 2, 4, 8):
+        kern = kernels_ms_one_gpu / n
+        xgmi = pairs_bytes / n / (PRED['xgmi_link_GBps'] * 1e6) if n > 1 else 0.0
+        sync = PRED['stage_sync_ms_per_stage'] * stages_of(n)
+        tail = PRED['piece_tail_ms'] / (1 if n == 1 else 1)
+        out['rccl_to_host'][str(n)] = max(kern, xgmi, pairs_bytes / (PRED['pcie_GBps'] * 1e6)) + tail + sync
+        out['host_segment'][str(n)] = max(kern, pairs_bytes / n / (PRED['pcie_GBps'] * 1e6)) + tail + sync
+        out['rccl_device_resident'][str(n)] = max(kern, xgmi) + sync + 0.3
+    return out
+
+
+class SpotProblem:
+    """one fixed-size spot-diagram problem (every (field, wavelength) grid of a workload) cut
+    over the ranks: the engine, the plan, and the intersections one pass actually performs"""
+
+    def __init__(self, torch, dist, multi, world, rank, name, num, by, field_idx=None, n_wvls=None):
+        from rayoptics_amd import abi, workloads
+        from rayoptics_amd import dist as rdist
+        from rayoptics_amd.engine import TraceEngine, make_opts, make_grid, DeviceResult
+        self.torch, self.dist, self.multi, self.world, self.rank = torch, dist, multi, world, rank
+        self.name, self.num, self.by = name, num, by
+        self.wl = wl = workloads.load(name)
+        self.eng = eng = TraceEngine(wl.table)
+        self.fields = list(wl.fields) if field_idx is None else [wl.fields[i] for i in field_idx]
+        self.image_pts = list(wl.image_pts) if field_idx is None else [wl.image_pts[i] for i in field_idx]
+        self.nf, self.nw = len(self.fields), (len(wl.table.wvls) if n_wvls is None else n_wvls)
+        self.plan = rdist.partition(self.nf, self.nw, num, world, by)
+        self.caps = [rdist.rays_of(b, num) for b in self.plan]
+        self.K = wl.n_ifcs - 1
+        self.pieces, self.order = rdist.schedule(self.plan, num, self.nw)
+        # untimed: what this rank's blocks really do (a ray blocked at surface s did s
+        # intersections) -- plain HITS launches with status / fail_surf, summed over the ranks
+        N = wl.n_ifcs
+        inters = 0
+        for b in self.plan[rank]:
+            R = b.row_count * num
+            res = DeviceResult(torch, eng.device, 0, R, abi.OUT_HITS, want_pupil=False, nan_fill=False)
+            o = make_opts(flags=SPOT_FLAGS, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
+                          foc=wl.foc, image_pt=self.image_pts[b.fi])
+            eng.trace_pupil_grid(self.fields[b.fi], make_grid((-1., -1.), (1., 1.), num, row_begin=b.row_begin,
+                                                            row_count=b.row_count), b.wi, o, out=res)
+            inters += work_of(res.status, res.fail_surf, N, abi, full=False)[0]
+            del res
+        tot = torch.tensor([float(inters)], dtype=torch.float64, device=eng.device)
+        if multi:
+            dist.all_reduce(tot)
+        self.intersections = int(tot.item())
+        self.what = (f'{name} ({wl.n_ifcs} interfaces, K={self.K}), {self.nf} fields x {self.nw} wvls x '
+                     f'{num}x{num} pupil grids = {sum(self.caps)} rays, packed hits, partition by {by}')
+
+    def segment(self, tag, fence):
+        """the shared pinned host segment of exchange='host' (one region per grid); collective"""
+        from rayoptics_amd import dist as rdist
+        torch, dist, rank = self.torch, self.dist, self.rank
+        name = f"rox_seg_{os.environ.get('MASTER_PORT', '0')}_{self.name}_{self.num}_{tag}"
+        err = torch.zeros(1, device=self.eng.device)
+        seg, first_err = None, None
+        if rank == 0:
+            try:
+                seg = rdist.HostSegment.for_grids(self.eng, name, self.nf * self.nw, self.num, rank, create=True)
+            except Exception as e:          # every rank must learn of it
+                err += 1
+                first_err = repr(e)
+        if self.multi:
+            dist.all_reduce(err)
+        if err.item() > 0:
+            raise RuntimeError(first_err if rank == 0 else 'rank 0 could not create the segment')
+        if rank != 0:
+            seg = rdist.HostSegment.for_grids(self.eng, name, self.nf * self.nw, self.num, rank, create=False)
+        fence()
+        return seg
+
+    def run(self, exchange, segment=None, result_on='host', pipeline=True, timings=None):
+        from rayoptics_amd import dist as rdist
+        wl = self.wl
+        return rdist.trace_spot_sharded(self.eng, self.fields, self.image_pts, self.nw, self.num, wl.foc,
+                                        by=self.by, exchange=exchange, segment=segment, timings=timings,
+                                        pipeline=pipeline, result_on=result_on)
+
+    def kernel_ms(self):
+        """this rank's launches alone (packed hits appended into HBM), events on the launch stream"""
+        from rayoptics_amd import dist as rdist
+        torch, wl = self.torch, self.wl
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        probe = rdist.trace_blocks(self.eng, self.plan[self.rank], self.num, self.fields, self.image_pts, wl.foc)
+        e1.record()
+        probe.counts()
+        return e0.elapsed_time(e1)
+
+    def timed(self, fence, steps, warmup, **kw):
+        """W untimed passes, then exactly K passes between two fences: each pass ends with rank 0
+        holding every grid's (R_ok, 2) array -- the exchange is INSIDE the timed region"""
+        tm = {}
+        n_views = 0
+        for _ in range(warmup):
+            v = self.run(timings=tm, **kw)
+            del v
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            v = self.run(timings=tm, **kw)
+            n_views = 0 if v is None else len(v)
+            del v
+        fence()
+        dt = time.perf_counter() - t0
+        t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.eng.device)
+        if self.multi:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        tm = dict(tm)
+        tm['grids_delivered'] = n_views if self.rank == 0 else None
+        return t.item() / steps * 1e3, tm
+
+    def stages_at(self, n):
+        """pipeline stages (= pieces of the busiest rank) if this problem ran on n ranks"""
+        from rayoptics_amd import dist as rdist
+        return max(len(o) for o in rdist.schedule(rdist.partition(self.nf, self.nw, self.num, n, self.by),
+                                                  self.num, self.nw)[1])
+
+    def close(self):
+        self.eng.close()
+        self.torch.cuda.empty_cache()
+
+
+def strong_headline(args, torch, dist, multi, world, rank, fence):
+    """N > 1: BASELINE configs[4]'s spot problem cut by pupil rows over the ranks, delivered to
+    rank 0's host memory by the pipelined RCCL gather -- K passes between two fences, the
+    exchange inside the timed region"""
+    prob = SpotProblem(torch, dist, multi, world, rank, 'litho_c5', args.strong_num, 'rows')
+    try:
+        ms, tm = prob.timed(fence, args.steps, max(args.warmup, 2), exchange='rccl')
+        pairs = tm['pairs_total']
+        return {'ms_per_step': ms, 'intersections_per_step': prob.intersections,
+                'rays_per_step': sum(prob.caps), 'workload': prob.what, 'pairs': pairs,
+                'stages': tm.get('stages'), 'pieces_per_rank': tm.get('pieces'),
+                'last_pass_phases_ms_rank0': {k: tm.get(k) for k in ('trace_ms', 'stage_sync_ms', 'gather_ms',
+                                                                     'd2h_ms', 'reassembly_ms')},
+                'grids_delivered': tm.get('grids_delivered'),
+                'predicted_ms': predicted_ms(pairs * 16, PRED['c5_kernels_ms_one_gpu'] * (args.strong_num / 2048) ** 2,
+                                             prob.stages_at)}
+    finally:
+        prob.close()
+
+
+def strong_scaling(args, torch, dist, multi, world, rank, fence, ranks_seen):
+    """The fixed-size problems with the path's one exchange step, every variant timed with the
+    exchange inside the timed region (3 passes between fences after 1 warm-up): BASELINE
+    configs[4] (44-interface lithography lens, 9 x 5 x num^2, by pupil rows), configs[3]
+    (Ritchey-Chretien, 5 fields x 256^2, whole fields per rank) and configs[1] (the N = 1 main
+    line's double Gauss grid, by pupil rows) -- delivered to rank 0's host memory by the
+    pipelined RCCL gather (`rccl`), by every rank's copy engine into a shared pinned host
+    segment (`host`), or left in rank 0's HBM (`rccl_device`); round 3's un-pipelined rccl
+    form beside them."""
+
+    def problem(name, num, by, variants, **sub):
+        prob = SpotProblem(torch, dist, multi, world, rank, name, num, by, **sub)
+        res = {'workload': prob.what, 'rays': sum(prob.caps), 'rays_per_rank_max': max(prob.caps),
+               'pieces_per_rank': [len(p) for p in prob.pieces], 'intersections': prob.intersections}
+        try:
+            k = torch.tensor([prob.kernel_ms(), prob.kernel_ms()][1:], dtype=torch.float64, device=prob.eng.device)
+            if multi:
+                dist.all_reduce(k, op=dist.ReduceOp.MAX)
+            res['kernel_ms_max_over_ranks'] = k.item()
+            res['ray_surface_per_s_kernel'] = prob.intersections / (k.item() * 1e-3)
+        except Exception as e:
+            res['kernel_ms_max_over_ranks'] = {'error': repr(e)}
+        if name == 'litho_c5' and isinstance(res.get('kernel_ms_max_over_ranks'), float):
+            res['predicted_ms'] = predicted_ms(0, 0, prob.stages_at)     # (pairs filled in below)
+        for key in variants:
             seg = None
             try:
+                kw = {'rccl': dict(exchange='rccl'), 'host': dict(exchange='host'),
+                      'rccl_device': dict(exchange='rccl', result_on='device'),
+                      'rccl_unpipelined': dict(exchange='rccl', pipeline=False)}[key]
                 setup_ms = 0.0
-                if exchange == 'host':
+                if key == 'host':
                     t_s = time.perf_counter()
-                    tag = f"rox_seg_{os.environ.get('MASTER_PORT', '0')}_{name}_{num}"
-                    err = torch.zeros(1, device=eng.device)
-                    if rank == 0:
-                        try:
-                            seg = rdist.HostSegment(eng, tag, caps, rank, create=True)
-                        except Exception as e:      # every rank must learn of it
-                            err += 1
-                            first_err = repr(e)
-                    if multi:
-                        dist.all_reduce(err)
-                    if err.item() > 0:
-                        raise RuntimeError(first_err if rank == 0 else 'rank 0 could not create the segment')
-                    if rank != 0:
-                        seg = rdist.HostSegment(eng, tag, caps, rank, create=False)
-                    fence()
+                    seg = prob.segment(key, fence)
                     setup_ms = (time.perf_counter() - t_s) * 1e3
-                recs = []
-                n_views = 0
-                for _rep in range(3):               # the first pass warms allocations, pinning and RCCL
-                    fence()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    tm = {}
-                    # kernel time alone: the same launches bracketed by events on the launch stream
-                    probe = rdist.trace_blocks(eng, plan[rank], num, wl.fields, wl.image_pts, wl.foc,
-                                               dest=None if seg is None else seg.dest(rank))
-                    e1.record()
-                    probe.counts()
-                    kern_ms = e0.elapsed_time(e1)
-                    del probe
-                    fence()
-                    t1 = time.perf_counter()
-                    views = rdist.trace_spot_sharded(eng, wl.fields, wl.image_pts, nw, num, wl.foc, by=by,
-                                                     exchange=exchange, segment=seg, timings=tm)
-                    fence()
-                    t_all = time.perf_counter() - t1
-                    n_views = 0 if views is None else len(views)
-                    del views
-                    tm.update(kernel_ms=kern_ms, end_to_end_ms=t_all * 1e3)
-                    recs.append(tm)
-                best = recs[-1]
-                vals = torch.tensor([best['kernel_ms'], best['trace_ms'], best['counts_ms'], best['gather_ms'],
-                                     best['end_to_end_ms']], dtype=torch.float64, device=eng.device)
-                if multi:
-                    dist.all_reduce(vals, op=dist.ReduceOp.MAX)
-                pairs = best['pairs_total']
-                out = {'kernel_ms_max_over_ranks': vals[0].item(),
-                       'trace_ms_max_over_ranks': vals[1].item(),
-                       'counts_exchange_ms': vals[2].item(),
-                       'gather_ms': vals[3].item(),
-                       'd2h_ms': best.get('d2h_ms') if rank == 0 else None,
-                       'reassembly_ms': best.get('reassembly_ms') if rank == 0 else None,
-                       'end_to_end_ms': vals[4].item(),
-                       'pairs': pairs, 'bytes_to_host': pairs * 16,
-                       'rays_per_s_end_to_end': sum(caps) / (vals[4].item() * 1e-3),
-                       'grids_delivered': n_views if rank == 0 else None}
-                if exchange == 'host':
+                    kw['segment'] = seg
+                ms, tm = prob.timed(fence, 3, 1, **kw)
+                out = {'end_to_end_ms': ms, 'pairs': tm['pairs_total'], 'bytes_to_host': tm['pairs_total'] * 16,
+                       'rays_per_s_end_to_end': sum(prob.caps) / (ms * 1e-3),
+                       'intersections_per_s_end_to_end': prob.intersections / (ms * 1e-3),
+                       'grids_delivered': tm.get('grids_delivered'),
+                       'phases_ms_last_pass_this_rank': {k2: tm.get(k2) for k2 in
+                                                         ('trace_ms', 'stage_sync_ms', 'counts_ms', 'gather_ms',
+                                                          'd2h_ms', 'reassembly_ms')},
+                       'stages': tm.get('stages')}
+                if key == 'host':
                     out['segment_setup_ms'] = setup_ms
-                    out['segment'] = None if seg is None else {'path': seg.path, 'MiB': seg.nbytes >> 20}
-                res[exchange] = out
+                    out['segment'] = {'path': seg.path, 'MiB': seg.nbytes >> 20}
+                if 'predicted_ms' in res and key == 'rccl':
+                    res['predicted_ms'] = predicted_ms(
+                        out['bytes_to_host'], PRED['c5_kernels_ms_one_gpu'] * (num / 2048) ** 2, prob.stages_at)
+                res[key] = out
             except Exception as e:
-                res[exchange] = {'error': repr(e)}
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                res[key] = {'error': repr(e)}
             finally:
                 if seg is not None:
                     seg.close(unlink=(rank == 0))
                 torch.cuda.empty_cache()
-        res['ray_surface_per_s_kernel'] = (res['rays'] * K / (res['rccl']['kernel_ms_max_over_ranks'] * 1e-3)
-                                           if 'kernel_ms_max_over_ranks' in res.get('rccl', {}) else None)
-        eng.close()
+        prob.close()
         return res
 
     return {'scaling': 'strong', 'ranks': world, 'ranks_seen_by_backend': ranks_seen,
             'backend': (dist.get_backend() if multi else 'none (single process)'),
-            'what': 'end_to_end_ms = fence -> launches -> counts -> exchange -> rank 0 holds '
-                    '{(field, wvl): (R_ok, 2) host array} -> fence; rccl = grouped send/recv of the '
-                    'packed pairs to rank 0 + one D2H copy; host = kernels write into a shared pinned '
-                    'host segment, no xGMI step (nominal R*K intersections: blocked rays stop early)',
-            'c5': problem('litho_c5', args.strong_num, 'rows'),
-            'c4': problem('rc_telescope_c4', 256, 'field')}
+            'what': 'end_to_end_ms = (fence, 3 passes, fence) / 3, each pass: launches -> counts -> exchange -> '
+                    'rank 0 holds {(field, wvl): (R_ok, 2) array} (host memory; rccl_device: its HBM).  '
+                    'Pipelined: a piece (<= 4 Mi rays) moves on while the next pieces are traced.  rccl = '
+                    'grouped send/recv of the packed pairs to rank 0 + copy-engine D2H per piece; host = '
+                    'copy-engine D2H of every rank over its own PCIe link into a shared pinned segment, no '
+                    'xGMI step',
+            'c5': problem('litho_c5', args.strong_num, 'rows', ('rccl', 'host', 'rccl_device', 'rccl_unpipelined')),
+            'c4': problem('rc_telescope_c4', 256, 'field', ('rccl', 'host')),
+            # the N = 1 main line's lens and grid (one field, one wavelength), by pupil rows
+            'c2_sharded': problem('dblgauss_c2', args.num, 'rows', ('rccl', 'rccl_device'),
+                                  field_idx=[0], n_wvls=1)}
 
 
 def reference_python():

@@ -54,9 +54,10 @@ extern "C" {
 
 /* ABI history: 4 = packed hits appended over launches (ROX_HITS_APPEND), rox_pin_host_memory,
  * rox_aim carries both branches of iterate_ray;  5 = rox_trace_pupil_grids (several grids, one
- * launch), rox_find_real_enp / rox_enp (the wide-angle pupil search).  rox_abi_version() of the
- * library must equal the header a binding was written against. */
-#define ROX_ABI_VERSION 5
+ * launch), rox_find_real_enp / rox_enp (the wide-angle pupil search);  6 = rox_out.ld is the
+ * capacity of seg in pairs for ROX_OUT_HITS_COMPACT (overflow: n_hits < 0), rox_copy_async.
+ * rox_abi_version() of the library must equal the header a binding was written against. */
+#define ROX_ABI_VERSION 6
 #define ROX_MAX_COEF 10   /* EvenPolynomial r^2..r^20 / RadialPolynomial r^1..r^10 */
 #define ROX_MAX_AP 4      /* clear apertures per surface carried in the table */
 #define ROX_SEG_DOUBLES 10 /* p[3], d[3], dst, nrml[3]  (model_constants.py:31) */
@@ -128,7 +129,9 @@ enum { ROX_CHECK_APERTURES = 1u,     /* raytrace.py:198-202                    *
  * a running count kept on the device side, so that several grids (the pupil-row
  * blocks of one rank of a sharded spot diagram, every (field, wavelength) of a
  * figure) pack into one buffer with no host round trip between the launches.
- * seg must have room for the old count + this call's rays.                    */
+ * rox_out.ld is the capacity of seg in pairs: nothing is stored at or beyond it, and a
+ * call that needed more room leaves the NEGATED pair count it needed in n_hits (later
+ * appending calls keep it negative).                                          */
 #define ROX_HITS_APPEND 32u
 /* rox_surface.rt_order: NumPy hands `rt.dot(v)` to OpenBLAS dgemv, whose FMA
  * chain runs over the columns in a different order for an F-ordered rt (the
@@ -298,7 +301,9 @@ typedef struct rox_out {
     uint8_t *status;         /* [ld] ROX_OK...                                 */
     int16_t *fail_surf;      /* [ld] surface index at which the ray failed, -1 if ok; or NULL */
     double *pupil;           /* [2][ld] pupil coords after vignetting (pupil entries) or NULL */
-    int64_t ld;              /* ray-axis leading dimension, >= number of rays  */
+    int64_t ld;              /* ray-axis leading dimension, >= number of rays;
+                                ROX_OUT_HITS_COMPACT: capacity of seg in (x, y) pairs
+                                (>= number of rays unless ROX_HITS_APPEND)         */
     int64_t *n_hits;         /* HITS_COMPACT only: receives the number of (x, y)
                                 pairs written to seg                          */
 } rox_out;
@@ -319,6 +324,11 @@ const char *rox_last_error(void);
  * for it.  The registration lasts until rox_unpin_host_memory(p).               */
 int rox_pin_host_memory(void *p, size_t bytes, void **device_ptr);
 int rox_unpin_host_memory(void *p);
+/* An asynchronous copy of `bytes` bytes in the order of `stream` between any two of device
+ * memory, page-locked host memory and memory registered with rox_pin_host_memory (copy
+ * engine; no kernel).  The pipelined multi-GPU spot diagram moves a row block's packed pairs
+ * to the consumer's host memory with it while the next block is being traced.          */
+int rox_copy_async(void *dst, const void *src, size_t bytes, void *stream);
 
 /* system table ----------------------------------------------------------- */
 /* rows[n_ifcs]; n_table[n_wvls][n_ifcs], n_table[w][i] = refractive index of

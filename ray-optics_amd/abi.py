@@ -5,7 +5,7 @@ by :mod:`rayoptics_amd.engine`, which fails loudly when it is missing.
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_COEF = 10
 MAX_AP = 4
 SEG_DOUBLES = 10
@@ -164,7 +164,7 @@ EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_system_num_segments', 'rox_trace_rays',
            'rox_trace_pupil_grid', 'rox_trace_pupil_grids', 'rox_trace_pupil_list',
            'rox_aim_chief_rays', 'rox_find_real_enp', 'rox_calc_vignetting', 'rox_calc_psf',
-           'rox_pin_host_memory', 'rox_unpin_host_memory')
+           'rox_pin_host_memory', 'rox_unpin_host_memory', 'rox_copy_async')
 # ... and the measurement / self-test helpers of include/roxtrace_diag.h
 DIAG_EXPORTS = ('rox_time_pupil_grid', 'rox_selftest_fp64', 'rox_diag_pack_launches')
 
@@ -210,6 +210,8 @@ def declare(lib):
     lib.rox_pin_host_memory.argtypes = [vp, C.c_size_t, P(vp)]
     lib.rox_unpin_host_memory.restype = C.c_int
     lib.rox_unpin_host_memory.argtypes = [vp]
+    lib.rox_copy_async.restype = C.c_int
+    lib.rox_copy_async.argtypes = [vp, vp, C.c_size_t, vp]
     lib.rox_time_pupil_grid.restype = C.c_int
     lib.rox_time_pupil_grid.argtypes = [vp, P(Field), P(Grid), i32, P(Opts),
                                         P(Out), vp, i32, P(dbl)]

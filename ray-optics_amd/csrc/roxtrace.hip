@@ -941,6 +941,16 @@ int rox_unpin_host_memory(void *p)
     return 0;
 }
 
+int rox_copy_async(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (bytes == 0)
+        return 0;
+    if (!dst || !src)
+        return fail(ROX_E_ARG, "rox_copy_async: null pointer");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, (hipStream_t)stream));
+    return 0;
+}
+
 int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_table,
                       const double *wvls, int32_t n_wvls, rox_system **out_sys)
 {

@@ -18,7 +18,18 @@ with the per-block counts kept on the device.  Ranks own contiguous runs of
 the global block order, so the concatenation of the ranks' buffers *is* the
 global order and each (field, wavelength) is one contiguous slice of it.
 
-Two ways to get the pairs into the consumer's host memory, both built:
+Two ways to get the pairs into the consumer's host memory, both built, and both PIPELINED
+(``trace_spot_sharded(..., pipeline=True)``, the default): a rank's row blocks are cut into
+pieces of at most 4 Mi rays, each piece is one packed-hits launch into its own region of the
+rank's HBM buffer (count on the device), and as soon as a piece's count is known -- while the
+next pieces are being traced -- its pairs move on: over xGMI to rank 0 and from there by the
+copy engine into host memory (``rccl``), or by the copy engine of the rank's own PCIe link
+straight into the shared host segment (``host``).  The host buffer holds one region per
+(field, wavelength) grid, so a piece's place depends only on the counts of the earlier pieces
+of ITS grid; a rank traces the head of the grid it shares with the next rank first and the
+tail of the grid it shares with the previous rank last, so those counts are known long before
+they are needed.  End to end -> max(kernels, transfers) instead of their sum.  The
+un-pipelined forms of round 3 (``pipeline=False``) are described next:
 
 ``exchange='rccl'``   the path's one exchange step: the per-block counts go
     round in a small all-gather, then every rank sends its packed pairs to
@@ -253,6 +264,17 @@ class HostSegment:
         self.dev_ptr = engine.pin_host_memory(self._t.data_ptr(), self.nbytes)
         self.array = np.frombuffer(memoryview(self._t.numpy()), dtype=np.float64).reshape(-1, 2)
 
+    @classmethod
+    def for_grids(cls, engine, name, n_grids, num, rank, create, dir=None):
+        """the segment of the pipelined exchange: one region of num * num pairs per (field,
+        wavelength) grid -- every rank copies its pieces to their final place in it"""
+        return cls(engine, name, [num * num] * n_grids, rank, create, dir)
+
+    @property
+    def host_ptr(self):
+        """host address of the mapping (destination of copy-engine transfers)"""
+        return self._t.data_ptr()
+
     def dest(self, rank=None):
         """(device-visible pointer, capacity in pairs) of a rank's slice"""
         k = self.rank if rank is None else rank
@@ -273,19 +295,336 @@ class HostSegment:
                 pass
 
 
+# ---------------------------------------------------------------- the pipelined exchange
+PIECE_RAYS = 1 << 22        # rays per packed-hits launch of the pipeline (a 2048 x 2048 grid)
+
+
+@dataclass(frozen=True)
+class Piece:
+    """rows [row_begin, row_begin + row_count) of grid g = (fi, wi), traced by `rank` into
+    its HBM buffer at ray offset `roff` (room for every ray of the piece)"""
+    rank: int
+    fi: int
+    wi: int
+    row_begin: int
+    row_count: int
+    roff: int
+    g: int
+
+
+def schedule(plan, num, n_wvls, max_rays=None):
+    """(pieces, order): pieces[rank] = the rank's blocks cut into Pieces of at most
+    `max_rays` rays, in ray order; order[rank] = the indices of pieces[rank] in TRACE order --
+    first the head of the grid the rank shares with the next rank (its count is what the next
+    rank's tail waits for), last the tail of the grid it shares with the previous rank."""
+    rows_max = max(1, (max_rays or PIECE_RAYS) // num)
+    pieces = []
+    for rank, blocks in enumerate(plan):
+        lst, roff = [], 0
+        for b in blocks:
+            r, end = b.row_begin, b.row_begin + b.row_count
+            while r < end:
+                take = min(rows_max, end - r)
+                lst.append(Piece(rank, b.fi, b.wi, r, take, roff, b.fi * n_wvls + b.wi))
+                roff += take * num
+                r += take
+        pieces.append(lst)
+    order = []
+    for lst in pieces:
+        idx = list(range(len(lst)))
+        if not lst:
+            order.append(idx)
+            continue
+        g_first, g_last = lst[0].g, lst[-1].g
+        shared_prev = lst[0].row_begin > 0
+        shared_next = lst[-1].row_begin + lst[-1].row_count < num
+        head = [i for i in idx if lst[i].g == g_last] \
+            if shared_next and not (shared_prev and g_first == g_last) else []
+        tail = [i for i in idx if lst[i].g == g_first and i not in head] if shared_prev else []
+        mid = [i for i in idx if i not in head and i not in tail]
+        order.append(head + mid + tail)
+    return pieces, order
+
+
+class _Placer:
+    """where a piece's pairs go inside its grid's host region: behind the survivors of the
+    earlier pieces of the same grid -- known once all their counts are"""
+
+    def __init__(self, pieces):
+        self.seq = {}
+        for lst in pieces:                      # rank-major = row order within a grid
+            for i, p in enumerate(lst):
+                self.seq.setdefault(p.g, []).append((p.rank, i))
+        self.count = {}
+
+    def set(self, rank, idx, n):
+        self.count[(rank, idx)] = int(n)
+
+    def offset(self, g, rank, idx):
+        off = 0
+        for key in self.seq[g]:
+            if key == (rank, idx):
+                return off
+            n = self.count.get(key)
+            if n is None:
+                return None
+            off += n
+        raise KeyError((g, rank, idx))
+
+    def total(self, g):
+        return sum(self.count[k] for k in self.seq[g])
+
+
+class _NoEvent:
+    def synchronize(self):
+        pass
+
+
+def _trace_spot_pipelined(engine, fields, image_pts, n_wvls, num, foc, flags, group, first_surf,
+                          last_surf, by, exchange, segment, timings, lookahead=2, max_rays=None,
+                          result_on='host'):
+    import contextlib
+    import ctypes as C
+    import time
+    import torch
+    import torch.distributed as dist
+    from .engine import make_opts, make_grid
+    world, rank, backend = _group_info(group)
+    plan = partition(len(fields), n_wvls, num, world, by)
+    pieces, order = schedule(plan, num, n_wvls, max_rays)
+    n_grids = len(fields) * n_wvls
+    mine, my_order = pieces[rank], order[rank]
+    n_mine = len(mine)
+    S = max(len(o) for o in order)
+    dev = getattr(engine, 'device', 'cpu')
+    cuda = str(dev).startswith('cuda')
+    nccl = backend == 'nccl'
+    N = engine.table.n_ifcs
+    if flags is None:
+        flags = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+    last = N - 2 if last_surf is None else last_surf
+    t0 = time.perf_counter()
+
+    if cuda:
+        main = torch.cuda.current_stream(dev)
+        side, copy = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        on_side = lambda: torch.cuda.stream(side)       # noqa: E731
+
+        def event(stream):
+            e = torch.cuda.Event()
+            e.record(stream)
+            return e
+    else:
+        main = side = copy = None
+        on_side = contextlib.nullcontext
+
+        def event(stream):
+            return _NoEvent()
+
+    # this rank's pieces: one region each in xy, one count word per STAGE
+    rays_mine = sum(p.row_count for p in mine) * num
+    xy = torch.empty((max(rays_mine, 1), 2), dtype=torch.float64, device=dev if cuda else 'cpu')
+    cnt = torch.zeros(max(S, 1), dtype=torch.int64, device=dev if cuda else 'cpu')
+    allc = torch.zeros((max(S, 1), world), dtype=torch.int64)
+    if cuda:
+        allc = allc.pin_memory()
+    allc_dev = torch.zeros((max(S, 1), world), dtype=torch.int64, device=dev) if (cuda and nccl) else None
+
+    # where the pairs end up: one region per (field, wavelength) grid
+    root = rank == 0
+    lease = None
+    if exchange == 'host':
+        if segment is None or len(segment.caps) != n_grids or min(segment.caps) < num * num:
+            raise ValueError("exchange='host' (pipelined) needs a HostSegment with one region of "
+                             "num*num pairs per (field, wavelength) grid: HostSegment.for_grids(...)")
+        host_ptr, grid_off, host_arr = segment.host_ptr, [int(o) for o in segment.offsets], segment.array
+    elif exchange == 'rccl':
+        grid_off = [g * num * num for g in range(n_grids + 1)]
+        host_ptr = host_arr = None
+        if root and result_on == 'device' and cuda:
+            # the gathered spot diagram stays in rank 0's HBM (a consumer on the device): the
+            # per-grid regions are device memory and the placement copies are device-to-device
+            host_arr = torch.empty((max(grid_off[-1], 1), 2), dtype=torch.float64, device=dev)
+            host_ptr = host_arr.data_ptr()
+        elif root:
+            if cuda:
+                from .engine import _pool
+                lease = _pool.take(torch, max(16 * grid_off[-1], 16))
+                host_ptr = lease.ptr
+                host_arr = lease.array((grid_off[-1], 2), np.float64)
+            else:
+                host_arr = np.empty((grid_off[-1], 2))
+                host_ptr = host_arr.ctypes.data
+    else:
+        raise ValueError(f'exchange {exchange!r}')
+    # rccl: rank 0 receives every other rank's pieces at the offsets they have over there
+    stage = {}
+    if exchange == 'rccl' and root and world > 1:
+        for r in range(1, world):
+            n_r = sum(p.row_count for p in pieces[r]) * num
+            stage[r] = torch.empty((max(n_r, 1), 2), dtype=torch.float64,
+                                   device=dev if (cuda and nccl) else 'cpu')
+
+    placer = _Placer(pieces)
+    evs = [None] * S
+    launched = 0
+
+    def launch_upto(k):
+        nonlocal launched
+        while launched < min(k, S):
+            s = launched
+            if s < n_mine:
+                p = mine[my_order[s]]
+                opts = make_opts(flags=flags, out_mode=abi.OUT_HITS_COMPACT, first_surf=first_surf,
+                                 last_surf=last, foc=foc, image_pt=image_pts[p.fi])
+                grid = make_grid((-1., -1.), (1., 1.), num, row_begin=p.row_begin, row_count=p.row_count)
+                engine.trace_pupil_grid_hits_at(fields[p.fi], grid, p.wi, opts,
+                                                xy.data_ptr() + 16 * p.roff, p.row_count * num,
+                                                cnt.data_ptr() + 8 * s)
+            evs[s] = event(main)
+            launched += 1
+
+    tm = {'stage_sync_ms': 0.0, 'gather_ms': 0.0}
+    t_kernels_done = None
+    pending = []
+    for s in range(S):
+        launch_upto(s + 1 + lookahead)
+        # ---- the counts of stage s, of every rank, on the host
+        t1 = time.perf_counter()
+        if cuda:
+            side.wait_event(evs[s])
+        with on_side():
+            if world > 1:
+                if nccl:
+                    dist.all_gather_into_tensor(allc_dev[s], cnt[s:s + 1], group=group)
+                    allc[s].copy_(allc_dev[s], non_blocking=True)
+                else:
+                    dist.all_gather_into_tensor(allc[s], cnt[s:s + 1].cpu(), group=group)
+            else:
+                allc[s, 0:1].copy_(cnt[s:s + 1], non_blocking=True)
+            ev_c = event(side)
+        ev_c.synchronize()
+        tm['stage_sync_ms'] += (time.perf_counter() - t1) * 1e3
+        counts_s = [int(v) for v in allc[s].tolist()]
+        for r in range(world):
+            if s < len(order[r]):
+                if counts_s[r] < 0:
+                    raise RuntimeError(f'rank {r}: packed-hits overflow in piece {order[r][s]}')
+                placer.set(r, order[r][s], counts_s[r])
+        if s == n_mine - 1 or (n_mine == 0 and s == 0):
+            t_kernels_done = time.perf_counter()
+        # ---- rccl: the pairs of stage s go to rank 0 (grouped point-to-point)
+        ev_x = None
+        arrived = []
+        if exchange == 'rccl' and world > 1:
+            t1 = time.perf_counter()
+            ops, keep = [], []
+            if not root:
+                if s < n_mine and counts_s[rank] > 0:
+                    p = mine[my_order[s]]
+                    with on_side():
+                        buf = xy[p.roff:p.roff + counts_s[rank]]
+                        buf = buf if nccl else buf.cpu()
+                    keep.append(buf)
+                    ops.append(dist.P2POp(dist.isend, buf, 0, group))
+            else:
+                for r in range(1, world):
+                    if s < len(order[r]):
+                        q = pieces[r][order[r][s]]
+                        arrived.append((r, order[r][s]))
+                        if counts_s[r] > 0:
+                            ops.append(dist.P2POp(dist.irecv, stage[r][q.roff:q.roff + counts_s[r]], r, group))
+            if ops:
+                with on_side():
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                    ev_x = event(side)
+            tm['gather_ms'] += (time.perf_counter() - t1) * 1e3
+        # ---- host placement: copy engine, behind the events of this stage
+        if exchange == 'host' or root:
+            cand = pending + ([(rank, my_order[s])] if s < n_mine else []) + arrived
+            pending = []
+            if cuda:
+                copy.wait_event(evs[s])
+                if ev_x is not None:
+                    copy.wait_event(ev_x)
+            for r, i in cand:
+                q = pieces[r][i]
+                off = placer.offset(q.g, r, i)
+                if off is None:
+                    pending.append((r, i))
+                    continue
+                n = placer.count[(r, i)]
+                if n:
+                    src = (xy.data_ptr() if r == rank else stage[r].data_ptr()) + 16 * q.roff
+                    engine.copy_async(host_ptr + 16 * (grid_off[q.g] + off), src, 16 * n, copy)
+    if t_kernels_done is None:
+        t_kernels_done = time.perf_counter()
+    tm['trace_ms'] = (t_kernels_done - t0) * 1e3
+    tm['counts_ms'] = tm['stage_sync_ms']
+    # pieces whose place depended on a later stage of another rank (a grid held by three ranks)
+    for r, i in pending:
+        q = pieces[r][i]
+        off = placer.offset(q.g, r, i)
+        assert off is not None, 'every count is known after the last stage'
+        n = placer.count[(r, i)]
+        if n:
+            src = (xy.data_ptr() if r == rank else stage[r].data_ptr()) + 16 * q.roff
+            engine.copy_async(host_ptr + 16 * (grid_off[q.g] + off), src, 16 * n, copy)
+    if cuda:
+        copy.synchronize()
+        side.synchronize()
+    if exchange == 'host' and world > 1:
+        # every rank's copies have landed in the shared segment before rank 0 reads it
+        tok = torch.zeros(1, device=dev if nccl else 'cpu')
+        dist.all_reduce(tok, group=group)
+        if nccl:
+            torch.cuda.current_stream(dev).synchronize()
+    t2 = time.perf_counter()
+    tm['d2h_ms'] = (t2 - t_kernels_done) * 1e3
+    result = None
+    totals = [sum(placer.count[(r, i)] for i in range(len(pieces[r]))) for r in range(world)]
+    if root:
+        result = {}
+        for g in range(n_grids):
+            n = placer.total(g)
+            result[(g // n_wvls, g % n_wvls)] = host_arr[grid_off[g]:grid_off[g] + n]
+        tm['reassembly_ms'] = (time.perf_counter() - t2) * 1e3
+    if timings is not None:
+        timings.update(tm)
+        timings['pairs_total'] = int(sum(totals))
+        timings['pairs_per_rank'] = totals
+        timings['pieces'] = [len(p) for p in pieces]
+        timings['stages'] = S
+        timings['pipelined'] = True
+    del lease
+    return result
+
+
 # ---------------------------------------------------------------- the sharded spot diagram
 def trace_spot_sharded(engine, fields, image_pts, n_wvls, num, foc, flags=None, group=None,
                        first_surf=1, last_surf=None, by='rows', exchange='rccl', segment=None,
-                       timings=None):
+                       timings=None, pipeline=True, max_piece_rays=None, result_on='host'):
     """Spot diagrams for every (field, wavelength), sharded over the process
     group: each rank traces its row blocks on its own GPU (packed hits), the
     pairs reach rank 0's host memory by the chosen exchange.  Returns on rank 0
     {(fi, wi): (R_ok, 2) float64 array in the reference's i-outer/j-inner ray
     order}; None on the other ranks.  ``timings`` (a dict) receives the phases in
     milliseconds: trace (launch -> counts on the host), counts, gather, d2h,
-    reassembly."""
+    reassembly.  ``pipeline=True`` (default): pieces of at most ``max_piece_rays`` rays move
+    on while later pieces are traced (module docstring); ``exchange='host'`` then wants a
+    ``HostSegment.for_grids`` segment (one region per grid).  ``pipeline=False``: round 3's
+    trace-everything-then-exchange form (per-rank slices of the segment).
+    ``result_on='device'`` (pipelined ``rccl`` only): the arrays are torch tensors in rank 0's
+    HBM -- the RCCL gather alone, for a consumer on the device."""
     import time
     import torch
+    if pipeline:
+        return _trace_spot_pipelined(engine, fields, image_pts, n_wvls, num, foc, flags, group,
+                                     first_surf, last_surf, by, exchange, segment, timings,
+                                     max_rays=max_piece_rays, result_on=result_on)
+    if result_on != 'host':
+        raise ValueError("result_on='device' needs the pipelined exchange")
     world, rank, backend = _group_info(group)
     plan = partition(len(fields), n_wvls, num, world, by)
     t = [time.perf_counter()]

@@ -511,6 +511,27 @@ class TraceEngine:
         pack.rays += R
         return pack
 
+    def trace_pupil_grid_hits_at(self, fld, grid, wvl_idx, opts, seg_ptr, cap, n_hits_ptr):
+        """enqueue one ROX_OUT_HITS_COMPACT launch (not appending) whose packed pairs go to
+        ``seg_ptr`` (room for ``cap`` pairs, device or device-visible memory) and whose count
+        goes to ``n_hits_ptr`` (int64, device-visible); nothing is synchronised.  The unit of
+        the pipelined sharded spot diagram (dist.trace_spot_sharded)"""
+        if opts.out_mode != abi.OUT_HITS_COMPACT or (opts.flags & abi.HITS_APPEND):
+            raise EngineError('trace_pupil_grid_hits_at needs OUT_HITS_COMPACT without HITS_APPEND')
+        o = abi.Out()
+        o.seg, o.n_hits, o.ld = int(seg_ptr), int(n_hits_ptr), int(cap)
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_trace_pupil_grid(self._handle, C.byref(fld), C.byref(grid),
+                                                 int(wvl_idx), C.byref(opts), C.byref(o),
+                                                 self._stream()), 'rox_trace_pupil_grid')
+
+    def copy_async(self, dst_ptr, src_ptr, nbytes, stream=None):
+        """rox_copy_async in the order of ``stream`` (a torch stream; None = the current one)"""
+        st = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_copy_async(C.c_void_p(int(dst_ptr)), C.c_void_p(int(src_ptr)),
+                                           C.c_size_t(int(nbytes)), st), 'rox_copy_async')
+
     # -- host memory other processes share (dist.HostSegment) ------------------------
     def pin_host_memory(self, ptr, nbytes):
         """register [ptr, ptr+nbytes) with the HIP runtime; returns the pointer kernels

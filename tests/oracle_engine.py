@@ -73,6 +73,20 @@ class OracleEngine:
         pack._cum.append(pack.n)
         return pack
 
+    def trace_pupil_grid_hits_at(self, fld, grid, wvl_idx, opts, seg_ptr, cap, n_hits_ptr):
+        import ctypes as C
+        assert opts.out_mode == abi.OUT_HITS_COMPACT and not (opts.flags & abi.HITS_APPEND)
+        hits = oracle.trace_pupil_grid(self.table, fld, grid, wvl_idx, opts).hits
+        assert len(hits) <= cap
+        if len(hits):
+            dst = np.ctypeslib.as_array((C.c_double * (2 * len(hits))).from_address(int(seg_ptr)))
+            dst[:] = hits.ravel()
+        C.c_int64.from_address(int(n_hits_ptr)).value = len(hits)
+
+    def copy_async(self, dst_ptr, src_ptr, nbytes, stream=None):
+        import ctypes as C
+        C.memmove(int(dst_ptr), int(src_ptr), int(nbytes))
+
     def pin_host_memory(self, ptr, nbytes):
         return ptr
 

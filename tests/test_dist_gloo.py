@@ -40,6 +40,35 @@ def test_partition_covers_everything_once():
                     assert all(b.row_begin == 0 and b.row_count == num for b in blocks)
 
 
+def test_pipeline_schedule_orders_shared_grids_first_and_last():
+    """dist.schedule: pieces tile every rank's rows exactly once, regions do not overlap, and a
+    rank traces the head of the grid it shares with the next rank first, the tail of the grid it
+    shares with the previous rank last (BASELINE configs[4] over 8 ranks)"""
+    from rayoptics_amd.dist import partition, schedule
+    nf, nw, num, world = 9, 5, 2048, 8
+    plan = partition(nf, nw, num, world)
+    pieces, order = schedule(plan, num, nw)
+    seen = np.zeros((nf * nw, num), dtype=int)
+    for r, lst in enumerate(pieces):
+        assert sorted(order[r]) == list(range(len(lst)))
+        roff = 0
+        for p in lst:
+            assert p.rank == r and p.roff == roff and p.row_count * num <= (1 << 22)
+            roff += p.row_count * num
+            seen[p.g, p.row_begin:p.row_begin + p.row_count] += 1
+        assert roff == sum(b.row_count for b in plan[r]) * num
+        first, last = lst[order[r][0]], lst[order[r][-1]]
+        if r < world - 1:       # shares its last grid with the next rank
+            assert first.g == lst[-1].g and lst[-1].row_begin + lst[-1].row_count < num
+        if r > 0:               # shares its first grid with the previous rank
+            assert last.g == lst[0].g and lst[0].row_begin > 0
+    assert (seen == 1).all()
+    # smaller pieces: the same cover
+    pieces2, _ = schedule(plan, num, nw, max_rays=300 * num)
+    assert sum(len(p) for p in pieces2) > sum(len(p) for p in pieces)
+    assert sum(p.row_count for lst in pieces2 for p in lst) == nf * nw * num
+
+
 def test_shard_by_field_of_baseline_config_3():
     """5 fields over 4 ranks: 2 / 1 / 1 / 1"""
     from rayoptics_amd.dist import partition
@@ -75,7 +104,7 @@ def test_spot_views_are_slices_of_one_buffer():
         np.testing.assert_array_equal(v2[key], v[key])
 
 
-def _worker(rank, world, port, q, by, exchange, num, name):
+def _worker(rank, world, port, q, by, exchange, num, name, pipeline=True, piece_rays=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -91,7 +120,8 @@ def _worker(rank, world, port, q, by, exchange, num, name):
     seg = None
     if exchange == 'host':
         plan = rdist.partition(len(wl.fields), nw, num, world, by)
-        caps = [rdist.rays_of(b, num) for b in plan]
+        # pipelined: one region per (field, wavelength) grid; round 3's form: one slice per rank
+        caps = [num * num] * (len(wl.fields) * nw) if pipeline else [rdist.rays_of(b, num) for b in plan]
         if rank == 0:
             seg = rdist.HostSegment(eng, f'rox_test_{port}', caps, rank, create=True, dir='/tmp')
         dist.barrier()
@@ -99,7 +129,8 @@ def _worker(rank, world, port, q, by, exchange, num, name):
             seg = rdist.HostSegment(eng, f'rox_test_{port}', caps, rank, create=False, dir='/tmp')
     tm = {}
     out = rdist.trace_spot_sharded(eng, wl.fields, wl.image_pts, nw, num, wl.foc, by=by,
-                                   exchange=exchange, segment=seg, timings=tm)
+                                   exchange=exchange, segment=seg, timings=tm, pipeline=pipeline,
+                                   max_piece_rays=piece_rays)
     q.put((rank, None if out is None else {k: v.copy() for k, v in out.items()}, tm))
     dist.barrier()
     if seg is not None:
@@ -107,11 +138,12 @@ def _worker(rank, world, port, q, by, exchange, num, name):
     dist.destroy_process_group()
 
 
-def _run(world, by, exchange, num, name, salt):
+def _run(world, by, exchange, num, name, salt, pipeline=True, piece_rays=None):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29500 + (os.getpid() * 7 + salt) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, by, exchange, num, name))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, by, exchange, num, name, pipeline,
+                                               piece_rays))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -125,19 +157,33 @@ def _run(world, by, exchange, num, name, salt):
     return got
 
 
-@pytest.mark.parametrize('world,by,exchange,name', [
-    (2, 'rows', 'rccl', 'dblgauss_c2'),
-    (3, 'rows', 'rccl', 'dblgauss_c2'),
-    (2, 'rows', 'host', 'dblgauss_c2'),
-    (4, 'field', 'rccl', 'rc_telescope_c4'),
+@pytest.mark.parametrize('world,by,exchange,name,pipeline,piece_rays', [
+    # pipelined (the default): pieces move on while later pieces are traced; small pieces so
+    # that every rank runs several stages and grids are cut between pieces and between ranks
+    (2, 'rows', 'rccl', 'dblgauss_c2', True, 36),
+    (3, 'rows', 'rccl', 'dblgauss_c2', True, 60),
+    (2, 'rows', 'host', 'dblgauss_c2', True, 36),
+    (3, 'rows', 'host', 'dblgauss_c2', True, None),
+    (4, 'field', 'rccl', 'rc_telescope_c4', True, 48),
+    (4, 'field', 'host', 'rc_telescope_c4', True, None),
+    # a grid held by three ranks (the middle rank's only grid is shared on both sides: its
+    # pieces wait for the previous rank's counts and the next rank's wait for its own)
+    (5, 'rows', 'rccl', 'singlet_c1', True, 24),
+    (5, 'rows', 'host', 'singlet_c1', True, 24),
+    # round 3's trace-everything-then-exchange form
+    (2, 'rows', 'rccl', 'dblgauss_c2', False, None),
+    (2, 'rows', 'host', 'dblgauss_c2', False, None),
+    (4, 'field', 'rccl', 'rc_telescope_c4', False, None),
 ])
-def test_sharded_spot_matches_single_process(world, by, exchange, name):
+def test_sharded_spot_matches_single_process(world, by, exchange, name, pipeline, piece_rays):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import rayoptics_amd  # noqa: F401
     from rayoptics_amd import workloads, abi
     from oracle import oracle
     num = 12
-    got = _run(world, by, exchange, num, name, salt=world * 10 + len(by) + len(exchange))
+    got = _run(world, by, exchange, num, name,
+               salt=world * 10 + len(by) + len(exchange) + 100 * pipeline + (piece_rays or 0),
+               pipeline=pipeline, piece_rays=piece_rays)
     assert got[0][0] is not None
     for r in range(1, world):
         assert got[r][0] is None
@@ -162,3 +208,7 @@ def test_sharded_spot_matches_single_process(world, by, exchange, name):
     assert tm['pairs_total'] == total and len(tm['pairs_per_rank']) == world
     for k in ('trace_ms', 'counts_ms', 'gather_ms', 'd2h_ms', 'reassembly_ms'):
         assert k in tm
+    if pipeline:
+        assert tm['pipelined'] and tm['stages'] == max(tm['pieces']) and len(tm['pieces']) == world
+        if piece_rays:
+            assert tm['stages'] > 2
