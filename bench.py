@@ -440,129 +440,6 @@ def main():
             line['strong_scaling'] = strong
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        rr = min(args.ref_sample_rows, num)
-        i0r = (num - rr) // 2
-        sl = slice(i0r * num, (i0r + rr) * num)
-        step()
-        torch.cuda.synchronize()
-        dev_sample = {'row0': i0r, 'rows': rr,
-                      'seg': out.seg[:, :, sl].cpu().numpy(), 'op': out.op[sl].cpu().numpy(),
-                      'status': out.status[sl].cpu().numpy(),
-                      'fail_surf': out.fail_surf[sl].cpu().numpy(),
-                      'pupil': out.pupil[:, sl].cpu().numpy()}
-    del xy, out
-
-    # the PSF of an OPD grid (analyses.calc_psf): the GEMM-shaped neighbour of the path,
-    # on the fp64 matrix cores; device-resident, mean of back-to-back calls
-    psf = None
-    if rank == 0:
-        try:
-            psf = psf_leg(torch)
-        except Exception as e:
-            psf = {'error': repr(e)}
-
-    # every BASELINE configuration at its own shape (rank 0's GPU; the others wait at the
-    # next fence)
-    configs = None
-    if rank == 0 and not args.no_configs:
-        try:
-            configs = configs_leg(torch, abi, workloads)
-        except Exception as e:
-            configs = {'error': repr(e)}
-    torch.cuda.empty_cache()
-
-    line = None
-    if rank == 0:
-        traffic, traffic_source = committed_traffic(num, wl.name)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        line = {
-            'metric': 'ray-surface intersections/sec',
-            'value': inters_all / dt * args.steps,
-            'unit': 'ray-surface intersections/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_steps_run': n_w,
-            'ms_per_step': dt / args.steps * 1e3,
-            'cold_ms_per_step': cold_dt / args.steps * 1e3,
-            'fence_ms': fence_ms,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'ranks_seen_by_backend': ranks_seen,
-            'config': {'workload': 'double-Gauss 13 interfaces (K=12), 1 field, 1 wvl, '
-                                   f'{num}x{num} pupil grid per GPU, FULL ray packets, '
-                                   'device-generated rays (BASELINE.json configs[1])',
-                       'rays_per_step': int(rays_all), 'interfaces': N,
-                       'intersections_per_step': int(inters_all),
-                       'nominal_R_times_K': int(rays_all) * K,
-                       'out_mode': 'FULL', 'field_index': fi, 'wvl_nm': wl.table.wvls[wi],
-                       'sharding': 'one (field,wvl) grid per rank' if world > 1 else 'single GPU'},
-            'rays_per_s': rays_all / dt * args.steps,
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': achieved / 8000.0, 'traffic': traffic,
-                         'traffic_source': traffic_source,
-                         'kernel': 'trace_kernel<FULL,PUPIL>', 'kernel_ms': kern_ms,
-                         'algorithmic_bytes_per_launch': alg_bytes,
-                         'frac_of_measured_copy_peak_6290': achieved / 6290.0},
-            'roofline_hits': roofline_hits(inters, R, hits_kern_ms),
-            'spot_diagram': {'wallclock_ms': float(np.median(spot_ms)),
-                             'wallclock_min_ms': float(np.min(spot_ms)), 'rays': R,
-                             'rays_through': n_through, 'kernel_hits_ms': hits_kern_ms,
-                             'pcie_floor_ms': n_through * 16 / 54.7e9 * 1e3,
-                             'what': 'rayoptics_amd.trace.trace_grid_spot(model, grid_rng, fld, wvl, '
-                                     'foc, image_pt): Python call -> host (R_ok, 2) float64 array '
-                                     '(survivors packed in ray order by the trace launch, written '
-                                     'straight into pinned host memory; 13 MB over PCIe at ~55 GB/s '
-                                     'is the floor)'},
-            'configs': configs,
-            'psf': psf,
-            'cpu_baseline': None,
-            'strong_scaling': None,
-            'library': library_id(),
-            'ok': True,
-        }
-
-    emitted = threading.Event()
-
-    def emit():
-        """the one JSON line goes to the real stdout (fd 1 was pointed at stderr while the
-        communicator was being built and the collectives ran)"""
-        nonlocal saved_stdout
-        if rank != 0 or emitted.is_set():
-            return
-        emitted.set()
-        sys.stdout.flush()
-        if saved_stdout is not None:
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
-            saved_stdout = None
-        print(json.dumps(line), flush=True)
-
-    # every run: the fixed-size problems with the path's one exchange step.  The main line is
-    # complete at this point and must not be lost to this extra leg: an exception is recorded,
-    # and a rank that hangs in an exchange (a divergent failure would leave the others waiting
-    # in a collective until the backend's own timeout kills the job) trips a watchdog that
-    # prints the line without the leg and ends every rank with status 0.
-    if not args.no_strong:
-        def give_up():
-            if rank == 0:
-                line['strong_scaling'] = {'error': f'timed out after {args.strong_timeout} s: a rank hung in '
-                                                   'an exchange; the main line above is unaffected'}
-                emit()
-            os._exit(0)
-        dog = threading.Timer(args.strong_timeout, give_up) if multi else None
-        if dog:
-            dog.daemon = True
-            dog.start()
-        try:
-            strong = strong_scaling(args, torch, dist, multi, world, rank, fence, ranks_seen)
-        except Exception as e:
-            import traceback
-            traceback.print_exc(file=sys.stderr)
-            strong = {'error': repr(e)}
-        if dog:
-            dog.cancel()
-        if rank == 0:
-            line['strong_scaling'] = strong
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(wl, fld, wi, opts, num, args.cpu_sample_rows,
                                             fi, dev_sample)
     emit()
