@@ -378,9 +378,13 @@ def main():
         if rank == 0:
             line['ok'] = False
             line['hung_in'] = hung_in[0]
-            line.setdefault('strong_scaling', {'error': f'timed out after {args.strong_timeout} s in '
-                                               f'{hung_in[0]}: a rank hung in an exchange'})
+            if not line.get('strong_scaling'):
+                line['strong_scaling'] = {'error': f'timed out after {args.strong_timeout} s in '
+                                                   f'{hung_in[0]}: a rank hung in an exchange'}
             emit()
+        else:
+            # the launcher ends every rank as soon as one fails: rank 0 prints first
+            time.sleep(3.0)
         os._exit(3)
 
     def guarded(what, fn):
