@@ -449,6 +449,50 @@ __device__ __forceinline__ bool quadric_hit(bool conic, double cv, double cc, do
 // (profiles.py:849-885 even, 1070-1113 radial; forward accumulation of the
 // powers, not Horner).  Returns false when the sag square root goes negative.
 // kind = ROX_EVENPOLY | ROX_RADIALPOLY | ROX_YTOROID | ROX_XTOROID (wave-uniform);
+// The sag and slope series of the polynomial profiles in one pass: two independent chains,
+//   z_asp += coef_i * z_pow;  z_pow *= m;     e_asp += (c_i * coef_i) * e_pow;  e_pow *= m
+// -- the same operations in the same order as the reference's two loops (forward power
+// accumulation, every product and sum separately rounded).  cd = the row's interleaved
+// (coef_i, c_i * coef_i) pairs, one 16-byte LDS word per term.
+//
+// A full-length series in the RadialPolynomial instance (all eight aspheres of the phone lens
+// carry ten coefficients) is straight-line code: the ten LDS words are requested before the
+// first product needs one, where the generic loop -- unrolled by eight plus a one-term
+// remainder loop by the compiler -- waits for most words one at a time.  Phone lens HITS 249
+// -> 232 us, FULL 284.5 -> 264 us per 2^20 rays, bit-identical.  Measured and not kept
+// (gpurun_out/r04e, r04f): the same for every instance (the EvenPolynomial instance pays for
+// the extra code: Nikkor HITS 319 -> 330 us), straight-line for every length with a scalar
+// branch per term (Nikkor 330, .zmx zoom 161 -> 171, phone lens 242), and prefetching the next
+// term's word in the loop (phone lens 253).
+template <int FEAT>
+__device__ __forceinline__ void series2(const d2 *cd, int ncoef, double m, double z_pow, double e_pow,
+                                        double &z_asp, double &e_asp)
+{
+    z_asp = 0.0;
+    e_asp = 0.0;
+    if ((FEAT & F_RADIAL) && !(FEAT & F_EVEN) && ncoef == ROX_MAX_COEF) {
+        d2 c[ROX_MAX_COEF];
+#pragma unroll
+        for (int i = 0; i < ROX_MAX_COEF; ++i)
+            c[i] = cd[i];
+#pragma unroll
+        for (int i = 0; i < ROX_MAX_COEF; ++i) {
+            z_asp += c[i].x * z_pow;
+            z_pow *= m;
+            e_asp += c[i].y * e_pow;
+            e_pow *= m;
+        }
+        return;
+    }
+    for (int i = 0; i < ncoef; ++i) {
+        const d2 c = cd[i];
+        z_asp += c.x * z_pow;
+        z_pow *= m;
+        e_asp += c.y * e_pow;           // (c_coef*coefs[i])*r_pow
+        e_pow *= m;
+    }
+}
+
 // FEAT says which of the three families this kernel instance carries code for.
 template <int FEAT, bool WANT_F>
 __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, double ec, double cR,
@@ -467,15 +511,8 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
         if (rad < 0.0)
             return false;
         const double srad = slim_sqrt(rad);
-        double z_asp = 0.0, y_pow = y2;
-        double e_asp = 0.0, d_pow = 1;
-        for (int i = 0; i < ncoef; ++i) {
-            const d2 c = cd[i];
-            z_asp += c.x * y_pow;
-            y_pow *= y2;
-            e_asp += c.y * d_pow;               // (c_coef*coefs[i])*y_pow
-            d_pow *= y2;
-        }
+        double z_asp, e_asp;
+        series2<FEAT>(cd, ncoef, y2, y2, 1, z_asp, e_asp);
         const double fY = slim_div(cv * y2, 1. + srad) + z_asp;
         if (WANT_F)
             f = p.z - fY - cR * (px * px + p.z * p.z - fY * fY) / 2;
@@ -503,16 +540,8 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
             srad_e = same ? srad : sqrt(rad_e);
             const double z = slim_div(cv * r2, 1. + srad);
             const double e = slim_div(cv, srad_e);
-            // sag and slope series in one pass: two independent chains, the same
-            // operations in the same order as the reference's two loops
-            double z_asp = 0.0, z_pow = r2, e_asp = 0.0, e_pow = 1;
-            for (int i = 0; i < ncoef; ++i) {
-                const d2 c = cd[i];
-                z_asp += c.x * z_pow;
-                z_pow *= r2;
-                e_asp += c.y * e_pow;           // (c_coef*coefs[i])*r_pow
-                e_pow *= r2;
-            }
+            double z_asp, e_asp;
+            series2<FEAT>(cd, ncoef, r2, r2, 1, z_asp, e_asp);
             f = p.z - (z + z_asp);
             e_tot = e + e_asp;
         } else {
@@ -535,14 +564,8 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
         double e_pow = (r == 0.0) ? 1.0 : slim_div(1.0, r);
         if (WANT_F) {
             const double z = slim_div(cv * r2, 1. + srad_e);
-            double z_asp = 0.0, z_pow = r;
-            for (int i = 0; i < ncoef; ++i) {   // both series in one pass (see above)
-                const d2 c = cd[i];
-                z_asp += c.x * z_pow;
-                z_pow *= r;
-                e_asp += c.y * e_pow;           // (c_coef*coef)*r_pow
-                e_pow *= r;
-            }
+            double z_asp;
+            series2<FEAT>(cd, ncoef, r, r, e_pow, z_asp, e_asp);
             f = p.z - (z + z_asp);
         } else {
             for (int i = 0; i < ncoef; ++i) {
