@@ -20,12 +20,16 @@
  *                             opticalspec.py:1339-1353 apply_vignetting)
  *   rox_aim_chief_rays     <- rayoptics/raytr/trace.py:313-415    iterate_ray() (both branches)
  *                             rayoptics/raytr/trace.py:627-640    aim_chief_ray()
+ *   rox_iterate_ray_raw    <- rayoptics/raytr/trace.py:866-961    iterate_ray_raw() -- the reverse
+ *                             chief ray of wideangle.py:620-665 eval_real_image_ht()
  *   rox_find_real_enp      <- rayoptics/raytr/wideangle.py:86-427 find_real_enp() /
  *                             find_edge() / find_z_enp_on_interval(), :46-83
  *                             enp_z_coordinate()
  *   rox_calc_vignetting    <- rayoptics/raytr/vigcalc.py:233-340, 396-461
  *                             calc_vignetting_for_field() / calc_vignetted_ray() /
  *                             iterate_pupil_ray()
+ *   rox_iterate_pupil_rays <- rayoptics/raytr/vigcalc.py:396-461 iterate_pupil_ray() as
+ *                             vigcalc.set_pupil (:123-230) calls it
  *   rox_system_create      <- rayoptics/seq/sequential.py:149-202 path()/path_sequence()
  *                             (the per-wavelength (Intfc, Gap, Tfrm, Indx, Zdir)
  *                             list flattened into one POD table)
@@ -55,7 +59,8 @@ extern "C" {
 /* ABI history: 4 = packed hits appended over launches (ROX_HITS_APPEND), rox_pin_host_memory,
  * rox_aim carries both branches of iterate_ray;  5 = rox_trace_pupil_grids (several grids, one
  * launch), rox_find_real_enp / rox_enp (the wide-angle pupil search);  6 = rox_out.ld is the
- * capacity of seg in pairs for ROX_OUT_HITS_COMPACT (overflow: n_hits < 0), rox_copy_async.
+ * capacity of seg in pairs for ROX_OUT_HITS_COMPACT (overflow: n_hits < 0), rox_copy_async,
+ * rox_iterate_ray_raw, rox_iterate_pupil_rays.
  * rox_abi_version() of the library must equal the header a binding was written against. */
 #define ROX_ABI_VERSION 6
 #define ROX_MAX_COEF 10   /* EvenPolynomial r^2..r^20 / RadialPolynomial r^1..r^10 */
@@ -377,6 +382,24 @@ typedef struct rox_vig {
 int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs,
                         double eps, double *vig, int32_t *clip_surf, void *stream);
 
+/* vigcalc.iterate_pupil_ray (rayoptics/raytr/vigcalc.py:396-461) on its own -- what
+ * vigcalc.set_pupil (:123-230, from the stop size to the pupil specification) iterates the
+ * axial marginal ray through the edge of the stop with: scipy's secant iteration (tol 1e-6)
+ * of the pupil coordinate `xy` from start_r0 until the ray, traced without aperture checks,
+ * meets interface `indx` at the radius r_target (the reference's "raised before the surface
+ * => 0.9 x that trial" rule included).  start_r[n] = the pupil coordinate found. */
+typedef struct rox_pupil_iter {
+    rox_field fld;           /* ray-start constants of the field               */
+    double start_r0;
+    double r_target;
+    int32_t xy;              /* 0 / 1: the pupil axis iterated                  */
+    int32_t wvl_idx;
+    int32_t indx;            /* the interface whose edge is the target          */
+    int32_t pad;
+} rox_pupil_iter;            /* 224 bytes */
+int rox_iterate_pupil_rays(rox_system *sys, int32_t n, const rox_pupil_iter *probs,
+                           double eps, double *start_r, void *stream);
+
 /* point spread function ---------------------------------------------------
  * analyses.calc_psf(wavefront, ndim, maxdim) (rayoptics/raytr/analyses.py:848-875;
  * callers: analyses.update_psf_data :878-883, mpl/analysisfigure.py:418).
@@ -461,6 +484,18 @@ typedef struct rox_aim {
 /* aim_xy: [n][2] = (x1, y1) per problem */
 int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs,
                        double eps, double *aim_xy, int32_t *result, void *stream);
+
+/* rayoptics/raytr/trace.py:866-961 iterate_ray_raw: the same two iterations over an explicit
+ * path list -- `sys` is the table of THAT path, e.g. the reversed path along which
+ * wideangle.eval_real_image_ht (wideangle.py:620-665; FieldSpec.obj_coords of fields given as
+ * real image heights, opticalspec.py:1019-1030, 1059-1070) sends the chief ray back from the
+ * image point.  The reference also hands back `rr`, the RayResult of the LAST TRIAL RAY it
+ * evaluated (not a ray through the root): last_xy[n][2] = that trial's (x1, y1) on the pupil
+ * plane, last_status[n] = its trace status (both NULL: exactly rox_aim_chief_rays).  All the
+ * problems of a model -- every field -- are one launch. */
+int rox_iterate_ray_raw(rox_system *sys, int32_t n, const rox_aim *probs, double eps,
+                        double *aim_xy, int32_t *result, double *last_xy,
+                        int32_t *last_status, void *stream);
 
 /* rayoptics/raytr/wideangle.py:86-427 find_real_enp (vselector 'rev1') +
  * find_z_enp_on_interval: the z of the real entrance pupil of a wide-angle

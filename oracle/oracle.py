@@ -45,6 +45,12 @@ def lib():
         L.rox_oracle_aim_chief_rays.restype = C.c_int
         L.rox_oracle_aim_chief_rays.argtypes = [P(abi.Surface), i32, vp, vp, i32, i32,
                                                 P(abi.Aim), C.c_double, vp, vp]
+        L.rox_oracle_iterate_ray_raw.restype = C.c_int
+        L.rox_oracle_iterate_ray_raw.argtypes = [P(abi.Surface), i32, vp, vp, i32, i32,
+                                                 P(abi.Aim), C.c_double, vp, vp, vp, vp]
+        L.rox_oracle_iterate_pupil_rays.restype = C.c_int
+        L.rox_oracle_iterate_pupil_rays.argtypes = [P(abi.Surface), i32, vp, vp, i32, i32,
+                                                    P(abi.PupilIter), C.c_double, vp]
         L.rox_oracle_find_real_enp.restype = C.c_int
         L.rox_oracle_find_real_enp.argtypes = [P(abi.Surface), i32, vp, vp, i32, i32,
                                                P(abi.Enp), C.c_double, vp, vp]
@@ -195,6 +201,37 @@ def aim_chief_rays(table, probs, eps=1.0e-12):
     if rc:
         raise RuntimeError(f'oracle error {rc}')
     return aim, result
+
+
+def iterate_pupil_rays(table, probs, eps=1.0e-12):
+    """vigcalc.iterate_pupil_ray per problem (abi.PupilIter) -> start_r float64[n]"""
+    n = len(probs)
+    arr = (abi.PupilIter * n)(*probs)
+    out = np.zeros(n)
+    rc = lib().rox_oracle_iterate_pupil_rays(table.rows, table.n_ifcs, table.n_table.ctypes.data,
+                                             _wvls(table).ctypes.data, len(table.wvls), n, arr,
+                                             eps, out.ctypes.data)
+    if rc:
+        raise RuntimeError(f'oracle error {rc}')
+    return out
+
+
+def iterate_ray_raw(table, probs, eps=1.0e-12):
+    """trace.iterate_ray_raw over the path `table` describes: (aim [n, 2], result [n],
+    last_xy [n, 2] = pupil-plane coordinates of the last trial ray, last_status [n])"""
+    n = len(probs)
+    arr = (abi.Aim * n)(*probs)
+    aim = np.zeros((n, 2))
+    result = np.zeros(n, dtype=np.int32)
+    last_xy = np.zeros((n, 2))
+    last_st = np.zeros(n, dtype=np.int32)
+    rc = lib().rox_oracle_iterate_ray_raw(table.rows, table.n_ifcs, table.n_table.ctypes.data,
+                                          _wvls(table).ctypes.data, len(table.wvls), n, arr,
+                                          eps, aim.ctypes.data, result.ctypes.data,
+                                          last_xy.ctypes.data, last_st.ctypes.data)
+    if rc:
+        raise RuntimeError(f'oracle error {rc}')
+    return aim, result, last_xy, last_st
 
 
 def find_real_enp(table, probs, eps=1.0e-12):

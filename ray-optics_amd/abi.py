@@ -146,6 +146,11 @@ class Vig(C.Structure):
                 ('max_iter', C.c_int32)]
 
 
+class PupilIter(C.Structure):
+    _fields_ = [('fld', Field), ('start_r0', C.c_double), ('r_target', C.c_double),
+                ('xy', C.c_int32), ('wvl_idx', C.c_int32), ('indx', C.c_int32), ('pad', C.c_int32)]
+
+
 assert C.sizeof(Aperture) == 40
 assert C.sizeof(Vig) == 240
 assert C.sizeof(Phase) == 168
@@ -163,7 +168,8 @@ EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_last_error', 'rox_system_create', 'rox_system_destroy',
            'rox_system_num_segments', 'rox_trace_rays',
            'rox_trace_pupil_grid', 'rox_trace_pupil_grids', 'rox_trace_pupil_list',
-           'rox_aim_chief_rays', 'rox_find_real_enp', 'rox_calc_vignetting', 'rox_calc_psf',
+           'rox_aim_chief_rays', 'rox_iterate_ray_raw', 'rox_find_real_enp', 'rox_calc_vignetting',
+           'rox_iterate_pupil_rays', 'rox_calc_psf',
            'rox_pin_host_memory', 'rox_unpin_host_memory', 'rox_copy_async')
 # ... and the measurement / self-test helpers of include/roxtrace_diag.h
 DIAG_EXPORTS = ('rox_time_pupil_grid', 'rox_selftest_fp64', 'rox_diag_pack_launches')
@@ -200,10 +206,14 @@ def declare(lib):
                                          P(Opts), P(Out), vp]
     lib.rox_aim_chief_rays.restype = C.c_int
     lib.rox_aim_chief_rays.argtypes = [vp, i32, P(Aim), dbl, vp, vp, vp]
+    lib.rox_iterate_ray_raw.restype = C.c_int
+    lib.rox_iterate_ray_raw.argtypes = [vp, i32, P(Aim), dbl, vp, vp, vp, vp, vp]
     lib.rox_find_real_enp.restype = C.c_int
     lib.rox_find_real_enp.argtypes = [vp, i32, P(Enp), dbl, vp, vp, vp]
     lib.rox_calc_vignetting.restype = C.c_int
     lib.rox_calc_vignetting.argtypes = [vp, i32, P(Vig), dbl, vp, vp, vp]
+    lib.rox_iterate_pupil_rays.restype = C.c_int
+    lib.rox_iterate_pupil_rays.argtypes = [vp, i32, P(PupilIter), dbl, vp, vp]
     lib.rox_calc_psf.restype = C.c_int
     lib.rox_calc_psf.argtypes = [vp, i32, i32, vp, C.c_uint32, vp]
     lib.rox_pin_host_memory.restype = C.c_int

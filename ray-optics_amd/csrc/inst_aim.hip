@@ -47,6 +47,17 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
     SegOut so{nullptr, 0, 0};
     const v3 pt0{pb.pt0[0], pb.pt0[1], pb.pt0[2]};
 
+    // the last trial ray evaluated -- the reference's `rr` (trace.py:334-346, 884-905), which
+    // iterate_ray_raw's caller reads the reverse chief ray from (wideangle.py:646-651)
+    double last_x = 0., last_y = 0.;
+    int last_st = -1;
+    auto keep_last = [&]() {
+        if (a.last_xy) {
+            a.last_xy[2 * i] = last_x;
+            a.last_xy[2 * i + 1] = last_y;
+            a.last_status[i] = last_st;
+        }
+    };
     // trace.py:322-349 y_stop_coordinate; `raised`: a trial ray failed before surf
     bool raised = false;
     auto f = [&](double y1) -> double {
@@ -56,6 +67,7 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
             dir0 = v3{-dir0.x, -dir0.y, -dir0.z};
         RayEnd e;
         trace_ray<MODE_PROBE, true, F_ALL>(c, so, pt0, dir0, pb.wvl_idx, true, e);
+        last_x = 0.; last_y = y1; last_st = e.status;
         double y_ray;
         if (e.status != ROX_OK) {
             y_ray = 0.;                         // final_coord = [0, 0, 0]
@@ -77,6 +89,7 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
                 dir0 = v3{-dir0.x, -dir0.y, -dir0.z};
             RayEnd e;
             trace_ray<MODE_PROBE, true, F_ALL>(c, so, pt0, dir0, pb.wvl_idx, true, e);
+            last_x = coord[0]; last_y = coord[1]; last_st = e.status;
             double xr = 0., yr = 0.;
             if (e.status != ROX_OK) {
                 if (e.fail_surf < pb.surf)
@@ -100,6 +113,7 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
         }
         a.aim_xy[2 * i] = x[0];
         a.aim_xy[2 * i + 1] = x[1];
+        keep_last();
         return;
     }
     const double tol = 1.48e-8;
@@ -144,6 +158,7 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
     a.aim_xy[2 * i] = 0.0;
     a.aim_xy[2 * i + 1] = p;
     a.result[i] = result;
+    keep_last();
 }
 
 
@@ -218,7 +233,16 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= a.n)
         return;
-    const rox_vig pb = a.probs[i];
+    rox_vig pb;
+    if (a.iters) {              // rox_iterate_pupil_rays: the field, the axis, the wavelength
+        const rox_pupil_iter it = a.iters[i];
+        pb = rox_vig{};
+        pb.fld = it.fld;
+        pb.xy = it.xy;
+        pb.wvl_idx = it.wvl_idx;
+    } else {
+        pb = a.probs[i];
+    }
     const int xy = pb.xy;
 
     Ctx c;
@@ -282,6 +306,10 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
         return raised ? 0.9 * raised_x : root;  // :456-459
     };
 
+    if (a.iters) {              // vigcalc.iterate_pupil_ray alone (set_pupil, vigcalc.py:141-143)
+        a.vig[i] = iterate(a.iters[i].indx, a.iters[i].start_r0, a.iters[i].r_target);
+        return;
+    }
     double rel[2] = {pb.start_dir[0], pb.start_dir[1]};
     int clip = -1;                              // None
     bool iterating = true;

@@ -117,6 +117,7 @@ static_assert(sizeof(rox_phase) == 168, "rox_phase layout");
 static_assert(sizeof(rox_surface) == 576, "rox_surface layout");
 static_assert(sizeof(rox_field) == 192, "rox_field layout");
 static_assert(sizeof(rox_enp) == 136, "rox_enp layout");
+static_assert(sizeof(rox_pupil_iter) == 224, "rox_pupil_iter layout");
 
 // Device-side row = the public rox_surface + per-surface values that are the
 // same for every ray and are therefore computed once at rox_system_create:
@@ -1746,6 +1747,8 @@ struct AimArgs {
     double eps;
     double *aim_xy;            // device [n][2]
     int32_t *result;           // device [n]
+    double *last_xy;           // device [n][2] or nullptr: the last trial ray's (x1, y1)
+    int32_t *last_status;      // device [n] or nullptr: ... and its trace status
 };
 void launch_aim(const AimArgs &, size_t lds, hipStream_t);
 
@@ -1770,6 +1773,8 @@ struct VigArgs {
     double eps;
     double *vig;               // device [n]
     int32_t *clip;             // device [n]
+    // rox_iterate_pupil_rays: iterate_pupil_ray on its own (probs unused, vig = start_r)
+    const rox_pupil_iter *iters;
 };
 void launch_vig(const VigArgs &, size_t lds, hipStream_t);
 

@@ -1330,11 +1330,12 @@ int rox_trace_pupil_list(rox_system *sys, const rox_field *fld, int64_t n_rays, 
     return rc ? rc : unstage_out(s, st);
 }
 
-int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs, double eps,
-                       double *aim_xy, int32_t *result, void *stream)
+int rox_iterate_ray_raw(rox_system *sys, int32_t n, const rox_aim *probs, double eps,
+                        double *aim_xy, int32_t *result, double *last_xy, int32_t *last_status,
+                        void *stream)
 {
-    if (!sys || n < 0 || (n > 0 && (!probs || !aim_xy || !result)))
-        return fail(ROX_E_ARG, "rox_aim_chief_rays: bad argument");
+    if (!sys || n < 0 || (n > 0 && (!probs || !aim_xy || !result)) || (!last_xy != !last_status))
+        return fail(ROX_E_ARG, "rox_iterate_ray_raw: bad argument");
     if (n == 0)
         return 0;
     for (int i = 0; i < n; ++i) {
@@ -1353,14 +1354,16 @@ int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs, double 
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
     void *d = nullptr;
     const size_t pb = sizeof(rox_aim) * n, yb = sizeof(double) * 2 * n, rb = sizeof(int32_t) * n;
-    HIP_TRY(hipMalloc(&d, pb + yb + rb));
+    HIP_TRY(hipMalloc(&d, pb + 2 * yb + 2 * rb));
     AimArgs a{};
     a.rows = sys->d_rows; a.n_table = sys->d_ntab; a.ph_consts = sys->d_phc; a.wvls = sys->d_wvls;
     a.slots = sys->d_slots[0];
     a.n_ifcs = sys->n_ifcs; a.n_wvls = sys->n_wvls; a.n = n;
     a.probs = (const rox_aim *)d;
     a.aim_xy = (double *)((char *)d + pb);
-    a.result = (int32_t *)((char *)d + pb + yb);
+    a.result = (int32_t *)((char *)d + pb + 2 * yb);
+    a.last_xy = last_xy ? a.aim_xy + 2 * (size_t)n : nullptr;
+    a.last_status = last_xy ? a.result + n : nullptr;
     a.eps = eps;
     hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
@@ -1371,12 +1374,22 @@ int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs, double 
         e = hipMemcpyAsync(aim_xy, a.aim_xy, yb, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess)
         e = hipMemcpyAsync(result, a.result, rb, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && last_xy)
+        e = hipMemcpyAsync(last_xy, a.last_xy, yb, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && last_xy)
+        e = hipMemcpyAsync(last_status, a.last_status, rb, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
     (void)hipFree(d);
     if (e != hipSuccess)
-        return fail(ROX_E_HIP, "rox_aim_chief_rays: %s", hipGetErrorString(e));
+        return fail(ROX_E_HIP, "rox_iterate_ray_raw: %s", hipGetErrorString(e));
     return 0;
+}
+
+int rox_aim_chief_rays(rox_system *sys, int32_t n, const rox_aim *probs, double eps,
+                       double *aim_xy, int32_t *result, void *stream)
+{
+    return rox_iterate_ray_raw(sys, n, probs, eps, aim_xy, result, nullptr, nullptr, stream);
 }
 
 int rox_find_real_enp(rox_system *sys, int32_t n, const rox_enp *probs, double eps,
@@ -1423,6 +1436,54 @@ int rox_find_real_enp(rox_system *sys, int32_t n, const rox_enp *probs, double e
     (void)hipFree(d);
     if (e != hipSuccess)
         return fail(ROX_E_HIP, "rox_find_real_enp: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int rox_iterate_pupil_rays(rox_system *sys, int32_t n, const rox_pupil_iter *probs, double eps,
+                           double *start_r, void *stream)
+{
+    if (!sys || n < 0 || (n > 0 && (!probs || !start_r)))
+        return fail(ROX_E_ARG, "rox_iterate_pupil_rays: bad argument");
+    if (n == 0)
+        return 0;
+    for (int i = 0; i < n; ++i) {
+        const rox_pupil_iter &p = probs[i];
+        if (p.wvl_idx < 0 || p.wvl_idx >= sys->n_wvls)
+            return fail(ROX_E_ARG, "probs[%d].wvl_idx %d out of range", i, p.wvl_idx);
+        if (p.indx < 0 || p.indx >= sys->n_ifcs || (p.xy != 0 && p.xy != 1))
+            return fail(ROX_E_ARG, "probs[%d] is malformed", i);
+        int rc = check_field(&p.fld);
+        if (rc)
+            return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = sys->n_ifcs, W = sys->n_wvls;
+    const size_t lds = (N * sizeof(dev_surface) + W * N * sizeof(double) * (1 + kPhaseConsts) +
+                        W * sizeof(double) + 2 * N * sizeof(int32_t) + 15) & ~size_t(15);
+    if (lds > 160 * 1024 - 64)
+        return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
+    void *d = nullptr;
+    const size_t pb = sizeof(rox_pupil_iter) * n, vb = sizeof(double) * n;
+    HIP_TRY(hipMalloc(&d, pb + vb));
+    VigArgs a{};
+    a.rows = sys->d_rows; a.n_table = sys->d_ntab; a.ph_consts = sys->d_phc; a.wvls = sys->d_wvls;
+    a.slots = sys->d_slots[0];
+    a.n_ifcs = sys->n_ifcs; a.n_wvls = sys->n_wvls; a.n = n;
+    a.iters = (const rox_pupil_iter *)d;
+    a.vig = (double *)((char *)d + pb);
+    a.eps = eps;
+    hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        launch_vig(a, lds, st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(start_r, a.vig, vb, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess)
+        return fail(ROX_E_HIP, "rox_iterate_pupil_rays: %s", hipGetErrorString(e));
     return 0;
 }
 

@@ -629,6 +629,33 @@ class TraceEngine:
                                                self._stream()), 'rox_aim_chief_rays')
         return aim, result
 
+    def iterate_pupil_rays(self, probs, eps=1.0e-12):
+        """probs: sequence of abi.PupilIter -> start_r float64[n] (vigcalc.iterate_pupil_ray)"""
+        n = len(probs)
+        arr = (abi.PupilIter * n)(*probs)
+        out = np.zeros(n)
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_iterate_pupil_rays(self._handle, n, arr, float(eps), out.ctypes.data,
+                                                   self._stream()), 'rox_iterate_pupil_rays')
+        return out
+
+    def iterate_ray_raw(self, probs, eps=1.0e-12):
+        """trace.iterate_ray_raw over the path this engine's table describes: (aim [n, 2],
+        result [n], last_xy [n, 2] = pupil-plane coordinates of the last trial ray the
+        iteration evaluated, last_status [n] = its trace status)"""
+        n = len(probs)
+        arr = (abi.Aim * n)(*probs)
+        aim = np.zeros((n, 2))
+        result = np.zeros(n, dtype=np.int32)
+        last_xy = np.zeros((n, 2))
+        last_st = np.zeros(n, dtype=np.int32)
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_iterate_ray_raw(self._handle, n, arr, float(eps), aim.ctypes.data,
+                                                result.ctypes.data, last_xy.ctypes.data,
+                                                last_st.ctypes.data, self._stream()),
+                   'rox_iterate_ray_raw')
+        return aim, result, last_xy, last_st
+
     def find_real_enp(self, probs, eps=1.0e-12):
         """probs: sequence of abi.Enp -> (z float64[n, 2] = (z_enp, z of the last trial ray),
         result int32[n] = abi.ENP_*)"""

@@ -66,6 +66,9 @@ def install(fallback='raise'):
              # chief-ray aiming: trace.aim_chief_ray is imported by name into
              # opticalspec (opticalspec.py:19), so both bindings are replaced, and
              # update_optical_properties aims all fields in one launch
+             # the reverse chief-ray iteration behind fields given as real image heights
+             # (wideangle.eval_real_image_ht calls it module-qualified, wideangle.py:646)
+             (rtrace, 'iterate_ray_raw', _t.iterate_ray_raw),
              (rtrace, 'aim_chief_ray', _t.aim_chief_ray),
              (ropticalspec, 'aim_chief_ray', _t.aim_chief_ray),
              # the wide-angle pupil search behind aim_chief_ray (trace.py:634-635) and
@@ -77,6 +80,9 @@ def install(fallback='raise'):
              # vignetting search and the boundary rays behind set_clear_apertures
              (rvigcalc, 'calc_vignetting_for_field', _v.calc_vignetting_for_field),
              (rvigcalc, 'set_vig', _v.set_vig),
+             # vigcalc.set_pupil's marginal-ray iteration (set_pupil / set_stop_aperture call
+             # iterate_pupil_ray, set_vig and set_clear_apertures through these module globals)
+             (rvigcalc, 'iterate_pupil_ray', _v.iterate_pupil_ray),
              (rtrace, 'trace_boundary_rays_at_field', _v.trace_boundary_rays_at_field)]
     for owner, name, ours in seams:
         theirs = getattr(owner, name)

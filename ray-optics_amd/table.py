@@ -368,15 +368,22 @@ def _obj_coords(opt_model, fld, cache):
     fov = osp['fov']
     if cache is None or tuple(fov.key) != ('image', 'real height'):
         return osp.obj_coords(fld)
+    # (the entry keeps the field and the first-order data object alive and compares them by
+    # identity: an id() alone could be reused by another object after an update_model();
+    # the stop surface is part of what eval_real_image_ht reads, wideangle.py:633-634)
+    parax = opt_model['analysis_results']['parax_data']
     key = (id(fld), float(fld.x), float(fld.y), float(fov.value), bool(fov.is_relative),
-           bool(fov.is_wide_angle), float(osp['wvls'].central_wvl),
-           id(opt_model['analysis_results']['parax_data']))
+           bool(fov.is_wide_angle), float(osp['wvls'].central_wvl), id(parax),
+           opt_model['seq_model'].stop_surface)
     hit = cache.get(key)
+    if hit is not None and (hit[3] is not fld or hit[4] is not parax):
+        hit = None
     if hit is None:
         p0, d0 = osp.obj_coords(fld)
         hit = cache[key] = (np.array(p0, dtype=float), np.array(d0, dtype=float),
-                            None if fld.aim_info is None else np.array(fld.aim_info, dtype=float))
-    p0, d0, aim = hit
+                            None if fld.aim_info is None else np.array(fld.aim_info, dtype=float),
+                            fld, parax)
+    p0, d0, aim = hit[:3]
     fld.aim_info = None if aim is None else (float(aim) if aim.ndim == 0 else aim.copy())
     return p0.copy(), d0.copy()
 

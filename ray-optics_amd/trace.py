@@ -10,6 +10,8 @@ the per-ray Python loop replaced by one device launch.
                      reference's own iterative callers (trace_base, iterate_ray's 2-D
                      fsolve branch, the wide-angle pupil search, trace_chief_ray ...)
   aim_chief_ray   <- rayoptics/raytr/trace.py:627-640 (iterate_ray's 1-D branch on the device)
+  iterate_ray_raw <- rayoptics/raytr/trace.py:866-961 (the reverse chief ray of
+                     wideangle.eval_real_image_ht: the whole iteration in one launch)
   osp_update_optical_properties <- rayoptics/raytr/opticalspec.py:263-281 (method; all
                                    fields aimed in one launch)
 Result filtering follows trace_safe, rayoptics/raytr/trace.py:160-221.
@@ -133,6 +135,50 @@ def raytrace_trace_raw(path, pt0, dir0, wvl, eps=1.0e-12, check_apertures=False,
     ray, op, _w = err.ray_pkg
     err.ray_pkg = (ray.to_list(), op, wvl)
     raise err
+
+
+def iterate_ray_raw(pthlist, ifcx, xy_target, pt0, d0, obj2pup_dist, eprad, wvl, not_wa, **kwargs):
+    """rayoptics/raytr/trace.py:866-961 ``iterate_ray_raw``: the chief-ray iteration over an
+    explicit path list -- the reversed path along which ``wideangle.eval_real_image_ht``
+    (wideangle.py:620-665; ``FieldSpec.obj_coords`` of fields given as real image heights,
+    BASELINE configs[2]'s .zmx) sends a ray back from the image point through the centre of
+    the stop.  The reference runs scipy's secant / MINPACK iteration around single Python
+    ray traces; here the whole iteration is one lane of one launch (``rox_iterate_ray_raw``)
+    on the table of that path, and the ``rr`` the reference hands back -- the RayResult of the
+    LAST TRIAL RAY it evaluated, which eval_real_image_ht reads the object-space ray from --
+    is that trial ray traced once more.  Returns ``(start_coords, rr)`` as the reference."""
+    from rayoptics.raytr import RayPkg as RefRayPkg, RayResult
+    from rayoptics.raytr.traceerror import TraceError
+    from rayoptics.util.misc_math import normalize
+    from .table import SurfaceTable
+    if ifcx is None:            # floating stop surface - use entrance pupil for aiming (:957-958)
+        return np.array([0., 0.]) + xy_target, None
+    path = list(pthlist)
+    tbl = SurfaceTable.from_paths([path], [0.0 if wvl is None else float(wvl)])
+    eng = session.engine_for_table(tbl)
+    z_dir0 = path[0][4]
+    a = abi.Aim()
+    for k in range(3):
+        a.pt0[k] = float(pt0[k])
+    a.z_enp = float(obj2pup_dist)
+    a.x_target, a.y_target = float(xy_target[0]), float(xy_target[1])
+    a.z_dir0 = float(z_dir0) if z_dir0 is not None else 1.0
+    a.wvl_idx, a.surf, a.flip = 0, int(ifcx), 1 if not_wa else 0
+    a.two_d = 0 if (pt0[0] == 0.0 and xy_target[0] == 0.0) else 1
+    a.epsfcn = 0.0001 * float(eprad)
+    aim, _res, last_xy, _last_st = eng.iterate_ray_raw([a], eps=kwargs.get('eps', 1.0e-12))
+    start_coords = aim[0].copy() if a.two_d else np.array([0., aim[0, 1]])
+    # `rr`: the last trial ray the iteration evaluated (y_stop_coordinate / surface_coordinate,
+    # :879-921), with the direction formed as the reference forms it
+    pt1 = np.array([last_xy[0, 0], last_xy[0, 1], obj2pup_dist])
+    dir0 = normalize(pt1 - pt0)
+    if not_wa and dir0[2] * z_dir0 < 0:
+        dir0 = -dir0
+    try:
+        rr = RayResult(RefRayPkg(*raytrace_trace_raw(iter(path), pt0, dir0, wvl)), None)
+    except TraceError as ray_error:
+        rr = RayResult(RefRayPkg(*ray_error.ray_pkg), ray_error)
+    return start_coords, rr
 
 
 def _launch_setup(opt_model, fld, wvl, kwargs, out_mode, foc=0.0, image_pt=(0., 0.), wf=None):

@@ -7,6 +7,12 @@ fast).
                                :259-340, iterate_pupil_ray :396-461)
   set_vig                   <- rayoptics/raytr/vigcalc.py:99-105: every field's four
                                pupil directions in one launch
+  iterate_pupil_ray         <- rayoptics/raytr/vigcalc.py:396-461 on its own: what
+                               vigcalc.set_pupil (:123-230) finds the edge of the stop with.
+                               set_pupil / set_stop_aperture (:108-121) themselves stay the
+                               reference's code: everything they iterate or trace in bulk --
+                               iterate_pupil_ray, set_vig, set_clear_apertures' boundary rays --
+                               resolves to these drop-ins through vigcalc's module globals
   trace_boundary_rays_at_field <- rayoptics/raytr/trace.py:436-452: the pupil-limiting
                                rays of a field in one launch (set_clear_apertures,
                                vigcalc.py:45-85, consumes them unchanged)
@@ -38,8 +44,27 @@ def _problems(opt_model, fld, wvl, tbl, max_iter):
     return probs
 
 
+def iterate_pupil_ray(opt_model, indx, xy, start_r0, r_target, fld, wvl, **kwargs):
+    """rayoptics/raytr/vigcalc.py:396-461: the pupil coordinate on axis ``xy`` whose ray meets
+    interface ``indx`` at radius ``r_target`` -- scipy's secant iteration around single Python
+    ray traces in the reference, one lane of one launch here (``rox_iterate_pupil_rays``).
+    ``vigcalc.set_pupil`` (:123-230) iterates the axial marginal ray to the edge of the stop
+    with it; the vignetting search has the same iteration inside its own launch."""
+    start_coords = np.array([0., 0.])
+    if indx is None:            # floating stop surface - use entrance pupil for aiming (:463-464)
+        start_coords[xy] = r_target
+        return start_coords
+    eng = session.engine_for(opt_model)
+    p = abi.PupilIter()
+    p.fld = field_from_model(opt_model, fld)
+    p.start_r0, p.r_target = float(start_r0), float(r_target)
+    p.xy, p.wvl_idx, p.indx = int(xy), eng.table.wvl_index(wvl), int(indx)
+    start_coords[xy] = eng.iterate_pupil_rays([p])[0]
+    return start_coords
+
+
 def _store(fld, vig4):
-    fld.vux, fld.vlx, fld.vuy, fld.vly = (float(v) for v in vig4)       # vigcalc.py:252-256
+    fld.vux, fld.vlx, fld.vuy, fld.vly = (np.float64(v) for v in vig4)  # vigcalc.py:252-256 (np.float64 there too)
 
 
 def calc_vignetting_for_field(opm, fld, wvl, **kwargs):

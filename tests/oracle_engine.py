@@ -144,6 +144,12 @@ class OracleEngine:
     def aim_chief_rays(self, probs, eps=1.0e-12):
         return oracle.aim_chief_rays(self.table, probs, eps)
 
+    def iterate_pupil_rays(self, probs, eps=1.0e-12):
+        return oracle.iterate_pupil_rays(self.table, probs, eps)
+
+    def iterate_ray_raw(self, probs, eps=1.0e-12):
+        return oracle.iterate_ray_raw(self.table, probs, eps)
+
     def find_real_enp(self, probs, eps=1.0e-12):
         return oracle.find_real_enp(self.table, probs, eps)
 

@@ -1285,3 +1285,166 @@ def test_spot_and_ray_fan_figures_on_the_other_config_models(ref, installed, mod
                 np.testing.assert_array_equal(xo, xt)
                 np.testing.assert_array_equal(yo, yt)
                 assert mo == mt
+
+
+def _perturbed_zmx(ref, rng, scale):
+    """the .zmx import with its curvatures, gaps and the image heights nudged: a family of
+    models whose reverse chief-ray iterations differ (1-D branch for fields on the y axis,
+    MINPACK's 2-D branch for the ones moved off it)"""
+    opm = ref.zmx_evenasph_c3()
+    sm = opm['seq_model']
+    for ifc in sm.ifcs[1:-1]:
+        ifc.profile.cv *= 1.0 + scale * rng.normal()
+    for g in sm.gaps[1:-1]:
+        g.thi *= 1.0 + 0.3 * scale * rng.normal()
+    ref.finish(opm, do_apertures=False)
+    for f in opm['osp']['fov'].fields:
+        f.y *= 1.0 + 0.05 * rng.normal()
+        if rng.random() < 0.5:
+            f.x = 0.3 * float(rng.normal())
+    return opm
+
+
+def test_reverse_chief_ray_iteration_on_the_device(ref, installed):
+    """trace.iterate_ray_raw rebound (verdict r3 #5, the f2 remainder): wideangle.
+    eval_real_image_ht -- FieldSpec.obj_coords of ('image', 'real height') fields -- gives the
+    reference's object-space ray and entrance-pupil distance bit for bit, for fields on and
+    off the y axis of the .zmx import and of perturbed copies of it, while NO single ray goes
+    through the raytrace.trace / trace_raw seams from reference code (the reference's own loop
+    makes 7-25 of them per field)"""
+    import rayoptics.raytr.raytrace as rraytrace
+    import rayoptics.raytr.wideangle as wa
+    rng = np.random.default_rng(20260926)
+    models = [ref.zmx_evenasph_c3()] + [_perturbed_zmx(ref, rng, s) for s in (1e-3, 5e-3, 2e-2)]
+    n_fields = n_2d = 0
+    for opm in models:
+        osp = opm['osp']
+        wvl = osp['wvls'].central_wvl
+        assert tuple(osp['fov'].key) == ('image', 'real height')
+        seen = {'n': 0}
+
+        def run():
+            # count what reaches the one-ray seams while the function under test runs
+            t0, r0 = rraytrace.trace, rraytrace.trace_raw
+
+            def ct(*a, **k):
+                seen['n'] += 1
+                return t0(*a, **k)
+
+            def cr(*a, **k):
+                seen['n'] += 1
+                return r0(*a, **k)
+            rraytrace.trace, rraytrace.trace_raw = ct, cr
+            try:
+                seen['n'] = 0
+                out = []
+                for fld in osp['fov'].fields:
+                    try:
+                        (p_o, d_o), z_enp = wa.eval_real_image_ht(opm, fld, wvl)
+                        out.append((np.array(p_o), np.array(d_o), float(z_enp)))
+                    except Exception as e:      # the same exception either way
+                        out.append(type(e).__name__)
+                return out, seen['n']
+            finally:
+                rraytrace.trace, rraytrace.trace_raw = t0, r0
+        (ours, n_ours), (theirs, n_theirs) = both(installed, run)
+        assert n_ours == 0 and n_theirs >= 3 * len(ours), (n_ours, n_theirs)
+        for fld, o, t in zip(osp['fov'].fields, ours, theirs):
+            if isinstance(t, str):
+                assert o == t
+                continue
+            np.testing.assert_array_equal(o[0], t[0])
+            np.testing.assert_array_equal(o[1], t[1])
+            assert o[2] == t[2]
+            n_fields += 1
+            n_2d += fld.x != 0.0
+    assert n_fields >= 9 and n_2d >= 2
+
+
+def test_spot_diagram_on_the_zmx_import_without_reference_side_single_rays(ref, installed):
+    """SpotDiagramFigure on BASELINE configs[2]'s model with the drop-ins: not one ray goes
+    through the one-ray seams (aiming, the reverse chief-ray iteration and the grids are all
+    launches); the figure's data is the reference's"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    import rayoptics.raytr.raytrace as rraytrace
+    from rayoptics.mpl.axisarrayfigure import SpotDiagramFigure
+    opm = ref.zmx_evenasph_c3()
+    for f in opm['osp']['fov'].fields:
+        f.aim_info = None
+
+    def run():
+        fig = plt.figure(FigureClass=SpotDiagramFigure, opt_model=opm, num_rays=6)
+        fig.update_data()
+        data = [[np.array(g) for g in row[0][0]] for row in fig.axis_data_array]
+        plt.close(fig)
+        return data
+    ours = run()
+    # how many single rays the figure sent through the seams with the drop-ins active:
+    # setup_pupil_coords' chief ray per field and wavelength stays the reference's (one ray
+    # each through raytrace.trace); nothing iterates through the seams any more
+    t0, r0 = rraytrace.trace, rraytrace.trace_raw
+    n = {'trace': 0, 'raw': 0}
+
+    def ct(*a, **k):
+        n['trace'] += 1
+        return t0(*a, **k)
+
+    def cr(*a, **k):
+        n['raw'] += 1
+        return r0(*a, **k)
+    rraytrace.trace, rraytrace.trace_raw = ct, cr
+    try:
+        again = run()
+    finally:
+        rraytrace.trace, rraytrace.trace_raw = t0, r0
+    assert n['raw'] == 0, n
+    assert n['trace'] <= 3 * 3 + 3, n       # at most the chief rays of setup_pupil_coords
+    installed.uninstall()
+    theirs = run()
+    installed.install()
+    for a, b, c in zip(ours, again, theirs):
+        for ga, gb, gc in zip(a, b, c):
+            np.testing.assert_array_equal(ga, gc)
+            np.testing.assert_array_equal(gb, gc)
+
+
+@pytest.mark.parametrize('model', ['dblgauss', 'nikkor', 'cell_phone', 'rc_telescope', 'singlet'])
+def test_set_pupil_and_set_stop_aperture(ref, installed, model):
+    """vigcalc.set_pupil (vigcalc.py:123-230: from the stop size to the pupil specification)
+    and set_stop_aperture (:108-121) stay the reference's code; what they iterate and trace
+    in bulk -- iterate_pupil_ray (rebound: one launch), set_vig, the boundary rays behind
+    set_clear_apertures -- resolves to the drop-ins.  After stopping the model down by 20 %:
+    the same pupil value, vignetting factors and apertures as the reference computes.  (On
+    the device the objective's `p[0]**2` is a correctly rounded product where the reference
+    calls libm pow, DESIGN 3.1: there the factors agree to 1e-12, here -- the oracle calls
+    pow -- bit for bit.)"""
+    import torch
+    import rayoptics.raytr.vigcalc as vc
+    exact = not torch.cuda.is_available()
+
+    def run():
+        opm = getattr(ref, model)()
+        sm, osp = opm['seq_model'], opm['osp']
+        # (the element model behind OpticalModel.update_model needs packages that are not
+        # installed here: the sequential update of refmodels.finish stands in for it)
+        opm.update_model = lambda **kw: ref.finish(opm, do_apertures=False)
+        st = sm.ifcs[sm.stop_surface]
+        st.max_aperture *= 0.8
+        for ca in st.clear_apertures:
+            ca.radius *= 0.8
+        vc.set_pupil(opm)
+        flds = osp['fov'].fields
+        a = [osp['pupil'].value] + [v for f in flds for v in (f.vux, f.vuy, f.vlx, f.vly)]
+        vc.set_stop_aperture(opm)
+        b = [ifc.max_aperture for ifc in sm.ifcs] + [v for f in flds for v in (f.vux, f.vuy, f.vlx, f.vly)]
+        return np.array(a, dtype=float), np.array(b, dtype=float)
+    (ao, bo), (at, bt) = both(installed, run)
+    assert ao[0] != getattr(ref, model)()['osp']['pupil'].value      # set_pupil did change it
+    if exact:
+        np.testing.assert_array_equal(ao, at)
+        np.testing.assert_array_equal(bo, bt)
+    else:
+        np.testing.assert_allclose(ao, at, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(bo, bt, rtol=0, atol=1e-11)

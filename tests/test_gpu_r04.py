@@ -190,3 +190,94 @@ def test_the_compaction_suites_pass_in_the_two_pass_form():
     tail = r.stdout[-1500:] + r.stderr[-1500:]
     assert r.returncode == 0, tail
     assert ' passed' in r.stdout and 'failed' not in r.stdout, tail
+
+
+def test_iterate_ray_raw_returns_the_last_trial_ray():
+    """rox_iterate_ray_raw (trace.py:866-961): aim point, result code AND the last trial ray
+    the iteration evaluated -- its pupil-plane coordinates and trace status, what the
+    reference keeps as `rr` -- device == oracle bit for bit, both branches, perturbed problems
+    incl. ones whose trial rays fail; with last_xy = NULL it is rox_aim_chief_rays"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine
+    from test_gpu_r03 import aim2d_problem
+    rng = np.random.default_rng(404)
+    n_fail_last = n_2d = n = 0
+    for name in ('dblgauss_c2', 'nikkor_c3', 'cell_phone', 'zmx_evenasph_c3', 'rc_telescope_c4', 'litho_c5'):
+        wl = workloads.load(name)
+        eng = TraceEngine(wl.table)
+        allp = []
+        for w in range(len(wl.table.wvls)):
+            for m in (wl.aim2d or []):
+                allp.append(aim2d_problem(m, w))
+                for _ in range(3):
+                    p = aim2d_problem(m, w)
+                    p.pt0[0] *= rng.uniform(0.2, 3.0)
+                    p.pt0[1] *= rng.uniform(0.2, 3.0)
+                    p.z_enp *= rng.uniform(0.7, 1.3)
+                    p.epsfcn *= 10.0 ** rng.uniform(-3, 1)
+                    p.x_target, p.y_target = rng.normal(size=2) * 0.05
+                    allp.append(p)
+            for m in wl.aim or []:
+                for scale in (1.0, rng.uniform(0.3, 2.5), rng.uniform(2.0, 6.0)):
+                    a = abi.Aim()
+                    for i in range(3):
+                        a.pt0[i] = m['pt0'][i] * (scale if i < 2 else 1.0)
+                    a.z_enp, a.y_target, a.z_dir0 = m['z_enp'], 0.0, m['z_dir0']
+                    a.wvl_idx, a.surf, a.flip = w, m['surf'], 1
+                    allp.append(a)
+        assert allp, name
+        a_dev, r_dev, l_dev, s_dev = eng.iterate_ray_raw(allp)
+        a_orc, r_orc, l_orc, s_orc = oracle.iterate_ray_raw(wl.table, allp)
+        np.testing.assert_array_equal(r_dev, r_orc)
+        np.testing.assert_array_equal(s_dev, s_orc)
+        assert np.array_equal(a_dev, a_orc, equal_nan=True), name
+        assert np.array_equal(l_dev, l_orc, equal_nan=True), name
+        a2, r2 = eng.aim_chief_rays(allp)
+        assert np.array_equal(a2, a_dev, equal_nan=True) and np.array_equal(r2, r_dev)
+        n += len(allp)
+        n_2d += sum(p.two_d for p in allp)
+        n_fail_last += int((s_dev != abi.OK).sum())
+        eng.close()
+    assert n > 300 and n_2d > 50 and n_fail_last > 0
+
+
+def test_iterate_pupil_rays_on_the_device():
+    """rox_iterate_pupil_rays (vigcalc.iterate_pupil_ray, vigcalc.py:396-461, as set_pupil
+    calls it): the pupil coordinate whose ray meets an interface at a target radius, device vs
+    oracle -- within 1e-12 (the objective's `p[0]**2` is libm pow in the reference and in the
+    oracle, a correctly rounded product on the device), incl. problems whose trial
+    rays miss before the target surface (the reference's 0.9 x rule)"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine
+    rng = np.random.default_rng(77)
+    n = n_far = 0
+    for name in ('dblgauss_c2', 'nikkor_c3', 'cell_phone', 'rc_telescope_c4', 'singlet_c1'):
+        wl = workloads.load(name)
+        N = wl.n_ifcs
+        eng = TraceEngine(wl.table)
+        stop = wl.table.stop_idx if wl.table.stop_idx is not None else 1
+        probs = []
+        for fld in wl.fields:
+            for wi in range(len(wl.table.wvls)):
+                for indx in sorted({stop, 1, N - 2}):
+                    r_edge = wl.table.rows[indx].max_aperture
+                    for xy in (0, 1):
+                        for r0, sgn, scale in ((1.0, 1.0, 1.0), (0.6, 1.0, 0.5), (-1.0, -1.0, 1.0),
+                                               (float(rng.uniform(0.2, 1.5)), 1.0, float(rng.uniform(0.3, 3.0)))):
+                            p = abi.PupilIter()
+                            p.fld = fld
+                            p.start_r0, p.r_target = r0, sgn * scale * r_edge
+                            p.xy, p.wvl_idx, p.indx = xy, wi, indx
+                            probs.append(p)
+        dev = eng.iterate_pupil_rays(probs)
+        orc = oracle.iterate_pupil_rays(wl.table, probs)
+        assert np.isfinite(orc).all() == np.isfinite(dev).all()
+        ok = np.isfinite(orc)
+        assert np.array_equal(ok, np.isfinite(dev)), name
+        np.testing.assert_allclose(dev[ok], orc[ok], rtol=0, atol=1e-11, err_msg=name)
+        n += len(probs)
+        n_far += int((np.abs(orc[ok]) > 1.2).sum())
+        eng.close()
+    assert n > 500

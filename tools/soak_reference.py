@@ -244,7 +244,67 @@ def soak_round3():
     session.ENGINE_FACTORY = None
 
 
+def soak_round4():
+    """round 4: the reverse chief-ray iteration (trace.iterate_ray_raw behind
+    wideangle.eval_real_image_ht) through the drop-in, oracle as the engine, against the
+    reference's own loop on perturbed copies of the .zmx import (real-image-height fields on
+    and off the y axis: scipy's secant iteration and MINPACK's hybrd)"""
+    import time
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import refmodels as ref
+    from rayoptics_amd import session, install
+    from oracle_engine import OracleEngine
+    import rayoptics.raytr.wideangle as wa
+    rng = np.random.default_rng(44)
+    session.ENGINE_FACTORY = OracleEngine
+    t0, n, n2d, n_exc, bad = time.time(), 0, 0, 0, []
+    for trial in range(120):
+        opm = ref.zmx_evenasph_c3()
+        sm = opm['seq_model']
+        scale = float(rng.choice([1e-3, 5e-3, 2e-2, 5e-2]))
+        for ifc in sm.ifcs[1:-1]:
+            ifc.profile.cv *= 1.0 + scale * rng.normal()
+        for g in sm.gaps[1:-1]:
+            g.thi *= 1.0 + 0.3 * scale * rng.normal()
+        try:
+            ref.finish(opm, do_apertures=False)
+        except Exception:
+            continue
+        osp = opm['osp']
+        wvl = osp['wvls'].central_wvl
+        for fld in osp['fov'].fields:
+            fld.y *= float(rng.uniform(0.2, 1.3))
+            if rng.random() < 0.5:
+                fld.x = float(rng.normal()) * 0.5
+
+            def run():
+                try:
+                    (p_o, d_o), z = wa.eval_real_image_ht(opm, fld, wvl)
+                    return [np.array(p_o).tolist(), np.array(d_o).tolist(), float(z)]
+                except Exception as e:
+                    return type(e).__name__
+            theirs = run()
+            install.install()
+            ours = run()
+            install.uninstall()
+            n += 1
+            n2d += fld.x != 0.0
+            n_exc += isinstance(theirs, str)
+            if json.dumps(ours) != json.dumps(theirs):
+                bad.append((trial, float(fld.x), float(fld.y), str(ours)[:80], str(theirs)[:80]))
+    print(json.dumps({'soak': 'wideangle.eval_real_image_ht through the rebound trace.iterate_ray_raw '
+                              '(oracle as the engine) == the reference, bit for bit',
+                      'cases': n, 'two_d_cases': int(n2d), 'cases_where_both_raise': int(n_exc),
+                      'mismatches': bad[:5], 'n_mismatches': len(bad), 'seconds': round(time.time() - t0, 1)}))
+    session.ENGINE_FACTORY = None
+
+
 if __name__ == '__main__':
+    if '--round4' in sys.argv:
+        soak_round4()
+        sys.exit(0)
     if '--round3' in sys.argv:
         soak_round3()
         sys.exit(0)
