@@ -7,6 +7,10 @@
 #include "rox_device.hpp"
 #include "rox_hybrd.hpp"
 
+#ifndef ROX_ENP_SPEC        // samples of the wide-angle walk traced at once, per direction (<= 32)
+#define ROX_ENP_SPEC 4
+#endif
+
 namespace rox {
 namespace {
 
@@ -460,10 +464,19 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
     for (int i = threadIdx.x; i < 2 * N; i += 64)
         slot_w[i] = a.slots[i];
     __syncthreads();
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.n)
-        return;
+    // One WAVE per problem (round 4).  With one lane per problem the lanes of a wave sit in
+    // different phases of the search -- the walk, find_edge, the secant iteration, brentq are
+    // different call sites of the trace -- and the wave executes their union one after the
+    // other (48 Nikkor fields: 5.9 ms for searches of 3-25 trial rays each).  Here every lane of
+    // the wave follows the same problem: the sequential decisions are wave-uniform, and the
+    // one phase whose trial rays do not depend on each other -- the sampled walk from the
+    // paraxial pupil -- is traced by the 64 lanes at once and then REPLAYED in the reference's
+    // order, so the outcome (every result code included) is unchanged.
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x;
     const rox_enp pb = a.probs[i];
+    __shared__ double s_z[64], s_h[64];
+    __shared__ int s_st[64], s_fs[64];
 
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
@@ -556,8 +569,56 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
         double z_enp = z_enp_0;
         bool keep_going = true, first = true;
         int first_surf_misses = 0, trials = 0, successes = 0;
+        // ---- the walk's samples, all at once.  Every z the walk can visit is an element of
+        // one of two chains from z_enp_0 -- steps of +del_z or of -del_z, each formed by the
+        // walk's own recurrence (`z += del_z`, a z that is fuzzily zero replaced by del_z / 10)
+        // -- because every change of direction restarts from z_enp_0.  Lane L < kSpec traces
+        // element L of the forward chain, lane kSpec <= L < 2 kSpec element L - kSpec + 1 of the
+        // backward one.  kSpec = 4 (ROX_ENP_SPEC): samples far from the pupil, which the walk
+        // itself rarely reaches, can be very slow to trace -- an asphere intersection there may
+        // run the Spencer-Murty iteration to the reference's cap of 1000 steps -- and the pass
+        // waits for its slowest lane.  Measured, ms for 9 / 37 double-Gauss and 9 / 48 Nikkor
+        // problems (profiles/r04_wide_angle_latency.jsonl): round 3 (a lane per problem) 0.65 /
+        // 1.27 / 0.55 / 5.87; a wave per problem without the pass 0.51 / 0.90 / 0.42 / 3.13;
+        // kSpec 4: 0.47 / 0.80 / 0.32 / 1.79; 8: 0.48 / 0.73 / 1.07 / 2.48; 32: 0.48 / 0.56 /
+        // 1.99 / 2.51.  (Dropping speculative samples that exceed a step budget and tracing them
+        // again on demand keeps the nine Nikkor fields at 0.34 ms for every kSpec but costs the
+        // 48: 3.8 ms -- one of them has such a sample ON its walk, and then pays for it alone
+        // instead of beside the others.  That one 1000-step trace, ~1.7 ms, is the floor.)
+        constexpr int kSpec = ROX_ENP_SPEC;
+        const double d0 = del_z;
+        if (lane < 2 * kSpec) {
+            const double dz = lane < kSpec ? d0 : -d0;
+            const int kk = lane < kSpec ? lane : lane - kSpec + 1;
+            double z = z_enp_0;
+            for (int k = 0; k < kk; ++k) {
+                z += dz;
+                if (fuzzy_zero(z))
+                    z = dz / 10;
+            }
+            double h;
+            (void)trial(z, h);
+            s_z[lane] = z;
+            s_h[lane] = h;
+            s_st[lane] = last.status;
+            s_fs[lane] = last.fail_surf;
+        }
+            __syncthreads();
+        int chain_k = 0;                            // z_enp is element chain_k of the chain of del_z
+        // the walk's trial at the current z_enp: read back when it was traced above
+        auto sample = [&](double &h) -> bool {
+            const int slot = (del_z == d0) ? (chain_k < kSpec ? chain_k : -1)
+                                           : (chain_k == 0 ? 0 : (chain_k <= kSpec ? kSpec - 1 + chain_k : -1));
+            if (slot < 0 || s_z[slot] != z_enp)
+                return trial(z_enp, h);             // beyond the speculated samples: trace it now
+            h = s_h[slot];
+            last.status = s_st[slot];
+            last.fail_surf = s_fs[slot];
+            z_last = z_enp;
+            return s_st[slot] == ROX_OK;
+        };
         while (keep_going && trials < 64 && first_surf_misses < 2) {
-            if (trial(z_enp, ht)) {
+            if (sample(ht)) {
                 ++successes;
                 if (!have_start) {
                     have_start = true; start_z = z_enp; start_h = ht;
@@ -569,7 +630,7 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
                 if (successes == 2 && pb.check_direction) {
                     if (fabs(start_h) < fabs(end_h) && first) {
                         del_z = -del_z;
-                        z_enp = z_enp_0;
+                        z_enp = z_enp_0; chain_k = 0;
                         first = false;
                         double t = end_z; end_z = start_z; start_z = t;
                         t = end_h; end_h = start_h; start_h = t;
@@ -578,13 +639,13 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
             } else {
                 if (last.status == ROX_MISSED_SURFACE && last.fail_surf == 1) {
                     del_z = -del_z;
-                    z_enp = z_enp_0;
+                    z_enp = z_enp_0; chain_k = 0;
                     ++first_surf_misses;
                 }
                 if (have_start) {
                     if (first) {
                         del_z = -del_z;
-                        z_enp = z_enp_0;
+                        z_enp = z_enp_0; chain_k = 0;
                         first = false;
                         double t = end_z; end_z = start_z; start_z = t;
                         t = end_h; end_h = start_h; start_h = t;
@@ -596,6 +657,7 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
             z_enp += del_z;
             if (fuzzy_zero(z_enp))
                 z_enp = del_z / 10;
+            ++chain_k;
             ++trials;
         }
         double ia = 0., ib = 0.;
@@ -678,9 +740,11 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
                 z_out = z;
         }
     }
-    a.z_out[2 * i] = z_out;
-    a.z_out[2 * i + 1] = z_last;
-    a.result[i] = code;
+    if (lane == 0) {
+        a.z_out[2 * i] = z_out;
+        a.z_out[2 * i + 1] = z_last;
+        a.result[i] = code;
+    }
 }
 
 }  // namespace
@@ -690,7 +754,7 @@ void launch_enp(const EnpArgs &a, size_t lds, hipStream_t st)
     if (lds > kDefaultDynLds)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(enp_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(enp_kernel, dim3((a.n + 63) / 64), dim3(64), lds, st, a);
+    hipLaunchKernelGGL(enp_kernel, dim3(a.n), dim3(64), lds, st, a);     // one wave per problem
 }
 
 void launch_vig(const VigArgs &a, size_t lds, hipStream_t st)
