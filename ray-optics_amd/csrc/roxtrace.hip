@@ -216,6 +216,11 @@ struct StreamCtx {
     uint64_t *d_btiles = nullptr;       // ... and [items][tiles] look-back states
     int64_t btickets_cap = 0, btiles_cap = 0;
     uint32_t bepoch = 0;
+    // Everything a pupil-grid call does between reading / rewriting the cached axes
+    // (prepare_grid) and handing its launches to the stream is one critical section per
+    // stream: two host threads enqueueing on the SAME stream take turns (their launches run
+    // in stream order anyway); different streams have different contexts and do not meet.
+    std::mutex enqueue_mu;
     std::mutex batch_mu;                // one batch enqueue at a time per stream
     std::mutex stage_mu;                // one ROX_HOST_POINTERS call at a time per stream
     std::mutex compact_mu;              // epoch / ticket state: one HITS_COMPACT enqueue at a time
@@ -258,6 +263,14 @@ StreamCtx *ctx_for(rox_system *sys, hipStream_t st)
         sys->ctxs.push_back(c);
     }
     return c;
+}
+
+// the per-stream enqueue lock of a pupil-grid call (StreamCtx::enqueue_mu); empty when the
+// context cannot be made (the call then fails in prepare_grid with the same condition)
+std::unique_lock<std::mutex> enqueue_lock(rox_system *sys, hipStream_t st)
+{
+    StreamCtx *cx = ctx_for(sys, st);
+    return cx ? std::unique_lock<std::mutex>(cx->enqueue_mu) : std::unique_lock<std::mutex>();
 }
 
 void slot_map(const rox_system *s, bool filter, std::vector<int32_t> &m, int32_t &n_seg)
@@ -1146,6 +1159,7 @@ int rox_trace_pupil_grid(rox_system *sys, const rox_field *fld, const rox_grid *
     int rc;
     if (opts && (opts->flags & ROX_HOST_POINTERS) && (rc = stage_lock(s, sys, st)))
         return rc;
+    auto enq = enqueue_lock(sys, st);
     rc = prepare_grid(sys, fld, grid, wvl_idx, opts, out, st, a);
     if (rc)
         return rc;
@@ -1184,6 +1198,7 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
                                    "same for every item (item %d)", i);
     }
     // the items, validated one by one exactly as single launches are
+    auto enq = enqueue_lock(sys, st);
     std::vector<TraceArgs> items((size_t)n_grids);
     int rc;
     for (int32_t i = 0; i < n_grids; ++i)
@@ -1575,6 +1590,7 @@ int rox_time_pupil_grid(rox_system *sys, const rox_field *fld, const rox_grid *g
         return fail(ROX_E_ARG, "rox_time_pupil_grid needs device buffers");
     hipStream_t st = (hipStream_t)stream;
     TraceArgs a;
+    auto enq = enqueue_lock(sys, st);
     int rc = prepare_grid(sys, fld, grid, wvl_idx, opts, out, st, a);
     if (rc)
         return rc;

@@ -109,12 +109,19 @@ ND_VD = {
     'N-SF6': (1.80518, 25.36), 'SF6': (1.80518, 25.43), 'N-SF8': (1.68894, 31.31),
     'N-SF10': (1.72828, 28.53), 'N-SF11': (1.78472, 25.68), 'N-SF57': (1.84666, 23.78),
 }
+# (BK7 -> N-BK7: Schott lists the lead-free melt with the classic BK7 dispersion constants,
+# nd 1.51680 / vd 64.17 for both)
 ALIASES = {'BK7': 'N-BK7', 'FUSEDSILICA': 'SILICA', 'F_SILICA': 'SILICA'}
 
 
 def _canon(name):
-    """NSK16_SCHOTT / N-SK16 / nsk16 -> N-SK16"""
-    n = name.upper().split('_')[0]
+    """NSK16_SCHOTT / N-SK16 / nsk16 -> N-SK16.  Aliases are looked up on the whole name first
+    (F_SILICA contains the separator the catalogue suffix is split at), then on the name
+    without its catalogue suffix (BK7_SCHOTT)"""
+    full = name.upper().strip()
+    if full in ALIASES:
+        return ALIASES[full]
+    n = full.split('_')[0]
     n = ALIASES.get(n, n)
     if n in SELLMEIER:
         return n

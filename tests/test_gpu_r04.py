@@ -283,3 +283,46 @@ def test_iterate_pupil_rays_on_the_device():
         n_far += int((np.abs(orc[ok]) > 1.2).sum())
         eng.close()
     assert n > 500
+
+
+def test_two_host_threads_share_one_stream():
+    """two Python threads (ctypes releases the GIL) enqueueing pupil grids of
+    DIFFERENT definitions on the SAME stream of one handle.  The cached pupil axes (their
+    key, their size, a reallocation when a larger grid arrives) are per-stream state that
+    prepare_grid rewrites: the whole prepare-and-launch of a call is one critical section per
+    stream, so every call still traces its own grid"""
+    import threading
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    wl = workloads.load('dblgauss_c2')
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    defs = [((-1., -1.), (1., 1.), 97), ((-0.7, -0.9), (0.8, 0.6), 301), ((-0.2, -1.0), (1.0, 0.3), 160)]
+    opts = make_opts(flags=SPOT, out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                     foc=wl.foc, image_pt=wl.image_pts[2])
+    want = []
+    for k, (a, b, num) in enumerate(defs):
+        o = oracle.make_opts(flags=SPOT, out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                             foc=wl.foc, image_pt=wl.image_pts[2])
+        want.append(oracle.trace_pupil_grid(wl.table, wl.fields[2], oracle.make_grid(a, b, num), k, o).hits.copy())
+    errs = []
+
+    def worker(k):
+        try:
+            a, b, num = defs[k]
+            grid = make_grid(a, b, num)
+            for _ in range(40):             # (all threads: the device's current stream)
+                xy = eng.trace_pupil_grid_hits(wl.fields[2], grid, k, opts)
+                if not np.array_equal(xy, want[k]):
+                    errs.append((k, 'mismatch'))
+                    return
+        except Exception as e:      # noqa: BLE001
+            errs.append((k, repr(e)))
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    eng.close()

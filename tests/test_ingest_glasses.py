@@ -108,3 +108,22 @@ def test_double_gauss_seq_default_indices_match_the_codev_listing():
     n = tbl.n_table[:, glass_cols]
     assert ((n > 1.55) & (n < 1.7)).all()
     assert (np.diff(n[np.argsort(tbl.wvls)], axis=0) < 0).all()     # normal dispersion
+
+
+def test_every_glass_alias_resolves_to_dispersion_data():
+    """'F_SILICA' contains the character the catalogue suffix is split at and never
+    reached its alias (it fell back to n = 1.5 with a warning).  Every alias, with and without
+    a catalogue suffix, in either case, reaches the Sellmeier data of its target"""
+    from rayoptics_amd import ingest
+    assert ingest.ALIASES
+    for alias, target in ingest.ALIASES.items():
+        assert target in ingest.SELLMEIER
+        want = ingest.sellmeier_index(target, 587.6)
+        forms = [alias, alias.lower()]
+        if '_' not in alias:
+            forms.append(alias + '_SCHOTT')
+        for name in forms:
+            assert ingest.knows_glass(name), name
+            assert ingest.nominal_index(name, 587.6) == want, name
+    assert abs(ingest.nominal_index('F_SILICA', 587.6) - 1.4585) < 2e-4
+    assert abs(ingest.nominal_index('BK7', 587.6) - 1.5168) < 1e-4
