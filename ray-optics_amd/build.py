@@ -59,6 +59,10 @@ def _stamp(lib):
 
 def stale(lib=None, extra=()):
     lib = lib or LIB
+    if not os.path.isdir(INC):
+        # an installed copy (`pip install .`) without the repository around it: the C ABI
+        # headers are not there to rebuild from -- the library that was installed is the one
+        return not os.path.exists(lib)
     if not os.path.exists(lib) or not os.path.exists(_stamp(lib)):
         return True
     with open(_stamp(lib)) as f:
