@@ -269,6 +269,26 @@ def main():
         xy = rox_trace.trace_grid_spot(model, grid_rng, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
         spot_ms.append((time.perf_counter() - t1) * 1e3)
     n_through = int(xy.shape[0])
+    # what an interactive caller meets: the same call after the GPU has idled for a second (the
+    # clocks have dropped), at the 1M-ray grid and at the 64 x 64 grid figures default to
+    cold_spot = {}
+    for cnum in (num, 64):
+        cgrid = [np.array([-1., -1.]), np.array([1., 1.]), cnum]
+        rox_trace.trace_grid_spot(model, cgrid, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            time.sleep(1.0)
+            t1 = time.perf_counter()
+            rox_trace.trace_grid_spot(model, cgrid, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
+            ts.append((time.perf_counter() - t1) * 1e3)
+        warm = []
+        for _ in range(21):
+            t1 = time.perf_counter()
+            rox_trace.trace_grid_spot(model, cgrid, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
+            warm.append((time.perf_counter() - t1) * 1e3)
+        cold_spot[f'{cnum}x{cnum}'] = {'first_call_after_1s_idle_ms': float(np.median(ts)),
+                                       'back_to_back_ms': float(np.median(warm))}
     # the rows of the timed launch's packets the CPU legs re-trace (the reference itself, when
     # it is staged on this host, is compared with them ray by ray)
     dev_sample = None
@@ -339,6 +359,7 @@ def main():
                              'wallclock_min_ms': float(np.min(spot_ms)), 'rays': R,
                              'rays_through': n_through, 'kernel_hits_ms': hits_kern_ms,
                              'pcie_floor_ms': n_through * 16 / 54.7e9 * 1e3,
+                             'after_idle': cold_spot,
                              'what': 'rayoptics_amd.trace.trace_grid_spot(model, grid_rng, fld, wvl, '
                                      'foc, image_pt): Python call -> host (R_ok, 2) float64 array '
                                      '(survivors packed in ray order by the trace launch, written '

@@ -1026,7 +1026,12 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         }
         tblp prow = tbl + (size_t)(surf - 1) * kRowDoubles;     // `before`
         tblp row = tbl + (size_t)surf * kRowDoubles;             // `after`
+#ifdef ROX_SPEC_EXPERIMENT  // (tools only: what compile-time knowledge of a spherical, centred
+        // table would be worth to the lean instance -- the per-system specialisation question)
+        const int mode = ((tbli)row)[0], prof = (FEAT == 0) ? (int)ROX_SPHERICAL : ((tbli)row)[1];
+#else
         const int mode = ((tbli)row)[0], prof = ((tbli)row)[1];
+#endif
         const double cv = row[O_CV];
         const bool thin = (FEAT & F_PHASE) && prof == ROX_THINLENS;
 
@@ -1041,8 +1046,13 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         // every active lane's six components are finite (their sum is: a conservative test).
         // (reduced-output modes only: in FULL mode, which is bound by its packet stores, the
         // extra branch measured 2 % slower)
+#ifdef ROX_SPEC_EXPERIMENT
+        if (FEAT == 0 || (kIdentRt && ((tbli)prow)[5] != 0 &&
+            __all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((bd.x + bd.y) + bd.z))))) {
+#else
         if (kIdentRt && ((tbli)prow)[5] != 0 &&
             __all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((bd.x + bd.y) + bd.z)))) {
+#endif
             b4p = v3{dp.x + 0.0, dp.y + 0.0, dp.z + 0.0};
             b4d = v3{bd.x + 0.0, bd.y + 0.0, bd.z + 0.0};
         } else {
