@@ -69,6 +69,8 @@ def install(fallback='raise'):
              # the reverse chief-ray iteration behind fields given as real image heights
              # (wideangle.eval_real_image_ht calls it module-qualified, wideangle.py:646)
              (rtrace, 'iterate_ray_raw', _t.iterate_ray_raw),
+             # the five close rays per field point of trace_astigmatism_curve (AstigmatismCurvePlot)
+             (rtrace, 'trace_astigmatism', _t.trace_astigmatism),
              (rtrace, 'aim_chief_ray', _t.aim_chief_ray),
              (ropticalspec, 'aim_chief_ray', _t.aim_chief_ray),
              # the wide-angle pupil search behind aim_chief_ray (trace.py:634-635) and

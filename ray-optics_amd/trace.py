@@ -10,6 +10,8 @@ the per-ray Python loop replaced by one device launch.
                      reference's own iterative callers (trace_base, iterate_ray's 2-D
                      fsolve branch, the wide-angle pupil search, trace_chief_ray ...)
   aim_chief_ray   <- rayoptics/raytr/trace.py:627-640 (iterate_ray's 1-D branch on the device)
+  trace_astigmatism <- rayoptics/raytr/trace.py:823-863 (five rays, one launch; the field loop
+                     of trace_astigmatism_curve calls it)
   iterate_ray_raw <- rayoptics/raytr/trace.py:866-961 (the reverse chief ray of
                      wideangle.eval_real_image_ht: the whole iteration in one launch)
   osp_update_optical_properties <- rayoptics/raytr/opticalspec.py:263-281 (method; all
@@ -179,6 +181,38 @@ def iterate_ray_raw(pthlist, ifcx, xy_target, pt0, d0, obj2pup_dist, eprad, wvl,
     except TraceError as ray_error:
         rr = RayResult(RefRayPkg(*ray_error.ray_pkg), ray_error)
     return start_coords, rr
+
+
+def trace_astigmatism(opt_model, fld, wvl, foc, dx=0.001, dy=0.001):
+    """rayoptics/raytr/trace.py:823-863 ``trace_astigmatism``: the sagittal and tangential focus
+    shifts at ``fld`` from the chief ray's four close neighbours -- five ``trace_ray`` calls in
+    the reference (``trace_astigmatism_curve``, :789-820, makes them for each of 21 field
+    points: ``AstigmatismCurvePlot``), one five-ray launch here; the two line intersections are
+    the reference's own ``intersect_2_lines`` on the same last segments.  A ray that fails
+    sends the call to the reference's function, which then does whatever it does."""
+    import rayoptics.raytr.trace as rtrace
+    kwargs = {'apply_vignetting': True}                      # trace_base's default (trace.py:253)
+    px = np.array([0., dx, 0., -dx, 0.])
+    py = np.array([0., 0., dy, 0., -dy])
+    pk = _trace_pupil(opt_model, fld, wvl, kwargs, 'last', None, pupil_list=(px, py),
+                      out_mode=abi.OUT_LAST)
+    if (pk.status[:5] != abi.OK).any():
+        from . import install
+        theirs = install._saved.get((rtrace, 'trace_astigmatism'))
+        if theirs is not None:
+            return theirs(opt_model, fld, wvl, foc, dx=dx, dy=dy)
+        raise pk.error(int(np.argmax(pk.status[:5] != abi.OK)), opt_model['seq_model'].ifcs,
+                       with_pkg=False)
+    last = [pk.pkg(r)[0][-1] for r in range(5)]              # ray[-1] = [p, d, dst, nrml]
+    s = rtrace.intersect_2_lines(last[1][0], last[1][1], last[3][0], last[3][1])
+    s_foc = s * last[1][1][2]
+    t = rtrace.intersect_2_lines(last[2][0], last[2][1], last[4][0], last[4][1])
+    t_foc = t * last[2][1][2]
+    if foc is not None:
+        focus_shift = foc
+        s_foc -= focus_shift
+        t_foc -= focus_shift
+    return s_foc, t_foc
 
 
 def _launch_setup(opt_model, fld, wvl, kwargs, out_mode, foc=0.0, image_pt=(0., 0.), wf=None):

@@ -1448,3 +1448,29 @@ def test_set_pupil_and_set_stop_aperture(ref, installed, model):
     else:
         np.testing.assert_allclose(ao, at, rtol=0, atol=1e-11)
         np.testing.assert_allclose(bo, bt, rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize('model', ['dblgauss', 'nikkor', 'singlet', 'rc_telescope'])
+def test_astigmatism_curve(ref, installed, model):
+    """trace.trace_astigmatism_curve (rayoptics/raytr/trace.py:789-820, AstigmatismCurvePlot):
+    21 field points x five close rays -- `trace_astigmatism` rebound to one five-ray launch per
+    field point; field heights and both focus-shift curves are the reference's, bit for bit
+    (incl. its quirk of aiming the chief ray for the first field point only)"""
+    import rayoptics.raytr.trace as trace
+    opm = getattr(ref, model)()
+
+    def run():
+        f, s, t = trace.trace_astigmatism_curve(opm, num_points=11)
+        return np.array(f), np.array(s), np.array(t)
+    (fo, so, to), (ft, st, tt) = both(installed, run)
+    np.testing.assert_array_equal(fo, ft)
+    np.testing.assert_array_equal(so, st)
+    np.testing.assert_array_equal(to, tt)
+    assert np.isfinite(so).all() and np.ptp(to) > 0
+    # a single field point, with other deltas
+    fld = opm['osp']['fov'].fields[-1]
+    wvl = opm['seq_model'].central_wavelength()
+
+    def one():
+        return trace.trace_astigmatism(opm, fld, wvl, 0.01, dx=0.002, dy=0.0005)
+    assert both(installed, one)[0] == both(installed, one)[1]
