@@ -34,7 +34,11 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
     for (int i = threadIdx.x; i < 2 * N; i += 64)
         slot_w[i] = a.slots[i];
     __syncthreads();
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    // a.wave_per_problem (small batches: the fields of a model): every lane of the wave follows
+    // the same problem -- problems in different phases of their iterations (the call sites of
+    // the trace inside MINPACK's hybrd) then run side by side on different CUs instead of
+    // one after the other in one wave; the 64 lanes store identical results
+    const int i = a.wave_per_problem ? (int)blockIdx.x : (int)(blockIdx.x * 64 + threadIdx.x);
     if (i >= a.n)
         return;
     const rox_aim pb = a.probs[i];
@@ -234,7 +238,7 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     for (int i = threadIdx.x; i < 2 * N; i += 64)
         slot_w[i] = a.slots[i];
     __syncthreads();
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int i = a.wave_per_problem ? (int)blockIdx.x : (int)(blockIdx.x * 64 + threadIdx.x);
     if (i >= a.n)
         return;
     rox_vig pb;
@@ -762,7 +766,7 @@ void launch_vig(const VigArgs &a, size_t lds, hipStream_t st)
     if (lds > kDefaultDynLds)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vig_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(vig_kernel, dim3((a.n + 63) / 64), dim3(64), lds, st, a);
+    hipLaunchKernelGGL(vig_kernel, dim3(a.wave_per_problem ? a.n : (a.n + 63) / 64), dim3(64), lds, st, a);
 }
 
 void launch_aim(const AimArgs &a, size_t lds, hipStream_t st)
@@ -770,7 +774,7 @@ void launch_aim(const AimArgs &a, size_t lds, hipStream_t st)
     if (lds > kDefaultDynLds)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(aim_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(aim_kernel, dim3((a.n + 63) / 64), dim3(64), lds, st, a);
+    hipLaunchKernelGGL(aim_kernel, dim3(a.wave_per_problem ? a.n : (a.n + 63) / 64), dim3(64), lds, st, a);
 }
 
 }  // namespace rox

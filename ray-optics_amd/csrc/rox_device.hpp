@@ -1759,6 +1759,7 @@ struct AimArgs {
     int32_t *result;           // device [n]
     double *last_xy;           // device [n][2] or nullptr: the last trial ray's (x1, y1)
     int32_t *last_status;      // device [n] or nullptr: ... and its trace status
+    int32_t wave_per_problem;  // 1: one wave (block) per problem; 0: one lane per problem
 };
 void launch_aim(const AimArgs &, size_t lds, hipStream_t);
 
@@ -1785,6 +1786,7 @@ struct VigArgs {
     int32_t *clip;             // device [n]
     // rox_iterate_pupil_rays: iterate_pupil_ray on its own (probs unused, vig = start_r)
     const rox_pupil_iter *iters;
+    int32_t wave_per_problem;  // 1: one wave (block) per problem; 0: one lane per problem
 };
 void launch_vig(const VigArgs &, size_t lds, hipStream_t);
 

@@ -1345,6 +1345,11 @@ int rox_trace_pupil_list(rox_system *sys, const rox_field *fld, int64_t n_rays, 
     return rc ? rc : unstage_out(s, st);
 }
 
+// the iterated single-ray searches (aiming, vignetting, pupil iterations): up to this many
+// problems per call get a wave each (latency: a model's fields, run side by side); larger
+// batches keep a lane per problem (throughput: soaks, sweeps)
+constexpr int32_t kWavePerProblemMax = 1024;
+
 int rox_iterate_ray_raw(rox_system *sys, int32_t n, const rox_aim *probs, double eps,
                         double *aim_xy, int32_t *result, double *last_xy, int32_t *last_status,
                         void *stream)
@@ -1380,6 +1385,7 @@ int rox_iterate_ray_raw(rox_system *sys, int32_t n, const rox_aim *probs, double
     a.last_xy = last_xy ? a.aim_xy + 2 * (size_t)n : nullptr;
     a.last_status = last_xy ? a.result + n : nullptr;
     a.eps = eps;
+    a.wave_per_problem = n <= kWavePerProblemMax;
     hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         launch_aim(a, lds, st);
@@ -1487,6 +1493,7 @@ int rox_iterate_pupil_rays(rox_system *sys, int32_t n, const rox_pupil_iter *pro
     a.iters = (const rox_pupil_iter *)d;
     a.vig = (double *)((char *)d + pb);
     a.eps = eps;
+    a.wave_per_problem = n <= kWavePerProblemMax;
     hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         launch_vig(a, lds, st);
@@ -1536,6 +1543,7 @@ int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs, double
     a.vig = (double *)((char *)d + pb);
     a.clip = (int32_t *)((char *)d + pb + vb);
     a.eps = eps;
+    a.wave_per_problem = n <= kWavePerProblemMax;
     hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         launch_vig(a, lds, st);
