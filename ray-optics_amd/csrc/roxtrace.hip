@@ -247,6 +247,13 @@ struct rox_system {
     int features = 0;                   // F_* of the table
     std::mutex mu;                      // guards ctxs
     std::vector<StreamCtx *> ctxs;
+    // the small synchronous search entries (aiming, pupil search, vignetting, pupil
+    // iterations): one device-mapped pinned block the kernel reads its problems from and
+    // writes its answers to -- no allocation, no copy-engine transfer per call (round 4; a
+    // call used to be hipMalloc + three hipMemcpyAsync + hipFree around a 10-300 us kernel)
+    char *h_search = nullptr;
+    size_t h_search_cap = 0;
+    std::mutex search_mu;
 };
 
 namespace {
@@ -271,6 +278,25 @@ std::unique_lock<std::mutex> enqueue_lock(rox_system *sys, hipStream_t st)
 {
     StreamCtx *cx = ctx_for(sys, st);
     return cx ? std::unique_lock<std::mutex>(cx->enqueue_mu) : std::unique_lock<std::mutex>();
+}
+
+// room for `bytes` in the system's search block; the caller holds search_mu until its results
+// are copied out
+int search_block(rox_system *sys, size_t bytes, char *&base)
+{
+    if (sys->h_search_cap < bytes) {
+        if (sys->h_search)
+            HIP_TRY(hipHostFree(sys->h_search));
+        sys->h_search = nullptr;
+        sys->h_search_cap = 0;
+        size_t cap = size_t(16) << 10;
+        while (cap < bytes)
+            cap *= 2;
+        HIP_TRY(hipHostMalloc((void **)&sys->h_search, cap, hipHostMallocMapped));
+        sys->h_search_cap = cap;
+    }
+    base = sys->h_search;
+    return 0;
 }
 
 void slot_map(const rox_system *s, bool filter, std::vector<int32_t> &m, int32_t &n_seg)
@@ -1093,6 +1119,7 @@ int rox_system_destroy(rox_system *sys)
                 (void)hipEventDestroy(ev);
         delete c;
     }
+    (void)hipHostFree(sys->h_search);
     delete sys;
     return 0;
 }
@@ -1372,36 +1399,36 @@ int rox_iterate_ray_raw(rox_system *sys, int32_t n, const rox_aim *probs, double
                         W * sizeof(double) + 2 * N * sizeof(int32_t) + 15) & ~size_t(15);
     if (lds > 160 * 1024 - 64)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
-    void *d = nullptr;
-    const size_t pb = sizeof(rox_aim) * n, yb = sizeof(double) * 2 * n, rb = sizeof(int32_t) * n;
-    HIP_TRY(hipMalloc(&d, pb + 2 * yb + 2 * rb));
+    const size_t pb = up16(sizeof(rox_aim) * n), yb = up16(sizeof(double) * 2 * n), rb = up16(sizeof(int32_t) * n);
+    std::lock_guard<std::mutex> lock(sys->search_mu);
+    char *d = nullptr;
+    int rc = search_block(sys, pb + 2 * yb + 2 * rb, d);
+    if (rc)
+        return rc;
+    memcpy(d, probs, sizeof(rox_aim) * n);
     AimArgs a{};
     a.rows = sys->d_rows; a.n_table = sys->d_ntab; a.ph_consts = sys->d_phc; a.wvls = sys->d_wvls;
     a.slots = sys->d_slots[0];
     a.n_ifcs = sys->n_ifcs; a.n_wvls = sys->n_wvls; a.n = n;
     a.probs = (const rox_aim *)d;
-    a.aim_xy = (double *)((char *)d + pb);
-    a.result = (int32_t *)((char *)d + pb + 2 * yb);
-    a.last_xy = last_xy ? a.aim_xy + 2 * (size_t)n : nullptr;
-    a.last_status = last_xy ? a.result + n : nullptr;
+    a.aim_xy = (double *)(d + pb);
+    a.result = (int32_t *)(d + pb + 2 * yb);
+    a.last_xy = last_xy ? (double *)(d + pb + yb) : nullptr;
+    a.last_status = last_xy ? (int32_t *)(d + pb + 2 * yb + rb) : nullptr;
     a.eps = eps;
     a.wave_per_problem = n <= kWavePerProblemMax;
-    hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        launch_aim(a, lds, st);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(aim_xy, a.aim_xy, yb, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(result, a.result, rb, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && last_xy)
-        e = hipMemcpyAsync(last_xy, a.last_xy, yb, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && last_xy)
-        e = hipMemcpyAsync(last_status, a.last_status, rb, hipMemcpyDeviceToHost, st);
+    launch_aim(a, lds, st);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
-    (void)hipFree(d);
+    if (e == hipSuccess) {
+        memcpy(aim_xy, a.aim_xy, sizeof(double) * 2 * n);
+        memcpy(result, a.result, sizeof(int32_t) * n);
+        if (last_xy) {
+            memcpy(last_xy, a.last_xy, sizeof(double) * 2 * n);
+            memcpy(last_status, a.last_status, sizeof(int32_t) * n);
+        }
+    }
     if (e != hipSuccess)
         return fail(ROX_E_HIP, "rox_iterate_ray_raw: %s", hipGetErrorString(e));
     return 0;
@@ -1432,29 +1459,29 @@ int rox_find_real_enp(rox_system *sys, int32_t n, const rox_enp *probs, double e
                         W * sizeof(double) + 2 * N * sizeof(int32_t) + 15) & ~size_t(15);
     if (lds > 160 * 1024 - 64)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
-    void *d = nullptr;
-    const size_t pb = sizeof(rox_enp) * n, zb = sizeof(double) * 2 * n, rb = sizeof(int32_t) * n;
-    HIP_TRY(hipMalloc(&d, pb + zb + rb));
+    const size_t pb = up16(sizeof(rox_enp) * n), zb = up16(sizeof(double) * 2 * n);
+    std::lock_guard<std::mutex> lock(sys->search_mu);
+    char *d = nullptr;
+    int rc = search_block(sys, pb + zb + sizeof(int32_t) * n, d);
+    if (rc)
+        return rc;
+    memcpy(d, probs, sizeof(rox_enp) * n);
     EnpArgs a{};
     a.rows = sys->d_rows; a.n_table = sys->d_ntab; a.ph_consts = sys->d_phc; a.wvls = sys->d_wvls;
     a.slots = sys->d_slots[0];
     a.n_ifcs = sys->n_ifcs; a.n_wvls = sys->n_wvls; a.n = n;
     a.probs = (const rox_enp *)d;
-    a.z_out = (double *)((char *)d + pb);
-    a.result = (int32_t *)((char *)d + pb + zb);
+    a.z_out = (double *)(d + pb);
+    a.result = (int32_t *)(d + pb + zb);
     a.eps = eps;
-    hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        launch_enp(a, lds, st);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(z_out, a.z_out, zb, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(result, a.result, rb, hipMemcpyDeviceToHost, st);
+    launch_enp(a, lds, st);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
-    (void)hipFree(d);
+    if (e == hipSuccess) {
+        memcpy(z_out, a.z_out, sizeof(double) * 2 * n);
+        memcpy(result, a.result, sizeof(int32_t) * n);
+    }
     if (e != hipSuccess)
         return fail(ROX_E_HIP, "rox_find_real_enp: %s", hipGetErrorString(e));
     return 0;
@@ -1483,27 +1510,27 @@ int rox_iterate_pupil_rays(rox_system *sys, int32_t n, const rox_pupil_iter *pro
                         W * sizeof(double) + 2 * N * sizeof(int32_t) + 15) & ~size_t(15);
     if (lds > 160 * 1024 - 64)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
-    void *d = nullptr;
-    const size_t pb = sizeof(rox_pupil_iter) * n, vb = sizeof(double) * n;
-    HIP_TRY(hipMalloc(&d, pb + vb));
+    const size_t pb = up16(sizeof(rox_pupil_iter) * n);
+    std::lock_guard<std::mutex> lock(sys->search_mu);
+    char *d = nullptr;
+    int rc = search_block(sys, pb + sizeof(double) * n, d);
+    if (rc)
+        return rc;
+    memcpy(d, probs, sizeof(rox_pupil_iter) * n);
     VigArgs a{};
     a.rows = sys->d_rows; a.n_table = sys->d_ntab; a.ph_consts = sys->d_phc; a.wvls = sys->d_wvls;
     a.slots = sys->d_slots[0];
     a.n_ifcs = sys->n_ifcs; a.n_wvls = sys->n_wvls; a.n = n;
     a.iters = (const rox_pupil_iter *)d;
-    a.vig = (double *)((char *)d + pb);
+    a.vig = (double *)(d + pb);
     a.eps = eps;
     a.wave_per_problem = n <= kWavePerProblemMax;
-    hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        launch_vig(a, lds, st);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(start_r, a.vig, vb, hipMemcpyDeviceToHost, st);
+    launch_vig(a, lds, st);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
-    (void)hipFree(d);
+    if (e == hipSuccess)
+        memcpy(start_r, a.vig, sizeof(double) * n);
     if (e != hipSuccess)
         return fail(ROX_E_HIP, "rox_iterate_pupil_rays: %s", hipGetErrorString(e));
     return 0;
@@ -1532,30 +1559,30 @@ int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs, double
                         W * sizeof(double) + 2 * N * sizeof(int32_t) + 15) & ~size_t(15);
     if (lds > 160 * 1024 - 64)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
-    void *d = nullptr;
-    const size_t pb = sizeof(rox_vig) * n, vb = sizeof(double) * n, cb = sizeof(int32_t) * n;
-    HIP_TRY(hipMalloc(&d, pb + vb + cb));
+    const size_t pb = up16(sizeof(rox_vig) * n), vb = up16(sizeof(double) * n);
+    std::lock_guard<std::mutex> lock(sys->search_mu);
+    char *d = nullptr;
+    int rc = search_block(sys, pb + vb + sizeof(int32_t) * n, d);
+    if (rc)
+        return rc;
+    memcpy(d, probs, sizeof(rox_vig) * n);
     VigArgs a{};
     a.rows = sys->d_rows; a.n_table = sys->d_ntab; a.ph_consts = sys->d_phc; a.wvls = sys->d_wvls;
     a.slots = sys->d_slots[0];
     a.n_ifcs = sys->n_ifcs; a.n_wvls = sys->n_wvls; a.n = n;
     a.probs = (const rox_vig *)d;
-    a.vig = (double *)((char *)d + pb);
-    a.clip = (int32_t *)((char *)d + pb + vb);
+    a.vig = (double *)(d + pb);
+    a.clip = (int32_t *)(d + pb + vb);
     a.eps = eps;
     a.wave_per_problem = n <= kWavePerProblemMax;
-    hipError_t e = hipMemcpyAsync(d, probs, pb, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        launch_vig(a, lds, st);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(vig, a.vig, vb, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(clip_surf, a.clip, cb, hipMemcpyDeviceToHost, st);
+    launch_vig(a, lds, st);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
-    (void)hipFree(d);
+    if (e == hipSuccess) {
+        memcpy(vig, a.vig, sizeof(double) * n);
+        memcpy(clip_surf, a.clip, sizeof(int32_t) * n);
+    }
     if (e != hipSuccess)
         return fail(ROX_E_HIP, "rox_calc_vignetting: %s", hipGetErrorString(e));
     return 0;
