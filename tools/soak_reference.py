@@ -3,7 +3,8 @@
 device): the suite's randomized tests over many more seeds, and the aiming / vignetting / OPD /
 fan drop-ins on randomly perturbed models.  Prints one JSON line per soak.
 
-    python tools/soak_reference.py"""
+    python tools/soak_reference.py [--round3 | --round4]
+    python tools/soak_reference.py --hip        (GPU box: the HIP engine instead of the oracle)"""
 import json
 import logging
 import os
@@ -59,14 +60,21 @@ def perturbed(build, rng, dcv, dfov=0.0):
     return opm
 
 
-def soak_dropins():
+def soak_dropins(hip=False):
+    """hip=True (GPU box, reference staged in oracle/_ref): the same soaks with the HIP engine
+    behind the drop-ins instead of the oracle double -- HIP vs the live reference directly;
+    the vignetting factors then agree to 1e-11 instead of bit for bit (libm pow)"""
     import refmodels as ref
     from rayoptics_amd import session, install
-    from oracle_engine import OracleEngine
     import rayoptics.raytr.vigcalc as vigcalc
     import rayoptics.raytr.analyses as analyses
-    session.ENGINE_FACTORY = OracleEngine
-    rng = np.random.default_rng(77)
+    if hip:
+        session.ENGINE_FACTORY = None
+    else:
+        from oracle_engine import OracleEngine
+        session.ENGINE_FACTORY = OracleEngine
+    eng = 'HIP engine' if hip else 'oracle double'
+    rng = np.random.default_rng(177 if hip else 77)
     t0, bad, n = time.time(), [], 0
     for build in (ref.dblgauss, ref.singlet, ref.rc_telescope, ref.cell_phone, ref.nikkor):
         for trial in range(30):
@@ -91,11 +99,16 @@ def soak_dropins():
             ours = run()
             install.uninstall()
             n += len(flds)
-            if ours != theirs:
+            if hip:
+                same = ours[0] == theirs[0] and np.allclose(np.array(ours[1], dtype=float),
+                                                            np.array(theirs[1], dtype=float), rtol=0, atol=1e-11)
+            else:
+                same = ours == theirs
+            if not same:
                 bad.append((build.__name__, trial))
-    print(json.dumps({'soak': 'aim_info and vignetting factors on perturbed models', 'fields': n,
+    print(json.dumps({'soak': 'aim_info and vignetting factors on perturbed models', 'engine': eng, 'fields': n,
                       'mismatches': bad[:5], 'seconds': round(time.time() - t0, 1)}))
-    rng = np.random.default_rng(91)
+    rng = np.random.default_rng(191 if hip else 91)
     t0, bad, n = time.time(), [], 0
     for build in (ref.dblgauss, ref.telecentric, ref.rc_telescope, ref.cell_phone, ref.singlet):
         for trial in range(25):
@@ -130,8 +143,75 @@ def soak_dropins():
             if not same:
                 bad.append((build.__name__, trial))
     print(json.dumps({'soak': 'eval_wavefront / trace+focus_wavefront / eval_fan on perturbed models',
-                      'cases': n, 'mismatches': bad[:5], 'seconds': round(time.time() - t0, 1)}))
+                      'engine': eng, 'cases': n, 'mismatches': bad[:5], 'seconds': round(time.time() - t0, 1)}))
+    if hip:
+        soak_packets_hip(ref, install)
     session.ENGINE_FACTORY = None
+
+
+def soak_packets_hip(ref, install):
+    """trace.trace_grid packets and SpotDiagramFigure data of perturbed models: HIP engine
+    behind the drop-ins vs the reference's per-ray loop, bit for bit"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    import rayoptics.raytr.trace as rtrace
+    from rayoptics.mpl.axisarrayfigure import SpotDiagramFigure
+    rng = np.random.default_rng(4242)
+    t0, n_models, n_rays, n_fig, bad = time.time(), 0, 0, 0, []
+    for build in (ref.dblgauss, ref.nikkor, ref.cell_phone, ref.rc_telescope, ref.tilted_singlet,
+                  ref.zmx_evenasph_c3):
+        for trial in range(6):
+            install.uninstall()
+            try:
+                opm = perturbed(build, rng, 0.01) if build is not ref.zmx_evenasph_c3 else build()
+            except Exception:
+                continue
+            osp = opm['osp']
+            fld = osp['fov'].fields[int(rng.integers(0, len(osp['fov'].fields)))]
+            wvl = osp['wvls'].wavelengths[int(rng.integers(0, len(osp['wvls'].wavelengths)))]
+
+            def packets():
+                got = []
+                rtrace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 20], fld, wvl, 0.0,
+                                  img_filter=lambda p, pkg: got.append((np.array(p), pkg)), form='list',
+                                  append_if_none=True)
+                out = []
+                for p, pkg in got:
+                    if pkg is None:
+                        out.append((p.tolist(), None))
+                    else:
+                        ray, op, w = pkg
+                        out.append((p.tolist(), [[np.asarray(sg[0]).tolist(), np.asarray(sg[1]).tolist(),
+                                                  float(sg[2]), np.asarray(sg[3]).tolist()] for sg in ray],
+                                    float(op), float(w)))
+                return out
+
+            def figure():
+                fig = plt.figure(FigureClass=SpotDiagramFigure, opt_model=opm, num_rays=12)
+                fig.update_data()
+                d = [[np.array(g).tolist() for g in row[0][0]] for row in fig.axis_data_array]
+                plt.close(fig)
+                return d
+            try:
+                theirs = (packets(), figure())
+            except Exception:
+                continue
+            install.install()
+            ours = (packets(), figure())
+            install.uninstall()
+            n_models += 1
+            n_rays += len(theirs[0])
+            n_fig += 1
+            # (== on the nested lists: -0.0 equals 0.0.  The reference's double Gauss data gives
+            # its flat surfaces the *integer* curvature 0, and `-0 * x` is +0 where `-0.0 * x` is
+            # -0: zero components of its normals carry the other sign than a float table's)
+            if ours != theirs:
+                bad.append((build.__name__, trial))
+    print(json.dumps({'soak': 'trace.trace_grid packets (20 x 20, every ray: segments, op_delta, None pattern) '
+                              'and SpotDiagramFigure data on perturbed models', 'engine': 'HIP engine',
+                      'models': n_models, 'rays': n_rays, 'figures': n_fig, 'mismatches': bad[:5],
+                      'n_mismatches': len(bad), 'seconds': round(time.time() - t0, 1)}))
 
 
 def soak_round3():
@@ -244,7 +324,7 @@ def soak_round3():
     session.ENGINE_FACTORY = None
 
 
-def soak_round4():
+def soak_round4(hip=False):
     """round 4: the reverse chief-ray iteration (trace.iterate_ray_raw behind
     wideangle.eval_real_image_ht) through the drop-in, oracle as the engine, against the
     reference's own loop on perturbed copies of the .zmx import (real-image-height fields on
@@ -257,8 +337,8 @@ def soak_round4():
     from rayoptics_amd import session, install
     from oracle_engine import OracleEngine
     import rayoptics.raytr.wideangle as wa
-    rng = np.random.default_rng(44)
-    session.ENGINE_FACTORY = OracleEngine
+    rng = np.random.default_rng(144 if hip else 44)
+    session.ENGINE_FACTORY = None if hip else OracleEngine
     t0, n, n2d, n_exc, bad = time.time(), 0, 0, 0, []
     for trial in range(120):
         opm = ref.zmx_evenasph_c3()
@@ -295,13 +375,17 @@ def soak_round4():
             if json.dumps(ours) != json.dumps(theirs):
                 bad.append((trial, float(fld.x), float(fld.y), str(ours)[:80], str(theirs)[:80]))
     print(json.dumps({'soak': 'wideangle.eval_real_image_ht through the rebound trace.iterate_ray_raw '
-                              '(oracle as the engine) == the reference, bit for bit',
+                              '(' + ('HIP engine' if hip else 'oracle as the engine') + ') == the reference, bit for bit',
                       'cases': n, 'two_d_cases': int(n2d), 'cases_where_both_raise': int(n_exc),
                       'mismatches': bad[:5], 'n_mismatches': len(bad), 'seconds': round(time.time() - t0, 1)}))
     session.ENGINE_FACTORY = None
 
 
 if __name__ == '__main__':
+    if '--hip' in sys.argv:     # GPU box, reference staged in oracle/_ref: HIP vs the live reference
+        soak_dropins(hip=True)
+        soak_round4(hip=True)
+        sys.exit(0)
     if '--round4' in sys.argv:
         soak_round4()
         sys.exit(0)
