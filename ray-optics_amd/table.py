@@ -17,6 +17,8 @@ import ctypes as C
 import json
 import numpy as np
 
+import numbers
+
 from . import abi
 
 
@@ -30,6 +32,13 @@ def _profile_row(row, prof):
         raise UnsupportedModelError(f'profile {kind} is not supported')
     row.profile = abi.PROFILE_NAMES[kind]
     row.cv = float(prof.cv)
+    if kind in ('Spherical', 'Conic') and isinstance(prof.cv, numbers.Integral) and prof.cv == 0:
+        # A curvature typed as the *integer* 0 (the reference's own double Gauss data,
+        # rayoptics/raytr/tests/ag_dblgauss_s.py): `-self.cv*p[0]` in Spherical/Conic.df
+        # (profiles.py:360-362, 605-609) is then `0 * x` = +0 for x > 0, where a float 0.0
+        # gives `-0.0 * x` = -0.  The float that reproduces the integer's zero signs in df is
+        # -0.0; every non-zero value is the same either way.
+        row.cv = -0.0
     if kind == 'Spherical':
         row.cc, row.ec = 0.0, 1.0
     elif kind == 'RadialPolynomial':

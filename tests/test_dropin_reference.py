@@ -1474,3 +1474,35 @@ def test_astigmatism_curve(ref, installed, model):
     def one():
         return trace.trace_astigmatism(opm, fld, wvl, 0.01, dx=0.002, dy=0.0005)
     assert both(installed, one)[0] == both(installed, one)[1]
+
+
+def test_integer_zero_curvature_keeps_the_references_zero_signs(ref, installed):
+    """the reference's double Gauss data gives its flat surfaces the integer curvature 0;
+    `-0 * x` is +0 where `-0.0 * x` is -0, so the zero components of those surfaces' normals
+    have their own sign pattern -- reproduced (the table stores -0.0 for an integer zero);
+    compared here with the sign bit, not with =="""
+    import rayoptics.raytr.trace as trace
+    opm = ref.dblgauss()
+    sm = opm['seq_model']
+    flats = [i for i, ifc in enumerate(sm.ifcs) if isinstance(ifc.profile.cv, int) and ifc.profile.cv == 0]
+    assert flats
+    fld = opm['osp']['fov'].fields[2]
+    wvl = sm.central_wavelength()
+
+    def run():
+        got = []
+        trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 9], fld, wvl, 0.0,
+                         img_filter=lambda p, pkg: got.append(pkg), form='list', append_if_none=True)
+        return got
+    ours, theirs = both(installed, run)
+    n = 0
+    for ko, kt in zip(ours, theirs):
+        if kt is None:
+            continue
+        for s in flats:
+            if s < len(kt[0]):
+                a, b = np.asarray(ko[0][s][3]), np.asarray(kt[0][s][3])
+                np.testing.assert_array_equal(a, b)
+                np.testing.assert_array_equal(np.signbit(a), np.signbit(b))
+                n += 1
+    assert n > 50
