@@ -214,8 +214,9 @@ def soak_packets_hip(ref, install):
                       'n_mismatches': len(bad), 'seconds': round(time.time() - t0, 1)}))
 
 
-def soak_round3():
-    """round 3: the wide-angle pupil search restated in the oracle against the reference's
+def soak_round3(hip=False):
+    """(hip=True, GPU box: the drop-ins over the HIP engine instead of the oracle restatement)
+    round 3: the wide-angle pupil search restated in the oracle against the reference's
     find_real_enp on random field angles of perturbed models (z_enp bit for bit; "the reference
     raises" exactly where it does), 2-D chief-ray aiming (fsolve) through the drop-in on random
     off-axis fields, SequentialModel.trace_fan with RayFanFigure's callbacks through the fused
@@ -251,6 +252,27 @@ def soak_round3():
                 fld = fov.fields[-1]
                 fld.x, fld.y, fld.aim_info = 0., float(ang) / (fov.value if fov.is_relative else 1.0), None
                 wvl = sm.central_wavelength()
+                if hip:
+                    # the rebound wideangle.find_real_enp (the HIP launch; where the reference
+                    # raises it calls the reference's own function) against the reference
+                    def call():
+                        fld.aim_info = None
+                        try:
+                            return float(wa.find_real_enp(opm, sm.stop_surface, fld, wvl)[0])
+                        except Exception as e:
+                            return type(e).__name__
+                    install.uninstall()
+                    z_ref = call()
+                    session.ENGINE_FACTORY = None
+                    install.install()
+                    z_dev = call()
+                    install.uninstall()
+                    ok = z_dev == z_ref
+                    codes[type(z_ref).__name__] = codes.get(type(z_ref).__name__, 0) + 1
+                    n += 1
+                    if not ok:
+                        bad.append((name, trial, float(ang), str(z_dev), str(z_ref)))
+                    continue
                 pb = T._enp_problem(opm, fld, wvl, tbl, sm.stop_surface)
                 z, res = oracle.find_real_enp(tbl, [pb])
                 codes[int(res[0])] = codes.get(int(res[0]), 0) + 1
@@ -262,11 +284,13 @@ def soak_round3():
                 n += 1
                 if not ok:
                     bad.append((name, trial, float(ang)))
-    print(json.dumps({'soak': 'wide-angle pupil search: oracle == reference find_real_enp', 'cases': n,
+    print(json.dumps({'soak': 'wide-angle pupil search: ' + ('drop-in over the HIP engine' if hip else 'oracle')
+                              + ' == reference find_real_enp', 'cases': n,
                       'mismatches': bad[:5], 'result_codes': {str(k): v for k, v in sorted(codes.items())},
                       'seconds': round(time.time() - t0, 1)}))
     # 2-D aiming and the fan figure callbacks through the drop-ins (oracle as the engine)
-    session.ENGINE_FACTORY = OracleEngine
+    session.ENGINE_FACTORY = None if hip else OracleEngine
+    eng = 'HIP engine' if hip else 'oracle double'
     t0, n, bad = time.time(), 0, []
     for build in (ref.dblgauss, ref.nikkor, ref.cell_phone):
         for trial in range(25):
@@ -287,7 +311,7 @@ def soak_round3():
             n += 1
             if not np.array_equal(ours, theirs):
                 bad.append((build.__name__, trial))
-    print(json.dumps({'soak': '2-D chief-ray aiming (fsolve / hybrd) through the drop-in on perturbed models',
+    print(json.dumps({'soak': '2-D chief-ray aiming (fsolve / hybrd) through the drop-in on perturbed models', 'engine': eng,
                       'cases': n, 'mismatches': bad[:5], 'seconds': round(time.time() - t0, 1)}))
     import matplotlib
     matplotlib.use('Agg')
@@ -319,7 +343,7 @@ def soak_round3():
                 n += 1
                 if json.dumps(ours) != json.dumps(theirs):
                     bad.append((build.__name__, trial, data_type))
-    print(json.dumps({'soak': 'RayFanFigure (Ray / OPD) through SequentialModel.trace_fan on perturbed models',
+    print(json.dumps({'soak': 'RayFanFigure (Ray / OPD) through SequentialModel.trace_fan on perturbed models', 'engine': eng,
                       'figures': n, 'mismatches': bad[:5], 'seconds': round(time.time() - t0, 1)}))
     session.ENGINE_FACTORY = None
 
@@ -385,6 +409,7 @@ if __name__ == '__main__':
     if '--hip' in sys.argv:     # GPU box, reference staged in oracle/_ref: HIP vs the live reference
         soak_dropins(hip=True)
         soak_round4(hip=True)
+        soak_round3(hip=True)
         sys.exit(0)
     if '--round4' in sys.argv:
         soak_round4()
