@@ -71,6 +71,8 @@ def install(fallback='raise'):
              (rtrace, 'iterate_ray_raw', _t.iterate_ray_raw),
              # the five close rays per field point of trace_astigmatism_curve (AstigmatismCurvePlot)
              (rtrace, 'trace_astigmatism', _t.trace_astigmatism),
+             # trace_field / trace_all_fields: a field's list of rays as one launch
+             (rtrace, 'trace_ray_list_at_field', _t.trace_ray_list_at_field),
              (rtrace, 'aim_chief_ray', _t.aim_chief_ray),
              (ropticalspec, 'aim_chief_ray', _t.aim_chief_ray),
              # the wide-angle pupil search behind aim_chief_ray (trace.py:634-635) and

@@ -10,6 +10,8 @@ the per-ray Python loop replaced by one device launch.
                      reference's own iterative callers (trace_base, iterate_ray's 2-D
                      fsolve branch, the wide-angle pupil search, trace_chief_ray ...)
   aim_chief_ray   <- rayoptics/raytr/trace.py:627-640 (iterate_ray's 1-D branch on the device)
+  trace_ray_list_at_field <- rayoptics/raytr/trace.py:478-486 (trace_field / trace_all_fields:
+                     a field's boundary rays in one launch)
   trace_astigmatism <- rayoptics/raytr/trace.py:823-863 (five rays, one launch; the field loop
                      of trace_astigmatism_curve calls it)
   iterate_ray_raw <- rayoptics/raytr/trace.py:866-961 (the reverse chief ray of
@@ -181,6 +183,31 @@ def iterate_ray_raw(pthlist, ifcx, xy_target, pt0, d0, obj2pup_dist, eprad, wvl,
     except TraceError as ray_error:
         rr = RayResult(RefRayPkg(*ray_error.ray_pkg), ray_error)
     return start_coords, rr
+
+
+def trace_ray_list_at_field(opt_model, ray_list, fld, wvl, foc, **kwargs):
+    """rayoptics/raytr/trace.py:478-486: a list of ray DataFrames for the pupil points of
+    ``ray_list`` at ``fld`` -- one ``trace_ray`` per point in the reference (``trace_field`` /
+    ``trace_all_fields``: the boundary rays of every field), one launch per field here; the
+    frames are built by the reference's own ``ray_df`` from the same segments (a failed ray
+    contributes its partial packet, as ``rayerr_filter='full'`` does there)"""
+    import rayoptics.raytr.trace as rtrace
+    kw = dict(kwargs)
+    output_filter = kw.pop('output_filter', None)
+    rayerr_filter = kw.pop('rayerr_filter', 'full')          # trace_ray's default (trace.py:104)
+    named = kw.get('use_named_tuples', False)
+    kw['apply_vignetting'] = kw.get('apply_vignetting', True)
+    pts = [np.asarray(p, dtype=float) for p in ray_list]
+    px = np.array([p[0] for p in pts])
+    py = np.array([p[1] for p in pts])
+    pk = _trace_pupil(opt_model, fld, wvl, kw, output_filter, rayerr_filter, pupil_list=(px, py))
+    ifcs = opt_model['seq_model'].ifcs
+    rayset = []
+    for r in range(len(pts)):
+        ray_pkg, _err = emit(pk, r, output_filter, rayerr_filter, named, ifcs)
+        ray, _op, _wvl = ray_pkg                             # (None here raises as there)
+        rayset.append(ray.to_list() if hasattr(ray, 'to_list') else ray)
+    return [rtrace.ray_df(r) for r in rayset]
 
 
 def trace_astigmatism(opt_model, fld, wvl, foc, dx=0.001, dy=0.001):

@@ -1506,3 +1506,24 @@ def test_integer_zero_curvature_keeps_the_references_zero_signs(ref, installed):
                 np.testing.assert_array_equal(np.signbit(a), np.signbit(b))
                 n += 1
     assert n > 50
+
+
+@pytest.mark.parametrize('model', ['dblgauss', 'rc_telescope', 'cell_phone'])
+def test_trace_all_fields_dataframes(ref, installed, model):
+    """trace.trace_all_fields (rayoptics/raytr/trace.py:499-510): the boundary rays of every
+    field as one DataFrame -- `trace_ray_list_at_field` rebound to one launch per field; the
+    frame (index, columns, every cell) is the reference's"""
+    import rayoptics.raytr.trace as trace
+    opm = getattr(ref, model)()
+
+    def run():
+        return trace.trace_all_fields(opm)
+    ours, theirs = both(installed, run)
+    assert list(ours.index.names) == list(theirs.index.names)
+    assert ours.index.equals(theirs.index) and list(ours.columns) == list(theirs.columns)
+    n = 0
+    for col in theirs.columns:
+        for a, b in zip(ours[col], theirs[col]):
+            np.testing.assert_array_equal(np.asarray(a, dtype=float), np.asarray(b, dtype=float))
+            n += 1
+    assert n > 100
