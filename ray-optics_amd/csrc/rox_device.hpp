@@ -1748,7 +1748,7 @@ struct PackArgs {
 constexpr int kPackBlock = 1024, kPackSub = 4, kPackTile = kPackBlock * kPackSub;
 void launch_pack(const PackArgs &, unsigned blocks, hipStream_t);
 
-// chief-ray aiming (csrc/inst_aim.hip)
+// chief-ray aiming (csrc/rox_search.hpp)
 struct AimArgs {
     const double *rows, *n_table, *ph_consts, *wvls;
     const int32_t *slots;
@@ -1761,9 +1761,8 @@ struct AimArgs {
     int32_t *last_status;      // device [n] or nullptr: ... and its trace status
     int32_t wave_per_problem;  // 1: one wave (block) per problem; 0: one lane per problem
 };
-void launch_aim(const AimArgs &, size_t lds, hipStream_t);
 
-// wide-angle pupil search (csrc/inst_aim.hip)
+// wide-angle pupil search (csrc/rox_search.hpp)
 struct EnpArgs {
     const double *rows, *n_table, *ph_consts, *wvls;
     const int32_t *slots;
@@ -1773,9 +1772,8 @@ struct EnpArgs {
     double *z_out;             // device [n][2]
     int32_t *result;           // device [n]
 };
-void launch_enp(const EnpArgs &, size_t lds, hipStream_t);
 
-// vignetting search (csrc/inst_aim.hip)
+// vignetting search (csrc/rox_search.hpp)
 struct VigArgs {
     const double *rows, *n_table, *ph_consts, *wvls;
     const int32_t *slots;
@@ -1788,6 +1786,19 @@ struct VigArgs {
     const rox_pupil_iter *iters;
     int32_t wave_per_problem;  // 1: one wave (block) per problem; 0: one lane per problem
 };
-void launch_vig(const VigArgs &, size_t lds, hipStream_t);
+
+// the feature instances the search kernels are compiled for (csrc/search_*.hip, rox_search.hpp);
+// the host launches the first one that covers the system's features
+constexpr int kSearchInstances[] = {0, F_EVEN, F_RADIAL, F_APLIST, F_ALL};
+#define ROX_SEARCH_DECL(name)                                          \
+    void launch_aim_##name(const AimArgs &, size_t lds, hipStream_t); \
+    void launch_enp_##name(const EnpArgs &, size_t lds, hipStream_t); \
+    void launch_vig_##name(const VigArgs &, size_t lds, hipStream_t);
+ROX_SEARCH_DECL(lean)
+ROX_SEARCH_DECL(even)
+ROX_SEARCH_DECL(radial)
+ROX_SEARCH_DECL(aplist)
+ROX_SEARCH_DECL(general)
+#undef ROX_SEARCH_DECL
 
 }  // namespace rox

@@ -4,7 +4,8 @@
 // qrfac / qform / dogleg / r1updt / r1mpyq / enorm with mode = 1, a dense forward-difference
 // Jacobian, nprint = 0).  One lane runs one problem; every array is a handful of registers.
 // The operations and their order are the Fortran's (the CPU restatement the tests check this
-// against is itself pinned bit for bit against the installed SciPy).
+// against is itself pinned bit for bit against the installed SciPy).  Every loop over the
+// compile-time n is unrolled so that the arrays are registers, not scratch memory.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,6 +23,7 @@ __device__ __forceinline__ double enorm(int n, const double *x)
     const double rdwarf = 3.834e-20, rgiant = 1.304e19;
     double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0;
     const double agiant = rgiant / (double)n;
+    #pragma unroll
     for (int i = 0; i < n; i++) {
         const double xabs = fabs(x[i]);
         if (xabs > rdwarf && xabs < agiant) {
@@ -87,9 +89,14 @@ __device__ __forceinline__ void recover(double t, double &c, double &s)
 
 // hybrd.f.  `fcn(x, fvec)` returns false to stop the iteration (MINPACK's iflag < 0): solve then
 // returns a negative info.  x holds the starting point and receives the last accepted iterate.
-template <int N, class F>
-__device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev, double epsfcn,
-                                     double factor, int &nfev)
+// `pts(x, h, need_f, fvec, cols)` evaluates the points of one forward-difference Jacobian --
+// f(x) into fvec when need_f (hybrd's evaluation at the starting point), f(x + h[j] e_j) into
+// cols + j * N -- in that order, and returns false as soon as one of them stops the iteration.
+// fdjac1 evaluates them one after the other, but none depends on another's value: a caller with
+// idle lanes traces them in one pass (rox_search.hpp), a caller without calls fcn in a loop.
+template <int N, class F, class P>
+__device__ __forceinline__ int solve(F &fcn, P &pts, double *x, double xtol, int maxfev,
+                                     double epsfcn, double factor, int &nfev)
 {
     constexpr int n = N;
 #define FJ(i, j) fjac[(i) + (j) * n]
@@ -97,52 +104,63 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
     double diag[N], wa1[N], wa2[N], wa3[N], wa4[N];
     int info = 0;
     double xnorm = 0.0, delta = 0.0;
-    bool ok = fcn(x, fvec);
-    nfev = 1;
-    if (!ok)
-        return -1;
-    double fnorm = enorm(n, fvec);
+    bool ok;
+    bool at_start = true;
+    double fnorm = 0.0;
+    nfev = 0;
     int iter = 1, ncsuc = 0, ncfail = 0, nslow1 = 0, nslow2 = 0;
     for (;;) {                                          // outer loop
         bool jeval = true;
         // fdjac1.f, dense: forward differences
         {
             const double eps = sqrt(epsfcn > EPSMCH ? epsfcn : EPSMCH);
+            double h[N], cols[N * N];
+            #pragma unroll
             for (int j = 0; j < n; j++) {
-                const double temp = x[j];
-                double h = eps * fabs(temp);
-                if (h == 0.0)
-                    h = eps;
-                x[j] = temp + h;
-                ok = fcn(x, wa1);
-                x[j] = temp;
-                if (!ok)
-                    break;
-                for (int i = 0; i < n; i++)
-                    FJ(i, j) = (wa1[i] - fvec[i]) / h;
+                h[j] = eps * fabs(x[j]);
+                if (h[j] == 0.0)
+                    h[j] = eps;
             }
+            ok = pts(x, h, at_start, fvec, cols);
+            if (at_start)
+                nfev = 1;
+            nfev += n;
+            if (!ok)
+                return -1;
+            if (at_start) {
+                fnorm = enorm(n, fvec);
+                at_start = false;
+            }
+            #pragma unroll
+            for (int j = 0; j < n; j++)
+                #pragma unroll
+                for (int i = 0; i < n; i++)
+                    FJ(i, j) = (cols[j * n + i] - fvec[i]) / h[j];
         }
-        nfev += n;
-        if (!ok)
-            return -1;
         // qrfac.f (no pivoting): rdiag = wa1, acnorm = wa2
+        #pragma unroll
         for (int j = 0; j < n; j++) {
             wa2[j] = enorm(n, &FJ(0, j));
             wa1[j] = wa2[j];
         }
+        #pragma unroll
         for (int j = 0; j < n; j++) {
             double ajnorm = enorm(n - j, &FJ(j, j));
             if (ajnorm != 0.0) {
                 if (FJ(j, j) < 0.0)
                     ajnorm = -ajnorm;
+                #pragma unroll
                 for (int i = j; i < n; i++)
                     FJ(i, j) /= ajnorm;
                 FJ(j, j) += 1.0;
+                #pragma unroll
                 for (int k = j + 1; k < n; k++) {
                     double sum = 0.0;
+                    #pragma unroll
                     for (int i = j; i < n; i++)
                         sum += FJ(i, j) * FJ(i, k);
                     const double temp = sum / FJ(j, j);
+                    #pragma unroll
                     for (int i = j; i < n; i++)
                         FJ(i, k) -= temp * FJ(i, j);
                 }
@@ -150,11 +168,13 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
             wa1[j] = -ajnorm;
         }
         if (iter == 1) {
+            #pragma unroll
             for (int j = 0; j < n; j++) {
                 diag[j] = wa2[j];
                 if (wa2[j] == 0.0)
                     diag[j] = 1.0;
             }
+            #pragma unroll
             for (int j = 0; j < n; j++)
                 wa3[j] = diag[j] * x[j];
             xnorm = enorm(n, wa3);
@@ -163,21 +183,27 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
                 delta = factor;
         }
         // (q transpose) * fvec
+        #pragma unroll
         for (int i = 0; i < n; i++)
             qtf[i] = fvec[i];
+        #pragma unroll
         for (int j = 0; j < n; j++) {
             if (FJ(j, j) != 0.0) {
                 double sum = 0.0;
+                #pragma unroll
                 for (int i = j; i < n; i++)
                     sum += FJ(i, j) * qtf[i];
                 const double temp = -sum / FJ(j, j);
+                #pragma unroll
                 for (int i = j; i < n; i++)
                     qtf[i] += FJ(i, j) * temp;
             }
         }
         // the triangular factor, by rows
+        #pragma unroll
         for (int j = 0; j < n; j++) {
             int l = j;
+            #pragma unroll
             for (int i = 0; i < j; i++) {
                 r[l] = FJ(i, j);
                 l += n - 1 - i;
@@ -185,11 +211,15 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
             r[l] = wa1[j];
         }
         // qform.f
+        #pragma unroll
         for (int j = 1; j < n; j++)
+            #pragma unroll
             for (int i = 0; i < j; i++)
                 FJ(i, j) = 0.0;
+        #pragma unroll
         for (int l = 0; l < n; l++) {
             const int k = n - 1 - l;
+            #pragma unroll
             for (int i = k; i < n; i++) {
                 wa1[i] = FJ(i, k);
                 FJ(i, k) = 0.0;
@@ -197,26 +227,32 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
             FJ(k, k) = 1.0;
             if (wa1[k] == 0.0)
                 continue;
+            #pragma unroll
             for (int j = k; j < n; j++) {
                 double sum = 0.0;
+                #pragma unroll
                 for (int i = k; i < n; i++)
                     sum += FJ(i, j) * wa1[i];
                 const double temp = sum / wa1[k];
+                #pragma unroll
                 for (int i = k; i < n; i++)
                     FJ(i, j) -= temp * wa1[i];
             }
         }
+        #pragma unroll
         for (int j = 0; j < n; j++)
             diag[j] = diag[j] > wa2[j] ? diag[j] : wa2[j];
         for (;;) {                                      // inner loop
             // dogleg.f: direction into wa1 (x of dogleg), scratch wa2, wa3
             {
                 int jj = (n * (n + 1)) / 2;
+                #pragma unroll
                 for (int k = 1; k <= n; k++) {
                     const int j = n - k;
                     jj -= k;
                     int l = jj + 1;
                     double sum = 0.0;
+                    #pragma unroll
                     for (int i = j + 1; i < n; i++) {
                         sum += r[l] * wa1[i];
                         l++;
@@ -224,6 +260,7 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
                     double temp = r[jj];
                     if (temp == 0.0) {
                         l = j;
+                        #pragma unroll
                         for (int i = 0; i <= j; i++) {
                             const double t = fabs(r[l]);
                             if (t > temp)
@@ -236,6 +273,7 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
                     }
                     wa1[j] = (qtf[j] - sum) / temp;
                 }
+                #pragma unroll
                 for (int j = 0; j < n; j++) {
                     wa2[j] = 0.0;
                     wa3[j] = diag[j] * wa1[j];
@@ -243,8 +281,10 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
                 const double qnorm = enorm(n, wa3);
                 if (qnorm > delta) {
                     int l = 0;
+                    #pragma unroll
                     for (int j = 0; j < n; j++) {
                         const double temp = qtf[j];
+                        #pragma unroll
                         for (int i = j; i < n; i++) {
                             wa2[i] += r[l] * temp;
                             l++;
@@ -255,11 +295,14 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
                     double sgnorm = 0.0;
                     double alpha = delta / qnorm;
                     if (gnorm != 0.0) {
+                        #pragma unroll
                         for (int j = 0; j < n; j++)
                             wa2[j] = (wa2[j] / gnorm) / diag[j];
                         l = 0;
+                        #pragma unroll
                         for (int j = 0; j < n; j++) {
                             double sum = 0.0;
+                            #pragma unroll
                             for (int i = j; i < n; i++) {
                                 sum += r[l] * wa2[i];
                                 l++;
@@ -279,10 +322,12 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
                         }
                     }
                     const double temp = (1.0 - alpha) * (sgnorm < delta ? sgnorm : delta);
+                    #pragma unroll
                     for (int j = 0; j < n; j++)
                         wa1[j] = temp * wa2[j] + alpha * wa1[j];
                 }
             }
+            #pragma unroll
             for (int j = 0; j < n; j++) {
                 wa1[j] = -wa1[j];
                 wa2[j] = x[j] + wa1[j];
@@ -303,8 +348,10 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
             }
             {
                 int l = 0;
+                #pragma unroll
                 for (int i = 0; i < n; i++) {
                     double sum = 0.0;
+                    #pragma unroll
                     for (int j = i; j < n; j++) {
                         sum += r[l] * wa1[j];
                         l++;
@@ -334,6 +381,7 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
                     delta = pnorm / 0.5;
             }
             if (ratio >= 1.0e-4) {
+                #pragma unroll
                 for (int j = 0; j < n; j++) {
                     x[j] = wa2[j];
                     wa2[j] = diag[j] * x[j];
@@ -370,8 +418,10 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
             if (ncfail == 2)
                 break;
             // rank one modification of the jacobian
+            #pragma unroll
             for (int j = 0; j < n; j++) {
                 double sum = 0.0;
+                #pragma unroll
                 for (int i = 0; i < n; i++)
                     sum += FJ(i, j) * wa4[i];
                 wa2[j] = (sum - wa3[j]) / pnorm;
@@ -387,6 +437,7 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
 #define U(i) wa1[(i) - 1]
                 int jj = (n * (n + 1)) / 2;
                 W(n) = S(jj);
+                #pragma unroll
                 for (int nmj = 1; nmj <= n - 1; nmj++) {
                     const int j = n - nmj;
                     jj -= (n - j + 1);
@@ -398,6 +449,7 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
                     V(n) = s * V(j) + c * V(n);
                     V(j) = tau;
                     int l = jj;
+                    #pragma unroll
                     for (int i = j; i <= n; i++) {
                         const double temp = c * S(l) - s * W(i);
                         W(i) = s * S(l) + c * W(i);
@@ -405,13 +457,16 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
                         l++;
                     }
                 }
+                #pragma unroll
                 for (int i = 1; i <= n; i++)
                     W(i) = W(i) + V(n) * U(i);
+                #pragma unroll
                 for (int j = 1; j <= n - 1; j++) {
                     if (W(j) != 0.0) {
                         double c, s, tau;
                         givens(S(jj), W(j), c, s, tau);
                         int l = jj;
+                        #pragma unroll
                         for (int i = j; i <= n; i++) {
                             const double temp = c * S(l) + s * W(i);
                             W(i) = -s * S(l) + c * W(i);
@@ -429,10 +484,12 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
 #undef W
 #undef U
             // r1mpyq.f on fjac (n x n) and on qtf (1 x n)
+            #pragma unroll
             for (int nmj = 1; nmj <= n - 1; nmj++) {
                 const int j = n - nmj - 1;
                 double c, s;
                 recover(wa2[j], c, s);
+                #pragma unroll
                 for (int i = 0; i < n; i++) {
                     const double temp = c * FJ(i, j) - s * FJ(i, n - 1);
                     FJ(i, n - 1) = s * FJ(i, j) + c * FJ(i, n - 1);
@@ -442,9 +499,11 @@ __device__ __forceinline__ int solve(F &fcn, double *x, double xtol, int maxfev,
                 qtf[n - 1] = s * qtf[j] + c * qtf[n - 1];
                 qtf[j] = temp;
             }
+            #pragma unroll
             for (int j = 0; j < n - 1; j++) {
                 double c, s;
                 recover(wa3[j], c, s);
+                #pragma unroll
                 for (int i = 0; i < n; i++) {
                     const double temp = c * FJ(i, j) + s * FJ(i, n - 1);
                     FJ(i, n - 1) = -s * FJ(i, j) + c * FJ(i, n - 1);

@@ -1,9 +1,15 @@
-// inst_aim.hip -- batched chief-ray aiming: the 1-D branch of trace.iterate_ray
+// rox_search.hpp -- the search kernels (many short dependent traces per problem), templates
+// over the feature instance of their trial-ray trace; csrc/search_*.hip instantiate them, one
+// translation unit per instance like the trace kernels (a lean system's trial ray is then the
+// lean trace: double Gauss aiming 0.43 -> 0.35 ms against the F_ALL trace it used to inline).
+//
+// Batched chief-ray aiming: the 1-D branch of trace.iterate_ray
 // (rayoptics/raytr/trace.py:313-415) with scipy.optimize.newton's secant
 // iteration (scipy/optimize/_zeros_py.py, `fprime is None` branch; x0 = 0,
 // tol = 1.48e-8, rtol = 0, maxiter = 50, disp = False) restated per lane: one
 // lane = one (field, wavelength) problem, every trial ray traced through the
 // whole system with raytrace.trace's defaults (raytrace.py:51-80).
+#pragma once
 #include "rox_device.hpp"
 #include "rox_hybrd.hpp"
 
@@ -12,8 +18,8 @@
 #endif
 
 namespace rox {
-namespace {
 
+template <int FEAT>
 __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
 {
     const int N = a.n_ifcs, W = a.n_wvls;
@@ -46,7 +52,7 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
     c.slot = slot_w; c.nslots_before = slot_w + N;
-    c.apthr = nullptr;          // (F_ALL instances test apertures through inside_aperture)
+    c.apthr = nullptr;          // (the trial rays of the aiming never test apertures)
     c.N = N;
     c.check_ap = false; c.intersect_obj = true; c.filter_ph = false;    // raytrace.py:51-80, 83-99
     c.first_surf = 1; c.last_surf = N - 2;
@@ -66,53 +72,117 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
             a.last_status[i] = last_st;
         }
     };
-    // trace.py:322-349 y_stop_coordinate; `raised`: a trial ray failed before surf
-    bool raised = false;
-    auto f = [&](double y1) -> double {
-        const v3 pt1{0., y1, pb.z_enp};
+    // With a wave per problem the lanes are idle copies of each other: the evaluations that do
+    // not depend on one another -- the secant iteration's two starting values, hybrd's value at
+    // the starting point together with the two forward-difference points of its Jacobian --
+    // are traced in ONE pass, lane k tracing the k-th point, and then taken in the reference's
+    // order (the same values, and the same `last trial ray' if one of them stops the search).
+    const bool wave = a.wave_per_problem != 0;
+    const int lane = threadIdx.x;
+    // one trial ray through (x1, y1) of the entrance pupil plane: status, whether it failed
+    // before surf (the reference's objective raises), its coordinates at surf
+    auto trial = [&](double x1, double y1, int &st, int &rs, double &xr, double &yr) {
+        const v3 pt1{x1, y1, pb.z_enp};
         v3 dir0 = unit(v3{pt1.x - pt0.x, pt1.y - pt0.y, pt1.z - pt0.z});
         if (pb.flip && dir0.z * pb.z_dir0 < 0)
             dir0 = v3{-dir0.x, -dir0.y, -dir0.z};
         RayEnd e;
-        trace_ray<MODE_PROBE, true, F_ALL>(c, so, pt0, dir0, pb.wvl_idx, true, e);
-        last_x = 0.; last_y = y1; last_st = e.status;
-        double y_ray;
-        if (e.status != ROX_OK) {
-            y_ray = 0.;                         // final_coord = [0, 0, 0]
-            if (e.fail_surf < pb.surf)
-                raised = true;
-        } else {
-            y_ray = e.probe_p.y;
+        trace_ray<MODE_PROBE, true, FEAT>(c, so, pt0, dir0, pb.wvl_idx, true, e);
+        st = e.status;
+        rs = 0;
+        xr = yr = 0.;                           // final_coord = [0, 0, 0]
+        if (e.status != ROX_OK)
+            rs = e.fail_surf < pb.surf;
+        else {
+            xr = e.probe_p.x;
+            yr = e.probe_p.y;
         }
-        return y_ray - pb.y_target;
+    };
+    // trace.py:322-349 y_stop_coordinate; `raised`: a trial ray failed before surf
+    bool raised = false;
+    auto f = [&](double y1) -> double {
+        int st, rs;
+        double xr, yr;
+        trial(0., y1, st, rs, xr, yr);
+        last_x = 0.; last_y = y1; last_st = st;
+        if (rs)
+            raised = true;
+        return yr - pb.y_target;
+    };
+    // f(ya) and then, unless it raised, f(yb)
+    auto f_two = [&](double ya, double yb, double &qa, double &qb) {
+        if (!wave) {
+            qa = f(ya);
+            qb = raised ? 0.0 : f(yb);
+            return;
+        }
+        int st, rs;
+        double xr, yr;
+        trial(0., lane == 1 ? yb : ya, st, rs, xr, yr);
+        last_x = 0.; last_y = ya; last_st = __shfl(st, 0);
+        qa = __shfl(yr, 0) - pb.y_target;
+        qb = 0.0;
+        if (__shfl(rs, 0)) {
+            raised = true;
+            return;
+        }
+        last_y = yb; last_st = __shfl(st, 1);
+        qb = __shfl(yr, 1) - pb.y_target;
+        if (__shfl(rs, 1))
+            raised = true;
     };
 
     if (pb.two_d) {
-        // trace.py:351-372 surface_coordinate under fsolve (MINPACK hybrd, rox_hybrd.hpp);
-        // fsolve evaluates f(x0) itself before MINPACK does
+        // trace.py:351-372 surface_coordinate under fsolve (MINPACK hybrd, rox_hybrd.hpp)
         auto f2 = [&](const double *coord, double *fv) -> bool {
-            const v3 pt1{coord[0], coord[1], pb.z_enp};
-            v3 dir0 = unit(v3{pt1.x - pt0.x, pt1.y - pt0.y, pt1.z - pt0.z});
-            if (pb.flip && dir0.z * pb.z_dir0 < 0)
-                dir0 = v3{-dir0.x, -dir0.y, -dir0.z};
-            RayEnd e;
-            trace_ray<MODE_PROBE, true, F_ALL>(c, so, pt0, dir0, pb.wvl_idx, true, e);
-            last_x = coord[0]; last_y = coord[1]; last_st = e.status;
-            double xr = 0., yr = 0.;
-            if (e.status != ROX_OK) {
-                if (e.fail_surf < pb.surf)
-                    return false;                       // raise ray_error
-            } else {
-                xr = e.probe_p.x;
-                yr = e.probe_p.y;
-            }
+            int st, rs;
+            double xr, yr;
+            trial(coord[0], coord[1], st, rs, xr, yr);
+            last_x = coord[0]; last_y = coord[1]; last_st = st;
+            if (rs)
+                return false;                           // raise ray_error
             fv[0] = xr - pb.x_target;
             fv[1] = yr - pb.y_target;
             return true;
         };
-        double x[2] = {0., 0.}, fv0[2];
+        // f(x) if need_f, f(x + h0 e0), f(x + h1 e1) (MINPACK's fdjac1), in that order.
+        // fsolve evaluates f(x0) itself before MINPACK evaluates it again: the same ray twice,
+        // traced once here -- a failure stops the search the same way in either call
+        auto f2_points = [&](const double *x, const double *h, bool need_f, double *fv,
+                             double *cols) -> bool {
+            if (!wave) {
+                if (need_f && !f2(x, fv))
+                    return false;
+                for (int j = 0; j < 2; ++j) {
+                    double xx[2] = {x[0], x[1]};
+                    xx[j] = x[j] + h[j];
+                    if (!f2(xx, cols + 2 * j))
+                        return false;
+                }
+                return true;
+            }
+            // lane 0 (and the lanes above 2): x, when it is asked for; lane 1: column 0; lane 2: column 1
+            const int v = lane == 2 ? 2 : ((lane == 1 || !need_f) ? 1 : 0);
+            const double cx = v == 1 ? x[0] + h[0] : x[0];
+            const double cy = v == 2 ? x[1] + h[1] : x[1];
+            int st, rs;
+            double xr, yr;
+            trial(cx, cy, st, rs, xr, yr);
+            for (int k = need_f ? 0 : 1; k < 3; ++k) {
+                last_x = k == 1 ? x[0] + h[0] : x[0];
+                last_y = k == 2 ? x[1] + h[1] : x[1];
+                last_st = __shfl(st, k);
+                if (__shfl(rs, k))
+                    return false;
+                double *out = k == 0 ? fv : cols + 2 * (k - 1);
+                out[0] = __shfl(xr, k) - pb.x_target;
+                out[1] = __shfl(yr, k) - pb.y_target;
+            }
+            return true;
+        };
+        double x[2] = {0., 0.};
         int nfev = 0;
-        int info = f2(x, fv0) ? hybrd::solve<2>(f2, x, 1.49012e-8, 600, pb.epsfcn, 100.0, nfev) : -1;
+        const int info = hybrd::solve<2>(f2, f2_points, x, 1.49012e-8, 600, pb.epsfcn, 100.0, nfev);
         if (info < 0) {                                 // except TraceError: start_coords = [0, 0]
             x[0] = x[1] = 0.0;
             a.result[i] = ROX_AIM_TRACE_ERROR;
@@ -130,8 +200,8 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
     const double eps = 1e-4;
     double p1 = p0 * (1 + eps);
     p1 += (p1 >= 0 ? eps : -eps);
-    double q0 = f(p0);
-    double q1 = raised ? 0.0 : f(p1);
+    double q0, q1;
+    f_two(p0, p1, q0, q1);
     if (!raised) {
         if (fabs(q1) < fabs(q0)) {
             double t = p0; p0 = p1; p1 = t;
@@ -174,18 +244,19 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
 // rtol=0, maxiter=50: returns the root estimate; `converged` as scipy flags it;
 // `raised` is set by f when the reference's objective would raise -- the
 // iteration stops at once.
-template <class F>
-__device__ __forceinline__ double secant(F &f, double x0, double tol, bool &raised, bool &converged)
+// `f_two(pa, pb, qa, qb)`: f(pa) and then, unless it raised, f(pb) -- the two starting values,
+// which a caller with idle lanes traces in one pass.
+template <class F, class F2>
+__device__ __forceinline__ double secant(F &f, F2 &f_two, double x0, double tol, bool &raised,
+                                         bool &converged)
 {
     converged = false;
     double p0 = x0, p = x0;
     const double eps = 1e-4;
     double p1 = x0 * (1 + eps);
     p1 += (p1 >= 0 ? eps : -eps);
-    double q0 = f(p0);
-    if (raised)
-        return p;
-    double q1 = f(p1);
+    double q0, q1;
+    f_two(p0, p1, q0, q1);
     if (raised)
         return p;
     if (fabs(q1) < fabs(q0)) {
@@ -218,6 +289,7 @@ __device__ __forceinline__ double secant(F &f, double x0, double tol, bool &rais
 
 // rayoptics/raytr/vigcalc.py:259-340 calc_vignetted_ray + :396-461 iterate_pupil_ray,
 // one lane per (field, pupil direction)
+template <int FEAT>
 __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
 {
     const int N = a.n_ifcs, W = a.n_wvls;
@@ -237,10 +309,19 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
         wvls_w[i] = a.wvls[i];
     for (int i = threadIdx.x; i < 2 * N; i += 64)
         slot_w[i] = a.slots[i];
+    // instances without F_APLIST: the sqrt-free aperture thresholds of the checked trace
+    // (pt_inside_fuzz = 1e-4), behind the slot map
+    double *apthr_w = reinterpret_cast<double *>(slot_w + 2 * N);
+    if (!(FEAT & F_APLIST))
+        for (int i = threadIdx.x; i < N; i += 64)
+            apthr_w[i] = sqrt_le_threshold(
+                a.rows[(size_t)i * kRowDoubles + offsetof(rox_surface, max_aperture) / 8] + 1e-4);
     __syncthreads();
     const int i = a.wave_per_problem ? (int)blockIdx.x : (int)(blockIdx.x * 64 + threadIdx.x);
     if (i >= a.n)
         return;
+    const bool wave = a.wave_per_problem != 0;
+    const int lane = threadIdx.x;
     rox_vig pb;
     if (a.iters) {              // rox_iterate_pupil_rays: the field, the axis, the wavelength
         const rox_pupil_iter it = a.iters[i];
@@ -256,7 +337,7 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
     c.slot = slot_w; c.nslots_before = slot_w + N;
-    c.apthr = nullptr;          // (F_ALL instances test apertures through inside_aperture)
+    c.apthr = apthr_w;          // (read by the instances without F_APLIST, checked trace only)
     c.N = N;
     c.filter_ph = false;
     c.intersect_obj = pb.fld.kind != ROX_FLD_EPD_WIDE && pb.fld.z_dir0 != 0.0;     // trace.py:302-303
@@ -271,7 +352,7 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
         c.probe_surf = probe;
         v3 pt0, dir0;
         ray_start(pb.fld, 0u, px, py, pt0, dir0);
-        trace_ray<MODE_PROBE, true, F_ALL>(c, so, pt0, dir0, pb.wvl_idx, true, e);
+        trace_ray<MODE_PROBE, true, FEAT>(c, so, pt0, dir0, pb.wvl_idx, true, e);
     };
     // ifcs[s].edge_pt_target(start_dir)[xy]: surface.py:210-218, 422-427, 459-464,
     // interface.py:94-111 (the first clear aperture that is not an obscuration)
@@ -292,25 +373,59 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     auto iterate = [&](int indx, double start_r0, double r_target) -> double {
         bool raised = false, conv;
         double raised_x = 0.0;
-        auto f = [&](double x) -> double {      // r_pupil_coordinate, :418-446
+        // r_pupil_coordinate, :418-446: whether the objective raises for this ray, its value
+        auto rpc = [&](double x, int &stop, double &val) {
             RayEnd e;
             trace(xy == 0 ? x : 0., xy == 1 ? x : 0., false, indx, e);
+            stop = 0;
+            val = 0.0;
             if (e.status != ROX_OK) {
-                const bool stop = (e.status == ROX_MISSED_SURFACE) ? (e.fail_surf <= indx)
-                                                                   : (e.fail_surf < indx);
-                if (stop) {
-                    raised = true;
-                    raised_x = x;
-                    return 0.0;
-                }
+                stop = (e.status == ROX_MISSED_SURFACE) ? (e.fail_surf <= indx)
+                                                        : (e.fail_surf < indx);
+                if (stop)
+                    return;
             }
             // ray_pkg[mc.ray][indx][mc.p]: the partial packet ends with inc_pt at the
             // failing surface
             const v3 p = (e.status != ROX_OK && e.fail_surf == indx) ? e.inc : e.probe_p;
             const double r_ray = copysign(sqrt(p.x * p.x + p.y * p.y), r_target);
-            return r_ray - r_target;
+            val = r_ray - r_target;
         };
-        const double root = secant(f, start_r0, 1e-6, raised, conv);
+        auto f = [&](double x) -> double {
+            int stop;
+            double val;
+            rpc(x, stop, val);
+            if (stop) {
+                raised = true;
+                raised_x = x;
+            }
+            return val;
+        };
+        // the secant iteration's two starting values: with a wave per problem lane 1 traces
+        // the second while the others trace the first
+        auto f_two = [&](double xa, double xb, double &qa, double &qb) {
+            if (!wave) {
+                qa = f(xa);
+                qb = raised ? 0.0 : f(xb);
+                return;
+            }
+            int stop;
+            double val;
+            rpc(lane == 1 ? xb : xa, stop, val);
+            qa = __shfl(val, 0);
+            qb = 0.0;
+            if (__shfl(stop, 0)) {
+                raised = true;
+                raised_x = xa;
+                return;
+            }
+            qb = __shfl(val, 1);
+            if (__shfl(stop, 1)) {
+                raised = true;
+                raised_x = xb;
+            }
+        };
+        const double root = secant(f, f_two, start_r0, 1e-6, raised, conv);
         return raised ? 0.9 * raised_x : root;  // :456-459
     };
 
@@ -349,16 +464,18 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
 
 // scipy.optimize.newton's secant branch with rtol (disp = False); see secant() above for
 // the rtol = 0 form the vignetting search uses.  `f` never raises here.
-template <class F>
-__device__ __forceinline__ double secant_rtol(F &f, double x0, double tol, double rtol, bool &converged)
+// `f_two(pa, pb, qa, qb)` = f(pa), then f(pb): the two starting values, in one pass of the wave.
+template <class F, class F2>
+__device__ __forceinline__ double secant_rtol(F &f, F2 &f_two, double x0, double tol, double rtol,
+                                              bool &converged)
 {
     converged = false;
     double p0 = x0, p = x0;
     const double eps = 1e-4;
     double p1 = x0 * (1 + eps);
     p1 += (p1 >= 0 ? eps : -eps);
-    double q0 = f(p0);
-    double q1 = f(p1);
+    double q0, q1;
+    f_two(p0, p1, q0, q1);
     if (fabs(q1) < fabs(q0)) {
         double t = p0; p0 = p1; p1 = t;
         t = q0; q0 = q1; q1 = t;
@@ -448,6 +565,7 @@ __device__ __forceinline__ double brentq(F &f, double xa, double xb, double xtol
 // rayoptics/raytr/wideangle.py:96-292 find_real_enp_rev1 + :295-315 find_edge + :317-427
 // find_z_enp_on_interval, one lane per (field, wavelength); every trial ray is
 // enp_z_coordinate (:46-83).  tuples-or-None of the reference are (value, have_*) pairs here.
+template <int FEAT>
 __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
 {
     const int N = a.n_ifcs, W = a.n_wvls;
@@ -505,7 +623,7 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
         const v3 pt1{0., 0., obj2enp_dist};
         const v3 m = rotate(pb.rot, pb.rot_order, v3{-pt1.x, -pt1.y, -pt1.z});
         const v3 pt0{m.x + pt1.x, m.y + pt1.y, m.z + pt1.z};
-        trace_ray<MODE_PROBE, true, F_ALL>(c, so, pt0, dir0, pb.wvl_idx, true, last);
+        trace_ray<MODE_PROBE, true, FEAT>(c, so, pt0, dir0, pb.wvl_idx, true, last);
         z_last = z_enp;
         if (last.status != ROX_OK) {
             ht = 0.;
@@ -519,6 +637,23 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
         (void)trial(z, ht);
         return ht - 0.;
     };
+    // trial rays that do not depend on one another, traced in one pass -- lane k traces the
+    // k-th -- and then taken in the reference's order: take(k, z) makes lane k's ray the
+    // `last trial ray' of every lane (what last_ht and the walk read of it)
+    auto take = [&](int k, double z) {
+        last.status = __shfl(last.status, k);
+        last.fail_surf = __shfl(last.fail_surf, k);
+        last.probe_p.y = __shfl(last.probe_p.y, k);
+        last.inc.y = __shfl(last.inc.y, k);
+        z_last = z;
+    };
+    auto eval_two = [&](double za, double zb, double &qa, double &qb) {
+        double ht;
+        (void)trial(lane == 1 ? zb : za, ht);
+        qa = __shfl(ht, 0) - 0.;
+        qb = __shfl(ht, 1) - 0.;
+        take(1, zb);
+    };
     // rr.pkg.ray[stop_idx][mc.p][mc.y]: a failed ray's partial packet reaches the stop only if
     // it failed behind it, or at it with an incident point (anything but a missed surface)
     auto last_ht = [&](bool &raises) -> double {
@@ -530,9 +665,12 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
         return 0.;
     };
     auto find_edge = [&](double ea, double eb, int max_iter, double &z_edge, double &h_edge) {
-        double fa, fb, fc;
-        (void)trial(ea, fa);
-        bool okb = trial(eb, fb);
+        double fa, fb, fc, h_mine;
+        const bool ok_mine = trial(lane == 1 ? eb : ea, h_mine);    // both ends in one pass
+        fa = __shfl(h_mine, 0);
+        fb = __shfl(h_mine, 1);
+        bool okb = __shfl((int)ok_mine, 1);
+        take(1, eb);
         for (int k = 0; k < max_iter; ++k) {
             const double cc = ea + (eb - ea) / 2;
             if (!trial(cc, fc)) {
@@ -674,17 +812,20 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
                 const double start_new = z_a - del_z, end_new = z_b + del_z;
                 have_start = have_end = false;
                 const double step = (end_new - start_new) / 7;      // np.linspace(num=8)
+                auto zk = [&](int k) { return k == 7 ? end_new : (double)k * step + start_new; };
+                double h_mine;
+                const bool ok_mine = trial(zk(lane & 7), h_mine);     // the eight samples at once
                 for (int k = 0; k < 8; ++k) {
-                    double z = (double)k * step + start_new;
-                    if (k == 7)
-                        z = end_new;
-                    if (trial(z, ht)) {
+                    const double z = zk(k);
+                    ht = __shfl(h_mine, k);
+                    if (__shfl((int)ok_mine, k)) {
                         if (!have_start) {
                             have_start = true; start_z = z; start_h = ht;
                         }
                         have_end = true; end_z = z; end_h = ht;
                     }
                 }
+                take(7, end_new);
                 if (!have_start) {
                     code = ROX_ENP_REFERENCE_RAISES;
                     done = true;
@@ -726,7 +867,7 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
             else
                 z_estimate = start_z - ((end_z - start_z) / (end_h - start_h)) * start_h;
             bool converged, raises = false;
-            double z = secant_rtol(eval, z_estimate, 1.48e-8, 1e-7, converged);
+            double z = secant_rtol(eval, eval_two, z_estimate, 1.48e-8, 1e-7, converged);
             const double ht_at_stop = last_ht(raises);
             if (!raises && fabs(ht_at_stop - 0.) < 1e-6)
                 converged = true;
@@ -751,30 +892,37 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
     }
 }
 
-}  // namespace
-
-void launch_enp(const EnpArgs &a, size_t lds, hipStream_t st)
+template <int FEAT>
+void launch_enp_instance(const EnpArgs &a, size_t lds, hipStream_t st)
 {
     if (lds > kDefaultDynLds)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(enp_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(enp_kernel<FEAT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(enp_kernel, dim3(a.n), dim3(64), lds, st, a);     // one wave per problem
+    hipLaunchKernelGGL(enp_kernel<FEAT>, dim3(a.n), dim3(64), lds, st, a);     // one wave per problem
 }
 
-void launch_vig(const VigArgs &a, size_t lds, hipStream_t st)
+template <int FEAT>
+void launch_vig_instance(const VigArgs &a, size_t lds, hipStream_t st)
 {
     if (lds > kDefaultDynLds)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vig_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vig_kernel<FEAT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(vig_kernel, dim3(a.wave_per_problem ? a.n : (a.n + 63) / 64), dim3(64), lds, st, a);
+    hipLaunchKernelGGL(vig_kernel<FEAT>, dim3(a.wave_per_problem ? a.n : (a.n + 63) / 64), dim3(64), lds, st, a);
 }
 
-void launch_aim(const AimArgs &a, size_t lds, hipStream_t st)
+template <int FEAT>
+void launch_aim_instance(const AimArgs &a, size_t lds, hipStream_t st)
 {
     if (lds > kDefaultDynLds)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(aim_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(aim_kernel<FEAT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(aim_kernel, dim3(a.wave_per_problem ? a.n : (a.n + 63) / 64), dim3(64), lds, st, a);
+    hipLaunchKernelGGL(aim_kernel<FEAT>, dim3(a.wave_per_problem ? a.n : (a.n + 63) / 64), dim3(64), lds, st, a);
 }
+
+// what a translation unit csrc/search_<name>.hip defines for its instance
+#define ROX_SEARCH_INSTANCE(name, FEAT)                                                          \
+    void launch_aim_##name(const AimArgs &a, size_t lds, hipStream_t st) { launch_aim_instance<FEAT>(a, lds, st); } \
+    void launch_enp_##name(const EnpArgs &a, size_t lds, hipStream_t st) { launch_enp_instance<FEAT>(a, lds, st); } \
+    void launch_vig_##name(const VigArgs &a, size_t lds, hipStream_t st) { launch_vig_instance<FEAT>(a, lds, st); }
 
 }  // namespace rox

@@ -5,7 +5,7 @@
 //
 //   rox_trace_rays / rox_trace_pupil_grid / rox_trace_pupil_list
 //       -> trace_kernel<OUT_MODE, GEN, PER_RAY_WVL, FEAT>  (csrc/inst_*.hip)
-//   rox_aim_chief_rays -> aim_kernel                          (csrc/inst_aim.hip)
+//   rox_aim_chief_rays -> aim_kernel                          (csrc/rox_search.hpp, search_*.hip)
 //   rayoptics/raytr/trace.py:563-605, 537-560 grid / fan pupil coordinates
 //       -> pupil_axes_kernel (repeated +=)
 #include <hip/hip_runtime.h>
@@ -431,6 +431,41 @@ int pick_instance(int need)
             return i;
     return n - 1;
 }
+
+// ---- the search kernels (csrc/rox_search.hpp): the leanest instance of kSearchInstances that
+// covers the system's features -- their trial rays never filter phantoms
+int pick_search_instance(const rox_system *sys)
+{
+    const int n = (int)(sizeof kSearchInstances / sizeof kSearchInstances[0]);
+    for (int i = 0; i < n; ++i)
+        if ((sys->features & ~kSearchInstances[i]) == 0)
+            return i;
+    return n - 1;
+}
+
+// surface table + index table + phase constants + wavelengths + slot map + the vignetting
+// search's aperture thresholds
+size_t search_lds_bytes(size_t N, size_t W)
+{
+    return (N * sizeof(dev_surface) + W * N * sizeof(double) * (1 + kPhaseConsts) +
+            W * sizeof(double) + 2 * N * sizeof(int32_t) + N * sizeof(double) + 15) & ~size_t(15);
+}
+
+#define ROX_SEARCH_DISPATCH(kind, Args)                                              \
+    void launch_##kind(const rox_system *sys, const Args &a, size_t lds, hipStream_t st) \
+    {                                                                                \
+        switch (pick_search_instance(sys)) {                                         \
+        case 0: launch_##kind##_lean(a, lds, st); break;                             \
+        case 1: launch_##kind##_even(a, lds, st); break;                             \
+        case 2: launch_##kind##_radial(a, lds, st); break;                           \
+        case 3: launch_##kind##_aplist(a, lds, st); break;                           \
+        default: launch_##kind##_general(a, lds, st); break;                         \
+        }                                                                            \
+    }
+ROX_SEARCH_DISPATCH(aim, AimArgs)
+ROX_SEARCH_DISPATCH(enp, EnpArgs)
+ROX_SEARCH_DISPATCH(vig, VigArgs)
+#undef ROX_SEARCH_DISPATCH
 
 void launch_feat(int inst, const LaunchCfg &k, const TraceArgs &a)
 {
@@ -1395,8 +1430,7 @@ int rox_iterate_ray_raw(rox_system *sys, int32_t n, const rox_aim *probs, double
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t N = sys->n_ifcs, W = sys->n_wvls;
-    const size_t lds = (N * sizeof(dev_surface) + W * N * sizeof(double) * (1 + kPhaseConsts) +
-                        W * sizeof(double) + 2 * N * sizeof(int32_t) + 15) & ~size_t(15);
+    const size_t lds = search_lds_bytes(N, W);
     if (lds > 160 * 1024 - 64)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
     const size_t pb = up16(sizeof(rox_aim) * n), yb = up16(sizeof(double) * 2 * n), rb = up16(sizeof(int32_t) * n);
@@ -1417,7 +1451,7 @@ int rox_iterate_ray_raw(rox_system *sys, int32_t n, const rox_aim *probs, double
     a.last_status = last_xy ? (int32_t *)(d + pb + 2 * yb + rb) : nullptr;
     a.eps = eps;
     a.wave_per_problem = n <= kWavePerProblemMax;
-    launch_aim(a, lds, st);
+    launch_aim(sys, a, lds, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
@@ -1455,8 +1489,7 @@ int rox_find_real_enp(rox_system *sys, int32_t n, const rox_enp *probs, double e
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t N = sys->n_ifcs, W = sys->n_wvls;
-    const size_t lds = (N * sizeof(dev_surface) + W * N * sizeof(double) * (1 + kPhaseConsts) +
-                        W * sizeof(double) + 2 * N * sizeof(int32_t) + 15) & ~size_t(15);
+    const size_t lds = search_lds_bytes(N, W);
     if (lds > 160 * 1024 - 64)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
     const size_t pb = up16(sizeof(rox_enp) * n), zb = up16(sizeof(double) * 2 * n);
@@ -1474,7 +1507,7 @@ int rox_find_real_enp(rox_system *sys, int32_t n, const rox_enp *probs, double e
     a.z_out = (double *)(d + pb);
     a.result = (int32_t *)(d + pb + zb);
     a.eps = eps;
-    launch_enp(a, lds, st);
+    launch_enp(sys, a, lds, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
@@ -1506,8 +1539,7 @@ int rox_iterate_pupil_rays(rox_system *sys, int32_t n, const rox_pupil_iter *pro
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t N = sys->n_ifcs, W = sys->n_wvls;
-    const size_t lds = (N * sizeof(dev_surface) + W * N * sizeof(double) * (1 + kPhaseConsts) +
-                        W * sizeof(double) + 2 * N * sizeof(int32_t) + 15) & ~size_t(15);
+    const size_t lds = search_lds_bytes(N, W);
     if (lds > 160 * 1024 - 64)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
     const size_t pb = up16(sizeof(rox_pupil_iter) * n);
@@ -1525,7 +1557,7 @@ int rox_iterate_pupil_rays(rox_system *sys, int32_t n, const rox_pupil_iter *pro
     a.vig = (double *)(d + pb);
     a.eps = eps;
     a.wave_per_problem = n <= kWavePerProblemMax;
-    launch_vig(a, lds, st);
+    launch_vig(sys, a, lds, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
@@ -1555,8 +1587,7 @@ int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs, double
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t N = sys->n_ifcs, W = sys->n_wvls;
-    const size_t lds = (N * sizeof(dev_surface) + W * N * sizeof(double) * (1 + kPhaseConsts) +
-                        W * sizeof(double) + 2 * N * sizeof(int32_t) + 15) & ~size_t(15);
+    const size_t lds = search_lds_bytes(N, W);
     if (lds > 160 * 1024 - 64)
         return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
     const size_t pb = up16(sizeof(rox_vig) * n), vb = up16(sizeof(double) * n);
@@ -1575,7 +1606,7 @@ int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs, double
     a.clip = (int32_t *)(d + pb + vb);
     a.eps = eps;
     a.wave_per_problem = n <= kWavePerProblemMax;
-    launch_vig(a, lds, st);
+    launch_vig(sys, a, lds, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);

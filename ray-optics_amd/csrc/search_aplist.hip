@@ -1,0 +1,8 @@
+// search_aplist.hip -- the search kernels (chief-ray aiming, vignetting search, wide-angle pupil
+// search; rox_search.hpp) with the trial-ray trace of feature instance F_APLIST: one translation
+// unit per instance so that the instances compile in parallel.
+#include "rox_search.hpp"
+
+namespace rox {
+ROX_SEARCH_INSTANCE(aplist, F_APLIST)
+}  // namespace rox

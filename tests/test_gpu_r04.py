@@ -326,3 +326,45 @@ def test_two_host_threads_share_one_stream():
         t.join()
     assert not errs, errs
     eng.close()
+
+
+def test_a_wave_or_a_lane_per_problem_give_the_same_answers():
+    """Up to 1024 problems a search call runs one wave per problem and traces the trial rays
+    that do not depend on each other side by side in its lanes (the secant iteration's two
+    starting values; hybrd's value at the start and the two forward-difference points of its
+    Jacobian; the ends of find_edge; the eight samples of a degenerate bracket); beyond that a
+    lane per problem evaluates them one after the other.  Same roots, result codes and last
+    trial rays, bit for bit -- and both equal the oracle's."""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine
+    rng = np.random.default_rng(404)
+    n = 0
+    for name in ('dblgauss_c2', 'nikkor_c3', 'cell_phone', 'rc_telescope_c4'):
+        wl = workloads.load(name)
+        eng = TraceEngine(wl.table)
+        probs = []
+        for _ in range(8):
+            for m in (wl.aim or []) + (wl.aim2d or []):
+                a = abi.Aim()
+                two_d = 'epsfcn' in m
+                a.pt0[0] = m['pt0'][0] * rng.uniform(0.3, 1.5) if two_d else 0.0
+                a.pt0[1], a.pt0[2] = m['pt0'][1] * rng.uniform(0.3, 1.4), m['pt0'][2]
+                a.z_enp = m['z_enp'] * rng.uniform(0.95, 1.05)
+                a.z_dir0 = m['z_dir0']
+                a.wvl_idx, a.surf, a.flip = int(rng.integers(0, len(wl.table.wvls))), m['surf'], 1
+                if two_d:
+                    a.two_d, a.epsfcn = 1, m['epsfcn']
+                probs.append(a)
+        assert 0 < len(probs) <= 1024
+        k = 1024 // len(probs) + 1
+        wave = eng.iterate_ray_raw(probs)
+        lane = eng.iterate_ray_raw(probs * k)
+        orc = oracle.iterate_ray_raw(wl.table, probs)
+        for w, l, o in zip(wave, lane, orc):
+            o = np.asarray(o)
+            assert np.array_equal(np.asarray(w), o, equal_nan=True), name
+            assert np.array_equal(np.asarray(l), np.concatenate([o] * k), equal_nan=True), name
+        n += len(probs)
+        eng.close()
+    assert n > 300

@@ -63,7 +63,7 @@ def main():
     eng.close()
     out['ray_starts'] = {'fields': n, 'mismatching': n_bad}
     # ---- aiming and vignetting on perturbed problems
-    n_aim = bad_aim = n_vig = bad_clip = 0
+    n_aim = bad_aim = n_vig = bad_clip = n_lane = bad_lane = 0
     worst_vig = 0.0
     for name in ('dblgauss_c2', 'nikkor_c3', 'cell_phone', 'singlet_c1', 'rc_telescope_c4'):
         wl = workloads.load(name)
@@ -93,6 +93,12 @@ def main():
             yo, ro = oracle.aim_chief_rays(wl.table, probs)
             n_aim += len(probs)
             bad_aim += int((~((yd == yo) | (np.isnan(yd) & np.isnan(yo))).all(axis=1)).sum() + (rd != ro).sum())
+            # up to 1024 problems run a wave each (the independent trial rays of a search traced
+            # side by side in its lanes), more run a lane each: the same answers either way
+            k = 1024 // len(probs) + 1
+            yl, rl = eng.aim_chief_rays(probs * k)
+            n_lane += len(probs) * k
+            bad_lane += int((~((yl == np.tile(yo, (k, 1))) | np.isnan(yl)).all(axis=1)).sum() + (rl != np.tile(ro, k)).sum())
         vp = []
         for trial in range(20):
             for v in wl.vig or []:
@@ -112,6 +118,10 @@ def main():
             vo, co = oracle.calc_vignetting(wl.table, vp)
             n_vig += len(vp)
             bad_clip += int((cd != co).sum())
+            k = 1024 // len(vp) + 1
+            vl, cl = eng.calc_vignetting(vp * k)
+            n_lane += len(vp) * k
+            bad_lane += int((cl != np.tile(cd, k)).sum() + (~((vl == np.tile(vd, k)) | np.isnan(vl))).sum())
             ok = np.isfinite(vd) & np.isfinite(vo)
             worst_vig = max(worst_vig, float(np.abs(vd[ok] - vo[ok]).max()) if ok.any() else 0.0)
         eng.close()
@@ -155,6 +165,7 @@ def main():
                                 'oracle_result_codes': {str(k): v for k, v in sorted(codes.items())}}
     out['aiming'] = {'problems': n_aim, 'mismatching': bad_aim}
     out['vignetting'] = {'problems': n_vig, 'clip_surface_mismatches': bad_clip, 'max_abs_diff': worst_vig}
+    out['lane_per_problem_vs_wave_per_problem'] = {'problems': n_lane, 'mismatching': bad_lane}
     out['seconds'] = round(time.time() - t0, 1)
     print(json.dumps(out))
 
