@@ -671,6 +671,42 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
         fb = __shfl(h_mine, 1);
         bool okb = __shfl((int)ok_mine, 1);
         take(1, eb);
+        if (!(FEAT & F_POLY) && max_iter == 6) {
+            // Without Newton code no sample is slow to trace: all 63 midpoints the six
+            // bisections can visit are traced at once -- lane L (heap order: 1 the first
+            // midpoint, 2 L the next one after a failed ray, 2 L + 1 after a good one) forms
+            // its interval by the bisection's own recurrence -- and the decisions replayed.
+            double la = ea, lb = eb, lc = ea;
+            int depth = 0;
+            for (int t = lane; t > 1; t >>= 1)
+                ++depth;
+            for (int d = depth; d >= 0; --d) {
+                lc = la + (lb - la) / 2;
+                if (d > 0) {
+                    if ((lane >> (d - 1)) & 1)
+                        la = lc;
+                    else
+                        lb = lc;
+                }
+            }
+            const bool ok_l = trial(lane == 0 ? ea : lc, h_mine);   // (lane 0: an idle copy)
+            int node = 1;
+            for (int k = 0; k < 6; ++k) {
+                const double cc = ea + (eb - ea) / 2;
+                fc = __shfl(h_mine, node);
+                const bool ok = __shfl((int)ok_l, node);
+                if (k == 5)
+                    take(node, cc);
+                if (!ok) {
+                    eb = cc; okb = false; fb = fc;
+                    node = 2 * node;
+                } else {
+                    ea = cc; fa = fc;
+                    node = 2 * node + 1;
+                }
+            }
+            max_iter = 0;
+        }
         for (int k = 0; k < max_iter; ++k) {
             const double cc = ea + (eb - ea) / 2;
             if (!trial(cc, fc)) {
@@ -727,7 +763,9 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
         // again on demand keeps the nine Nikkor fields at 0.34 ms for every kSpec but costs the
         // 48: 3.8 ms -- one of them has such a sample ON its walk, and then pays for it alone
         // instead of beside the others.  That one 1000-step trace, ~1.7 ms, is the floor.)
-        constexpr int kSpec = ROX_ENP_SPEC;
+        // (instances without Newton code have no slow samples: they speculate the whole chain a
+        // wave holds -- double Gauss, 37 problems: 0.80 ms with 4, 0.56 ms with 32)
+        constexpr int kSpec = (FEAT & F_POLY) ? ROX_ENP_SPEC : 32;
         const double d0 = del_z;
         if (lane < 2 * kSpec) {
             const double dz = lane < kSpec ? d0 : -d0;
