@@ -425,7 +425,8 @@ def main():
                 dog.cancel()
 
     # N > 1: the headline is the path north_star describes -- the fixed-size spot problem cut
-    # over the ranks with the RCCL gather INSIDE the timed region -- and the collective-free
+    # over the ranks with the exchange INSIDE the timed region (the faster of the pipelined
+    # RCCL gather and the shared-host-segment delivery, both timed) -- and the collective-free
     # one-grid-per-rank figure above moves to `weak_full`.  (--force-dist rehearses this with
     # one rank.)  If the leg fails, the weak figure stays the headline and says so.
     if multi and not args.no_strong:
@@ -443,18 +444,23 @@ def main():
                 line['rays_per_s'] = head['rays_per_step'] / (head['ms_per_step'] * 1e-3)
                 line['scaling'] = 'strong'
                 line['cold_ms_per_step'] = None
+                how = {'rccl': 'grouped send/recv of the packed pairs to rank 0 over RCCL -> rank 0\'s '
+                               'copy-engine D2H',
+                       'host': 'every rank\'s copy-engine D2H over its own PCIe link into a shared pinned '
+                               'host segment (RCCL carries the per-piece counts only)'}[head['exchange']]
                 line['config'] = {
                     'workload': head['workload'] + ' (BASELINE.json configs[4]); each step = launches -> '
-                                'per-piece counts -> grouped send/recv of the packed pairs to rank 0 over '
-                                'RCCL -> copy-engine D2H -> rank 0 holds every (field, wvl) grid\'s (R_ok, 2) '
-                                'host array; pipelined per piece of <= 4 Mi rays',
+                                'per-piece counts -> ' + how + ' -> rank 0 holds every (field, wvl) '
+                                'grid\'s (R_ok, 2) host array; pipelined per piece of <= 4 Mi rays',
                     'rays_per_step': head['rays_per_step'],
                     'intersections_per_step': head['intersections_per_step'],
-                    'out_mode': 'HITS_COMPACT (two-pass: HITS + pack)', 'exchange': 'rccl, pipelined',
+                    'out_mode': 'HITS_COMPACT (two-pass: HITS + pack)',
+                    'exchange': head['exchange'] + ', pipelined (the faster of rccl / host, both timed)',
                     'sharding': f'pupil-row blocks over {world} ranks', 'pairs_to_host': head['pairs'],
                     'pieces_per_rank': head['pieces_per_rank'], 'stages': head['stages']}
                 line['predicted_ms'] = head['predicted_ms']
-                line['strong_headline'] = {k: head[k] for k in ('last_pass_phases_ms_rank0', 'grids_delivered')}
+                line['strong_headline'] = {k: head[k] for k in ('exchange', 'ms_per_step_by_exchange', 'errors',
+                                                                  'last_pass_phases_ms_rank0', 'grids_delivered')}
 
     # every run: the fixed-size problems in every exchange variant (extra; the line above is
     # complete without it)
@@ -835,18 +841,39 @@ class SpotProblem:
 
 
 def strong_headline(args, torch, dist, multi, world, rank, fence):
-    """N > 1: BASELINE configs[4]'s spot problem cut by pupil rows over the ranks, delivered to
-    rank 0's host memory by the pipelined RCCL gather -- K passes between two fences, the
-    exchange inside the timed region"""
+    """N > 1: BASELINE configs[4]'s spot problem cut by pupil rows over the ranks and delivered to
+    rank 0 as host arrays -- K passes between two fences, the exchange inside the timed region
+    -- by both exchanges the path has: `rccl` (pipelined grouped send/recv of the packed pairs
+    to rank 0 over xGMI, then rank 0's copy engine over ITS PCIe link) and `host` (every rank's
+    copy engine over its OWN PCIe link into a shared pinned host segment; the only collective
+    is the per-piece count exchange).  The headline is the faster one: rank 0's single PCIe
+    link carries all 2.2 GB in the first, 1/N of them in the second."""
     prob = SpotProblem(torch, dist, multi, world, rank, 'litho_c5', args.strong_num, 'rows')
     try:
-        ms, tm = prob.timed(fence, args.steps, max(args.warmup, 2), exchange='rccl')
+        legs, errors = {}, {}
+        warm = max(args.warmup, 2)
+        legs['rccl'] = prob.timed(fence, args.steps, warm, exchange='rccl')
+        seg = None
+        try:
+            seg = prob.segment('headline', fence)
+            legs['host'] = prob.timed(fence, args.steps, warm, exchange='host', segment=seg)
+        except Exception as e:
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            errors['host'] = repr(e)
+        finally:
+            if seg is not None:
+                seg.close(unlink=(rank == 0))
+        best = min(legs, key=lambda k: legs[k][0])      # (max-over-ranks times: the same on every rank)
+        ms, tm = legs[best]
         pairs = tm['pairs_total']
-        return {'ms_per_step': ms, 'intersections_per_step': prob.intersections,
+        phases = ('trace_ms', 'stage_sync_ms', 'gather_ms', 'd2h_ms', 'reassembly_ms')
+        return {'ms_per_step': ms, 'exchange': best, 'intersections_per_step': prob.intersections,
                 'rays_per_step': sum(prob.caps), 'workload': prob.what, 'pairs': pairs,
                 'stages': tm.get('stages'), 'pieces_per_rank': tm.get('pieces'),
-                'last_pass_phases_ms_rank0': {k: tm.get(k) for k in ('trace_ms', 'stage_sync_ms', 'gather_ms',
-                                                                     'd2h_ms', 'reassembly_ms')},
+                'ms_per_step_by_exchange': {k: v[0] for k, v in legs.items()},
+                'errors': errors,
+                'last_pass_phases_ms_rank0': {k: {q: v[1].get(q) for q in phases} for k, v in legs.items()},
                 'grids_delivered': tm.get('grids_delivered'),
                 'predicted_ms': predicted_ms(pairs * 16, PRED['c5_kernels_ms_one_gpu'] * (args.strong_num / 2048) ** 2,
                                              prob.stages_at)}

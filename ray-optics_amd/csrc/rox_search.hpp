@@ -333,6 +333,9 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
         pb = a.probs[i];
     }
     const int xy = pb.xy;
+    // (selected once: indexing the problem record with a run-time xy would keep it in scratch)
+    const double unit_xy = xy == 0 ? pb.unit_dir[0] : pb.unit_dir[1];
+    const double start_xy = xy == 0 ? pb.start_dir[0] : pb.start_dir[1];
 
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
@@ -364,10 +367,10 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
             if (((tbli)ap)[1])
                 continue;
             if (((tbli)ap)[0] == ROX_AP_CIRCULAR)
-                return ap[3] * pb.unit_dir[xy];
-            return (xy == 0 ? ap[3] : ap[4]) * pb.unit_dir[xy];
+                return ap[3] * unit_xy;
+            return (xy == 0 ? ap[3] : ap[4]) * unit_xy;
         }
-        return row[offsetof(rox_surface, max_aperture) / sizeof(double)] * pb.unit_dir[xy];
+        return row[offsetof(rox_surface, max_aperture) / sizeof(double)] * unit_xy;
     };
     // iterate_pupil_ray(opm, indx, xy, start_r0, r_target, fld, wvl)
     auto iterate = [&](int indx, double start_r0, double r_target) -> double {
@@ -453,12 +456,12 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
             }
             indx = pb.stop_surf;                // first pass: go to the edge of the stop
         }
-        const double r = iterate(indx, rel[xy], edge(indx));
-        rel[0] = rel[1] = 0.0;
-        rel[xy] = r;
+        const double r = iterate(indx, xy == 0 ? rel[0] : rel[1], edge(indx));
+        rel[0] = xy == 0 ? r : 0.0;
+        rel[1] = xy == 0 ? 0.0 : r;
         clip = indx;
     }
-    a.vig[i] = 1.0 - (rel[xy] / pb.start_dir[xy]);
+    a.vig[i] = 1.0 - ((xy == 0 ? rel[0] : rel[1]) / start_xy);
     a.clip[i] = clip;
 }
 

@@ -260,7 +260,13 @@ def test_bench_launches_its_own_ranks():
     assert b['n_gpus'] == 2 and b['ranks_seen_by_backend'] == 2
     # the headline: fixed total work, exchange inside the timed region
     assert b['scaling'] == 'strong' and 'exchange inside the timed region' in b['headline']
-    assert 'configs[4]' in b['config']['workload'] and b['config']['exchange'].startswith('rccl')
+    assert 'configs[4]' in b['config']['workload']
+    # both exchanges are timed with the exchange inside the timed region; the headline is the faster
+    h = b['strong_headline']
+    assert set(h['ms_per_step_by_exchange']) == {'rccl', 'host'} and not h['errors']
+    assert h['exchange'] == min(h['ms_per_step_by_exchange'], key=h['ms_per_step_by_exchange'].get)
+    assert b['config']['exchange'].startswith(h['exchange'])
+    assert b['ms_per_step'] == pytest.approx(h['ms_per_step_by_exchange'][h['exchange']])
     assert b['config']['rays_per_step'] == 45 * 192 * 192
     assert 0 < b['config']['pairs_to_host'] < b['config']['rays_per_step']
     assert b['strong_headline']['grids_delivered'] == 45
