@@ -258,6 +258,16 @@ class HostSegment:
                               f'the segment needs {self.nbytes >> 20} MiB')
             with open(self.path, 'wb') as f:
                 f.truncate(self.nbytes)
+                try:
+                    # reserve the pages now: a full tmpfs then fails here with ENOSPC instead
+                    # of with SIGBUS when a copy engine or a reader first touches them
+                    os.posix_fallocate(f.fileno(), 0, self.nbytes)
+                except OSError:
+                    try:
+                        os.unlink(self.path)
+                    except OSError:
+                        pass
+                    raise
         self.rank = rank
         self._t = torch.from_file(self.path, shared=True, size=self.nbytes, dtype=torch.uint8)
         self._engine = engine
