@@ -61,6 +61,7 @@ exchange variant incl. the N = 1 line's own grid cut by rows (`c2_sharded`).  A 
 in an exchange ends the run with "ok": false and exit status 3 (the line is still printed).
 """
 import argparse
+import atexit
 import json
 import os
 import socket
@@ -396,6 +397,7 @@ def main():
     hung_in = ['']
 
     def give_up():
+        drop_segments()
         if rank == 0:
             line['ok'] = False
             line['hung_in'] = hung_in[0]
@@ -705,6 +707,23 @@ def configs_leg(torch, abi, workloads):
 
 # measured on one MI355X (profiles/r04_pack_crossover.jsonl, profiles/r02_pcie_store.jsonl) and
 # the link rates DESIGN section 7 prices the exchanges with
+# shared host segments that exist right now (files under /dev/shm): a run that gives up on a
+# hung exchange, or dies, must not leave gigabytes of tmpfs behind
+LIVE_SEGMENTS = set()
+
+
+def drop_segments():
+    for path in list(LIVE_SEGMENTS):
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+        LIVE_SEGMENTS.discard(path)
+
+
+atexit.register(drop_segments)
+
+
 PRED = {'c5_kernels_ms_one_gpu': 75.2, 'pcie_GBps': 55.0, 'xgmi_link_GBps': 153.0,
         'piece_tail_ms': 0.9, 'stage_sync_ms_per_stage': 0.06}
 
@@ -786,6 +805,7 @@ class SpotProblem:
         if rank != 0:
             seg = rdist.HostSegment.for_grids(self.eng, name, self.nf * self.nw, self.num, rank, create=False)
         fence()
+        LIVE_SEGMENTS.add(seg.path)
         return seg
 
     def run(self, exchange, segment=None, result_on='host', pipeline=True, timings=None):
@@ -863,6 +883,7 @@ def strong_headline(args, torch, dist, multi, world, rank, fence):
             errors['host'] = repr(e)
         finally:
             if seg is not None:
+                LIVE_SEGMENTS.discard(seg.path)
                 seg.close(unlink=(rank == 0))
         best = min(legs, key=lambda k: legs[k][0])      # (max-over-ranks times: the same on every rank)
         ms, tm = legs[best]
@@ -939,6 +960,7 @@ def strong_scaling(args, torch, dist, multi, world, rank, fence, ranks_seen):
                 res[key] = {'error': repr(e)}
             finally:
                 if seg is not None:
+                    LIVE_SEGMENTS.discard(seg.path)
                     seg.close(unlink=(rank == 0))
                 torch.cuda.empty_cache()
         prob.close()
