@@ -60,9 +60,10 @@ extern "C" {
  * rox_aim carries both branches of iterate_ray;  5 = rox_trace_pupil_grids (several grids, one
  * launch), rox_find_real_enp / rox_enp (the wide-angle pupil search);  6 = rox_out.ld is the
  * capacity of seg in pairs for ROX_OUT_HITS_COMPACT (overflow: n_hits < 0), rox_copy_async,
- * rox_iterate_ray_raw, rox_iterate_pupil_rays.
+ * rox_iterate_ray_raw, rox_iterate_pupil_rays;  7 = rox_synchronize (a binding without the
+ * HIP runtime can wait for the asynchronous entries).
  * rox_abi_version() of the library must equal the header a binding was written against. */
-#define ROX_ABI_VERSION 6
+#define ROX_ABI_VERSION 7
 #define ROX_MAX_COEF 10   /* EvenPolynomial r^2..r^20 / RadialPolynomial r^1..r^10 */
 #define ROX_MAX_AP 4      /* clear apertures per surface carried in the table */
 #define ROX_SEG_DOUBLES 10 /* p[3], d[3], dst, nrml[3]  (model_constants.py:31) */
@@ -334,6 +335,11 @@ int rox_unpin_host_memory(void *p);
  * engine; no kernel).  The pipelined multi-GPU spot diagram moves a row block's packed pairs
  * to the consumer's host memory with it while the next block is being traced.          */
 int rox_copy_async(void *dst, const void *src, size_t bytes, void *stream);
+/* Wait until everything enqueued on `stream` (a hipStream_t, NULL = the default stream) has
+ * finished: the trace entries with device / pinned pointers and rox_copy_async return as soon
+ * as their work is enqueued.  For callers that do not link the HIP runtime themselves
+ * (examples/spot_diagram.c); the Python engine waits through torch's stream instead.        */
+int rox_synchronize(void *stream);
 
 /* system table ----------------------------------------------------------- */
 /* rows[n_ifcs]; n_table[n_wvls][n_ifcs], n_table[w][i] = refractive index of

@@ -5,7 +5,7 @@ by :mod:`rayoptics_amd.engine`, which fails loudly when it is missing.
 """
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_COEF = 10
 MAX_AP = 4
 SEG_DOUBLES = 10
@@ -170,7 +170,7 @@ EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_trace_pupil_grid', 'rox_trace_pupil_grids', 'rox_trace_pupil_list',
            'rox_aim_chief_rays', 'rox_iterate_ray_raw', 'rox_find_real_enp', 'rox_calc_vignetting',
            'rox_iterate_pupil_rays', 'rox_calc_psf',
-           'rox_pin_host_memory', 'rox_unpin_host_memory', 'rox_copy_async')
+           'rox_pin_host_memory', 'rox_unpin_host_memory', 'rox_copy_async', 'rox_synchronize')
 # ... and the measurement / self-test helpers of include/roxtrace_diag.h
 DIAG_EXPORTS = ('rox_time_pupil_grid', 'rox_selftest_fp64', 'rox_diag_pack_launches')
 
@@ -222,6 +222,8 @@ def declare(lib):
     lib.rox_unpin_host_memory.argtypes = [vp]
     lib.rox_copy_async.restype = C.c_int
     lib.rox_copy_async.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.rox_synchronize.restype = C.c_int
+    lib.rox_synchronize.argtypes = [vp]
     lib.rox_time_pupil_grid.restype = C.c_int
     lib.rox_time_pupil_grid.argtypes = [vp, P(Field), P(Grid), i32, P(Opts),
                                         P(Out), vp, i32, P(dbl)]

@@ -1025,6 +1025,12 @@ int rox_copy_async(void *dst, const void *src, size_t bytes, void *stream)
     return 0;
 }
 
+int rox_synchronize(void *stream)
+{
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
 int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_table,
                       const double *wvls, int32_t n_wvls, rox_system **out_sys)
 {
