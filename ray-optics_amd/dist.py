@@ -680,3 +680,104 @@ def trace_spot_sharded(engine, fields, image_pts, n_wvls, num, foc, flags=None, 
         timings['pairs_total'] = int(sum(totals))
         timings['pairs_per_rank'] = totals
     return result
+
+
+# ---------------------------------------------------------------- FULL packets stay where they are
+class ShardedPackets:
+    """The FULL packets of one (field, wavelength) pupil grid cut by pupil rows over the ranks
+    (SURVEY section 8e): rank k keeps ``local`` -- seg [n_seg, 10, R_k], op, status, fail_surf
+    of its rows [row_begin, row_begin + row_count) -- in its own HBM.  Packets are never
+    exchanged wholesale (BASELINE configs[1] is 1.1 GB per grid, configs[4] would be 636 GB);
+    a consumer that needs some of them asks for those rays with :meth:`fetch`."""
+
+    def __init__(self, local, plan, num, n_seg, group):
+        self.local, self.plan, self.num, self.n_seg, self.group = local, plan, int(num), int(n_seg), group
+        self.world, self.rank, self.backend = _group_info(group)
+        mine = plan[self.rank]
+        self.row_begin = mine[0].row_begin if mine else 0
+        self.row_count = sum(b.row_count for b in mine)
+
+    def owner_of(self, rays):
+        """rank that holds each global ray index r = i * num + j (i: pupil row)"""
+        rows = np.asarray(rays, dtype=np.int64) // self.num
+        ends = np.array([(self.num * (k + 1)) // self.world for k in range(self.world)], dtype=np.int64)
+        return np.searchsorted(ends, rows, side='right').astype(np.int64)     # partition()'s bounds
+
+    def fetch(self, rays, dst=0):
+        """COLLECTIVE (every rank calls it with the same ``rays``): the packets of the global ray
+        indices ``rays`` travel from the ranks that hold them to rank ``dst`` -- grouped
+        point-to-point, one message per owner; who owns what follows from the plan, so no
+        sizes are exchanged.  Returns on ``dst`` a dict seg [n_seg, 10, n] / op [n] / status [n] /
+        fail_surf [n] (NumPy, in the order of ``rays``), None elsewhere."""
+        import torch
+        import torch.distributed as dist
+        rays = np.asarray(rays, dtype=np.int64).ravel()
+        if rays.size and (rays.min() < 0 or rays.max() >= self.num * self.num):
+            raise IndexError('ray index outside the grid')
+        owner = self.owner_of(rays)
+        width = self.n_seg * abi.SEG_DOUBLES + 3        # + op, status, fail_surf (as doubles)
+
+        def rows_of(k):
+            return np.nonzero(owner == k)[0]
+
+        def pack_mine():
+            sel = rows_of(self.rank)
+            if not len(sel):
+                return sel, torch.empty((0, width), dtype=torch.float64)
+            loc = torch.as_tensor(rays[sel] - self.row_begin * self.num, device=self.local.seg.device)
+            seg = self.local.seg[:self.n_seg].index_select(2, loc)          # [n_seg, 10, n]
+            out = torch.empty((len(sel), width), dtype=torch.float64, device=seg.device)
+            out[:, :width - 3] = seg.permute(2, 0, 1).reshape(len(sel), width - 3)
+            out[:, width - 3] = self.local.op.index_select(0, loc)
+            out[:, width - 2] = self.local.status.index_select(0, loc).to(torch.float64)
+            out[:, width - 1] = self.local.fail_surf.index_select(0, loc).to(torch.float64)
+            return sel, out
+
+        sel_mine, mine = pack_mine()
+        if self.world > 1:
+            if self.rank != dst:
+                if len(sel_mine):
+                    buf = _wire(mine, self.backend).contiguous()
+                    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, dst, self.group)]):
+                        w.wait()
+                return None
+            wire_dev = mine.device if self.backend == 'nccl' else 'cpu'
+            got = {self.rank: _wire(mine, self.backend)}
+            ops = []
+            for k in range(self.world):
+                n_k = len(rows_of(k))
+                if k != dst and n_k:
+                    got[k] = torch.empty((n_k, width), dtype=torch.float64, device=wire_dev)
+                    ops.append(dist.P2POp(dist.irecv, got[k], k, self.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        else:
+            got = {0: mine}
+        table = np.empty((len(rays), width))
+        for k, t in got.items():
+            table[rows_of(k)] = t.cpu().numpy()
+        return {'seg': np.ascontiguousarray(table[:, :width - 3].reshape(len(rays), self.n_seg, abi.SEG_DOUBLES)
+                                            .transpose(1, 2, 0)),
+                'op': table[:, width - 3].copy(),
+                'status': table[:, width - 2].astype(np.uint8),
+                'fail_surf': table[:, width - 1].astype(np.int16)}
+
+
+def trace_packets_sharded(engine, fld, wvl_idx, num, opts, group=None):
+    """One (field, wavelength) pupil grid with FULL packets, the pupil rows cut over the ranks;
+    every rank traces its rows into its own HBM and nothing is exchanged.  ``opts`` as for
+    ``engine.trace_pupil_grid`` with ``out_mode`` ROX_OUT_FULL.  Returns :class:`ShardedPackets`."""
+    from .engine import make_grid
+    if opts.out_mode != abi.OUT_FULL:
+        raise ValueError('trace_packets_sharded keeps FULL packets: opts.out_mode must be OUT_FULL')
+    world, rank, _backend = _group_info(group)
+    plan = partition(1, 1, num, world, 'rows')
+    mine = plan[rank]
+    row_begin = mine[0].row_begin if mine else 0
+    row_count = sum(b.row_count for b in mine)
+    local = None
+    if row_count:
+        grid = make_grid((-1., -1.), (1., 1.), num, row_begin=row_begin, row_count=row_count)
+        local = engine.trace_pupil_grid(fld, grid, wvl_idx, opts)
+    return ShardedPackets(local, plan, num, engine.num_segments(opts.flags), group)

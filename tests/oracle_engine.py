@@ -29,6 +29,16 @@ class _Res:
         import torch
         return torch.from_numpy(self._h.status)
 
+    @property
+    def op(self):
+        import torch
+        return torch.from_numpy(self._h.op)
+
+    @property
+    def fail_surf(self):
+        import torch
+        return torch.from_numpy(self._h.fail_surf)
+
 
 class _Pack:
     """engine.HitsPack look-alike on host memory"""

@@ -212,3 +212,74 @@ def test_sharded_spot_matches_single_process(world, by, exchange, name, pipeline
         assert tm['pipelined'] and tm['stages'] == max(tm['pieces']) and len(tm['pieces']) == world
         if piece_rays:
             assert tm['stages'] > 2
+
+
+def _packets_worker(rank, world, port, q, num, name, rays, dst):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import rayoptics_amd  # noqa: F401
+    from rayoptics_amd import workloads, abi
+    from rayoptics_amd import dist as rdist
+    from rayoptics_amd.engine import make_opts
+    from oracle_engine import OracleEngine
+    wl = workloads.load(name)
+    eng = OracleEngine(wl.table)
+    opts = make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING,
+                     out_mode=abi.OUT_FULL, first_surf=1, last_surf=wl.n_ifcs - 2)
+    sp = rdist.trace_packets_sharded(eng, wl.fields[-1], 0, num, opts)
+    held = 0 if sp.local is None else int(sp.local.status.shape[0])
+    got = sp.fetch(rays, dst=dst)
+    none_again = sp.fetch([], dst=dst)          # an empty request is a valid collective too
+    q.put((rank, held, got, none_again is None or len(none_again['op']) == 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,dst', [(2, 0), (3, 1), (5, 0)])
+def test_full_packets_stay_on_their_rank_and_are_fetched_lazily(world, dst):
+    """FULL packets are never exchanged wholesale -- a grid cut by pupil rows keeps
+    each rank's packets where they were traced; `ShardedPackets.fetch` moves the requested rays
+    only (grouped point-to-point to one rank), and they equal the single-process trace"""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import rayoptics_amd  # noqa: F401
+    from rayoptics_amd import workloads, abi
+    from rayoptics_amd.engine import make_opts, make_grid
+    from oracle import oracle
+    name, num = 'dblgauss_c2', 14
+    rng = np.random.default_rng(5 + world)
+    rays = rng.permutation(num * num)[:41].tolist() + [0, num * num - 1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 11 + 600 + world) % 2000
+    procs = [ctx.Process(target=_packets_worker, args=(r, world, port, q, num, name, rays, dst))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        r, held, got, ok_empty = q.get(timeout=180)
+        out[r] = (held, got)
+        assert ok_empty
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every ray is held exactly once, by pupil rows
+    assert sum(h for h, _ in out.values()) == num * num
+    assert all(h % num == 0 for h, _ in out.values())
+    for r in range(world):
+        assert (out[r][1] is not None) == (r == dst)
+    got = out[dst][1]
+    wl = workloads.load(name)
+    opts = make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING,
+                     out_mode=abi.OUT_FULL, first_surf=1, last_surf=wl.n_ifcs - 2)
+    ref = oracle.trace_pupil_grid(wl.table, wl.fields[-1], make_grid((-1., -1.), (1., 1.), num), 0, opts)
+    idx = np.asarray(rays)
+    np.testing.assert_array_equal(got['status'], ref.status[idx])
+    np.testing.assert_array_equal(got['fail_surf'], ref.fail_surf[idx])
+    ok = ref.status[idx] == abi.OK
+    assert ok.any() and (~ok).any()
+    np.testing.assert_array_equal(got['op'][ok], ref.op[idx][ok])
+    np.testing.assert_array_equal(got['seg'][:, :, ok], ref.seg[:wl.n_ifcs][:, :, idx][:, :, ok])

@@ -368,3 +368,32 @@ def test_a_wave_or_a_lane_per_problem_give_the_same_answers():
         n += len(probs)
         eng.close()
     assert n > 300
+
+
+def test_sharded_packets_fetch_on_the_device():
+    """dist.trace_packets_sharded / ShardedPackets.fetch with the HIP engine (one rank: the
+    packets are selected out of the resident DeviceResult on the device and come back in the
+    order asked for) == the oracle's packets of those rays"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd import dist as rdist
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    wl = workloads.load('nikkor_c3')
+    eng = TraceEngine(wl.table)
+    num = 96
+    opts = make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING,
+                     out_mode=abi.OUT_FULL, first_surf=1, last_surf=wl.n_ifcs - 2)
+    sp = rdist.trace_packets_sharded(eng, wl.fields[-1], 1, num, opts)
+    assert sp.world == 1 and sp.row_count == num
+    rays = np.random.default_rng(12).permutation(num * num)[:500]
+    got = sp.fetch(rays)
+    ref = oracle.trace_pupil_grid(wl.table, wl.fields[-1], make_grid((-1., -1.), (1., 1.), num), 1, opts)
+    np.testing.assert_array_equal(got['status'], ref.status[rays])
+    np.testing.assert_array_equal(got['fail_surf'], ref.fail_surf[rays])
+    ok = ref.status[rays] == abi.OK
+    assert 50 < ok.sum() < 500
+    assert np.array_equal(got['op'][ok].view(np.int64), ref.op[rays][ok].view(np.int64))
+    want = ref.seg[:wl.n_ifcs][:, :, rays][:, :, ok]
+    assert np.array_equal(np.ascontiguousarray(got['seg'][:, :, ok]).view(np.int64),
+                          np.ascontiguousarray(want).view(np.int64))
+    eng.close()
