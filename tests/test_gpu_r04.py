@@ -397,3 +397,23 @@ def test_sharded_packets_fetch_on_the_device():
     assert np.array_equal(np.ascontiguousarray(got['seg'][:, :, ok]).view(np.int64),
                           np.ascontiguousarray(want).view(np.int64))
     eng.close()
+
+
+def test_rccl_calls_of_the_pipelined_exchange_over_the_real_backend():
+    """RCCL refuses two ranks on one GPU, so the multi-rank logic of the pipelined exchange runs
+    over gloo (tests/test_dist_gloo.py); what CAN run here over the real backend is its call
+    pattern with one rank -- a slice all-gathered on a side stream and copied to pinned memory
+    behind it, grouped isend / irecv of row slices of 2-D tensors (to itself), events for the
+    copy stream: tools/rccl_self_p2p_probe.py"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29300 + os.getpid() % 600))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rccl_self_p2p_probe.py')],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['backend'] == 'nccl' and d['self_p2p_and_count_gather_ok'] is True
