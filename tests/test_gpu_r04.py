@@ -417,3 +417,100 @@ def test_rccl_calls_of_the_pipelined_exchange_over_the_real_backend():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
     d = json.loads(line)
     assert d['backend'] == 'nccl' and d['self_p2p_and_count_gather_ok'] is True
+
+
+def test_null_and_out_of_range_arguments_are_errors_not_crashes():
+    """every entry point of include/roxtrace.h called through raw ctypes with null handles, null
+    structures, negative counts and out-of-range indices: a negative rox_err and a message from
+    rox_last_error(), never a crash (the process survives to make the last, valid call)"""
+    import ctypes as C
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, load_library, make_opts, make_grid
+    lib = load_library()
+    wl = workloads.load('dblgauss_c2')
+    eng = TraceEngine(wl.table)
+    h = eng._handle
+    N = wl.n_ifcs
+    fld = wl.fields[0]
+    opts = make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.HOST_POINTERS, out_mode=abi.OUT_HITS,
+                     first_surf=1, last_surf=N - 2)
+    grid = make_grid((-1., -1.), (1., 1.), 8)
+    seg = np.zeros((2, 64))
+    st = np.zeros(64, dtype=np.uint8)
+    out = abi.Out()
+    out.seg, out.status, out.ld = seg.ctypes.data, st.ctypes.data, 64
+    null = None
+    bad = []
+
+    def expect_error(what, rc):
+        msg = lib.rox_last_error().decode()
+        if not (rc < 0 and msg):
+            bad.append((what, rc, msg))
+
+    expect_error('device_count(NULL)', lib.rox_device_count(null))
+    expect_error('pin(NULL)', lib.rox_pin_host_memory(null, 4096, C.byref(C.c_void_p())))
+    expect_error('pin(size 0)', lib.rox_pin_host_memory(seg.ctypes.data, 0, C.byref(C.c_void_p())))
+    expect_error('unpin(NULL)', lib.rox_unpin_host_memory(null))
+    expect_error('copy_async(NULL)', lib.rox_copy_async(null, seg.ctypes.data, 16, null))
+    sys_out = C.c_void_p()
+    expect_error('create(NULL rows)', lib.rox_system_create(null, N, wl.table.n_table.ctypes.data, null, 1,
+                                                           C.byref(sys_out)))
+    expect_error('create(1 interface)', lib.rox_system_create(wl.table.rows, 1, wl.table.n_table.ctypes.data,
+                                                             null, 1, C.byref(sys_out)))
+    expect_error('create(0 wavelengths)', lib.rox_system_create(wl.table.rows, N, wl.table.n_table.ctypes.data,
+                                                               null, 0, C.byref(sys_out)))
+    assert lib.rox_system_destroy(null) == 0        # like free(NULL)
+    expect_error('num_segments(NULL)', lib.rox_system_num_segments(null, 0, C.byref(C.c_int32())))
+    expect_error('num_segments(NULL out)', lib.rox_system_num_segments(h, 0, null))
+    # trace entries
+    expect_error('pupil_grid(NULL sys)', lib.rox_trace_pupil_grid(null, C.byref(fld), C.byref(grid), 0,
+                                                                 C.byref(opts), C.byref(out), null))
+    expect_error('pupil_grid(NULL fld)', lib.rox_trace_pupil_grid(h, null, C.byref(grid), 0, C.byref(opts),
+                                                                 C.byref(out), null))
+    expect_error('pupil_grid(NULL grid)', lib.rox_trace_pupil_grid(h, C.byref(fld), null, 0, C.byref(opts),
+                                                                  C.byref(out), null))
+    expect_error('pupil_grid(NULL opts)', lib.rox_trace_pupil_grid(h, C.byref(fld), C.byref(grid), 0, null,
+                                                                  C.byref(out), null))
+    expect_error('pupil_grid(NULL out)', lib.rox_trace_pupil_grid(h, C.byref(fld), C.byref(grid), 0,
+                                                                 C.byref(opts), null, null))
+    expect_error('pupil_grid(wvl -1)', lib.rox_trace_pupil_grid(h, C.byref(fld), C.byref(grid), -1,
+                                                               C.byref(opts), C.byref(out), null))
+    g0 = make_grid((-1., -1.), (1., 1.), 0)
+    expect_error('pupil_grid(num 0)', lib.rox_trace_pupil_grid(h, C.byref(fld), C.byref(g0), 0, C.byref(opts),
+                                                              C.byref(out), null))
+    small = abi.Out()
+    small.seg, small.status, small.ld = seg.ctypes.data, st.ctypes.data, 8
+    expect_error('pupil_grid(ld < rays)', lib.rox_trace_pupil_grid(h, C.byref(fld), C.byref(grid), 0,
+                                                                  C.byref(opts), C.byref(small), null))
+    expect_error('trace_rays(NULL rays)', lib.rox_trace_rays(h, 4, null, null, null, 0, C.byref(opts),
+                                                            C.byref(out), null))
+    expect_error('trace_rays(n < 0)', lib.rox_trace_rays(h, -4, seg.ctypes.data, seg.ctypes.data, null, 0,
+                                                        C.byref(opts), C.byref(out), null))
+    expect_error('pupil_list(NULL px)', lib.rox_trace_pupil_list(h, C.byref(fld), 4, null, null, 0,
+                                                                C.byref(opts), C.byref(out), null))
+    expect_error('pupil_grids(-1 grids)', lib.rox_trace_pupil_grids(h, -1, C.byref(fld), null, C.byref(grid),
+                                                                  C.byref(opts), C.byref(out), null))
+    # search entries
+    res = np.zeros(8)
+    ires = np.zeros(8, dtype=np.int32)
+    expect_error('aim(NULL probs)', lib.rox_aim_chief_rays(h, 2, null, 1e-12, res.ctypes.data,
+                                                          ires.ctypes.data, null))
+    expect_error('aim(n < 0)', lib.rox_aim_chief_rays(h, -1, null, 1e-12, res.ctypes.data, ires.ctypes.data, null))
+    a = abi.Aim()
+    a.wvl_idx, a.surf = 99, 1
+    expect_error('aim(wvl 99)', lib.rox_aim_chief_rays(h, 1, C.byref(a), 1e-12, res.ctypes.data,
+                                                      ires.ctypes.data, null))
+    a.wvl_idx, a.surf = 0, N + 5
+    expect_error('aim(surf out of range)', lib.rox_aim_chief_rays(h, 1, C.byref(a), 1e-12, res.ctypes.data,
+                                                                 ires.ctypes.data, null))
+    expect_error('enp(NULL probs)', lib.rox_find_real_enp(h, 1, null, 1e-12, res.ctypes.data, ires.ctypes.data, null))
+    expect_error('vig(NULL probs)', lib.rox_calc_vignetting(h, 1, null, 1e-12, res.ctypes.data,
+                                                           ires.ctypes.data, null))
+    expect_error('pupil_iter(NULL probs)', lib.rox_iterate_pupil_rays(h, 1, null, 1e-12, res.ctypes.data, null))
+    expect_error('psf(NULL)', lib.rox_calc_psf(null, 8, 32, res.ctypes.data, abi.HOST_POINTERS, null))
+    expect_error('psf(odd ndim)', lib.rox_calc_psf(res.ctypes.data, 7, 32, res.ctypes.data, abi.HOST_POINTERS, null))
+    assert not bad, bad
+    # and the handle still works
+    assert lib.rox_trace_pupil_grid(h, C.byref(fld), C.byref(grid), 0, C.byref(opts), C.byref(out), null) == 0
+    assert (st == abi.OK).any()
+    eng.close()
