@@ -725,7 +725,7 @@ atexit.register(drop_segments)
 
 
 PRED = {'c5_kernels_ms_one_gpu': 75.2, 'pcie_GBps': 55.0, 'xgmi_link_GBps': 153.0,
-        'piece_tail_ms': 0.9, 'stage_sync_ms_per_stage': 0.06}
+        'piece_tail_ms': 0.3, 'stage_sync_ms_per_stage': 0.06}
 
 
 def predicted_ms(pairs_bytes, kernels_ms_one_gpu, stages_of):
@@ -739,7 +739,7 @@ def predicted_ms(pairs_bytes, kernels_ms_one_gpu, stages_of):
         kern = kernels_ms_one_gpu / n
         xgmi = pairs_bytes / n / (PRED['xgmi_link_GBps'] * 1e6) if n > 1 else 0.0
         sync = PRED['stage_sync_ms_per_stage'] * stages_of(n)
-        tail = PRED['piece_tail_ms'] / (1 if n == 1 else 1)
+        tail = PRED['piece_tail_ms']
         out['rccl_to_host'][str(n)] = max(kern, xgmi, pairs_bytes / (PRED['pcie_GBps'] * 1e6)) + tail + sync
         out['host_segment'][str(n)] = max(kern, pairs_bytes / n / (PRED['pcie_GBps'] * 1e6)) + tail + sync
         out['rccl_device_resident'][str(n)] = max(kern, xgmi) + sync + 0.3

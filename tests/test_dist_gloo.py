@@ -63,6 +63,18 @@ def test_pipeline_schedule_orders_shared_grids_first_and_last():
         if r > 0:               # shares its first grid with the previous rank
             assert last.g == lst[0].g and lst[0].row_begin > 0
     assert (seen == 1).all()
+    # the piece every rank traces last was cut into a half and two quarters: only a quarter's
+    # pack / copy / send is left behind the last kernel
+    flat, flat_order = schedule(plan, num, nw, taper=False)
+    n_cut = 0
+    for r, lst in enumerate(pieces):
+        was = flat[r][flat_order[r][-1]]
+        cut = was.row_count * num >= (1 << 20)
+        n_cut += cut
+        assert len(lst) == len(flat[r]) + (2 if cut else 0)
+        last = lst[order[r][-1]]
+        assert last.row_count * num <= (1 << 20) + num
+    assert n_cut >= 2
     # smaller pieces: the same cover
     pieces2, _ = schedule(plan, num, nw, max_rays=300 * num)
     assert sum(len(p) for p in pieces2) > sum(len(p) for p in pieces)
@@ -104,7 +116,7 @@ def test_spot_views_are_slices_of_one_buffer():
         np.testing.assert_array_equal(v2[key], v[key])
 
 
-def _worker(rank, world, port, q, by, exchange, num, name, pipeline=True, piece_rays=None):
+def _worker(rank, world, port, q, by, exchange, num, name, pipeline=True, piece_rays=None, taper_min=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -114,6 +126,8 @@ def _worker(rank, world, port, q, by, exchange, num, name, pipeline=True, piece_
     from rayoptics_amd import workloads
     from rayoptics_amd import dist as rdist
     from oracle_engine import OracleEngine
+    if taper_min is not None:           # (the cut of a rank's last piece starts at 2^20 rays)
+        rdist.TAPER_MIN_RAYS = taper_min
     wl = workloads.load(name)
     eng = OracleEngine(wl.table)
     nw = len(wl.table.wvls)
@@ -138,12 +152,12 @@ def _worker(rank, world, port, q, by, exchange, num, name, pipeline=True, piece_
     dist.destroy_process_group()
 
 
-def _run(world, by, exchange, num, name, salt, pipeline=True, piece_rays=None):
+def _run(world, by, exchange, num, name, salt, pipeline=True, piece_rays=None, taper_min=None):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29500 + (os.getpid() * 7 + salt) % 2000
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, by, exchange, num, name, pipeline,
-                                               piece_rays))
+                                               piece_rays, taper_min))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -160,6 +174,9 @@ def _run(world, by, exchange, num, name, salt, pipeline=True, piece_rays=None):
 @pytest.mark.parametrize('world,by,exchange,name,pipeline,piece_rays', [
     # pipelined (the default): pieces move on while later pieces are traced; small pieces so
     # that every rank runs several stages and grids are cut between pieces and between ranks
+    # (piece_rays < 0: also with the last piece of every rank cut into a half and two quarters)
+    (2, 'rows', 'rccl', 'dblgauss_c2', True, -96),
+    (3, 'rows', 'host', 'dblgauss_c2', True, -96),
     (2, 'rows', 'rccl', 'dblgauss_c2', True, 36),
     (3, 'rows', 'rccl', 'dblgauss_c2', True, 60),
     (2, 'rows', 'host', 'dblgauss_c2', True, 36),
@@ -181,9 +198,12 @@ def test_sharded_spot_matches_single_process(world, by, exchange, name, pipeline
     from rayoptics_amd import workloads, abi
     from oracle import oracle
     num = 12
+    taper_min = None
+    if piece_rays is not None and piece_rays < 0:
+        piece_rays, taper_min = -piece_rays, 48
     got = _run(world, by, exchange, num, name,
-               salt=world * 10 + len(by) + len(exchange) + 100 * pipeline + (piece_rays or 0),
-               pipeline=pipeline, piece_rays=piece_rays)
+               salt=world * 10 + len(by) + len(exchange) + 100 * pipeline + (piece_rays or 0) + (taper_min or 0),
+               pipeline=pipeline, piece_rays=piece_rays, taper_min=taper_min)
     assert got[0][0] is not None
     for r in range(1, world):
         assert got[r][0] is None
