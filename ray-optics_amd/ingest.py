@@ -111,6 +111,8 @@ ND_VD = {
 }
 # (BK7 -> N-BK7: Schott lists the lead-free melt with the classic BK7 dispersion constants,
 # nd 1.51680 / vd 64.17 for both)
+# (BK7 -> N-BK7: the lead-free successor melt; SCHOTT's data sheets give both the same Sellmeier
+# coefficients, nd 1.51680, vd 64.17 -- the only dispersion data this module carries for either)
 ALIASES = {'BK7': 'N-BK7', 'FUSEDSILICA': 'SILICA', 'F_SILICA': 'SILICA'}
 
 
