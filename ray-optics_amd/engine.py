@@ -147,6 +147,12 @@ class PinnedPool:
 
     def __init__(self):
         self._free = {}         # nbytes (rounded) -> [uint8 pinned tensors]
+        self._held = 0          # bytes sitting in _free
+        # Blocks are kept up to a byte budget, not a count: a SpotDiagramFigure holds nine arrays
+        # of one size at a time, and releasing / re-pinning the surplus cost 3 ms per block
+        # (hipHostFree + hipHostMalloc) -- 95 ms per refresh at num_rays = 256 with a bound of
+        # four blocks per size (tools/spot_figure_profile.py).
+        self.budget = int(os.environ.get('ROX_PINNED_POOL_MB', '2048')) << 20
 
     @staticmethod
     def _round(nbytes):
@@ -160,13 +166,17 @@ class PinnedPool:
     def take(self, torch, nbytes):
         n = self._round(max(int(nbytes), 1))
         lst = self._free.get(n)
-        t = lst.pop() if lst else torch.empty(n, dtype=torch.uint8).pin_memory()
+        if lst:
+            t = lst.pop()
+            self._held -= n
+        else:
+            t = torch.empty(n, dtype=torch.uint8).pin_memory()
         return _Lease(self, n, t)
 
     def give_back(self, n, t):
-        lst = self._free.setdefault(n, [])
-        if len(lst) < (2 if n > (256 << 20) else 4):    # bounded: surplus blocks are unpinned
-            lst.append(t)
+        if self._held + n <= self.budget:               # bounded: surplus blocks are unpinned
+            self._free.setdefault(n, []).append(t)
+            self._held += n
 
 
 class _Lease:

@@ -47,22 +47,34 @@ def main():
     from rayoptics.mpl.axisarrayfigure import SpotDiagramFigure, RayFanFigure
     from rayoptics.raytr import analyses
 
+    # a figure is built once (with the drop-ins active, so that the constructor's own first
+    # update_data is quick) and its refresh -- update_data() on the existing figure, what a
+    # model edit triggers -- is what is timed, without and with the drop-ins
+    figs = []
+
+    def figure(cls, opm, **kw):
+        install.install()
+        try:
+            fig = plt.figure(FigureClass=cls, opt_model=opm, **kw)
+        finally:
+            install.uninstall()
+        figs.append(fig)
+        return fig
+
     def spot(opm, num):
+        fig = figure(SpotDiagramFigure, opm, num_rays=num)
+
         def run():
-            fig = plt.figure(FigureClass=SpotDiagramFigure, opt_model=opm, num_rays=num)
             fig.update_data()
-            data = [[np.array(g) for g in row[0][0]] for row in fig.axis_data_array]
-            plt.close(fig)
-            return data
+            return [[np.array(g) for g in row[0][0]] for row in fig.axis_data_array]
         return run
 
     def fan(opm, data_type, num):
+        fig = figure(RayFanFigure, opm, data_type=data_type, num_rays=num)
+
         def run():
-            fig = plt.figure(FigureClass=RayFanFigure, opt_model=opm, data_type=data_type, num_rays=num)
             fig.update_data()
-            data = fig.axis_data_array
-            plt.close(fig)
-            return data
+            return flat(fig.axis_data_array)        # (numbers only: the figure rebuilds its lists)
         return run
 
     def wavefront(opm, num):
@@ -125,5 +137,47 @@ def main():
         print(json.dumps(rec), flush=True)
 
 
+def big():
+    """figure sizes the reference cannot be waited for: the drop-ins alone, the reference's time
+    extrapolated from its measured rays per second at num_rays = 64 (it is a per-ray loop)"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    import refmodels as ref
+    import rayoptics_amd  # noqa: F401
+    from rayoptics_amd import install
+    from rayoptics.mpl.axisarrayfigure import SpotDiagramFigure
+    for model in ('dblgauss', 'nikkor'):
+        opm = getattr(ref, model)()
+        n_fw = len(opm['osp']['fov'].fields) * len(opm['osp']['wvls'].wavelengths)
+
+        def refresh(fig):
+            fig.update_data()
+            return sum(len(g) for row in fig.axis_data_array for g in row[0][0])
+        install.install()
+        fig64 = plt.figure(FigureClass=SpotDiagramFigure, opt_model=opm, num_rays=64)
+        install.uninstall()
+        t0 = time.perf_counter()
+        refresh(fig64)
+        ref_rays_per_s = 64 * 64 * n_fw / (time.perf_counter() - t0)
+        plt.close(fig64)
+        install.install()
+        try:
+            for num in (256, 512, 1024):
+                fig = plt.figure(FigureClass=SpotDiagramFigure, opt_model=opm, num_rays=num)
+                refresh(fig)
+                ms, n = timed(lambda: refresh(fig), 7)
+                plt.close(fig)
+                print(json.dumps({'model': model, 'what': 'SpotDiagramFigure.update_data (refresh of an existing figure)', 'num_rays': num,
+                                  'rays': num * num * n_fw, 'points_in_the_figure': int(n), 'drop_in_ms': ms,
+                                  'reference_rays_per_s_measured_at_64': ref_rays_per_s,
+                                  'reference_extrapolated_s': num * num * n_fw / ref_rays_per_s}), flush=True)
+        finally:
+            install.uninstall()
+
+
 if __name__ == '__main__':
-    main()
+    if '--big' in sys.argv:
+        big()
+    else:
+        main()
