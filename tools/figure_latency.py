@@ -172,6 +172,21 @@ def big():
                                   'rays': num * num * n_fw, 'points_in_the_figure': int(n), 'drop_in_ms': ms,
                                   'reference_rays_per_s_measured_at_64': ref_rays_per_s,
                                   'reference_extrapolated_s': num * num * n_fw / ref_rays_per_s}), flush=True)
+            from rayoptics.raytr import analyses
+            for num in (256, 512, 1024):
+                def grids():
+                    return [analyses.RayGrid(opm, f=f, num_rays=num) for f in range(len(opm['osp']['fov'].fields))]
+                grids()
+                ms, gs = timed(grids, 5)
+                rec = {'model': model, 'what': 'analyses.RayGrid of every field', 'num_rays': num,
+                       'rays': num * num * len(gs), 'drop_in_ms': ms,
+                       'reference_extrapolated_s': num * num * len(gs) / ref_rays_per_s}
+                g0 = gs[0]
+                ms_psf, psf = timed(lambda: analyses.calc_psf(g0.grid[2], num, 2 * num), 5)
+                rec['calc_psf_ndim_maxdim'] = [num, 2 * num]
+                rec['calc_psf_ms'] = ms_psf
+                rec['psf_peak'] = float(np.nanmax(psf))
+                print(json.dumps(rec), flush=True)
         finally:
             install.uninstall()
 
