@@ -97,15 +97,21 @@ def trace_ray_list(opt_model, pupil_coords, fld, wvl, foc, append_if_none=False,
     kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', True)
     named = kwargs.get('use_named_tuples', False)
     items = pupil_coords if isinstance(pupil_coords, (list, np.ndarray)) else list(pupil_coords)
-    pc = np.array([[p[0], p[1]] for p in items], dtype=float).reshape(-1, 2)
+    if isinstance(items, np.ndarray) and items.ndim == 2 and items.shape[1] >= 2 and items.dtype.kind == 'f':
+        pc = items[:, :2].astype(float)
+    else:
+        pc = np.array([[p[0], p[1]] for p in items], dtype=float).reshape(-1, 2)
     pk = _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter,
                       pupil_list=(pc[:, 0].copy(), pc[:, 1].copy()))
     ifcs = opt_model['seq_model'].ifcs
     ray_list = []
+    # Field.apply_vignetting scales `pupil[:]`: a view for an ndarray (the caller's
+    # coordinates change in place), a copy for a list or tuple
+    whole = isinstance(items, np.ndarray) and items.ndim == 2 and items.shape[1] >= 2
+    if whole:                                   # every row at once
+        items[:, 0], items[:, 1] = pk.pupil[0], pk.pupil[1]
     for r, p in enumerate(items):
-        # Field.apply_vignetting scales `pupil[:]`: a view for an ndarray (the
-        # caller's coordinates change in place), a copy for a list or tuple
-        if isinstance(p, np.ndarray):
+        if not whole and isinstance(p, np.ndarray):
             p[0], p[1] = pk.pupil[0, r], pk.pupil[1, r]
         pkg, _err = emit(pk, r, output_filter, rayerr_filter, named, ifcs)
         if pkg is not None:

@@ -77,6 +77,10 @@ class HostPackets:
         self.out_mode = out_mode
         self.flags = flags
         self._wvl = wvl_of_ray          # float or array of floats
+        # per-ray accessors run once per ray of a list-shaped result: plain Python numbers,
+        # not NumPy scalar indexing (100 000 rays: 2.4 us -> 0.1 us per ray for the wavelength alone)
+        self._wvl_scalar = float(wvl_of_ray) if np.ndim(wvl_of_ray) == 0 else None
+        self._st_l = self._fs_l = self._op_l = None
         N = table.n_ifcs
         filt = bool(flags & abi.FILTER_PHANTOMS)
         nb, nxt = [], 0
@@ -88,15 +92,25 @@ class HostPackets:
         self._n_full = nxt
 
     def wvl(self, r):
-        return float(self._wvl if np.ndim(self._wvl) == 0 else self._wvl[r])
+        return self._wvl_scalar if self._wvl_scalar is not None else float(self._wvl[r])
+
+    def _lists(self):
+        if self._st_l is None:
+            self._st_l = self.status.tolist()
+            self._fs_l = self.fail_surf.tolist() if self.fail_surf is not None else None
+            self._op_l = self.op.tolist() if self.op is not None else None
+        return self._st_l
+
+    def status_of(self, r):
+        return (self._st_l or self._lists())[r]
 
     def nseg(self, r):
-        st = self.status[r]
+        st = (self._st_l or self._lists())[r]
         if self.out_mode != abi.OUT_FULL:
             return 1 if st == abi.OK else 0
         if st == abi.OK:
             return self._n_full
-        s = int(self.fail_surf[r])
+        s = self._fs_l[r]
         if s <= 0:
             return 0
         if st == abi.MISSED_SURFACE:        # raytrace.py:231-237
@@ -105,7 +119,7 @@ class HostPackets:
 
     def pkg(self, r, named=False):
         ray = LazyRay(self.seg, r, self.nseg(r), named)
-        op, wvl = float(self.op[r]), self.wvl(r)
+        op, wvl = self._op_l[r], self.wvl(r)
         return RayPkg(ray, op, wvl) if named else (ray, op, wvl)
 
     def error(self, r, ifcs=None, with_pkg=True, named=True):

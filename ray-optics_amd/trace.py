@@ -52,7 +52,7 @@ def opts_from_kwargs(n_ifcs, kwargs, out_mode, foc=0.0, image_pt=(0., 0.), wf=No
 
 def emit(pk, r, output_filter, rayerr_filter, named, ifcs):
     """(pkg, err) for ray r, as trace_safe would return it (trace.py:186-221)"""
-    if pk.status[r] != abi.OK:
+    if pk.status_of(r) != abi.OK:
         if rayerr_filter == 'full':
             err = pk.error(r, ifcs, with_pkg=True, named=True)
             return err.ray_pkg, err
