@@ -289,11 +289,12 @@ def trace_grid(opt_model, grid_rng, fld, wvl, foc, img_filter=None,
                       grid=make_grid(grid_rng[0], grid_rng[1], num))
     ifcs = opt_model['seq_model'].ifcs
     grid = []
+    pup = np.ascontiguousarray(pk.pupil[:2].T)      # [R, 2]: one (x, y) row per ray
     for i in range(num):
         working_grid = grid if form == 'list' else []
         for j in range(num):
             r = i * num + j
-            pupil = np.array([pk.pupil[0, r], pk.pupil[1, r]])
+            pupil = pup[r]
             pkg, _err = emit(pk, r, output_filter, rayerr_filter, named, ifcs)
             if pkg is not None:
                 if img_filter:
@@ -325,8 +326,9 @@ def trace_fan(opt_model, fan_rng, fld, wvl, foc, img_filter=None, **kwargs):
                       grid=make_grid(fan_rng[0], fan_rng[1], fan_rng[2], abi.GRID_FAN))
     ifcs = opt_model['seq_model'].ifcs
     fan = []
+    pup = np.ascontiguousarray(pk.pupil[:2].T)
     for r in range(fan_rng[2]):
-        pupil = np.array([pk.pupil[0, r], pk.pupil[1, r]])
+        pupil = pup[r]
         pkg, _err = emit(pk, r, output_filter, rayerr_filter, named, ifcs)
         if pkg is not None:
             fan.append([pupil, img_filter(pupil, pkg) if img_filter else pkg])
