@@ -152,7 +152,7 @@ class PinnedPool:
         # of one size at a time, and releasing / re-pinning the surplus cost 3 ms per block
         # (hipHostFree + hipHostMalloc) -- 95 ms per refresh at num_rays = 256 with a bound of
         # four blocks per size (tools/spot_figure_profile.py).
-        self.budget = int(os.environ.get('ROX_PINNED_POOL_MB', '2048')) << 20
+        self.budget = int(os.environ.get('ROX_PINNED_POOL_MB', '4096')) << 20
 
     @staticmethod
     def _round(nbytes):
@@ -174,8 +174,11 @@ class PinnedPool:
         return _Lease(self, n, t)
 
     def give_back(self, n, t):
-        if self._held + n <= self.budget:               # bounded: surplus blocks are unpinned
-            self._free.setdefault(n, []).append(t)
+        # bounded: surplus blocks are unpinned -- but one block of a size is always kept, however
+        # large (the 3 GB of BASELINE configs[4]'s pairs: re-pinning that per pass costs a second)
+        lst = self._free.setdefault(n, [])
+        if self._held + n <= self.budget or not lst:
+            lst.append(t)
             self._held += n
 
 
