@@ -389,6 +389,8 @@ def _obj_coords(opt_model, fld, cache):
         hit = None
     if hit is None:
         p0, d0 = osp.obj_coords(fld)
+        if len(cache) >= 64:        # every update_model() brings a new first-order data object:
+            cache.clear()           # entries of past updates can never hit again
         hit = cache[key] = (np.array(p0, dtype=float), np.array(d0, dtype=float),
                             None if fld.aim_info is None else np.array(fld.aim_info, dtype=float),
                             fld, parax)
