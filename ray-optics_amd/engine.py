@@ -174,11 +174,19 @@ class PinnedPool:
         return _Lease(self, n, t)
 
     def give_back(self, n, t):
-        # bounded: surplus blocks are unpinned -- but one block of a size is always kept, however
-        # large (the 3 GB of BASELINE configs[4]'s pairs: re-pinning that per pass costs a second)
-        lst = self._free.setdefault(n, [])
-        if self._held + n <= self.budget or not lst:
-            lst.append(t)
+        # bounded by max(budget, one block): what does not fit is unpinned.  Room is made by
+        # dropping blocks of OTHER sizes first (largest first) -- a pool that has swept many sizes
+        # keeps what is in use now -- and a single block larger than the whole budget is still
+        # kept while nothing else is (re-pinning gigabytes per call costs a second)
+        if self._held + n > self.budget:
+            for m in sorted((m for m, lst in self._free.items() if m != n and lst), reverse=True):
+                while self._free[m] and self._held + n > self.budget:
+                    self._free[m].pop()
+                    self._held -= m
+                if self._held + n <= self.budget:
+                    break
+        if self._held + n <= self.budget or self._held == 0:
+            self._free.setdefault(n, []).append(t)
             self._held += n
 
 

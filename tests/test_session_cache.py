@@ -111,3 +111,53 @@ def test_table_keyed_handles_for_explicit_paths(sess):
         assert not b.open and a.open and c.open
     finally:
         session.MAX_TABLE_ENGINES = saved
+
+
+def test_pinned_pool_keeps_blocks_by_a_byte_budget():
+    """engine.PinnedPool (no GPU needed: a stand-in for torch's pinned tensors): a figure's nine
+    same-size arrays all come back to the pool and are reused (a bound of four per size cost
+    3 ms of un-pinning / re-pinning per block and refresh); a sweep over many sizes stays within
+    the budget by dropping other sizes first; one block larger than the whole budget is kept"""
+    import gc
+    from rayoptics_amd.engine import PinnedPool
+
+    pinned = []
+
+    class _T:
+        def __init__(self, n):
+            self.n = n
+            pinned.append(n)
+
+        def data_ptr(self):
+            return 0
+
+    class _Torch:
+        uint8 = None
+
+        @staticmethod
+        def empty(n, dtype=None):
+            class _E:
+                def pin_memory(self):
+                    return _T(n)
+            return _E()
+
+    pool = PinnedPool()
+    pool.budget = 64 << 20
+    one = 1 << 20
+    for _ in range(3):                      # three refreshes of a figure with nine 1 MiB arrays
+        held = [pool.take(_Torch, one) for _ in range(9)]
+        del held
+        gc.collect()
+    assert len(pinned) == 9 and pool._held == 9 * one
+    for k in range(1, 40):                  # a sweep over 39 other sizes, 4 MiB each rounded up
+        lease = pool.take(_Torch, 3 * one + 4096 * k)
+        del lease
+    gc.collect()
+    assert pool._held <= pool.budget
+    big = pool.take(_Torch, 200 << 20)      # larger than the whole budget
+    del big
+    gc.collect()
+    n_pins = len(pinned)
+    again = pool.take(_Torch, 200 << 20)
+    assert len(pinned) == n_pins            # ... and still reused
+    del again
