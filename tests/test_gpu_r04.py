@@ -514,3 +514,24 @@ def test_null_and_out_of_range_arguments_are_errors_not_crashes():
     assert lib.rox_trace_pupil_grid(h, C.byref(fld), C.byref(grid), 0, C.byref(opts), C.byref(out), null) == 0
     assert (st == abi.OK).any()
     eng.close()
+
+
+def test_a_grid_of_two_to_the_32_rays_in_one_launch():
+    """maximum size: a 65536 x 65536 pupil grid = 2^32 rays in ONE launch (73 GB of HITS output
+    on the 288 GB part) -- ray indices above 2^31 land where they belong: four rows at 0.6 num
+    equal the same rows traced as a row block, and sampled rays equal the oracle's, bit for bit
+    (tools/huge_grid_check.py, in its own process so that the memory goes back at once)"""
+    import json
+    import subprocess
+    import sys
+    import torch
+    free, _total = torch.cuda.mem_get_info()
+    if free < 100 << 30:
+        pytest.skip('needs 100 GB of free HBM')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'huge_grid_check.py'), '65536'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['rays'] == 2 ** 32 and d['above_int32']
+    assert d['rows_equal_their_row_block'] and d['sampled_rays_equal_the_oracle']
+    assert d['of_them_through'] > 100 and 0 < d['rays_through'] < d['rays']
