@@ -535,3 +535,10 @@ def test_a_grid_of_two_to_the_32_rays_in_one_launch():
     assert d['rays'] == 2 ** 32 and d['above_int32']
     assert d['rows_equal_their_row_block'] and d['sampled_rays_equal_the_oracle']
     assert d['of_them_through'] > 100 and 0 < d['rays_through'] < d['rays']
+    # FULL packets of an 8192 x 8192 grid: 70 GB, element offsets up to 8.7e9
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'huge_grid_check.py'), '--full'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['largest_element_offset'] > 2 ** 32 and d['rows_equal_their_row_block']
+    assert d['rays_through_in_them'] > 10000

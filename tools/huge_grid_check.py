@@ -59,5 +59,45 @@ def main(num=65536):
     eng.close()
 
 
+def full(num=8192):
+    """FULL packets of an 8192 x 8192 grid (67 M rays, 72 GB: element offsets up to 8.7e9 in
+    seg[13][10][ld]): the last four rows equal the same rows traced as a row block, every
+    segment of every ray, and their hits equal the HITS launch's"""
+    import torch
+    import rayoptics_amd  # noqa: F401
+    from rayoptics_amd import abi, workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    wl = workloads.load('dblgauss_c2')
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    fld = wl.fields[0]
+    opts = make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING, out_mode=abi.OUT_FULL,
+                     first_surf=1, last_surf=N - 2)
+    t0 = time.perf_counter()
+    res = eng.trace_pupil_grid(fld, make_grid((-1., -1.), (1., 1.), num), 0, opts, want_pupil=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    R = num * num
+    rows, r0 = 4, num // 2 - 2                          # rows through the middle of the pupil
+    lo, hi = r0 * num, (r0 + rows) * num
+    blk = eng.trace_pupil_grid(fld, make_grid((-1., -1.), (1., 1.), num, row_begin=r0, row_count=rows), 0, opts,
+                               want_pupil=True)
+    sa, sb = res.status[lo:hi].cpu().numpy(), blk.status[:rows * num].cpu().numpy()
+    ok = sa == 0
+    a = res.seg[:, :, lo:hi].cpu().numpy()[:, :, ok]
+    b = blk.seg[:, :, :rows * num].cpu().numpy()[:, :, ok]
+    same = bool(np.array_equal(sa, sb) and np.array_equal(a.view(np.int64), b.view(np.int64)) and
+                np.array_equal(res.op[lo:hi].cpu().numpy()[ok].view(np.int64),
+                               blk.op[:rows * num].cpu().numpy()[ok].view(np.int64)))
+    print(json.dumps({'mode': 'FULL', 'num': num, 'rays': R, 'packet_GB': round(res._seg.numel() * 8 / 1e9, 1),
+                      'largest_element_offset': int(res._seg.numel()), 'launch_ms_incl_allocation': ms,
+                      'rows_compared': [r0, r0 + rows], 'rays_through_in_them': int(ok.sum()),
+                      'rows_equal_their_row_block': same}))
+    eng.close()
+
+
 if __name__ == '__main__':
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 65536)
+    if '--full' in sys.argv:
+        full()
+    else:
+        main(int(sys.argv[1]) if len(sys.argv) > 1 else 65536)
