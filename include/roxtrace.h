@@ -186,13 +186,20 @@ typedef struct rox_phase {
     double coefs[ROX_MAX_COEF];
 } rox_phase;                 /* 168 bytes */
 
+/* rox_surface.flags.  ROX_SURF_CV_INT_ZERO: the reference model holds this Spherical / Conic
+ * curvature as the Python *integer* 0 (its own double Gauss data does,
+ * rayoptics/raytr/tests/ag_dblgauss_s.py).  `-self.cv*p[0]` in Spherical/Conic.df
+ * (profiles.py:360-362, 605-609) is then `0 * x` -- +0 for x > 0 -- where the float 0.0 gives
+ * `-0.0 * x` = -0; intersect() and sag() see +0.0 either way.  cv itself is 0.0.            */
+#define ROX_SURF_CV_INT_ZERO 1
+
 typedef struct rox_surface {
     int32_t mode;            /* ROX_TRANSMIT...                                */
     int32_t profile;         /* ROX_SPHERICAL...                               */
     int32_t ncoef;           /* max_nonzero_coef (profiles.py:827-832)         */
     int32_t n_ap;            /* len(clear_apertures); 0 -> max_aperture test   */
     int32_t rt_order;        /* summation order of rt.dot(v), see ROX_RT_*      */
-    int32_t reserved;
+    int32_t flags;           /* ROX_SURF_* (0 from callers that predate it)     */
     double cv;               /* vertex curvature                               */
     double cc;               /* conic constant                                 */
     double ec;               /* cc + 1.0 as the reference evaluates it         */

@@ -61,10 +61,13 @@ class Phase(C.Structure):
                 ('coefs', C.c_double * MAX_COEF)]
 
 
+SURF_CV_INT_ZERO = 1        # rox_surface.flags (include/roxtrace.h ROX_SURF_CV_INT_ZERO)
+
+
 class Surface(C.Structure):
     _fields_ = [('mode', C.c_int32), ('profile', C.c_int32),
                 ('ncoef', C.c_int32), ('n_ap', C.c_int32),
-                ('rt_order', C.c_int32), ('reserved', C.c_int32),
+                ('rt_order', C.c_int32), ('flags', C.c_int32),
                 ('cv', C.c_double), ('cc', C.c_double), ('ec', C.c_double),
                 ('cR', C.c_double),
                 ('coefs', C.c_double * MAX_COEF),

@@ -36,6 +36,8 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <mutex>
 
 #include "../../include/roxtrace.h"
 
@@ -60,6 +62,18 @@
 #endif
 #ifndef ROX_BLOCK            // workgroup size of the reduced-output modes (HITS sustained: 512 -> 124 us,
 #define ROX_BLOCK 512         // 1024 -> 131 us)
+#endif
+#ifndef ROX_BLOCK_POLY       // ... of the instances that carry Newton code
+#define ROX_BLOCK_POLY ROX_BLOCK
+#endif
+#ifndef ROX_MIN_WAVES_POLY   // waves per SIMD the reduced-output modes of those instances are compiled for
+#define ROX_MIN_WAVES_POLY ROX_MIN_WAVES
+#endif
+#ifndef ROX_WAVE_TICKETS     // 1: the reduced-output modes (HITS, LAST, OPD, FAN) run as resident waves that
+#define ROX_WAVE_TICKETS 1    //    draw 64-ray tiles by ticket (wave_ticketed() below)
+#endif
+#ifndef ROX_BLOCK_SMALL      // workgroup size of launches that do not fill the chip (block_of() below)
+#define ROX_BLOCK_SMALL 256
 #endif
 #ifndef ROX_BLOCK_COMPACT    // workgroup = tile size of HITS_COMPACT: fewer, larger tiles make the
 #define ROX_BLOCK_COMPACT 1024 // look-back cheaper (into pinned memory 128 -> 501, 256 -> 371,
@@ -90,6 +104,21 @@
 #ifndef ROX_MIN_WAVES_FULL_POLY  // 5 caps the VGPRs at 96 (five workgroups per CU) at the price of 12-28 B
 #define ROX_MIN_WAVES_FULL_POLY ROX_MIN_WAVES  // of scratch per lane: phone lens 273, but the .zmx zoom 386 us
 #endif
+#ifndef ROX_POLY_SAME_BRANCH  // 1: sqrt(rad_e) of an EvenPolynomial only when (cc + 1.0) != ec -- a real
+#define ROX_POLY_SAME_BRANCH 1 //    wave-uniform branch.  Written as a select, hipcc evaluated the second (full,
+#endif                         //    ~23 VALU incl. a quarter-rate v_rsq_f64) square root in EVERY evaluation
+#ifndef ROX_POLY_SHARED_POW   // 1: the sag and slope series of EvenPolynomial / toroid profiles share one
+#define ROX_POLY_SHARED_POW 1  //    power chain (r2^i of the slope loop IS r2^(i-1) * r2 of the sag loop, bit for bit)
+#endif
+#ifndef ROX_NEWTON_SLIM_DIV   // 1: the Spencer-Murty quotient f / dot(d, df) through slim_div()
+#define ROX_NEWTON_SLIM_DIV 1
+#endif
+#ifndef ROX_NEWTON_UNROLL     // Spencer-Murty steps spelled straight-line before the residual loop
+#define ROX_NEWTON_UNROLL 4
+#endif
+#ifndef ROX_COSI_SLIM         // 1: cosI = dot(d, n) / |n| of refract() / mirror() through slim_div()
+#define ROX_COSI_SLIM 1
+#endif
 #ifndef ROX_IDENT_RT_FULL_POLY   // 1: the identity-rotation short cut also in the FULL mode of those
 #define ROX_IDENT_RT_FULL_POLY 1 //    instances, which are closer to their VALU bound (283 / 473 / 187 us)
 #endif
@@ -101,15 +130,43 @@ constexpr int kWaves = kBlock / 64;
 // threads per workgroup (= rays per tile) of an output mode of a feature instance
 // (feat & kFeatNewton: the instance carries Newton code -- F_EVEN | F_RADIAL | F_TOROID)
 constexpr int kFeatNewton = 1 | 2 | 4;
-constexpr int block_of(int out_mode, int feat)
+// `small`: the launch does not fill the chip several times over (roxtrace.hip want_small()): it
+// runs in workgroups of ROX_BLOCK_SMALL threads, which spread over the CUs wave by wave instead
+// of sixteen (FULL) or eight waves at a time.  A CU holds 5 waves per SIMD of the lean FULL
+// instance (84 VGPRs) but only ONE 1024-thread workgroup (4 per SIMD); BASELINE configs[3]
+// (5 x 256^2 rays = 5120 waves) is 320 such workgroups on 256 CUs -- two rounds -- and 1280
+// workgroups of 256 threads on 1280 slots: one.
+constexpr int block_of(int out_mode, int feat, bool small = false)
 {
-    return out_mode == ROX_OUT_FULL ? ((feat & kFeatNewton) ? ROX_BLOCK_FULL_POLY : ROX_BLOCK_FULL)
-         : out_mode == ROX_OUT_HITS_COMPACT ? ROX_BLOCK_COMPACT : ROX_BLOCK;
+    return out_mode == ROX_OUT_HITS_COMPACT ? ROX_BLOCK_COMPACT
+         : small ? ROX_BLOCK_SMALL
+         : out_mode == ROX_OUT_FULL ? ((feat & kFeatNewton) ? ROX_BLOCK_FULL_POLY : ROX_BLOCK_FULL)
+         : ((feat & kFeatNewton) ? ROX_BLOCK_POLY : ROX_BLOCK);
+}
+// The reduced-output modes have no reason to keep a workgroup's waves together (no packet rows
+// to write in step): there a launch is one chip-load of resident workgroups whose WAVES draw
+// 64-ray tiles by ticket until the batch is through.  A wave whose rays die at the first
+// aperture draws its next tile at once instead of idling until its workgroup retires, the table
+// is staged once per resident workgroup instead of once per 512 rays, and no wave slot waits for
+// a workgroup launch: counters of round 4 (r04_pmc_summary_*) put the AVERAGE occupancy of the
+// one-tile-per-workgroup form at 2.7 of 4 waves per SIMD on the 13-interface asphere models and
+// 4.1 of 6 on the double Gauss.
+constexpr bool wave_ticketed(int out_mode)
+{
+    return ROX_WAVE_TICKETS && out_mode != ROX_OUT_FULL && out_mode != ROX_OUT_HITS_COMPACT &&
+           out_mode != 100 /* MODE_PROBE */;
+}
+// whether a distinct small-workgroup kernel exists for (mode, instance)
+constexpr bool has_small(int out_mode, int feat)
+{
+    return block_of(out_mode, feat, true) != block_of(out_mode, feat, false);
 }
 constexpr int min_waves_of(int out_mode, int feat)
 {
     return (out_mode == ROX_OUT_FULL && (feat & kFeatNewton)) ? ROX_MIN_WAVES_FULL_POLY
          : (out_mode == ROX_OUT_HITS_COMPACT && !(feat & ~8)) ? ROX_MIN_WAVES_COMPACT_LEAN
+         : (out_mode != ROX_OUT_FULL && out_mode != ROX_OUT_HITS_COMPACT && (feat & kFeatNewton))
+               ? ROX_MIN_WAVES_POLY
          : ROX_MIN_WAVES;
 }
 static_assert(sizeof(rox_aperture) == 40, "rox_aperture layout");
@@ -181,7 +238,7 @@ struct TraceArgs {
     int32_t row_begin;         // AXIS_PRODUCT: first pupil row of this launch
     // HITS_COMPACT: decoupled look-back state of this launch
     uint64_t *tile_state;      // [tiles] (epoch << 32 | flag << 30 | count)
-    uint32_t *ticket;          // [0] next tile, [1] workgroups done
+    uint32_t *ticket;          // [0] next tile, [1] workgroups (wave tickets: waves) done
     // pairs already in out.seg when this launch starts (earlier launches of a chunked
     // call; earlier calls with ROX_HITS_APPEND) -- nullptr = none -- and where the running
     // total goes.  Never the same word: a tile may still be reading the base while the
@@ -244,6 +301,21 @@ __device__ __forceinline__ v3 cross3(const v3 &a, const v3 &b)
 //   band: biased exponent in [640, 1408)  <=>  2^-383 <= |x| < 2^385
 //   (v_div_scale scales when exponents differ by >= 768 or the numerator's
 //   exponent <= 53; the sqrt expansion scales below 2^-767)
+// every active lane of the wave passes `p`.  __all() goes through an integer (v_cndmask 0/1,
+// v_cmp_ne, s_cmp vcc == exec); the ballot of the failing lanes is the compare mask itself
+// (inactive lanes read 0): two VALU instructions fewer per test site.
+#ifndef ROX_WAVE_ALL_BALLOT
+#define ROX_WAVE_ALL_BALLOT 1
+#endif
+__device__ __forceinline__ bool wave_all(bool p)
+{
+#if ROX_WAVE_ALL_BALLOT
+    return __builtin_amdgcn_ballot_w64(!p) == 0;
+#else
+    return __all(p);
+#endif
+}
+
 __device__ __forceinline__ bool in_band(double x)
 {
     const uint32_t h = (uint32_t)__double2hiint(x) & 0x7fffffffu;
@@ -271,7 +343,7 @@ __device__ __forceinline__ double sqrt_band(double x)
 __device__ __forceinline__ double slim_sqrt(double x)
 {
 #if ROX_SLIM_FP64
-    if (__all(in_band(x)))
+    if (wave_all(in_band(x)))
         return sqrt_band(x);
 #endif
     return sqrt(x);
@@ -299,7 +371,7 @@ __device__ __forceinline__ double div_band(double a, double b, double r)
 __device__ __forceinline__ double slim_div(double a, double b)
 {
 #if ROX_SLIM_FP64
-    if (__all(in_band(b) && in_band_or_zero(a)))
+    if (wave_all(in_band(b) && in_band_or_zero(a)))
         return div_band(a, b, rcp_band(b));
 #endif
     return a / b;
@@ -309,7 +381,7 @@ __device__ __forceinline__ double slim_div(double a, double b)
 __device__ __forceinline__ v3 slim_div3(const v3 &a, double b)
 {
 #if ROX_SLIM_FP64
-    if (__all(in_band(b) && in_band_or_zero(a.x) && in_band_or_zero(a.y) && in_band_or_zero(a.z))) {
+    if (wave_all(in_band(b) && in_band_or_zero(a.x) && in_band_or_zero(a.y) && in_band_or_zero(a.z))) {
         const double r = rcp_band(b);
         return v3{div_band(a.x, b, r), div_band(a.y, b, r), div_band(a.z, b, r)};
     }
@@ -361,7 +433,7 @@ __device__ __forceinline__ v3 unit(const v3 &v)
     // len = sqrt(l2) in [2^-192, 2^193) -- inside the band and non-zero, no test needed --
     // and every |v_i| <= len (1 + 2^-51) < 2^385, so only the lower edge of the numerators
     // is tested.  The instruction sequences are those of slim_sqrt / slim_div3.
-    if (__all(in_band(l2) && zero_or_not_tiny(v.x) && zero_or_not_tiny(v.y) && zero_or_not_tiny(v.z))) {
+    if (wave_all(in_band(l2) && zero_or_not_tiny(v.x) && zero_or_not_tiny(v.y) && zero_or_not_tiny(v.z))) {
         const double len = sqrt_band(l2);
         const double r = rcp_band(len);
         return v3{div_band(v.x, len, r), div_band(v.y, len, r), div_band(v.z, len, r)};
@@ -383,7 +455,11 @@ __device__ __forceinline__ bool refract(const v3 &d, const v3 &nrm, double n_in,
                                         double n_out, v3 &out)
 {
     const double nlen = slim_sqrt(dot3(nrm, nrm));
+#if ROX_COSI_SLIM
+    const double cosI = slim_div(dot3(d, nrm), nlen);
+#else
     const double cosI = dot3(d, nrm) / nlen;
+#endif
     const double sin2 = 1.0 - cosI * cosI;
     const double rad = n_out * n_out - n_in * n_in * sin2;
     if (rad < 0.0)
@@ -399,7 +475,11 @@ __device__ __forceinline__ bool refract(const v3 &d, const v3 &nrm, double n_in,
 __device__ __forceinline__ v3 mirror(const v3 &d, const v3 &nrm)
 {
     const double nlen = slim_sqrt(dot3(nrm, nrm));
+#if ROX_COSI_SLIM
+    const double cosI = slim_div(dot3(d, nrm), nlen);
+#else
     const double cosI = dot3(d, nrm) / nlen;
+#endif
     const double k = 2.0 * cosI;
     return v3{d.x - k * nrm.x, d.y - k * nrm.y, d.z - k * nrm.z};
 }
@@ -465,12 +545,27 @@ __device__ __forceinline__ bool quadric_hit(bool conic, double cv, double cc, do
 // the extra code: Nikkor HITS 319 -> 330 us), straight-line for every length with a scalar
 // branch per term (Nikkor 330, .zmx zoom 161 -> 171, phone lens 242), and prefetching the next
 // term's word in the loop (phone lens 253).
-template <int FEAT>
+//
+// SHARED (the EvenPolynomial and toroid call sites: z_pow = m, e_pow = 1): the slope loop's power
+// 1 * m * m ... and the sag loop's m * m ... are the same numbers one term apart (1 * m is m
+// exactly, and from there both chains multiply the same value by m), so one chain serves both --
+// five operations per term instead of six, every result the one the two loops produce.
+template <int FEAT, bool SHARED = false>
 __device__ __forceinline__ void series2(const d2 *cd, int ncoef, double m, double z_pow, double e_pow,
                                         double &z_asp, double &e_asp)
 {
     z_asp = 0.0;
     e_asp = 0.0;
+    if (SHARED && ROX_POLY_SHARED_POW) {
+        double pw = 1.0;                    // e_pow of term i; pw * m = z_pow of term i
+        for (int i = 0; i < ncoef; ++i) {
+            const d2 c = cd[i];
+            e_asp += c.y * pw;
+            pw *= m;
+            z_asp += c.x * pw;
+        }
+        return;
+    }
     if ((FEAT & F_RADIAL) && !(FEAT & F_EVEN) && ncoef == ROX_MAX_COEF) {
         d2 c[ROX_MAX_COEF];
 #pragma unroll
@@ -513,7 +608,7 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
             return false;
         const double srad = slim_sqrt(rad);
         double z_asp, e_asp;
-        series2<FEAT>(cd, ncoef, y2, y2, 1, z_asp, e_asp);
+        series2<FEAT, true>(cd, ncoef, y2, y2, 1, z_asp, e_asp);
         const double fY = slim_div(cv * y2, 1. + srad) + z_asp;
         if (WANT_F)
             f = p.z - fY - cR * (px * px + p.z * p.z - fY * fY) / 2;
@@ -538,11 +633,21 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
             if (rad < 0.0)
                 return false;
             const double srad = slim_sqrt(rad);
+#if ROX_POLY_SAME_BRANCH
+            srad_e = srad;
+            if (!same) {
+                // (the empty asm keeps this a branch: as a select the compiler evaluated the
+                // second square root -- the full expansion -- in every evaluation)
+                asm volatile("" ::: "memory");
+                srad_e = sqrt(rad_e);
+            }
+#else
             srad_e = same ? srad : sqrt(rad_e);
+#endif
             const double z = slim_div(cv * r2, 1. + srad);
             const double e = slim_div(cv, srad_e);
             double z_asp, e_asp;
-            series2<FEAT>(cd, ncoef, r2, r2, 1, z_asp, e_asp);
+            series2<FEAT, true>(cd, ncoef, r2, r2, 1, z_asp, e_asp);
             f = p.z - (z + z_asp);
             e_tot = e + e_asp;
         } else {
@@ -592,7 +697,11 @@ __device__ __forceinline__ bool newton_hit(int kind, double cv, double cc1, doub
     double f;
     if (!poly_eval<FEAT, true>(kind, cv, cc1, ec, cR, ncoef, coefs, p, f, df))
         return false;
+#if ROX_NEWTON_SLIM_DIV
+    double s1 = slim_div(-f, dot3(d, df));
+#else
     double s1 = -f / dot3(d, df);
+#endif
     double delta = fabs(s1);
     int iter = 0;
     bool ok = true;
@@ -604,7 +713,11 @@ __device__ __forceinline__ bool newton_hit(int kind, double cv, double cc1, doub
             delta = 0.0;            // leave the iteration; the caller reports the miss
             return;
         }
+#if ROX_NEWTON_SLIM_DIV
+        const double s2 = s1 - slim_div(f, dot3(d, df));
+#else
         const double s2 = s1 - f / dot3(d, df);
+#endif
         delta = fabs(s2 - s1);
         s1 = s2;
         ++iter;
@@ -613,7 +726,7 @@ __device__ __forceinline__ bool newton_hit(int kind, double cv, double cc1, doub
     // 4 steps 6 %, more < 1 % -- four steps straight-line and
     // predicated per lane, then the residual loop (cap 1000 as in the reference)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < ROX_NEWTON_UNROLL; ++u)
         if (delta > eps)
             step();
     while (delta > eps && iter < 1000)
@@ -988,7 +1101,8 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
                 ok = quadric_hit(mp.y == ROX_CONIC, row[O_CV], row[O_CC], row[O_EC], pt0, dir0,
                                  row[O_ZDIR], s_, bp);
                 const double k = (mp.y == ROX_CONIC) ? (row[O_CC] + 1.0) * row[O_CV] : row[O_CV];
-                df = v3{-row[O_CV] * bp.x, -row[O_CV] * bp.y, 1.0 - k * bp.z};
+                const double ncv = row[O_CR];       // -cv as df forms it (roxtrace.hip, device row)
+                df = v3{ncv * bp.x, ncv * bp.y, 1.0 - k * bp.z};
             } else {
                 ok = newton_hit<FEAT>(mp.y, row[O_CV], row[O_CC] + 1.0, row[O_EC], row[O_CR],
                                       ((tbli)row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
@@ -1047,11 +1161,11 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         // (reduced-output modes only: in FULL mode, which is bound by its packet stores, the
         // extra branch measured 2 % slower)
 #ifdef ROX_SPEC_EXPERIMENT
-        if (FEAT == 0 || (kIdentRt && ((tbli)prow)[5] != 0 &&
-            __all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((bd.x + bd.y) + bd.z))))) {
+        if (FEAT == 0 || (kIdentRt && (((tbli)prow)[5] & 2) != 0 &&
+            wave_all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((bd.x + bd.y) + bd.z))))) {
 #else
-        if (kIdentRt && ((tbli)prow)[5] != 0 &&
-            __all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((bd.x + bd.y) + bd.z)))) {
+        if (kIdentRt && (((tbli)prow)[5] & 2) != 0 &&
+            wave_all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((bd.x + bd.y) + bd.z)))) {
 #endif
             b4p = v3{dp.x + 0.0, dp.y + 0.0, dp.z + 0.0};
             b4d = v3{bd.x + 0.0, bd.y + 0.0, bd.z + 0.0};
@@ -1115,7 +1229,8 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         } else {
             if (!kPoly || prof <= ROX_CONIC) {
                 const double k = (prof == ROX_CONIC) ? (row[O_CC] + 1.0) * cv : cv;
-                df = v3{-cv * inc.x, -cv * inc.y, 1.0 - k * inc.z};
+                const double ncv = row[O_CR];       // -cv as df forms it (roxtrace.hip, device row)
+                df = v3{ncv * inc.x, ncv * inc.y, 1.0 - k * inc.z};
             }
             nrm = unit(df);
         }
@@ -1372,11 +1487,11 @@ __host__ __device__ inline int64_t compact_tiles(int64_t n_rays, int32_t want_sm
 
 // ------------------------------------------------------------------ the kernel
 // the work of one workgroup on one launch item: its share of the item's ray tiles
-template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT, class ARGS>
+template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT, bool SMALL, class ARGS>
 __device__ __forceinline__ void trace_tiles(ARGS &a)
 {
     constexpr bool kCompact = (OUT_MODE == ROX_OUT_HITS_COMPACT);
-    constexpr int kB = block_of(OUT_MODE, FEAT);    // threads per workgroup = rays per tile
+    constexpr int kB = block_of(OUT_MODE, FEAT, SMALL);     // threads per workgroup = rays per tile
 
     const int N = a.n_ifcs;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1424,8 +1539,10 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     c.eps = a.opts.eps; c.fuzz = a.opts.fuzz;
     c.probe_surf = -1;
     const int64_t ld = a.out.ld;
+    constexpr bool kWaveTick = wave_ticketed(OUT_MODE);
     const int64_t n_small = kCompact ? compact_small_tiles(a.n_rays, a.small_tiles) : 0;
-    const int64_t n_tiles = kCompact ? compact_tiles(a.n_rays, a.small_tiles, kB) : (a.n_rays + kB - 1) / kB;
+    const int64_t n_tiles = kCompact ? compact_tiles(a.n_rays, a.small_tiles, kB)
+                          : kWaveTick ? (a.n_rays + 63) / 64 : (a.n_rays + kB - 1) / kB;
 
     // HITS_COMPACT: tiles are handed out by ticket, so that the tile a workgroup
     // waits for in the look-back is always held by a running workgroup
@@ -1437,6 +1554,11 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     int64_t pend_tile = -1, pend_it = 0;    // HITS_COMPACT: the tile whose finish is deferred
     int pend_total = 0;
 
+    // wave tickets: lane 0 holds the wave's next ticket.  It is drawn one tile ahead, so the
+    // atomic's round trip to L2 passes behind the trace of the current tile.
+    uint32_t tk = 0;
+    if (kWaveTick && lane == 0)
+        tk = atomicAdd(&a.ticket[0], 1u);
     for (int64_t it = 0;; ++it) {
         int64_t tile;
         if (kCompact) {
@@ -1445,12 +1567,16 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
             __syncthreads();
             // (wave-uniform by construction: keep it in scalar registers across the trace)
             tile = (int64_t)__builtin_amdgcn_readfirstlane((int)s_tile);
+        } else if (kWaveTick) {
+            tile = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+            if (tile < n_tiles && lane == 0)
+                tk = atomicAdd(&a.ticket[0], 1u);
         } else {
             tile = (int64_t)blockIdx.x + it * gridDim.x;
         }
         if (tile >= n_tiles)
             break;
-        int64_t r = tile * kB + threadIdx.x;
+        int64_t r = kWaveTick ? tile * 64 + lane : tile * kB + threadIdx.x;
         bool active = r < a.n_rays;
         if (kCompact) {
             const bool small = tile < n_small;
@@ -1586,6 +1712,14 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     }
     if (kCompact && kDefer && pend_tile >= 0)
         finish_tile<kB>(a, pend_tile, pend_total, stash_w + (size_t)(pend_it & 1) * kB, n_tiles, &s_excl);
+    if (kWaveTick && lane == 0) {
+        // the last wave out re-arms the ticket (every wave's last draw -- the one that ran past
+        // the end -- has returned before it counts itself out)
+        if (atomicAdd(&a.ticket[1], 1u) == gridDim.x * (unsigned)(kB / 64) - 1) {
+            __hip_atomic_store(&a.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (kCompact && threadIdx.x == 0) {
         // the last workgroup out re-arms the ticket for the next launch of this
         // stream context (every workgroup leaves exactly once, after its last draw)
@@ -1596,11 +1730,11 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     }
 }
 
-template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT>
-__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT), min_waves_of(OUT_MODE, FEAT))
+template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT, bool SMALL = false>
+__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT, SMALL), min_waves_of(OUT_MODE, FEAT))
 trace_kernel(const TraceArgs a)
 {
-    trace_tiles<OUT_MODE, GEN, PER_RAY_WVL, FEAT>(a);
+    trace_tiles<OUT_MODE, GEN, PER_RAY_WVL, FEAT, SMALL>(a);
 }
 
 // One launch for several pupil grids of one system -- the (field x wavelength) loops of
@@ -1609,17 +1743,19 @@ trace_kernel(const TraceArgs a)
 // that item's tiles.  The items sit in device memory and are read through the constant
 // address space, i.e. with the same scalar loads that read a kernel argument.
 typedef const __attribute__((address_space(4))) TraceArgs *ConstTraceArgs;
-template <int OUT_MODE, int FEAT>
-__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT), min_waves_of(OUT_MODE, FEAT))
+template <int OUT_MODE, int FEAT, bool SMALL = false>
+__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT, SMALL), min_waves_of(OUT_MODE, FEAT))
 trace_kernel_batch(const TraceArgs *items)
 {
-    trace_tiles<OUT_MODE, GEN_PUPIL, false, FEAT>(*(ConstTraceArgs)(items + blockIdx.y));
+    trace_tiles<OUT_MODE, GEN_PUPIL, false, FEAT, SMALL>(*(ConstTraceArgs)(items + blockIdx.y));
 }
 
 // ------------------------------------------------------------------ launching
 struct LaunchCfg {
     int gen;            // GEN_*
     bool per_ray_wvl;
+    bool small;         // workgroups of ROX_BLOCK_SMALL threads (pupil launches; see block_of())
+    int num_cus;        // wave-ticketed modes: the grid is clamped to the workgroups the chip holds
     int out_mode;       // ROX_OUT_*
     dim3 grid;
     size_t lds;
@@ -1639,29 +1775,81 @@ inline void launch_with_lds(K kernel, const dim3 &grid, const dim3 &block, size_
     hipLaunchKernelGGL(kernel, grid, block, lds, st, a);
 }
 
+// Wave-ticketed modes: no more workgroups than the chip holds at once (the resident waves draw
+// every tile; a workgroup dispatched after them would stage the table to find the tickets gone).
+// The runtime's occupancy figure for (kernel, workgroup size, dynamic LDS) is cached per kernel
+// instantiation; should it be one workgroup per CU high (it has been seen to be at some SGPR
+// counts), the surplus workgroups start when the first resident ones retire and leave at once.
+// ROX_TICKET_BLOCKS_PER_CU overrides it for experiments.
+struct OccCache {
+    std::mutex mu;
+    size_t lds = ~size_t(0);
+    int per_cu = 0;
+};
+template <class K>
+inline dim3 ticket_grid(OccCache &oc, K kernel, const LaunchCfg &k, int block)
+{
+    static const int forced = [] {
+        const char *e = getenv("ROX_TICKET_BLOCKS_PER_CU");
+        return (e && *e) ? atoi(e) : 0;
+    }();
+    int per_cu;
+    {
+        std::lock_guard<std::mutex> g(oc.mu);
+        if (oc.lds != k.lds) {
+            if (k.lds > kDefaultDynLds)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds);
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, k.lds) != hipSuccess || n < 1) {
+                (void)hipGetLastError();
+                n = 1;
+            }
+            oc.per_cu = n;
+            oc.lds = k.lds;
+        }
+        per_cu = oc.per_cu;
+    }
+    if (forced > 0)
+        per_cu = forced;
+    const unsigned cap = (unsigned)per_cu * (unsigned)(k.num_cus > 0 ? k.num_cus : 256);
+    dim3 g = k.grid;
+    if (g.x > cap)
+        g.x = cap;
+    return g;
+}
+
+// the small-workgroup kernels exist for the modes whose regular workgroup is larger
+// (per-ray-wavelength lists keep to the regular one)
+template <int OUT_MODE, int GEN, bool PRW, int FEAT>
+inline void launch_one(const LaunchCfg &k, const TraceArgs &a)
+{
+    static OccCache oc[2];
+    if constexpr (!PRW && has_small(OUT_MODE, FEAT)) {
+        if (k.small) {
+            constexpr int bs = block_of(OUT_MODE, FEAT, true);
+            auto kern = trace_kernel<OUT_MODE, GEN, PRW, FEAT, true>;
+            launch_with_lds(kern, wave_ticketed(OUT_MODE) ? ticket_grid(oc[1], kern, k, bs) : k.grid,
+                            dim3(bs), k.lds, k.stream, a);
+            return;
+        }
+    }
+    constexpr int bs = block_of(OUT_MODE, FEAT);
+    auto kern = trace_kernel<OUT_MODE, GEN, PRW, FEAT, false>;
+    launch_with_lds(kern, wave_ticketed(OUT_MODE) ? ticket_grid(oc[0], kern, k, bs) : k.grid, dim3(bs),
+                    k.lds, k.stream, a);
+}
+
 template <int GEN, bool PRW, int FEAT>
 inline void launch_mode(const LaunchCfg &k, const TraceArgs &a)
 {
-    const dim3 block(block_of(k.out_mode, FEAT));
     switch (k.out_mode) {
-    case ROX_OUT_FULL:
-        launch_with_lds(trace_kernel<ROX_OUT_FULL, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
-        break;
-    case ROX_OUT_LAST:
-        launch_with_lds(trace_kernel<ROX_OUT_LAST, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
-        break;
-    case ROX_OUT_OPD:
-        launch_with_lds(trace_kernel<ROX_OUT_OPD, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
-        break;
-    case ROX_OUT_HITS_COMPACT:
-        launch_with_lds(trace_kernel<ROX_OUT_HITS_COMPACT, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
-        break;
-    case ROX_OUT_FAN:
-        launch_with_lds(trace_kernel<ROX_OUT_FAN, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
-        break;
-    default:
-        launch_with_lds(trace_kernel<ROX_OUT_HITS, GEN, PRW, FEAT>, k.grid, block, k.lds, k.stream, a);
-        break;
+    case ROX_OUT_FULL: launch_one<ROX_OUT_FULL, GEN, PRW, FEAT>(k, a); break;
+    case ROX_OUT_LAST: launch_one<ROX_OUT_LAST, GEN, PRW, FEAT>(k, a); break;
+    case ROX_OUT_OPD: launch_one<ROX_OUT_OPD, GEN, PRW, FEAT>(k, a); break;
+    case ROX_OUT_HITS_COMPACT: launch_one<ROX_OUT_HITS_COMPACT, GEN, PRW, FEAT>(k, a); break;
+    case ROX_OUT_FAN: launch_one<ROX_OUT_FAN, GEN, PRW, FEAT>(k, a); break;
+    default: launch_one<ROX_OUT_HITS, GEN, PRW, FEAT>(k, a); break;
     }
 }
 
@@ -1688,29 +1876,35 @@ inline void launch_batch_with_lds(K kernel, const dim3 &grid, const dim3 &block,
     hipLaunchKernelGGL(kernel, grid, block, lds, st, items);
 }
 
+template <int OUT_MODE, int FEAT>
+inline void launch_one_batch(const LaunchCfg &k, const TraceArgs *items)
+{
+    static OccCache oc[2];
+    if constexpr (has_small(OUT_MODE, FEAT)) {
+        if (k.small) {
+            constexpr int bs = block_of(OUT_MODE, FEAT, true);
+            auto kern = trace_kernel_batch<OUT_MODE, FEAT, true>;
+            launch_batch_with_lds(kern, wave_ticketed(OUT_MODE) ? ticket_grid(oc[1], kern, k, bs) : k.grid,
+                                  dim3(bs), k.lds, k.stream, items);
+            return;
+        }
+    }
+    constexpr int bs = block_of(OUT_MODE, FEAT);
+    auto kern = trace_kernel_batch<OUT_MODE, FEAT, false>;
+    launch_batch_with_lds(kern, wave_ticketed(OUT_MODE) ? ticket_grid(oc[0], kern, k, bs) : k.grid,
+                          dim3(bs), k.lds, k.stream, items);
+}
+
 template <int FEAT>
 inline void launch_instance_batch(const LaunchCfg &k, const TraceArgs *items)
 {
-    const dim3 block(block_of(k.out_mode, FEAT));
     switch (k.out_mode) {
-    case ROX_OUT_FULL:
-        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_FULL, FEAT>, k.grid, block, k.lds, k.stream, items);
-        break;
-    case ROX_OUT_LAST:
-        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_LAST, FEAT>, k.grid, block, k.lds, k.stream, items);
-        break;
-    case ROX_OUT_OPD:
-        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_OPD, FEAT>, k.grid, block, k.lds, k.stream, items);
-        break;
-    case ROX_OUT_HITS_COMPACT:
-        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_HITS_COMPACT, FEAT>, k.grid, block, k.lds, k.stream, items);
-        break;
-    case ROX_OUT_FAN:
-        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_FAN, FEAT>, k.grid, block, k.lds, k.stream, items);
-        break;
-    default:
-        launch_batch_with_lds(trace_kernel_batch<ROX_OUT_HITS, FEAT>, k.grid, block, k.lds, k.stream, items);
-        break;
+    case ROX_OUT_FULL: launch_one_batch<ROX_OUT_FULL, FEAT>(k, items); break;
+    case ROX_OUT_LAST: launch_one_batch<ROX_OUT_LAST, FEAT>(k, items); break;
+    case ROX_OUT_OPD: launch_one_batch<ROX_OUT_OPD, FEAT>(k, items); break;
+    case ROX_OUT_HITS_COMPACT: launch_one_batch<ROX_OUT_HITS_COMPACT, FEAT>(k, items); break;
+    case ROX_OUT_FAN: launch_one_batch<ROX_OUT_FAN, FEAT>(k, items); break;
+    default: launch_one_batch<ROX_OUT_HITS, FEAT>(k, items); break;
     }
 }
 

@@ -224,6 +224,7 @@ struct StreamCtx {
     std::mutex batch_mu;                // one batch enqueue at a time per stream
     std::mutex stage_mu;                // one ROX_HOST_POINTERS call at a time per stream
     std::mutex compact_mu;              // epoch / ticket state: one HITS_COMPACT enqueue at a time
+    std::mutex ticket_mu;               // first allocation of d_ticket / d_hits_base
 };
 
 }  // namespace
@@ -422,14 +423,44 @@ int64_t rays_per_launch()
     return v;
 }
 
-// the leanest compiled instance that covers `need` (index into kInstances)
+// the leanest compiled instance that covers `need` (index into kInstances).
+// ROX_FORCE_INSTANCE=<index> (experiments: what a richer instance costs on a plain table) is
+// honoured when that instance covers the need.
 int pick_instance(int need)
 {
     const int n = (int)(sizeof kInstances / sizeof kInstances[0]);
+    static const int forced = [] {
+        const char *e = getenv("ROX_FORCE_INSTANCE");
+        return (e && *e) ? atoi(e) : -1;
+    }();
+    if (forced >= 0 && forced < n && (need & ~kInstances[forced]) == 0)
+        return forced;
     for (int i = 0; i < n; ++i)
         if ((need & ~kInstances[i]) == 0)
             return i;
     return n - 1;
+}
+
+// Workgroup size of a pupil launch (rox_device.hpp block_of()): a launch of at most
+// kSmallWavesPerCu waves per CU -- one that does not fill the chip more than about once --
+// runs in ROX_BLOCK_SMALL-thread workgroups, which the dispatcher spreads over the CUs four
+// waves at a time; larger launches keep the large workgroups whose waves write packet rows
+// together.  Measured rule: profiles/r05_block_rule.jsonl.
+// ROX_SMALL_BLOCKS=0 / 1 forces one form, ROX_SMALL_WAVES_PER_CU moves the threshold.
+constexpr int kSmallWavesPerCu = 24;
+bool want_small(const rox_system *sys, int64_t total_rays)
+{
+    static const int forced = [] {
+        const char *e = getenv("ROX_SMALL_BLOCKS");
+        return (e && *e) ? atoi(e) : -1;
+    }();
+    static const int per_cu = [] {
+        const char *e = getenv("ROX_SMALL_WAVES_PER_CU");
+        return (e && *e && atoi(e) > 0) ? atoi(e) : kSmallWavesPerCu;
+    }();
+    if (forced == 0 || forced == 1)
+        return forced == 1;
+    return (total_rays + 63) / 64 <= (int64_t)sys->num_cus * per_cu;
 }
 
 // ---- the search kernels (csrc/rox_search.hpp): the leanest instance of kSearchInstances that
@@ -485,14 +516,29 @@ void launch_feat_batch(int inst, const LaunchCfg &k, const TraceArgs *items)
 
 // (initialisations are enqueued on the launch stream itself: a stream created with
 // hipStreamNonBlocking is not ordered after NULL-stream memsets)
+// the stream context's ticket words (HITS_COMPACT tiles, the pack pass, and the wave tickets of
+// the reduced-output modes: launches of one stream run in order and each leaves them zero)
+int ensure_ticket(StreamCtx *cx, hipStream_t st)
+{
+    std::lock_guard<std::mutex> g(cx->ticket_mu);
+    if (!cx->d_ticket) {
+        uint32_t *t = nullptr;
+        int64_t *b = nullptr;
+        HIP_TRY(hipMalloc(&t, 2 * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(t, 0, 2 * sizeof(uint32_t), st));
+        HIP_TRY(hipMalloc(&b, 2 * sizeof(int64_t)));
+        HIP_TRY(hipMemsetAsync(b, 0, 2 * sizeof(int64_t), st));
+        cx->d_hits_base = b;
+        cx->d_ticket = t;
+    }
+    return 0;
+}
+
 int ensure_compact(StreamCtx *cx, int64_t tiles, hipStream_t st)
 {
-    if (!cx->d_ticket) {
-        HIP_TRY(hipMalloc(&cx->d_ticket, 2 * sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(cx->d_ticket, 0, 2 * sizeof(uint32_t), st));
-        HIP_TRY(hipMalloc(&cx->d_hits_base, 2 * sizeof(int64_t)));
-        HIP_TRY(hipMemsetAsync(cx->d_hits_base, 0, 2 * sizeof(int64_t), st));
-    }
+    int rc = ensure_ticket(cx, st);
+    if (rc)
+        return rc;
     if (tiles > cx->tiles_cap) {
         if (cx->d_tiles)
             HIP_TRY(hipFree(cx->d_tiles));      // synchronises: no launch is still reading it
@@ -517,6 +563,7 @@ int ensure_compact(StreamCtx *cx, int64_t tiles, hipStream_t st)
 // ROX_PACK_TWO_PASS=0 / 1 forces one form (experiments, tests).
 std::atomic<uint64_t> g_two_pass_launches{0}, g_fused_pack_launches{0};
 constexpr int64_t kTwoPassMinRays = 1 << 16;
+constexpr int64_t kTwoPassChunk = int64_t(1) << 24;     // rays per launch of the two-pass form
 bool want_two_pass(const rox_system *sys, int inst, int64_t n_rays, const void *dst)
 {
     const char *e = getenv("ROX_PACK_TWO_PASS");        // (read per call: tests flip it)
@@ -571,6 +618,8 @@ int launch_setup(rox_system *sys, TraceArgs &a, int gen, bool prw, hipStream_t s
         need |= F_PHFILT;
     k.gen = gen;
     k.per_ray_wvl = prw;
+    k.small = false;
+    k.num_cus = sys->num_cus;
     k.out_mode = a.opts.out_mode;
     k.stream = st;
     inst = pick_instance(need);
@@ -600,7 +649,9 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
     if (rc0)
         return rc0;
     // lane byte offsets are 32-bit: at most 2^28 rays per launch
-    const int64_t total = a.n_rays, chunk_max = rays_per_launch();
+    const int64_t total = a.n_rays;
+    int64_t chunk_max = rays_per_launch();
+    k.small = want_small(sys, total);
     const bool compact = a.opts.out_mode == ROX_OUT_HITS_COMPACT;
     StreamCtx *cx = nullptr;
     bool two_pass = false;
@@ -612,16 +663,38 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
         if (!cx)
             return fail(ROX_E_NOMEM, "out of host memory");
         compact_lock = std::unique_lock<std::mutex>(cx->compact_mu);
-        const int64_t per = total < chunk_max ? total : chunk_max;
         const int tb = block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]);
         two_pass = want_two_pass(sys, inst, total, a.out.seg);
+        if (two_pass) {
+            // the scratch of the two passes is 17 B per ray of one launch: launches of at most
+            // kTwoPassChunk rays bound it (272 MiB) whatever the call's size; the running base
+            // carries the packed order across the launches exactly as it does across 2^28-ray
+            // chunks.  Should the scratch still not be had, the fused instance -- which needs
+            // none -- takes the call.
+            if (chunk_max > kTwoPassChunk)
+                chunk_max = kTwoPassChunk;
+            const int64_t per2 = total < chunk_max ? total : chunk_max;
+            if (ensure_pack_scratch(cx, per2, a.out.status == nullptr) != 0) {
+                (void)hipGetLastError();
+                two_pass = false;
+                chunk_max = rays_per_launch();
+            }
+        }
+        const int64_t per = total < chunk_max ? total : chunk_max;
         a.small_tiles = two_pass ? 0 : compact_small_want(sys, per);
         int rc = ensure_compact(cx, two_pass ? (per + kPackTile - 1) / kPackTile
                                              : compact_tiles(per, a.small_tiles, tb), st);
-        if (!rc && two_pass)
-            rc = ensure_pack_scratch(cx, per, a.out.status == nullptr);
         if (rc)
             return rc;
+    }
+    if (!compact && wave_ticketed(a.opts.out_mode)) {
+        cx = ctx_for(sys, st);
+        if (!cx)
+            return fail(ROX_E_NOMEM, "out of host memory");
+        int rc = ensure_ticket(cx, st);
+        if (rc)
+            return rc;
+        a.ticket = cx->d_ticket;
     }
     const rox_out out0 = a.out;
     a.in_ld = total;
@@ -666,7 +739,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
             LaunchCfg kh = k;
             kh.out_mode = ROX_OUT_HITS;
             kh.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0);
-            const int hb = block_of(ROX_OUT_HITS, kInstances[inst]);
+            const int hb = block_of(ROX_OUT_HITS, kInstances[inst], kh.small);
             int64_t hblocks = (a.n_rays + hb - 1) / hb;
             const int64_t hcap = (int64_t)sys->num_cus * blocks_per_cu(hb);
             kh.grid = dim3((unsigned)(hblocks > hcap ? hcap : hblocks));
@@ -690,7 +763,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
             continue;
         }
         // enough workgroups to fill 256 CUs several times over, grid-stride the rest
-        const int bs = block_of(a.opts.out_mode, kInstances[inst]);
+        const int bs = block_of(a.opts.out_mode, kInstances[inst], k.small);
         int64_t blocks = compact ? compact_tiles(a.n_rays, a.small_tiles, bs) : (a.n_rays + bs - 1) / bs;
         const int64_t cap = (int64_t)sys->num_cus * (compact ? compact_blocks_per_cu() : blocks_per_cu(bs));
         if (blocks > cap)
@@ -1086,8 +1159,13 @@ int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_t
                 bool ident = true;
                 for (int k = 0; k < 9; ++k)
                     ident = ident && rows[i].rt[k] == eye[k] && !std::signbit(rows[i].rt[k]);
-                drows[i].pub.reserved = ident ? 1 : 0;
+                // device copy of flags: bit 1 = identity rotation (bit 0 = ROX_SURF_CV_INT_ZERO)
+                drows[i].pub.flags = (rows[i].flags & ROX_SURF_CV_INT_ZERO) | (ident ? 2 : 0);
             }
+            // device copy only: `-self.cv` as Spherical/Conic.df forms it (rox_device.hpp reads
+            // it from the cR slot, which only toroids use): +0.0 for an integer-zero curvature
+            if (rows[i].profile <= ROX_CONIC)
+                drows[i].pub.cR = (rows[i].flags & ROX_SURF_CV_INT_ZERO) ? 0.0 : -rows[i].cv;
             const double c0 = rows[i].profile == ROX_RADIALPOLY ? 1.0 : 2.0;
             double c_coef = c0;                 // profiles.py:877-882, 1104-1109, 1364-1369
             for (int k = 0; k < ROX_MAX_COEF; ++k) {
@@ -1293,14 +1371,11 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
     if (!cx)
         return fail(ROX_E_NOMEM, "out of host memory");
     std::lock_guard<std::mutex> lock(cx->batch_mu);
-    const int bs = block_of(opts[0].out_mode, kInstances[inst]);
+    k.small = want_small(sys, (int64_t)n_grids * R);
+    const int bs = block_of(opts[0].out_mode, kInstances[inst], k.small);
     int64_t blocks = (R + bs - 1) / bs;
-    if (compact) {
-        // per-item tickets and look-back states; small tiles when the whole batch is small
-        const int32_t small = ((int64_t)n_grids * R <= (int64_t)sys->num_cus * kSmallTile)
-                                  ? compact_small_want(sys, R) : 0;
-        const int64_t tiles = compact_tiles(R, small, bs);
-        blocks = tiles;
+    if (compact || wave_ticketed(opts[0].out_mode)) {
+        // per-item tickets (HITS_COMPACT tiles / the wave tickets of the reduced-output modes)
         if ((int64_t)n_grids > cx->btickets_cap) {
             if (cx->d_btickets)
                 HIP_TRY(hipFree(cx->d_btickets));
@@ -1310,6 +1385,16 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
             HIP_TRY(hipMemsetAsync(cx->d_btickets, 0, sizeof(uint32_t) * 2 * (size_t)n_grids, st));
             cx->btickets_cap = n_grids;
         }
+        if (!compact)
+            for (int32_t i = 0; i < n_grids; ++i)
+                items[i].ticket = cx->d_btickets + 2 * (size_t)i;
+    }
+    if (compact) {
+        // per-item look-back states; small tiles when the whole batch is small
+        const int32_t small = ((int64_t)n_grids * R <= (int64_t)sys->num_cus * kSmallTile)
+                                  ? compact_small_want(sys, R) : 0;
+        const int64_t tiles = compact_tiles(R, small, bs);
+        blocks = tiles;
         if ((int64_t)n_grids * tiles > cx->btiles_cap) {
             if (cx->d_btiles)
                 HIP_TRY(hipFree(cx->d_btiles));

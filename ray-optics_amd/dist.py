@@ -161,6 +161,15 @@ def exchange_counts(counts_local, plan, group=None, device='cpu'):
     return [allc[k, :len(plan[k])].copy() for k in range(world)]
 
 
+def _peer(group, r):
+    """the GLOBAL rank of group-local rank r: P2POp names its peer by global rank, and a
+    sub-group's members need not be global ranks 0..world-1"""
+    if group is None:
+        return r
+    import torch.distributed as dist
+    return dist.get_global_rank(group, r)
+
+
 def gather_packed(xy_local, n_local, totals, group=None, dst=0):
     """the path's one data exchange: every rank's packed pairs xy_local[:n_local]
     ([*, 2] f64) to rank `dst`, received at their final offsets (prefix sums of
@@ -176,7 +185,7 @@ def gather_packed(xy_local, n_local, totals, group=None, dst=0):
     mine = _wire(xy_local[:n_local], backend)
     if rank != dst:
         if n_local:
-            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine.contiguous(), dst, group)]):
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine.contiguous(), _peer(group, dst), group)]):
                 w.wait()
         return None
     out = torch.empty((sum(totals), 2), dtype=torch.float64, device=mine.device)
@@ -186,7 +195,7 @@ def gather_packed(xy_local, n_local, totals, group=None, dst=0):
         if k == dst:
             out[offs[k]:offs[k + 1]].copy_(mine)
         elif totals[k]:
-            ops.append(dist.P2POp(dist.irecv, out[offs[k]:offs[k + 1]], k, group))
+            ops.append(dist.P2POp(dist.irecv, out[offs[k]:offs[k + 1]], _peer(group, k), group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
@@ -519,77 +528,95 @@ def _trace_spot_pipelined(engine, fields, image_pts, n_wvls, num, foc, flags, gr
     tm = {'stage_sync_ms': 0.0, 'gather_ms': 0.0}
     t_kernels_done = None
     pending = []
-    for s in range(S):
-        launch_upto(s + 1 + lookahead)
-        # ---- the counts of stage s, of every rank, on the host
-        t1 = time.perf_counter()
-        if cuda:
-            side.wait_event(evs[s])
-        with on_side():
-            if world > 1:
-                if nccl:
-                    dist.all_gather_into_tensor(allc_dev[s], cnt[s:s + 1], group=group)
-                    allc[s].copy_(allc_dev[s], non_blocking=True)
-                else:
-                    dist.all_gather_into_tensor(allc[s], cnt[s:s + 1].cpu(), group=group)
-            else:
-                allc[s, 0:1].copy_(cnt[s:s + 1], non_blocking=True)
-            ev_c = event(side)
-        ev_c.synchronize()
-        tm['stage_sync_ms'] += (time.perf_counter() - t1) * 1e3
-        counts_s = [int(v) for v in allc[s].tolist()]
-        for r in range(world):
-            if s < len(order[r]):
-                if counts_s[r] < 0:
-                    raise RuntimeError(f'rank {r}: packed-hits overflow in piece {order[r][s]}')
-                placer.set(r, order[r][s], counts_s[r])
-        if s == n_mine - 1 or (n_mine == 0 and s == 0):
-            t_kernels_done = time.perf_counter()
-        # ---- rccl: the pairs of stage s go to rank 0 (grouped point-to-point)
-        ev_x = None
-        arrived = []
-        if exchange == 'rccl' and world > 1:
+    overflow = None
+    try:
+        for s in range(S):
+            launch_upto(s + 1 + lookahead)
+            # ---- the counts of stage s, of every rank, on the host
             t1 = time.perf_counter()
-            ops, keep = [], []
-            if not root:
-                if s < n_mine and counts_s[rank] > 0:
-                    p = mine[my_order[s]]
-                    with on_side():
-                        buf = xy[p.roff:p.roff + counts_s[rank]]
-                        buf = buf if nccl else buf.cpu()
-                    keep.append(buf)
-                    ops.append(dist.P2POp(dist.isend, buf, 0, group))
-            else:
-                for r in range(1, world):
-                    if s < len(order[r]):
-                        q = pieces[r][order[r][s]]
-                        arrived.append((r, order[r][s]))
-                        if counts_s[r] > 0:
-                            ops.append(dist.P2POp(dist.irecv, stage[r][q.roff:q.roff + counts_s[r]], r, group))
-            if ops:
-                with on_side():
-                    for w in dist.batch_isend_irecv(ops):
-                        w.wait()
-                    ev_x = event(side)
-            tm['gather_ms'] += (time.perf_counter() - t1) * 1e3
-        # ---- host placement: copy engine, behind the events of this stage
-        if exchange == 'host' or root:
-            cand = pending + ([(rank, my_order[s])] if s < n_mine else []) + arrived
-            pending = []
             if cuda:
-                copy.wait_event(evs[s])
-                if ev_x is not None:
-                    copy.wait_event(ev_x)
-            for r, i in cand:
-                q = pieces[r][i]
-                off = placer.offset(q.g, r, i)
-                if off is None:
-                    pending.append((r, i))
-                    continue
-                n = placer.count[(r, i)]
-                if n:
-                    src = (xy.data_ptr() if r == rank else stage[r].data_ptr()) + 16 * q.roff
-                    engine.copy_async(host_ptr + 16 * (grid_off[q.g] + off), src, 16 * n, copy)
+                side.wait_event(evs[s])
+            with on_side():
+                if world > 1:
+                    if nccl:
+                        dist.all_gather_into_tensor(allc_dev[s], cnt[s:s + 1], group=group)
+                        allc[s].copy_(allc_dev[s], non_blocking=True)
+                    else:
+                        dist.all_gather_into_tensor(allc[s], cnt[s:s + 1].cpu(), group=group)
+                else:
+                    allc[s, 0:1].copy_(cnt[s:s + 1], non_blocking=True)
+                ev_c = event(side)
+            ev_c.synchronize()
+            tm['stage_sync_ms'] += (time.perf_counter() - t1) * 1e3
+            counts_s = [int(v) for v in allc[s].tolist()]
+            for r in range(world):
+                if s < len(order[r]):
+                    if counts_s[r] < 0:
+                        # every rank sees the same counts: all of them finish this stage's
+                        # exchange (nothing moves for the overflowed piece) and raise together
+                        # below, so no peer is left waiting in a collective
+                        overflow = overflow or f'rank {r}: packed-hits overflow in piece {order[r][s]}'
+                        counts_s[r] = 0
+                    placer.set(r, order[r][s], counts_s[r])
+            if s == n_mine - 1 or (n_mine == 0 and s == 0):
+                t_kernels_done = time.perf_counter()
+            # ---- rccl: the pairs of stage s go to rank 0 (grouped point-to-point)
+            ev_x = None
+            arrived = []
+            if exchange == 'rccl' and world > 1:
+                t1 = time.perf_counter()
+                ops, keep = [], []
+                if not root:
+                    if s < n_mine and counts_s[rank] > 0:
+                        p = mine[my_order[s]]
+                        with on_side():
+                            buf = xy[p.roff:p.roff + counts_s[rank]]
+                            buf = buf if nccl else buf.cpu()
+                        keep.append(buf)
+                        ops.append(dist.P2POp(dist.isend, buf, _peer(group, 0), group))
+                else:
+                    for r in range(1, world):
+                        if s < len(order[r]):
+                            q = pieces[r][order[r][s]]
+                            arrived.append((r, order[r][s]))
+                            if counts_s[r] > 0:
+                                ops.append(dist.P2POp(dist.irecv, stage[r][q.roff:q.roff + counts_s[r]], _peer(group, r), group))
+                if ops:
+                    with on_side():
+                        for w in dist.batch_isend_irecv(ops):
+                            w.wait()
+                        ev_x = event(side)
+                tm['gather_ms'] += (time.perf_counter() - t1) * 1e3
+            if overflow:
+                raise RuntimeError(overflow)
+            # ---- host placement: copy engine, behind the events of this stage
+            if exchange == 'host' or root:
+                cand = pending + ([(rank, my_order[s])] if s < n_mine else []) + arrived
+                pending = []
+                if cuda:
+                    copy.wait_event(evs[s])
+                    if ev_x is not None:
+                        copy.wait_event(ev_x)
+                for r, i in cand:
+                    q = pieces[r][i]
+                    off = placer.offset(q.g, r, i)
+                    if off is None:
+                        pending.append((r, i))
+                        continue
+                    n = placer.count[(r, i)]
+                    if n:
+                        src = (xy.data_ptr() if r == rank else stage[r].data_ptr()) + 16 * q.roff
+                        engine.copy_async(host_ptr + 16 * (grid_off[q.g] + off), src, 16 * n, copy)
+    except BaseException:
+        # an exception out of the stage loop (overflow, a launch or collective error) must not
+        # hand xy / stage[] / the pinned lease back while copies or sends still use them
+        if cuda:
+            try:
+                copy.synchronize()
+                side.synchronize()
+            except Exception:       # noqa: BLE001  (the original error is the one to report)
+                pass
+        raise
     if t_kernels_done is None:
         t_kernels_done = time.perf_counter()
     tm['trace_ms'] = (t_kernels_done - t0) * 1e3
@@ -760,7 +787,7 @@ class ShardedPackets:
             if self.rank != dst:
                 if len(sel_mine):
                     buf = _wire(mine, self.backend).contiguous()
-                    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, dst, self.group)]):
+                    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, _peer(self.group, dst), self.group)]):
                         w.wait()
                 return None
             wire_dev = mine.device if self.backend == 'nccl' else 'cpu'
@@ -770,7 +797,7 @@ class ShardedPackets:
                 n_k = len(rows_of(k))
                 if k != dst and n_k:
                     got[k] = torch.empty((n_k, width), dtype=torch.float64, device=wire_dev)
-                    ops.append(dist.P2POp(dist.irecv, got[k], k, self.group))
+                    ops.append(dist.P2POp(dist.irecv, got[k], _peer(self.group, k), self.group))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()

@@ -3,8 +3,11 @@
 PyTorch is used only as plumbing: device buffers and the current HIP stream.
 There is no CPU fallback -- a missing library, or a missing GPU, raises.
 """
+import collections
 import ctypes as C
+import functools
 import os
+import threading
 
 import numpy as np
 
@@ -139,20 +142,48 @@ def padded_ld(R):
     return (R + 511) // 512 * 512 + 256
 
 
+def _default_pool_budget():
+    """ROX_PINNED_POOL_MB, else an eighth of the host's RAM, at most 4 GiB: page-locked memory
+    kept by the pool is taken from what HostSegment registration, RCCL and other pinned
+    allocations can get"""
+    env = os.environ.get('ROX_PINNED_POOL_MB')
+    if env:
+        return int(env) << 20
+    try:
+        ram = os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES')
+    except (ValueError, OSError, AttributeError):
+        ram = 32 << 30
+    return int(min(4 << 30, max(256 << 20, ram // 8)))
+
+
 class PinnedPool:
     """page-locked host buffers that outlive one call: handing the caller a
     NumPy array that *is* the pinned buffer saves a second pass over the data
     (a 13 MB spot diagram is ~1.5 ms of memcpy, five times the trace).  A block
-    goes back to the pool when the last array viewing it is garbage-collected."""
+    goes back to the pool when the last array viewing it is garbage-collected.
+
+    Thread safety: ``take`` and ``trim`` hold the pool's lock.  A block comes back from
+    ``_Lease.__del__`` -- any thread, any time, possibly inside a garbage collection that a
+    thread holding the lock triggered -- so ``give_back`` takes no lock: it appends to a deque
+    (atomic under the GIL) that the next ``take`` / ``trim`` shelves under the lock."""
 
     def __init__(self):
+        self._lock = threading.Lock()
+        self._returned = collections.deque()    # (nbytes, tensor) not yet shelved
         self._free = {}         # nbytes (rounded) -> [uint8 pinned tensors]
-        self._held = 0          # bytes sitting in _free
+        self._shelved = 0       # bytes sitting in _free
         # Blocks are kept up to a byte budget, not a count: a SpotDiagramFigure holds nine arrays
         # of one size at a time, and releasing / re-pinning the surplus cost 3 ms per block
         # (hipHostFree + hipHostMalloc) -- 95 ms per refresh at num_rays = 256 with a bound of
         # four blocks per size (tools/spot_figure_profile.py).
-        self.budget = int(os.environ.get('ROX_PINNED_POOL_MB', '4096')) << 20
+        self.budget = _default_pool_budget()
+
+    @property
+    def _held(self):
+        """bytes the pool keeps pinned right now (shelved + returned and not yet shelved)"""
+        with self._lock:
+            self._drain()
+            return self._shelved
 
     @staticmethod
     def _round(nbytes):
@@ -165,29 +196,54 @@ class PinnedPool:
 
     def take(self, torch, nbytes):
         n = self._round(max(int(nbytes), 1))
-        lst = self._free.get(n)
-        if lst:
-            t = lst.pop()
-            self._held -= n
-        else:
+        with self._lock:
+            self._drain()
+            lst = self._free.get(n)
+            t = None
+            if lst:
+                t = lst.pop()
+                self._shelved -= n
+        if t is None:
             t = torch.empty(n, dtype=torch.uint8).pin_memory()
         return _Lease(self, n, t)
 
     def give_back(self, n, t):
+        # (from _Lease.__del__: no lock, see the class docstring)
+        self._returned.append((n, t))
+
+    def _drain(self):
+        while True:
+            try:
+                n, t = self._returned.popleft()
+            except IndexError:
+                return
+            self._shelve(n, t)
+
+    def _shelve(self, n, t):
         # bounded by max(budget, one block): what does not fit is unpinned.  Room is made by
         # dropping blocks of OTHER sizes first (largest first) -- a pool that has swept many sizes
         # keeps what is in use now -- and a single block larger than the whole budget is still
         # kept while nothing else is (re-pinning gigabytes per call costs a second)
-        if self._held + n > self.budget:
+        if self._shelved + n > self.budget:
             for m in sorted((m for m, lst in self._free.items() if m != n and lst), reverse=True):
-                while self._free[m] and self._held + n > self.budget:
+                while self._free[m] and self._shelved + n > self.budget:
                     self._free[m].pop()
-                    self._held -= m
-                if self._held + n <= self.budget:
+                    self._shelved -= m
+                if self._shelved + n <= self.budget:
                     break
-        if self._held + n <= self.budget or self._held == 0:
+        if self._shelved + n <= self.budget or self._shelved == 0:
             self._free.setdefault(n, []).append(t)
-            self._held += n
+            self._shelved += n
+
+    def trim(self):
+        """un-pin everything the pool keeps (blocks on loan are not touched); returns the
+        bytes released.  ``session.clear()`` calls it."""
+        with self._lock:
+            self._drain()
+            freed = self._shelved
+            self._free.clear()
+            self._shelved = 0
+        return freed
 
 
 class _Lease:
@@ -319,6 +375,18 @@ class HitsPack:
         return np.diff(np.concatenate([[0], c])).astype(np.int64)
 
 
+def _in_flight(fn):
+    """a TraceEngine entry that uses the device handle (see TraceEngine.__init__)"""
+    @functools.wraps(fn)
+    def guarded(self, *args, **kwargs):
+        self._enter()
+        try:
+            return fn(self, *args, **kwargs)
+        finally:
+            self._leave()
+    return guarded
+
+
 class TraceEngine:
     """one immutable surface table on one GPU.
 
@@ -337,26 +405,65 @@ class TraceEngine:
         self.table = table
         self._nseg = {}
         self._handle = C.c_void_p()
-        with torch.cuda.device(self.device):
+        # lifetime of the device handle under threads (session.engine_for hands one engine to
+        # every thread that traces the same model, and evicts by LRU): calls in flight are
+        # counted; close() with calls in flight is carried out by the last of them; a call on
+        # a closed engine re-creates the handle from the table it was built from.  The handle
+        # is therefore never destroyed under a running rox_* call (ctypes drops the GIL).
+        self._life = threading.Lock()
+        self._calls = 0
+        self._close_pending = False
+        with self._life:
+            self._open()
+
+    def _open(self):
+        with self.torch.cuda.device(self.device):
             _check(self.lib.rox_set_device(self.device.index), 'rox_set_device')
-            _check(self.lib.rox_system_create(table.rows, table.n_ifcs,
-                                              table.n_table.ctypes.data,
-                                              table.wvls_arr.ctypes.data,
-                                              len(table.wvls), C.byref(self._handle)),
+            _check(self.lib.rox_system_create(self.table.rows, self.table.n_ifcs,
+                                              self.table.n_table.ctypes.data,
+                                              self.table.wvls_arr.ctypes.data,
+                                              len(self.table.wvls), C.byref(self._handle)),
                    'rox_system_create')
 
-    def close(self):
+    def _destroy(self):
         if self._handle:
             self.lib.rox_system_destroy(self._handle)
             self._handle = C.c_void_p()
+        self._close_pending = False
+
+    def _enter(self):
+        with self._life:
+            if not self._handle:
+                self._open()
+            self._calls += 1
+
+    def _leave(self):
+        with self._life:
+            self._calls -= 1
+            if self._calls == 0 and self._close_pending:
+                self._destroy()
+
+    @property
+    def is_open(self):
+        return bool(self._handle)
+
+    def close(self):
+        """destroy the device handle -- at once, or, with calls in flight on other threads,
+        when the last of them returns.  A later call re-creates it."""
+        with self._life:
+            if self._calls > 0:
+                self._close_pending = True
+            else:
+                self._destroy()
 
     def __del__(self):
         try:
-            self.close()
+            self._destroy()
         except Exception:
             pass
 
     # -- helpers ------------------------------------------------------------
+    @_in_flight
     def num_segments(self, flags=0):
         n = C.c_int32()
         _check(self.lib.rox_system_num_segments(self._handle, int(flags), C.byref(n)),
@@ -379,6 +486,7 @@ class TraceEngine:
                             opts.out_mode, want_pupil, nan_fill)
 
     # -- entries --------------------------------------------------------------
+    @_in_flight
     def trace_rays(self, pt0, dir0, wvl_idx=0, opts=None, nan_fill=False, out=None):
         """pt0, dir0: [3, R] (numpy or torch); wvl_idx: int or int32[R]"""
         t = self.torch
@@ -400,6 +508,7 @@ class TraceEngine:
         res._keep = (pt0, dir0, wi)     # inputs must outlive the async launch
         return res
 
+    @_in_flight
     def trace_pupil_grid(self, fld, grid, wvl_idx=0, opts=None, want_pupil=True,
                          nan_fill=False, out=None):
         opts = opts or make_opts()
@@ -422,6 +531,7 @@ class TraceEngine:
         out_arr = (abi.Out * n)(*outs)
         return n, f_arr, w_arr, o_arr, out_arr
 
+    @_in_flight
     def trace_pupil_grids(self, flds, wvl_idxs, grid, opts_list, want_pupil=True,
                           nan_fill=False, outs=None):
         """``grid`` traced for every (flds[i], wvl_idxs[i], opts_list[i]) in ONE launch
@@ -440,6 +550,7 @@ class TraceEngine:
                    'rox_trace_pupil_grids')
         return res
 
+    @_in_flight
     def trace_pupil_grids_hits(self, flds, wvl_idxs, grid, opts_list):
         """ROX_OUT_HITS_COMPACT for several (field, wavelength) pairs in one launch: a list of
         (R_ok, 2) arrays, each a view of the pinned block the kernel packed that item's
@@ -459,6 +570,7 @@ class TraceEngine:
         return [lease.array((C.c_int64.from_address(lease.ptr + 16 * R).value, 2), np.float64)
                 for lease in leases]
 
+    @_in_flight
     def trace_pupil_list(self, fld, px, py, wvl_idx=0, opts=None, want_pupil=True,
                          nan_fill=False, out=None):
         t = self.torch
@@ -495,6 +607,7 @@ class TraceEngine:
         n = C.c_int64.from_address(lease.ptr + 16 * R).value
         return lease.array((n, 2), np.float64)
 
+    @_in_flight
     def trace_pupil_grid_hits(self, fld, grid, wvl_idx, opts):
         """ROX_OUT_HITS_COMPACT over a pupil grid: the (R_ok, 2) array of
         transverse aberrations, in ray order, as a NumPy array that views the
@@ -510,6 +623,7 @@ class TraceEngine:
     def hits_pack(self, cap, max_launches, dest=None):
         return HitsPack(self.torch, self.device, cap, max_launches, dest)
 
+    @_in_flight
     def trace_pupil_grid_hits_append(self, fld, grid, wvl_idx, opts, pack):
         """enqueue one ROX_OUT_HITS_COMPACT | ROX_HITS_APPEND launch behind the pairs
         ``pack`` already holds; nothing is synchronised"""
@@ -532,6 +646,7 @@ class TraceEngine:
         pack.rays += R
         return pack
 
+    @_in_flight
     def trace_pupil_grid_hits_at(self, fld, grid, wvl_idx, opts, seg_ptr, cap, n_hits_ptr):
         """enqueue one ROX_OUT_HITS_COMPACT launch (not appending) whose packed pairs go to
         ``seg_ptr`` (room for ``cap`` pairs, device or device-visible memory) and whose count
@@ -566,6 +681,7 @@ class TraceEngine:
     def unpin_host_memory(self, ptr):
         _check(self.lib.rox_unpin_host_memory(C.c_void_p(ptr)), 'rox_unpin_host_memory')
 
+    @_in_flight
     def trace_pupil_list_hits(self, fld, px, py, wvl_idx, opts):
         t = self.torch
         px = self._dev(px, t.float64)
@@ -579,6 +695,7 @@ class TraceEngine:
                    'rox_trace_pupil_list')
         return self._hits_finish(lease, R)
 
+    @_in_flight
     def trace_rays_hits(self, pt0, dir0, wvl_idx, opts):
         t = self.torch
         pt0 = self._dev(pt0, t.float64)
@@ -597,6 +714,7 @@ class TraceEngine:
         return self._hits_finish(lease, R)
 
     # -- one ray (raytrace.trace) -----------------------------------------------
+    @_in_flight
     def trace_one(self, pt0, dir0, wvl_idx, opts):
         """one explicit ray, FULL packets, through the library's ROX_HOST_POINTERS
         path: the ray and its packet live in one NumPy block; the library copies
@@ -638,6 +756,7 @@ class TraceEngine:
         return h
 
     # -- chief-ray aiming ---------------------------------------------------------
+    @_in_flight
     def aim_chief_rays(self, probs, eps=1.0e-12):
         """probs: sequence of abi.Aim -> (aim float64[n, 2] = (x1, y1), result int32[n])"""
         n = len(probs)
@@ -650,6 +769,7 @@ class TraceEngine:
                                                self._stream()), 'rox_aim_chief_rays')
         return aim, result
 
+    @_in_flight
     def iterate_pupil_rays(self, probs, eps=1.0e-12):
         """probs: sequence of abi.PupilIter -> start_r float64[n] (vigcalc.iterate_pupil_ray)"""
         n = len(probs)
@@ -660,6 +780,7 @@ class TraceEngine:
                                                    self._stream()), 'rox_iterate_pupil_rays')
         return out
 
+    @_in_flight
     def iterate_ray_raw(self, probs, eps=1.0e-12):
         """trace.iterate_ray_raw over the path this engine's table describes: (aim [n, 2],
         result [n], last_xy [n, 2] = pupil-plane coordinates of the last trial ray the
@@ -677,6 +798,7 @@ class TraceEngine:
                    'rox_iterate_ray_raw')
         return aim, result, last_xy, last_st
 
+    @_in_flight
     def find_real_enp(self, probs, eps=1.0e-12):
         """probs: sequence of abi.Enp -> (z float64[n, 2] = (z_enp, z of the last trial ray),
         result int32[n] = abi.ENP_*)"""
@@ -690,6 +812,7 @@ class TraceEngine:
                                               self._stream()), 'rox_find_real_enp')
         return z, result
 
+    @_in_flight
     def calc_vignetting(self, probs, eps=1.0e-12):
         """probs: sequence of abi.Vig -> (vig float64[n], clip_surf int32[n])"""
         n = len(probs)
@@ -716,6 +839,7 @@ class TraceEngine:
                     for _ in range(batches))
         return ts[len(ts) // 2]
 
+    @_in_flight
     def time_pupil_grid(self, fld, grid, wvl_idx, opts, out, launches):
         """mean duration (ms) of the trace kernel over `launches` launches,
         from HIP events recorded on the launch stream"""

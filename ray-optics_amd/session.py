@@ -23,20 +23,38 @@ interface, profile or phase classes):
   'raise'      (default) UnsupportedModelError
   'reference'  the call is handed to the reference's own, unmodified function
 A missing library or GPU is never a fallback case: that always raises.
+
+Threads: the caches are guarded by one lock (``engine_for`` / ``engine_for_table`` /
+``clear`` are safe to call from any thread; a new handle is created under the lock).  Eviction
+``close()``s the least recently used engine; ``TraceEngine.close`` defers the destruction of
+the device handle until no call is in flight on it, and an evicted engine that a thread still
+holds re-creates its handle on its next call (engine.py), so an engine returned by
+``engine_for`` stays usable whatever other threads do to the cache.
 """
+import threading
 import weakref
 
 from .table import SurfaceTable
 
-ENGINE_FACTORY = None       # None -> engine.TraceEngine (the HIP path)
 FALLBACK = 'raise'
 MAX_ENGINES = 16            # device handles kept alive (least recently used out first)
 _cache = {}                 # id(seq_model) -> _Entry, in LRU order
+_lock = threading.RLock()
+_engine_factory = None      # None -> engine.TraceEngine (the HIP path)
+
+
+def _set_engine_factory(factory):
+    """TEST HOOK (tests/oracle_engine.py, tests/test_session_cache.py): the class the caches
+    instantiate instead of engine.TraceEngine; ``None`` restores the HIP engine.  Nothing in
+    the product calls it."""
+    global _engine_factory
+    with _lock:
+        _engine_factory = factory
 
 
 def _factory():
-    if ENGINE_FACTORY is not None:
-        return ENGINE_FACTORY
+    if _engine_factory is not None:
+        return _engine_factory
     from .engine import TraceEngine
     return TraceEngine
 
@@ -87,6 +105,11 @@ def _evict():
 
 
 def engine_for(opt_model):
+    with _lock:
+        return _engine_for(opt_model)
+
+
+def _engine_for(opt_model):
     sm = opt_model['seq_model']
     key = id(sm)
     ent = _cache.get(key)
@@ -140,19 +163,24 @@ def engine_for_table(table):
     list handed to ``raytrace.trace_raw``: ``gen_sequence`` output, reversed paths),
     cached by the table's bytes"""
     sig = bytes(table.rows) + table.n_table.tobytes() + repr(table.wvls).encode()
-    eng = _by_table.pop(sig, None)
-    if eng is None:
-        eng = _factory()(table)
-    _by_table[sig] = eng                # most recently used last
-    while len(_by_table) > MAX_TABLE_ENGINES:
-        _by_table.pop(next(iter(_by_table))).close()
-    return eng
+    with _lock:
+        eng = _by_table.pop(sig, None)
+        if eng is None:
+            eng = _factory()(table)
+        _by_table[sig] = eng                # most recently used last
+        while len(_by_table) > MAX_TABLE_ENGINES:
+            _by_table.pop(next(iter(_by_table))).close()
+        return eng
 
 
 def clear():
-    for ent in _cache.values():
-        ent.engine.close()
-    _cache.clear()
-    for eng in _by_table.values():
-        eng.close()
-    _by_table.clear()
+    """close every cached engine and un-pin the host blocks the pinned pool keeps"""
+    with _lock:
+        for ent in _cache.values():
+            ent.engine.close()
+        _cache.clear()
+        for eng in _by_table.values():
+            eng.close()
+        _by_table.clear()
+    from . import engine
+    engine._pool.trim()

@@ -32,13 +32,15 @@ def _profile_row(row, prof):
         raise UnsupportedModelError(f'profile {kind} is not supported')
     row.profile = abi.PROFILE_NAMES[kind]
     row.cv = float(prof.cv)
+    row.flags = 0
     if kind in ('Spherical', 'Conic') and isinstance(prof.cv, numbers.Integral) and prof.cv == 0:
         # A curvature typed as the *integer* 0 (the reference's own double Gauss data,
         # rayoptics/raytr/tests/ag_dblgauss_s.py): `-self.cv*p[0]` in Spherical/Conic.df
         # (profiles.py:360-362, 605-609) is then `0 * x` = +0 for x > 0, where a float 0.0
-        # gives `-0.0 * x` = -0.  The float that reproduces the integer's zero signs in df is
-        # -0.0; every non-zero value is the same either way.
-        row.cv = -0.0
+        # gives `-0.0 * x` = -0.  The row says so in a flag that only the df expression reads;
+        # cv stays +0.0, which is what intersect() and sag() make of the integer (a cv of
+        # -0.0 would reproduce df but turn `cv*p.dot(p) - 2*p[2]` into -0.0 at p[2] == 0).
+        row.flags = abi.SURF_CV_INT_ZERO
     if kind == 'Spherical':
         row.cc, row.ec = 0.0, 1.0
     elif kind == 'RadialPolynomial':
@@ -283,7 +285,7 @@ class SurfaceTable:
         for r in self.rows:
             rows.append(dict(
                 mode=r.mode, profile=r.profile, ncoef=r.ncoef, n_ap=r.n_ap,
-                rt_order=r.rt_order,
+                rt_order=r.rt_order, flags=r.flags,
                 cv=r.cv, cc=r.cc, ec=r.ec, cR=r.cR, coefs=list(r.coefs),
                 rt=list(r.rt), t=list(r.t), z_dir=r.z_dir,
                 max_aperture=r.max_aperture,
@@ -308,6 +310,13 @@ class SurfaceTable:
             row.ncoef, row.n_ap = s['ncoef'], s['n_ap']
             row.rt_order = s.get('rt_order', abi.RT_F_ORDER)
             row.cv, row.cc, row.ec = s['cv'], s['cc'], s['ec']
+            if 'flags' in s:
+                row.flags = s['flags']
+            elif (s['profile'] in (abi.SPHERICAL, abi.CONIC) and s['cv'] == 0.0
+                  and np.signbit(s['cv'])):
+                # tables written before the flag existed spelled an integer-zero curvature
+                # as the float -0.0 (whose df has the same zero signs)
+                row.cv, row.flags = 0.0, abi.SURF_CV_INT_ZERO
             row.cR = s.get('cR', 0.0)
             for k, c in enumerate(s['coefs']):
                 row.coefs[k] = c

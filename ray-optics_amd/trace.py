@@ -310,10 +310,10 @@ def trace_grid(opt_model, grid_rng, fld, wvl, foc, img_filter=None,
                     working_grid.append([pupil[0], pupil[1], None])
         if form == 'grid':
             grid.append(working_grid)
-    try:
-        return np.array(grid)
-    except ValueError:      # ragged packets under NumPy >= 1.24
-        return np.array(grid, dtype=object)
+    # :605 as the reference has it: ragged entries (packets, or an array-returning img_filter
+    # beside None entries) make NumPy >= 1.24 raise ValueError here exactly as they do in the
+    # reference; older NumPy builds the object array with its deprecation warning in both
+    return np.array(grid)
 
 
 def trace_fan(opt_model, fan_rng, fld, wvl, foc, img_filter=None, **kwargs):

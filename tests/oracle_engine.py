@@ -2,7 +2,7 @@
 served by the CPU oracle.  It exists so that the *host logic* of the drop-in
 layer (result views, filters, grid ordering, install/uninstall) can be
 exercised against the live reference in the build container, which has no GPU.
-It is injected through rayoptics_amd.session.ENGINE_FACTORY by tests only; the
+It is injected through rayoptics_amd.session._set_engine_factory() by tests only; the
 product default is the HIP engine, which raises without a GPU."""
 import numpy as np
 

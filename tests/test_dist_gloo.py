@@ -116,7 +116,8 @@ def test_spot_views_are_slices_of_one_buffer():
         np.testing.assert_array_equal(v2[key], v[key])
 
 
-def _worker(rank, world, port, q, by, exchange, num, name, pipeline=True, piece_rays=None, taper_min=None):
+def _worker(rank, world, port, q, by, exchange, num, name, pipeline=True, piece_rays=None, taper_min=None,
+            subgroup=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -132,6 +133,23 @@ def _worker(rank, world, port, q, by, exchange, num, name, pipeline=True, piece_
     eng = OracleEngine(wl.table)
     nw = len(wl.table.wvls)
     seg = None
+    group = None
+    if subgroup is not None:
+        # a real sub-group whose members are NOT global ranks 0..n-1 (every process creates it)
+        group = dist.new_group(ranks=list(subgroup))
+        if rank not in subgroup:
+            q.put((rank, 'outside', {}))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+        tm = {}
+        out = rdist.trace_spot_sharded(eng, wl.fields, wl.image_pts, nw, num, wl.foc, by=by,
+                                       exchange=exchange, timings=tm, pipeline=pipeline,
+                                       max_piece_rays=piece_rays, group=group)
+        q.put((rank, None if out is None else {k: v.copy() for k, v in out.items()}, tm))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if exchange == 'host':
         plan = rdist.partition(len(wl.fields), nw, num, world, by)
         # pipelined: one region per (field, wavelength) grid; round 3's form: one slice per rank
@@ -152,12 +170,12 @@ def _worker(rank, world, port, q, by, exchange, num, name, pipeline=True, piece_
     dist.destroy_process_group()
 
 
-def _run(world, by, exchange, num, name, salt, pipeline=True, piece_rays=None, taper_min=None):
+def _run(world, by, exchange, num, name, salt, pipeline=True, piece_rays=None, taper_min=None, subgroup=None):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29500 + (os.getpid() * 7 + salt) % 2000
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, by, exchange, num, name, pipeline,
-                                               piece_rays, taper_min))
+                                               piece_rays, taper_min, subgroup))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -232,6 +250,36 @@ def test_sharded_spot_matches_single_process(world, by, exchange, name, pipeline
         assert tm['pipelined'] and tm['stages'] == max(tm['pieces']) and len(tm['pieces']) == world
         if piece_rays:
             assert tm['stages'] > 2
+
+
+@pytest.mark.parametrize('pipeline', [True, False])
+def test_sharded_spot_on_a_sub_group(pipeline):
+    """the exchange names its peers by group-local rank; torch's point-to-point operations take
+    GLOBAL ranks.  On the sub-group {3, 1, 2} of a 4-process world (group rank 0 = global 3) the
+    pairs must still reach the group's root, and the process outside the group is not involved"""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import rayoptics_amd  # noqa: F401
+    from rayoptics_amd import workloads, abi
+    from oracle import oracle
+    num, name = 12, 'dblgauss_c2'
+    got = _run(4, 'rows', 'rccl', num, name, salt=777 + pipeline, pipeline=pipeline,
+               piece_rays=36 if pipeline else None, subgroup=(3, 1, 2))
+    assert got[0][0] == 'outside'
+    roots = [r for r in (1, 2, 3) if got[r][0] is not None]
+    assert roots == [1] or roots == [3] or roots == [2]
+    # torch orders a new group's ranks by global rank: group rank 0 is global rank 1
+    res, tm = got[roots[0]]
+    wl = workloads.load(name)
+    N = wl.n_ifcs
+    assert len(res) == len(wl.fields) * len(wl.table.wvls)
+    for (fi, wi), xy in res.items():
+        opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING,
+                                out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                                foc=wl.foc, image_pt=wl.image_pts[fi])
+        ref = oracle.trace_pupil_grid(wl.table, wl.fields[fi], oracle.make_grid((-1., -1.), (1., 1.), num),
+                                      wi, opts)
+        np.testing.assert_array_equal(xy, ref.hits)
+    assert len(tm['pairs_per_rank']) == 3
 
 
 def _packets_worker(rank, world, port, q, num, name, rays, dst):

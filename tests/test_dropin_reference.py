@@ -25,11 +25,11 @@ def ref():
 def installed(ref):
     from rayoptics_amd import session, install
     from oracle_engine import OracleEngine
-    session.ENGINE_FACTORY = OracleEngine
+    session._set_engine_factory(OracleEngine)
     install.install()
     yield install
     install.uninstall()
-    session.ENGINE_FACTORY = None
+    session._set_engine_factory(None)
 
 
 def both(install, fn):
@@ -1476,36 +1476,91 @@ def test_astigmatism_curve(ref, installed, model):
     assert both(installed, one)[0] == both(installed, one)[1]
 
 
+def _same_bits(ours, theirs):
+    """every component of every segment of every packet equal INCLUDING the sign of zeros"""
+    n = 0
+    for ko, kt in zip(ours, theirs):
+        assert (ko is None) == (kt is None)
+        if kt is None:
+            continue
+        assert len(ko[0]) == len(kt[0])
+        for so, st in zip(ko[0], kt[0]):
+            for k in (0, 1, 3):
+                a, b = np.asarray(so[k], dtype=float), np.asarray(st[k], dtype=float)
+                np.testing.assert_array_equal(a, b)
+                np.testing.assert_array_equal(np.signbit(a), np.signbit(b))
+            assert so[2] == st[2] and np.signbit(so[2]) == np.signbit(st[2])
+            n += 1
+        assert ko[1] == kt[1] and np.signbit(ko[1]) == np.signbit(kt[1])
+    return n
+
+
 def test_integer_zero_curvature_keeps_the_references_zero_signs(ref, installed):
     """the reference's double Gauss data gives its flat surfaces the integer curvature 0;
     `-0 * x` is +0 where `-0.0 * x` is -0, so the zero components of those surfaces' normals
-    have their own sign pattern -- reproduced (the table stores -0.0 for an integer zero);
-    compared here with the sign bit, not with =="""
+    have their own sign pattern.  The row carries ROX_SURF_CV_INT_ZERO, read by the df
+    expression only (cv stays +0.0 for intersect): every component of every segment is compared
+    here with its sign bit, not with =="""
     import rayoptics.raytr.trace as trace
     opm = ref.dblgauss()
     sm = opm['seq_model']
     flats = [i for i, ifc in enumerate(sm.ifcs) if isinstance(ifc.profile.cv, int) and ifc.profile.cv == 0]
     assert flats
-    fld = opm['osp']['fov'].fields[2]
     wvl = sm.central_wavelength()
+    for fi in (0, 2):
+        fld = opm['osp']['fov'].fields[fi]
 
-    def run():
-        got = []
-        trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 9], fld, wvl, 0.0,
-                         img_filter=lambda p, pkg: got.append(pkg), form='list', append_if_none=True)
-        return got
-    ours, theirs = both(installed, run)
-    n = 0
-    for ko, kt in zip(ours, theirs):
-        if kt is None:
-            continue
-        for s in flats:
-            if s < len(kt[0]):
-                a, b = np.asarray(ko[0][s][3]), np.asarray(kt[0][s][3])
-                np.testing.assert_array_equal(a, b)
-                np.testing.assert_array_equal(np.signbit(a), np.signbit(b))
-                n += 1
-    assert n > 50
+        def run():
+            got = []
+            trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 9], fld, wvl, 0.0,
+                             img_filter=lambda p, pkg: got.append(pkg), form='list', append_if_none=True)
+            return got
+        ours, theirs = both(installed, run)
+        assert _same_bits(ours, theirs) > 30 * 13
+
+
+def test_rays_starting_on_a_flat_integer_curvature_surface(ref, installed):
+    """finite conjugates with the object surface's curvature typed as the integer 0: every ray
+    starts at p[2] == 0 exactly, on axis with negative-zero lateral components
+    (`obj2enp_dist * [0/1, 0/1, 0]`), so `cx2 = cv*p.dot(p) - 2*p[2]`, the root `s` and the
+    object-surface intercept all carry zero signs that a curvature of -0.0 would flip"""
+    import rayoptics.raytr.trace as trace
+    import rayoptics.raytr.raytrace as rt
+    from rayoptics.elem.profiles import Conic
+    opm = ref.new_model(('object', 'epd'), 8.0, ('object', 'height'), 5.0, [0., 0.7, 1.0],
+                        [(550.0, 1.0)], 0, obj_thi=120.0)
+    sm = opm['seq_model']
+    sm.ifcs[0].profile.cv = 0                  # the integer
+    sm.add_surface([0, 3.0])                   # a flat dummy (integer again)
+    sm.add_surface([1 / 45.0, 6.0, 1.6, 50.0])
+    sm.set_stop()
+    sm.add_surface([0, 4.0])
+    sm.add_surface([-1 / 60.0, 80.0])
+    sm.ifcs[4].profile = Conic(c=0, cc=-0.5)   # a Conic with the integer, too
+    ref.finish(opm)
+    assert all(isinstance(sm.ifcs[i].profile.cv, int) for i in (0, 1, 3, 4))
+    wvl = sm.central_wavelength()
+    total = 0
+    for fld in opm['osp']['fov'].fields:
+        def run():
+            got = []
+            trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 7], fld, wvl, 0.0,
+                             img_filter=lambda p, pkg: got.append(pkg), form='list', append_if_none=True)
+            return got
+        ours, theirs = both(installed, run)
+        total += _same_bits(ours, theirs)
+    assert total > 3 * 20 * 6
+
+    # explicit rays from a point ON the flat object surface with signed zeros spelled out
+    def run_one():
+        out = []
+        for p0 in ([0.0, 0.0, 0.0], [-0.0, -0.0, 0.0], [-0.0, 2.0, 0.0], [1.5, -0.0, -0.0]):
+            for d0 in ([0.0, 0.0, 1.0], [0.02, -0.01, np.sqrt(1 - 0.02 ** 2 - 0.01 ** 2)],
+                       [-0.0, 0.0, 1.0]):
+                out.append(rt.trace(sm, np.array(p0), np.array(d0), wvl))
+        return out
+    ours, theirs = both(installed, run_one)
+    assert _same_bits(ours, theirs) == 12 * 6
 
 
 @pytest.mark.parametrize('model', ['dblgauss', 'rc_telescope', 'cell_phone'])
@@ -1527,3 +1582,43 @@ def test_trace_all_fields_dataframes(ref, installed, model):
             np.testing.assert_array_equal(np.asarray(a, dtype=float), np.asarray(b, dtype=float))
             n += 1
     assert n > 100
+
+
+def test_trace_grid_fails_where_the_reference_fails(ref, installed):
+    """trace.trace_grid ends in np.array(grid) (trace.py:605).  Ragged content -- packets in the
+    entries (no img_filter), or an array-returning img_filter beside None entries -- makes
+    NumPy >= 1.24 raise ValueError there; the drop-in must end the same way under the running
+    NumPy, whatever that is, for both forms"""
+    import rayoptics.raytr.trace as trace
+    opm = ref.dblgauss()
+    fld = opm['optical_spec']['fov'].fields[2]     # vignetted field: some entries are None
+
+    def outcome(fn):
+        try:
+            out = fn()
+        except Exception as e:      # noqa: BLE001
+            return ('raised', type(e).__name__, str(e).split('.')[0])
+        return ('returned', out.shape, out.dtype.str)
+
+    cases = [
+        dict(img_filter=None, form='grid', append_if_none=True),
+        dict(img_filter=None, form='list', append_if_none=True),
+        dict(img_filter=None, form='list', append_if_none=False),
+        dict(img_filter=lambda p, pkg: None if pkg is None else np.array([p[0], p[1], pkg[1]]),
+             form='grid', append_if_none=True),
+        dict(img_filter=lambda p, pkg: None if pkg is None else np.array([p[0], p[1], pkg[1]]),
+             form='list', append_if_none=True),
+        dict(img_filter=lambda p, pkg: None if pkg is None else np.array([p[0], p[1], pkg[1]]),
+             form='list', append_if_none=False),
+        dict(img_filter=lambda p, pkg: None if pkg is None else np.array([p[0], p[1], pkg[1]]),
+             form='grid', append_if_none=False),
+    ]
+    seen = set()
+    for kw in cases:
+        def run():
+            return trace.trace_grid(opm, [np.array([-1., -1.]), np.array([1., 1.]), 9], fld, 587.6, 0.0,
+                                    **kw)
+        ours, theirs = both(installed, lambda: outcome(run))
+        assert ours == theirs, (kw['form'], kw['append_if_none'], ours, theirs)
+        seen.add(ours[0])
+    assert seen == {'raised', 'returned'}       # both endings occur under this NumPy

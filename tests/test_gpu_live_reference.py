@@ -28,11 +28,11 @@ from test_dropin_reference import ref, both      # noqa: E402,F401  (fixture + h
 
 @pytest.fixture()
 def installed(ref):
-    """the drop-ins over the product engine: ENGINE_FACTORY None = engine.TraceEngine = HIP"""
+    """the drop-ins over the product engine: engine factory None = engine.TraceEngine = HIP"""
     from rayoptics_amd import session, install
     from rayoptics_amd.engine import TraceEngine, load_library
     load_library()
-    session.ENGINE_FACTORY = None
+    session._set_engine_factory(None)
     assert session._factory() is TraceEngine
     install.install()
     yield install

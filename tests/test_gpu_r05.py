@@ -1,0 +1,190 @@
+"""-m gpu, round 5: the small-workgroup kernels (roxtrace.hip want_small) give the bytes the
+large-workgroup kernels give; the reworked asphere evaluation against the oracle at full size;
+many threads over more models than the session keeps handles for."""
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from rayoptics_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+SPOT = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SMALL_SCRIPT = r'''
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import rayoptics_amd
+from rayoptics_amd import abi, workloads
+from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+SPOT = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+out = {}
+for name, num in (('dblgauss_c2', 97), ('rc_telescope_c4', 256), ('nikkor_c3', 130), ('cell_phone', 65),
+                  ('zmx_evenasph_c3', 200)):
+    wl = workloads.load(name)
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    grid = make_grid((-1., -1.), (1., 1.), num)
+    fis = list(range(len(wl.fields)))
+    for mode in (abi.OUT_FULL, abi.OUT_HITS, abi.OUT_LAST):
+        h = hashlib.sha256()
+        optl = [make_opts(flags=SPOT, out_mode=mode, first_surf=1, last_surf=N - 2, foc=wl.foc,
+                          image_pt=wl.image_pts[f]) for f in fis]
+        # one launch per grid, then the same grids batched into one launch
+        singles = [eng.trace_pupil_grid(wl.fields[f], grid, wl.ref_wvl_idx, optl[f], nan_fill=True).to_host()
+                   for f in fis]
+        batch = [r.to_host() for r in eng.trace_pupil_grids([wl.fields[f] for f in fis],
+                                                            [wl.ref_wvl_idx] * len(fis), grid, optl,
+                                                            nan_fill=True)]
+        for a, b in zip(singles, batch):
+            for x, y in ((a.seg, b.seg), (a.op, b.op), (a.status, b.status), (a.fail_surf, b.fail_surf)):
+                assert np.array_equal(x, y, equal_nan=True), (name, mode, 'batch differs from single launches')
+            for x in (a.seg, a.op, a.status, a.fail_surf):
+                h.update(np.ascontiguousarray(x).tobytes())
+        out['%%s/%%d' %% (name, mode)] = h.hexdigest()
+    # explicit rays (the list seam): a few hundred rays = a small launch
+    rng = np.random.default_rng(5)
+    R = 333
+    pt0 = np.stack([rng.uniform(-2, 2, R), rng.uniform(-2, 2, R), np.full(R, -50.0)])
+    d = np.stack([rng.uniform(-.02, .02, R), rng.uniform(-.02, .02, R), np.ones(R)])
+    d /= np.sqrt((d * d).sum(0))
+    o = make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES, out_mode=abi.OUT_FULL, first_surf=1, last_surf=N - 2)
+    r = eng.trace_rays(pt0, d, wl.ref_wvl_idx, o, nan_fill=True).to_host()
+    h = hashlib.sha256()
+    for x in (r.seg, r.op, r.status, r.fail_surf):
+        h.update(np.ascontiguousarray(x).tobytes())
+    out[name + '/rays'] = h.hexdigest()
+    eng.close()
+print(json.dumps(out))
+'''
+
+
+def test_small_and_large_workgroups_give_the_same_bytes():
+    """ROX_SMALL_BLOCKS is read once per process: the same launches in two processes, one
+    forcing the small-workgroup kernels and one forbidding them -- FULL / HITS / LAST packets,
+    single and batched launches, explicit rays, five instances -- must hash the same"""
+    import json
+    res = {}
+    for v in ('0', '1'):
+        env = dict(os.environ, ROX_SMALL_BLOCKS=v)
+        p = subprocess.run([sys.executable, '-c', _SMALL_SCRIPT % {'root': ROOT}], env=env, cwd=ROOT,
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[v] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res['0'] == res['1']
+    assert len(res['0']) == 5 * 4
+
+
+@pytest.mark.parametrize('name,fi', [('zmx_evenasph_c3', 0), ('zmx_evenasph_c3', 2), ('nikkor_c3', 1),
+                                     ('cell_phone', 2)])
+def test_asphere_instances_full_size_against_the_oracle(name, fi):
+    """a 1024 x 1024 grid through the Newton instances (shared power chain, branch on
+    (cc + 1) == ec, slim Spencer-Murty quotient): every packet component of every ray equals
+    the oracle's -- compared in row blocks so that the oracle's share stays in seconds"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    wl = workloads.load(name)
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    wi = wl.ref_wvl_idx
+    num = 1024
+    o = make_opts(flags=SPOT, out_mode=abi.OUT_FULL, first_surf=1, last_surf=N - 2, foc=wl.foc,
+                  image_pt=wl.image_pts[fi])
+    dev = eng.trace_pupil_grid(wl.fields[fi], make_grid((-1., -1.), (1., 1.), num), wi, o,
+                               nan_fill=True).to_host()
+    oo = oracle.make_opts(flags=SPOT, out_mode=abi.OUT_FULL, first_surf=1, last_surf=N - 2, foc=wl.foc,
+                          image_pt=wl.image_pts[fi])
+    for row0 in (0, 311, 512, 1000):
+        rows = 24
+        orc = oracle.trace_pupil_grid(wl.table, wl.fields[fi],
+                                      oracle.make_grid((-1., -1.), (1., 1.), num, row_begin=row0,
+                                                       row_count=rows), wi, oo)
+        sl = slice(row0 * num, (row0 + rows) * num)
+        assert np.array_equal(dev.status[sl], orc.status)
+        assert np.array_equal(dev.fail_surf[sl], orc.fail_surf)
+        assert np.array_equal(dev.seg[:, :, sl], orc.seg, equal_nan=True)
+        assert np.array_equal(dev.op[sl], orc.op, equal_nan=True)
+    eng.close()
+
+
+def _perturbed_models(n):
+    """n table-backed models with distinct surface tables (curvatures of the double Gauss and of
+    the phone lens nudged): distinct device handles for the session cache"""
+    from rayoptics_amd import workloads
+    from rayoptics_amd.table import SurfaceTable
+    models = []
+    for k in range(n):
+        base = workloads.load('dblgauss_c2' if k % 2 == 0 else 'cell_phone')
+        d = base.table.to_dict()
+        t = SurfaceTable.from_dict(d)
+        t.rows[2].cv = t.rows[2].cv * (1.0 + 1e-4 * (k + 1))
+        wl = workloads.SimpleWorkload(t, base.fields, base.image_pts, foc=base.foc,
+                                      ref_wvl_idx=base.ref_wvl_idx, name=f'm{k}')
+        models.append(workloads.TableModel(wl))
+    return models
+
+
+def test_eight_threads_over_twenty_models_with_sixteen_handles():
+    """session.engine_for from 8 threads over 20 distinct models while the cache keeps 16
+    handles: engines are evicted (closed) under threads that still hold them and re-open on
+    their next call; PinnedPool leases come and go on every thread.  No crash, no error, every
+    result equal to the oracle's."""
+    from oracle import oracle
+    from rayoptics_amd import session
+    from rayoptics_amd.engine import make_opts, make_grid, TraceEngine
+    session.clear()
+    assert session.MAX_ENGINES == 16
+    models = _perturbed_models(20)
+    grid = make_grid((-1., -1.), (1., 1.), 48)
+    want = []
+    for m in models:
+        wl = m.workload
+        N = wl.n_ifcs
+        oo = oracle.make_opts(flags=SPOT, out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                              foc=wl.foc, image_pt=wl.image_pts[1])
+        want.append(oracle.trace_pupil_grid(wl.table, wl.fields[1], oracle.make_grid((-1., -1.), (1., 1.), 48),
+                                            wl.ref_wvl_idx, oo).hits)
+    errors, counts = [], [0] * 8
+    stop = time.time() + 10.0
+    reopened = [0]
+
+    def worker(tid):
+        rng = np.random.default_rng(100 + tid)
+        try:
+            while time.time() < stop:
+                k = int(rng.integers(len(models)))
+                m = models[k]
+                wl = m.workload
+                eng = session.engine_for(m)
+                assert isinstance(eng, TraceEngine)
+                if rng.random() < 0.2:
+                    time.sleep(0.002)           # hold the engine while others evict it
+                    if not eng.is_open:
+                        reopened[0] += 1
+                o = make_opts(flags=SPOT, out_mode=abi.OUT_HITS_COMPACT, first_surf=1,
+                              last_surf=wl.n_ifcs - 2, foc=wl.foc, image_pt=wl.image_pts[1])
+                xy = eng.trace_pupil_grid_hits(wl.fields[1], grid, wl.ref_wvl_idx, o)
+                if not np.array_equal(xy, want[k]):
+                    errors.append((tid, k, 'result differs from the oracle'))
+                    return
+                counts[tid] += 1
+        except Exception as e:      # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    session.clear()
+    assert not errors, errors[:3]
+    assert min(counts) > 20, counts
+    assert len(session._cache) == 0

@@ -57,7 +57,7 @@ def test_calc_psf_dropin_against_the_live_reference():
     from oracle import oracle
     from oracle_engine import OracleEngine
     from rayoptics_amd import analyses, install, session
-    session.ENGINE_FACTORY = OracleEngine
+    session._set_engine_factory(OracleEngine)
     analyses.PSF_BACKEND = oracle.calc_psf
     opm = rm.dblgauss()
     fld = opm['osp']['fov'].fields[1]
@@ -72,7 +72,7 @@ def test_calc_psf_dropin_against_the_live_reference():
         direct = ranalyses.calc_psf(ours_grid.grid[2], 16, 48)
     finally:
         install.uninstall()
-        session.ENGINE_FACTORY = None
+        session._set_engine_factory(None)
         analyses.PSF_BACKEND = None
     assert ours.shape == theirs.shape == (48, 48)
     np.testing.assert_allclose(ours, theirs, rtol=0, atol=ATOL)

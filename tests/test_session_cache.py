@@ -31,10 +31,10 @@ def sess():
     from rayoptics_amd import session
     session.clear()
     CountingEngine.made = CountingEngine.closed = 0
-    session.ENGINE_FACTORY = CountingEngine
+    session._set_engine_factory(CountingEngine)
     yield session, rm
     session.clear()
-    session.ENGINE_FACTORY = None
+    session._set_engine_factory(None)
 
 
 def test_handle_reuse_revalidation_and_replacement(sess):
@@ -161,3 +161,100 @@ def test_pinned_pool_keeps_blocks_by_a_byte_budget():
     again = pool.take(_Torch, 200 << 20)
     assert len(pinned) == n_pins            # ... and still reused
     del again
+
+
+def test_pinned_pool_under_threads():
+    """take / give_back from eight threads (leases dropped on any thread, some inside
+    collections): no block is handed out twice at the same time, nothing is lost, and the
+    byte budget holds"""
+    import gc
+    import threading
+    from rayoptics_amd.engine import PinnedPool
+
+    made = []
+    lock = threading.Lock()
+
+    class _T:
+        def __init__(self, n):
+            self.n = n
+            self.owner = None
+            with lock:
+                made.append(self)
+
+        def data_ptr(self):
+            return id(self)
+
+    class _Torch:
+        uint8 = None
+
+        @staticmethod
+        def empty(n, dtype=None):
+            class _E:
+                def pin_memory(self):
+                    return _T(n)
+            return _E()
+
+    pool = PinnedPool()
+    pool.budget = 8 << 20
+    errors = []
+
+    def worker(tid):
+        rng = np.random.default_rng(tid)
+        held = []
+        for it in range(3000):
+            lease = pool.take(_Torch, int(rng.choice([4096, 65536, 1 << 20])))
+            t = lease.tensor
+            if t.owner is not None:
+                errors.append('block handed out twice')
+                return
+            t.owner = tid
+            held.append(lease)
+            if len(held) > 4 or rng.random() < 0.3:
+                old = held.pop(0)
+                old.tensor.owner = None
+                del old
+            if it % 500 == 0:
+                gc.collect()
+        for l in held:
+            l.tensor.owner = None
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors
+    gc.collect()
+    assert pool._held <= pool.budget
+    assert pool.trim() >= 0 and pool._held == 0
+
+
+def test_engine_cache_under_threads(sess):
+    """engine_for from six threads over more models than MAX_ENGINES: one engine per model
+    state at any time (no two threads build the same model's engine concurrently), the cache
+    never exceeds its bound"""
+    import threading
+    session, rm = sess
+    session.MAX_ENGINES, saved = 4, session.MAX_ENGINES
+    try:
+        models = [rm.singlet() for _ in range(7)]
+        errors = []
+
+        def worker(tid):
+            rng = np.random.default_rng(tid)
+            for _ in range(300):
+                m = models[int(rng.integers(len(models)))]
+                e = session.engine_for(m)
+                if e.table is None or len(session._cache) > session.MAX_ENGINES:
+                    errors.append('bad cache state')
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errors
+        assert len(session._cache) <= 4
+        # every engine ever made and no longer cached was closed exactly once
+        assert CountingEngine.made - CountingEngine.closed == len(session._cache)
+    finally:
+        session.MAX_ENGINES = saved

@@ -69,10 +69,10 @@ def soak_dropins(hip=False):
     import rayoptics.raytr.vigcalc as vigcalc
     import rayoptics.raytr.analyses as analyses
     if hip:
-        session.ENGINE_FACTORY = None
+        session._set_engine_factory(None)
     else:
         from oracle_engine import OracleEngine
-        session.ENGINE_FACTORY = OracleEngine
+        session._set_engine_factory(OracleEngine)
     eng = 'HIP engine' if hip else 'oracle double'
     rng = np.random.default_rng(177 if hip else 77)
     t0, bad, n = time.time(), [], 0
@@ -146,7 +146,7 @@ def soak_dropins(hip=False):
                       'engine': eng, 'cases': n, 'mismatches': bad[:5], 'seconds': round(time.time() - t0, 1)}))
     if hip:
         soak_packets_hip(ref, install)
-    session.ENGINE_FACTORY = None
+    session._set_engine_factory(None)
 
 
 def soak_packets_hip(ref, install):
@@ -263,7 +263,7 @@ def soak_round3(hip=False):
                             return type(e).__name__
                     install.uninstall()
                     z_ref = call()
-                    session.ENGINE_FACTORY = None
+                    session._set_engine_factory(None)
                     install.install()
                     z_dev = call()
                     install.uninstall()
@@ -289,7 +289,7 @@ def soak_round3(hip=False):
                       'mismatches': bad[:5], 'result_codes': {str(k): v for k, v in sorted(codes.items())},
                       'seconds': round(time.time() - t0, 1)}))
     # 2-D aiming and the fan figure callbacks through the drop-ins (oracle as the engine)
-    session.ENGINE_FACTORY = None if hip else OracleEngine
+    session._set_engine_factory(None if hip else OracleEngine)
     eng = 'HIP engine' if hip else 'oracle double'
     t0, n, bad = time.time(), 0, []
     for build in (ref.dblgauss, ref.nikkor, ref.cell_phone):
@@ -345,7 +345,7 @@ def soak_round3(hip=False):
                     bad.append((build.__name__, trial, data_type))
     print(json.dumps({'soak': 'RayFanFigure (Ray / OPD) through SequentialModel.trace_fan on perturbed models', 'engine': eng,
                       'figures': n, 'mismatches': bad[:5], 'seconds': round(time.time() - t0, 1)}))
-    session.ENGINE_FACTORY = None
+    session._set_engine_factory(None)
 
 
 def soak_round4(hip=False):
@@ -362,7 +362,7 @@ def soak_round4(hip=False):
     from oracle_engine import OracleEngine
     import rayoptics.raytr.wideangle as wa
     rng = np.random.default_rng(144 if hip else 44)
-    session.ENGINE_FACTORY = None if hip else OracleEngine
+    session._set_engine_factory(None if hip else OracleEngine)
     t0, n, n2d, n_exc, bad = time.time(), 0, 0, 0, []
     for trial in range(120):
         opm = ref.zmx_evenasph_c3()
@@ -402,7 +402,7 @@ def soak_round4(hip=False):
                               '(' + ('HIP engine' if hip else 'oracle as the engine') + ') == the reference, bit for bit',
                       'cases': n, 'two_d_cases': int(n2d), 'cases_where_both_raise': int(n_exc),
                       'mismatches': bad[:5], 'n_mismatches': len(bad), 'seconds': round(time.time() - t0, 1)}))
-    session.ENGINE_FACTORY = None
+    session._set_engine_factory(None)
 
 
 if __name__ == '__main__':
