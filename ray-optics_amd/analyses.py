@@ -202,6 +202,11 @@ def eval_wavefront(opt_model, fld, wvl, foc, image_pt_2d=None, image_delta=None,
 
 
 def seq_trace_wavefront(self, fld, wvl, foc, num_rays=32):
+    with session.hold(self.opt_model):      # one validation of the model for the whole call
+        return _seq_trace_wavefront(self, fld, wvl, foc, num_rays)
+
+
+def _seq_trace_wavefront(self, fld, wvl, foc, num_rays=32):
     """rayoptics/seq/sequential.py:1087-1114 as a replacement *method* of
     SequentialModel: [x, y, opd] over the unit pupil square, opd in waves
     (``opd / nm_to_sys_units(wvl)``), 0.0 where the ray failed.  The reference

@@ -18,7 +18,7 @@
 //   rayoptics/elem/profiles.py:849-885   EvenPolynomial.sag/df \ poly_eval()
 //   rayoptics/elem/profiles.py:1070-1113 RadialPolynomial.sag/df/
 //   rayoptics/elem/profiles.py:1317-1437 Y/XToroid            /
-//   rayoptics/elem/surface.py:198-208, 416-457 point_inside    -> inside_aperture()
+//   rayoptics/elem/surface.py:198-208, 416-457 point_inside    -> inside_aperture_list()
 //   rayoptics/raytr/opticalspec.py:289-400, 1339-1353; trace.py:298-308
 //                                         pupil -> (pt0, dir0) -> ray_start()
 //
@@ -69,8 +69,16 @@
 #ifndef ROX_MIN_WAVES_POLY   // waves per SIMD the reduced-output modes of those instances are compiled for
 #define ROX_MIN_WAVES_POLY ROX_MIN_WAVES
 #endif
+#ifndef ROX_KERNEL_ALIGN     // alignment of the trace kernels' code (0: the compiler's 256 bytes)
+#define ROX_KERNEL_ALIGN 0
+#endif
+#if ROX_KERNEL_ALIGN > 0
+#define ROX_KERNEL_ALIGNED __attribute__((aligned(ROX_KERNEL_ALIGN)))
+#else
+#define ROX_KERNEL_ALIGNED
+#endif
 #ifndef ROX_WAVE_TICKETS     // 1: the reduced-output modes (HITS, LAST, OPD, FAN) run as resident waves that
-#define ROX_WAVE_TICKETS 1    //    draw 64-ray tiles by ticket (wave_ticketed() below)
+#define ROX_WAVE_TICKETS 0    //    stride over 64-ray tiles (wave_ticketed() below): measured slower, off
 #endif
 #ifndef ROX_BLOCK_SMALL      // workgroup size of launches that do not fill the chip (block_of() below)
 #define ROX_BLOCK_SMALL 256
@@ -143,14 +151,21 @@ constexpr int block_of(int out_mode, int feat, bool small = false)
          : out_mode == ROX_OUT_FULL ? ((feat & kFeatNewton) ? ROX_BLOCK_FULL_POLY : ROX_BLOCK_FULL)
          : ((feat & kFeatNewton) ? ROX_BLOCK_POLY : ROX_BLOCK);
 }
-// The reduced-output modes have no reason to keep a workgroup's waves together (no packet rows
-// to write in step): there a launch is one chip-load of resident workgroups whose WAVES draw
-// 64-ray tiles by ticket until the batch is through.  A wave whose rays die at the first
-// aperture draws its next tile at once instead of idling until its workgroup retires, the table
-// is staged once per resident workgroup instead of once per 512 rays, and no wave slot waits for
-// a workgroup launch: counters of round 4 (r04_pmc_summary_*) put the AVERAGE occupancy of the
-// one-tile-per-workgroup form at 2.7 of 4 waves per SIMD on the 13-interface asphere models and
-// 4.1 of 6 on the double Gauss.
+// EXPERIMENT (ROX_WAVE_TICKETS=1, off): the reduced-output modes as one chip-load of resident
+// workgroups whose WAVES stride over the 64-ray tiles of the batch -- wave w takes tiles w,
+// w + W, w + 2W ... -- so that the table is staged once per resident workgroup and no wave slot
+// waits for a workgroup launch.  Round 4's counters had put the average occupancy of the
+// one-tile-per-workgroup form at 2.7 of 4 waves per SIMD on the 13-interface asphere models
+// (4.1 of 6 on the double Gauss) and VALU utilisation tracks it.  Measured (profiles/
+// r05_wave_striding.txt): the hardware dispatcher handing out four times as many workgroups as
+// fit IS the better balancer -- static striding over exactly the resident waves is 3-10 % slower
+// (double Gauss HITS 112 -> 115 us, .zmx zoom 160 -> 174, Nikkor 328 -> 355), and drawing tiles
+// dynamically by an atomic ticket per wave three times slower: a device-scope atomic on one
+// address is performed at the memory side of the eight L2s, 15-35 ns each, serialised
+// (profiles/r05_wave_tickets.txt).  What the low average is made of is the drain of a single
+// launch (the last workgroups' lifetime with the chip emptying), which a batch of grids in one
+// launch pays once.
+constexpr int kWtShards = 32, kWtStride = 64;      // 32 counters, 256 B apart
 constexpr bool wave_ticketed(int out_mode)
 {
     return ROX_WAVE_TICKETS && out_mode != ROX_OUT_FULL && out_mode != ROX_OUT_HITS_COMPACT &&
@@ -238,7 +253,10 @@ struct TraceArgs {
     int32_t row_begin;         // AXIS_PRODUCT: first pupil row of this launch
     // HITS_COMPACT: decoupled look-back state of this launch
     uint64_t *tile_state;      // [tiles] (epoch << 32 | flag << 30 | count)
-    uint32_t *ticket;          // [0] next tile, [1] workgroups (wave tickets: waves) done
+    uint32_t *ticket;          // [0] next tile, [1] workgroups done
+    // ROX_WAVE_TICKETS == 2: this launch's sharded tile counters (kWtShards words, kWtStride
+    // apart) and the set the NEXT launch of the stream will use, which this one zeroes
+    uint32_t *wt_cur, *wt_next;
     // pairs already in out.seg when this launch starts (earlier launches of a chunked
     // call; earlier calls with ROX_HITS_APPEND) -- nullptr = none -- and where the running
     // total goes.  Never the same word: a tile may still be reading the base while the
@@ -738,31 +756,52 @@ __device__ __forceinline__ bool newton_hit(int kind, double cv, double cc1, doub
     return true;
 }
 
-// surface.py:198-208 (+ interface.py:113-122, surface.py:416-419, 453-457)
-__device__ __forceinline__ bool inside_aperture(tblp row, int n_ap, double x,
-                                                double y, double fuzz)
+// surface.py:198-208 (+ surface.py:416-419, 453-457): the AND over an interface's
+// clear_apertures.  A circular aperture's radius slot of the STAGED row holds
+// sqrt_le_threshold(radius + fuzz) (stage_aperture_thresholds() below), so that
+// `sqrt(xx*xx + yy*yy) <= radius + fuzz` is decided without the square root, outcome for
+// outcome; interfaces without a list take the max_aperture threshold (Ctx.apthr).
+__device__ __forceinline__ bool inside_aperture_list(tblp row, int n_ap, double x, double y, double fuzz)
 {
-    if (n_ap > 0) {
-        tblp ap = row + (offsetof(rox_surface, ap) / sizeof(double));
-        for (int k = 0; k < n_ap; ++k, ap += sizeof(rox_aperture) / sizeof(double)) {
-            const int2 ki{((tbli)ap)[0], ((tbli)ap)[1]};            // kind, is_obscuration
-            const double xx = x - ap[1];
-            const double yy = y - ap[2];
-            bool ans;
-            if (ki.x == ROX_AP_CIRCULAR)
-                ans = sqrt(xx * xx + yy * yy) <= ap[3] + fuzz;
-            else if (ki.x == ROX_AP_RECTANGULAR)
-                ans = (fabs(xx) <= ap[3] + fuzz) && (fabs(yy) <= ap[4] + fuzz);
-            else
-                return false;               // Elliptical: point_inside() returns None
-            if (ki.y)
-                ans = !ans;
-            if (!ans)
-                return false;
-        }
-        return true;
+    tblp ap = row + (offsetof(rox_surface, ap) / sizeof(double));
+    for (int k = 0; k < n_ap; ++k, ap += sizeof(rox_aperture) / sizeof(double)) {
+        const int2 ki{((tbli)ap)[0], ((tbli)ap)[1]};            // kind, is_obscuration
+        const double xx = x - ap[1];
+        const double yy = y - ap[2];
+        bool ans;
+        if (ki.x == ROX_AP_CIRCULAR)
+            ans = (xx * xx + yy * yy) <= ap[3];                 // the staged threshold
+        else if (ki.x == ROX_AP_RECTANGULAR)
+            ans = (fabs(xx) <= ap[3] + fuzz) && (fabs(yy) <= ap[4] + fuzz);
+        else
+            return false;               // Elliptical: point_inside() returns None
+        if (ki.y)
+            ans = !ans;
+        if (!ans)
+            return false;
     }
-    return sqrt(x * x + y * y) <= row[offsetof(rox_surface, max_aperture) / sizeof(double)] + fuzz;
+    return true;
+}
+
+// Post-pass over the table a workgroup has staged in LDS (instances with aperture lists; call
+// between two workgroup barriers): the radius of every circular clear aperture becomes the
+// largest s with sqrt(s) <= radius + fuzz.  `fuzz` is the launch's pt_inside_fuzz.
+template <int FEAT>
+__device__ __forceinline__ void stage_aperture_thresholds(double *tbl_w, int N, double fuzz, int tid,
+                                                          int nthreads)
+{
+    if (!(FEAT & F_APLIST))
+        return;
+    for (int i = tid; i < N * ROX_MAX_AP; i += nthreads) {
+        double *row = tbl_w + (size_t)(i / ROX_MAX_AP) * kRowDoubles;
+        const int k = i % ROX_MAX_AP;
+        if (k < reinterpret_cast<const int32_t *>(row)[3]) {
+            double *ap = row + offsetof(rox_surface, ap) / sizeof(double) +
+                         (size_t)k * (sizeof(rox_aperture) / sizeof(double));
+            if (reinterpret_cast<const int32_t *>(ap)[0] == ROX_AP_CIRCULAR)
+                ap[3] = sqrt_le_threshold(ap[3] + fuzz);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ phase
@@ -1036,7 +1075,7 @@ struct Ctx {
     tblp phc;               // [N][kPhaseConsts] or [W][N][kPhaseConsts]; FEAT & F_PHASE only
     tblp wvls;              // [W]
     tbli slot, nslots_before;
-    tblp apthr;             // [N] sqrt_le_threshold(max_aperture + fuzz) (instances without F_APLIST)
+    tblp apthr;             // [N] sqrt_le_threshold(max_aperture + fuzz)
     int N;
     bool check_ap, intersect_obj, filter_ph;
     int first_surf, last_surf;
@@ -1238,8 +1277,9 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         // :198-202 aperture test (in_surface_range, :134-142)
         if (c.check_ap && surf >= c.first_surf && (c.last_surf < 0 || surf <= c.last_surf) &&
             mode != ROX_PHANTOM) {
-            const bool in = (FEAT & F_APLIST)
-                ? inside_aperture(row, ((tbli)row)[3], inc.x, inc.y, c.fuzz)
+            const int n_ap = (FEAT & F_APLIST) ? ((tbli)row)[3] : 0;
+            const bool in = n_ap > 0
+                ? inside_aperture_list(row, n_ap, inc.x, inc.y, c.fuzz)
                 : (inc.x * inc.x + inc.y * inc.y) <= c.apthr[surf];   // sqrt-free, see above
             if (!in)
                 status = ROX_BLOCKED;               // :247-251
@@ -1521,11 +1561,14 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
         wvls_w[i] = a.wvls[i];
     for (int i = threadIdx.x; i < 2 * N; i += kB)
         slot_w[i] = a.slots[i];
-    if (!(FEAT & F_APLIST))
-        for (int i = threadIdx.x; i < N; i += kB)
-            apthr_w[i] = sqrt_le_threshold(
-                a.rows[(size_t)i * kRowDoubles + offsetof(rox_surface, max_aperture) / 8] + a.opts.fuzz);
+    for (int i = threadIdx.x; i < N; i += kB)
+        apthr_w[i] = sqrt_le_threshold(
+            a.rows[(size_t)i * kRowDoubles + offsetof(rox_surface, max_aperture) / 8] + a.opts.fuzz);
     __syncthreads();
+    if (FEAT & F_APLIST) {
+        stage_aperture_thresholds<FEAT>(tbl_w, N, a.opts.fuzz, threadIdx.x, kB);
+        __syncthreads();
+    }
 
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w; c.apthr = apthr_w;
@@ -1554,11 +1597,24 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     int64_t pend_tile = -1, pend_it = 0;    // HITS_COMPACT: the tile whose finish is deferred
     int pend_total = 0;
 
-    // wave tickets: lane 0 holds the wave's next ticket.  It is drawn one tile ahead, so the
-    // atomic's round trip to L2 passes behind the trace of the current tile.
+    // wave striding: this wave's first tile and the stride (all waves of the launch)
+    const int64_t wv_first = (int64_t)blockIdx.x * (kB / 64) + __builtin_amdgcn_readfirstlane(wave);
+    const int64_t wv_stride = (int64_t)gridDim.x * (kB / 64);
+    // sharded tickets (ROX_WAVE_TICKETS == 2): the workgroups with blockIdx.x = s (mod shards)
+    // draw the tiles = s (mod shards) from counter s -- dynamic within a shard, every shard the
+    // same interleaved sample of the batch.  One word takes ~90 returning device-scope atomics
+    // per microsecond; 32 words on 32 lines take them side by side.  Lane 0 holds the wave's
+    // next draw, made one tile ahead.
+    const int wt_shards = (int)gridDim.x < kWtShards ? (int)gridDim.x : kWtShards;
+    const int wt_shard = (int)(blockIdx.x % (unsigned)wt_shards);
     uint32_t tk = 0;
-    if (kWaveTick && lane == 0)
-        tk = atomicAdd(&a.ticket[0], 1u);
+    if (kWaveTick && ROX_WAVE_TICKETS == 2) {
+        if (blockIdx.x == 0 && threadIdx.x < kWtShards)
+            __hip_atomic_store(&a.wt_next[threadIdx.x * kWtStride], 0u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0)
+            tk = atomicAdd(&a.wt_cur[wt_shard * kWtStride], 1u);
+    }
     for (int64_t it = 0;; ++it) {
         int64_t tile;
         if (kCompact) {
@@ -1567,10 +1623,12 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
             __syncthreads();
             // (wave-uniform by construction: keep it in scalar registers across the trace)
             tile = (int64_t)__builtin_amdgcn_readfirstlane((int)s_tile);
-        } else if (kWaveTick) {
-            tile = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+        } else if (kWaveTick && ROX_WAVE_TICKETS == 2) {
+            tile = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk) * wt_shards + wt_shard;
             if (tile < n_tiles && lane == 0)
-                tk = atomicAdd(&a.ticket[0], 1u);
+                tk = atomicAdd(&a.wt_cur[wt_shard * kWtStride], 1u);
+        } else if (kWaveTick) {
+            tile = wv_first + it * wv_stride;
         } else {
             tile = (int64_t)blockIdx.x + it * gridDim.x;
         }
@@ -1712,14 +1770,6 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     }
     if (kCompact && kDefer && pend_tile >= 0)
         finish_tile<kB>(a, pend_tile, pend_total, stash_w + (size_t)(pend_it & 1) * kB, n_tiles, &s_excl);
-    if (kWaveTick && lane == 0) {
-        // the last wave out re-arms the ticket (every wave's last draw -- the one that ran past
-        // the end -- has returned before it counts itself out)
-        if (atomicAdd(&a.ticket[1], 1u) == gridDim.x * (unsigned)(kB / 64) - 1) {
-            __hip_atomic_store(&a.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     if (kCompact && threadIdx.x == 0) {
         // the last workgroup out re-arms the ticket for the next launch of this
         // stream context (every workgroup leaves exactly once, after its last draw)
@@ -1732,7 +1782,7 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
 
 template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT, bool SMALL = false>
 __global__ void __launch_bounds__(block_of(OUT_MODE, FEAT, SMALL), min_waves_of(OUT_MODE, FEAT))
-trace_kernel(const TraceArgs a)
+ROX_KERNEL_ALIGNED trace_kernel(const TraceArgs a)
 {
     trace_tiles<OUT_MODE, GEN, PER_RAY_WVL, FEAT, SMALL>(a);
 }
@@ -1745,7 +1795,7 @@ trace_kernel(const TraceArgs a)
 typedef const __attribute__((address_space(4))) TraceArgs *ConstTraceArgs;
 template <int OUT_MODE, int FEAT, bool SMALL = false>
 __global__ void __launch_bounds__(block_of(OUT_MODE, FEAT, SMALL), min_waves_of(OUT_MODE, FEAT))
-trace_kernel_batch(const TraceArgs *items)
+ROX_KERNEL_ALIGNED trace_kernel_batch(const TraceArgs *items)
 {
     trace_tiles<OUT_MODE, GEN_PUPIL, false, FEAT, SMALL>(*(ConstTraceArgs)(items + blockIdx.y));
 }
@@ -1775,12 +1825,11 @@ inline void launch_with_lds(K kernel, const dim3 &grid, const dim3 &block, size_
     hipLaunchKernelGGL(kernel, grid, block, lds, st, a);
 }
 
-// Wave-ticketed modes: no more workgroups than the chip holds at once (the resident waves draw
-// every tile; a workgroup dispatched after them would stage the table to find the tickets gone).
-// The runtime's occupancy figure for (kernel, workgroup size, dynamic LDS) is cached per kernel
-// instantiation; should it be one workgroup per CU high (it has been seen to be at some SGPR
-// counts), the surplus workgroups start when the first resident ones retire and leave at once.
-// ROX_TICKET_BLOCKS_PER_CU overrides it for experiments.
+// Wave-strided modes: no more workgroups than the chip holds at once.  The runtime's occupancy
+// figure for (kernel, workgroup size, dynamic LDS) is cached per kernel instantiation and capped
+// at six waves per SIMD (every trace kernel uses 106 SGPRs: 800 / (112 + 16) waves; the API has
+// been seen one workgroup per CU high near such limits -- a surplus workgroup would run its
+// share of the tiles alone after everyone else).  ROX_TICKET_BLOCKS_PER_CU overrides it.
 struct OccCache {
     std::mutex mu;
     size_t lds = ~size_t(0);
@@ -1805,7 +1854,8 @@ inline dim3 ticket_grid(OccCache &oc, K kernel, const LaunchCfg &k, int block)
                 (void)hipGetLastError();
                 n = 1;
             }
-            oc.per_cu = n;
+            const int sgpr_cap = 6 * 4 * 64 / block;        // six waves per SIMD
+            oc.per_cu = n > sgpr_cap && sgpr_cap >= 1 ? sgpr_cap : n;
             oc.lds = k.lds;
         }
         per_cu = oc.per_cu;
@@ -1910,18 +1960,23 @@ inline void launch_instance_batch(const LaunchCfg &k, const TraceArgs *items)
 
 // the feature instances that are compiled (one translation unit each,
 // csrc/inst_*.hip); the host launches the first one that covers the need
-constexpr int kInstances[] = {0, F_EVEN, F_RADIAL, F_POLY, F_APLIST, F_ALL};
+// (F_EVEN | F_APLIST: what a Zemax import with an EVENASPH surface needs -- every .zmx interface
+// carries a clear-aperture list.  BASELINE configs[2]'s file ran on the general instance until
+// round 5: 392 wave-VALU per wave-surface against 300 lean, profiles/r05_valu_account.json.)
+constexpr int kInstances[] = {0, F_EVEN, F_RADIAL, F_POLY, F_APLIST, F_EVEN | F_APLIST, F_ALL};
 void launch_lean(const LaunchCfg &, const TraceArgs &);
 void launch_even(const LaunchCfg &, const TraceArgs &);
 void launch_radial(const LaunchCfg &, const TraceArgs &);
 void launch_poly(const LaunchCfg &, const TraceArgs &);
 void launch_aplist(const LaunchCfg &, const TraceArgs &);
+void launch_evenap(const LaunchCfg &, const TraceArgs &);
 void launch_general(const LaunchCfg &, const TraceArgs &);
 void launch_lean_batch(const LaunchCfg &, const TraceArgs *);
 void launch_even_batch(const LaunchCfg &, const TraceArgs *);
 void launch_radial_batch(const LaunchCfg &, const TraceArgs *);
 void launch_poly_batch(const LaunchCfg &, const TraceArgs *);
 void launch_aplist_batch(const LaunchCfg &, const TraceArgs *);
+void launch_evenap_batch(const LaunchCfg &, const TraceArgs *);
 void launch_general_batch(const LaunchCfg &, const TraceArgs *);
 
 // the pack pass of two-pass packed hits (csrc/pack.hip): a plain ROX_OUT_HITS launch has left

@@ -309,14 +309,17 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
         wvls_w[i] = a.wvls[i];
     for (int i = threadIdx.x; i < 2 * N; i += 64)
         slot_w[i] = a.slots[i];
-    // instances without F_APLIST: the sqrt-free aperture thresholds of the checked trace
+    // the sqrt-free aperture thresholds of the checked trace
     // (pt_inside_fuzz = 1e-4), behind the slot map
     double *apthr_w = reinterpret_cast<double *>(slot_w + 2 * N);
-    if (!(FEAT & F_APLIST))
-        for (int i = threadIdx.x; i < N; i += 64)
-            apthr_w[i] = sqrt_le_threshold(
-                a.rows[(size_t)i * kRowDoubles + offsetof(rox_surface, max_aperture) / 8] + 1e-4);
+    for (int i = threadIdx.x; i < N; i += 64)
+        apthr_w[i] = sqrt_le_threshold(
+            a.rows[(size_t)i * kRowDoubles + offsetof(rox_surface, max_aperture) / 8] + 1e-4);
     __syncthreads();
+    if (FEAT & F_APLIST) {      // (only the checked trace, fuzz 1e-4, tests apertures here)
+        stage_aperture_thresholds<FEAT>(tbl_w, N, 1e-4, threadIdx.x, 64);
+        __syncthreads();
+    }
     const int i = a.wave_per_problem ? (int)blockIdx.x : (int)(blockIdx.x * 64 + threadIdx.x);
     if (i >= a.n)
         return;
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
     c.slot = slot_w; c.nslots_before = slot_w + N;
-    c.apthr = apthr_w;          // (read by the instances without F_APLIST, checked trace only)
+    c.apthr = apthr_w;          // (checked trace only)
     c.N = N;
     c.filter_ph = false;
     c.intersect_obj = pb.fld.kind != ROX_FLD_EPD_WIDE && pb.fld.z_dir0 != 0.0;     // trace.py:302-303
@@ -359,8 +362,10 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     };
     // ifcs[s].edge_pt_target(start_dir)[xy]: surface.py:210-218, 422-427, 459-464,
     // interface.py:94-111 (the first clear aperture that is not an obscuration)
+    // (read from the table in global memory: the staged copy's circular radii have become the
+    // aperture test's thresholds, stage_aperture_thresholds())
     auto edge = [&](int s) -> double {
-        tblp row = tbl_w + (size_t)s * kRowDoubles;
+        tblp row = a.rows + (size_t)s * kRowDoubles;
         const int n_ap = ((tbli)row)[3];
         tblp ap = row + (offsetof(rox_surface, ap) / sizeof(double));
         for (int k = 0; k < n_ap; ++k, ap += sizeof(rox_aperture) / sizeof(double)) {

@@ -225,6 +225,12 @@ struct StreamCtx {
     std::mutex stage_mu;                // one ROX_HOST_POINTERS call at a time per stream
     std::mutex compact_mu;              // epoch / ticket state: one HITS_COMPACT enqueue at a time
     std::mutex ticket_mu;               // first allocation of d_ticket / d_hits_base
+    // ROX_WAVE_TICKETS == 2 (experiment): two sets of [items][kWtShards] sharded tile counters;
+    // launch n of the stream draws from set n & 1 and zeroes the other for launch n + 1
+    uint32_t *d_wt = nullptr;
+    int64_t wt_items_cap = 0;
+    uint32_t wt_parity = 0;
+    std::mutex wt_mu;
 };
 
 }  // namespace
@@ -441,14 +447,20 @@ int pick_instance(int need)
     return n - 1;
 }
 
-// Workgroup size of a pupil launch (rox_device.hpp block_of()): a launch of at most
-// kSmallWavesPerCu waves per CU -- one that does not fill the chip more than about once --
-// runs in ROX_BLOCK_SMALL-thread workgroups, which the dispatcher spreads over the CUs four
-// waves at a time; larger launches keep the large workgroups whose waves write packet rows
-// together.  Measured rule: profiles/r05_block_rule.jsonl.
-// ROX_SMALL_BLOCKS=0 / 1 forces one form, ROX_SMALL_WAVES_PER_CU moves the threshold.
+// Workgroup size of a launch (rox_device.hpp block_of()), measured rule
+// (profiles/r05_block_rule.jsonl, tools/block_rule_sweep.py):
+//  * FULL packets (1024-thread workgroups, one per CU, whose waves write packet rows in step
+//    -- worth 13-23 % of the store rate on launches that fill the chip): a launch of at most
+//    four rounds of such workgroups that would leave >= 30 % of its CU-rounds idle -- 64
+//    workgroups (256^2 rays: 75 %), BASELINE configs[3]'s 320 on 256 CUs (two rounds, 37.5 %)
+//    -- runs in ROX_BLOCK_SMALL-thread workgroups instead,
+//    five of which fit a CU (256^2: 49 -> 29 us, configs[3]: 43.6 -> 34.0 us per pass);
+//  * the reduced-output modes (512-thread workgroups): small workgroups up to kSmallWavesPerCu
+//    waves per CU (configs[3]: 25.8 -> 23.9 us, 3 x 256^2: 43 -> 37 us), equal beyond, 3 % worse
+//    at 2^20 rays.
+// ROX_SMALL_BLOCKS=0 / 1 forces one form, ROX_SMALL_WAVES_PER_CU moves the second threshold.
 constexpr int kSmallWavesPerCu = 24;
-bool want_small(const rox_system *sys, int64_t total_rays)
+bool want_small(const rox_system *sys, int64_t total_rays, int out_mode, int feat, int64_t n_items = 1)
 {
     static const int forced = [] {
         const char *e = getenv("ROX_SMALL_BLOCKS");
@@ -460,6 +472,16 @@ bool want_small(const rox_system *sys, int64_t total_rays)
     }();
     if (forced == 0 || forced == 1)
         return forced == 1;
+    if (out_mode == ROX_OUT_FULL) {
+        const int64_t big = block_of(ROX_OUT_FULL, feat, false);
+        if (big <= ROX_BLOCK_SMALL)
+            return false;                   // (the Newton instances: already small)
+        const int64_t per_item = (total_rays / n_items + big - 1) / big;
+        const int64_t wgs = per_item * n_items, cus = sys->num_cus;
+        const int64_t rounds = (wgs + cus - 1) / cus;
+        const int64_t idle = rounds * cus - wgs;
+        return rounds <= 4 && idle * 10 >= 3 * rounds * cus;
+    }
     return (total_rays + 63) / 64 <= (int64_t)sys->num_cus * per_cu;
 }
 
@@ -502,7 +524,7 @@ void launch_feat(int inst, const LaunchCfg &k, const TraceArgs &a)
 {
     typedef void (*fn)(const LaunchCfg &, const TraceArgs &);
     static const fn fns[] = {launch_lean, launch_even, launch_radial, launch_poly,
-                             launch_aplist, launch_general};
+                             launch_aplist, launch_evenap, launch_general};
     fns[inst](k, a);
 }
 
@@ -510,14 +532,15 @@ void launch_feat_batch(int inst, const LaunchCfg &k, const TraceArgs *items)
 {
     typedef void (*fn)(const LaunchCfg &, const TraceArgs *);
     static const fn fns[] = {launch_lean_batch, launch_even_batch, launch_radial_batch,
-                             launch_poly_batch, launch_aplist_batch, launch_general_batch};
+                             launch_poly_batch, launch_aplist_batch, launch_evenap_batch,
+                             launch_general_batch};
     fns[inst](k, items);
 }
 
 // (initialisations are enqueued on the launch stream itself: a stream created with
 // hipStreamNonBlocking is not ordered after NULL-stream memsets)
-// the stream context's ticket words (HITS_COMPACT tiles, the pack pass, and the wave tickets of
-// the reduced-output modes: launches of one stream run in order and each leaves them zero)
+// the stream context's ticket words (HITS_COMPACT tiles and the pack pass: launches of one
+// stream run in order and each leaves them zero)
 int ensure_ticket(StreamCtx *cx, hipStream_t st)
 {
     std::lock_guard<std::mutex> g(cx->ticket_mu);
@@ -531,6 +554,31 @@ int ensure_ticket(StreamCtx *cx, hipStream_t st)
         cx->d_hits_base = b;
         cx->d_ticket = t;
     }
+    return 0;
+}
+
+// sharded wave tickets of a launch of n_items items: items[i].wt_cur / wt_next
+int assign_wave_tickets(StreamCtx *cx, TraceArgs *items, int64_t n_items, hipStream_t st)
+{
+    const size_t per_item = (size_t)kWtShards * kWtStride;
+    if (n_items > cx->wt_items_cap) {
+        if (cx->d_wt)
+            HIP_TRY(hipFree(cx->d_wt));         // synchronises with the launches using it
+        cx->d_wt = nullptr;
+        cx->wt_items_cap = 0;
+        const int64_t cap = n_items < 16 ? 16 : n_items;
+        HIP_TRY(hipMalloc(&cx->d_wt, sizeof(uint32_t) * 2 * per_item * (size_t)cap));
+        HIP_TRY(hipMemsetAsync(cx->d_wt, 0, sizeof(uint32_t) * 2 * per_item * (size_t)cap, st));
+        cx->wt_items_cap = cap;
+        cx->wt_parity = 0;
+    }
+    uint32_t *cur = cx->d_wt + (size_t)(cx->wt_parity & 1) * per_item * (size_t)cx->wt_items_cap;
+    uint32_t *nxt = cx->d_wt + (size_t)((cx->wt_parity & 1) ^ 1) * per_item * (size_t)cx->wt_items_cap;
+    for (int64_t i = 0; i < n_items; ++i) {
+        items[i].wt_cur = cur + (size_t)i * per_item;
+        items[i].wt_next = nxt + (size_t)i * per_item;
+    }
+    ++cx->wt_parity;
     return 0;
 }
 
@@ -651,7 +699,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
     // lane byte offsets are 32-bit: at most 2^28 rays per launch
     const int64_t total = a.n_rays;
     int64_t chunk_max = rays_per_launch();
-    k.small = want_small(sys, total);
+    k.small = want_small(sys, total, a.opts.out_mode, kInstances[inst]);
     const bool compact = a.opts.out_mode == ROX_OUT_HITS_COMPACT;
     StreamCtx *cx = nullptr;
     bool two_pass = false;
@@ -686,15 +734,6 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
                                              : compact_tiles(per, a.small_tiles, tb), st);
         if (rc)
             return rc;
-    }
-    if (!compact && wave_ticketed(a.opts.out_mode)) {
-        cx = ctx_for(sys, st);
-        if (!cx)
-            return fail(ROX_E_NOMEM, "out of host memory");
-        int rc = ensure_ticket(cx, st);
-        if (rc)
-            return rc;
-        a.ticket = cx->d_ticket;
     }
     const rox_out out0 = a.out;
     a.in_ld = total;
@@ -743,7 +782,15 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
             int64_t hblocks = (a.n_rays + hb - 1) / hb;
             const int64_t hcap = (int64_t)sys->num_cus * blocks_per_cu(hb);
             kh.grid = dim3((unsigned)(hblocks > hcap ? hcap : hblocks));
-            launch_feat(inst, kh, h);
+            if (ROX_WAVE_TICKETS == 2) {
+                std::lock_guard<std::mutex> wg(cx->wt_mu);
+                int rcw = assign_wave_tickets(cx, &h, 1, st);
+                if (rcw)
+                    return rcw;
+                launch_feat(inst, kh, h);
+            } else {
+                launch_feat(inst, kh, h);
+            }
             // pass 2: survivors to their final place, in ray order
             PackArgs p;
             p.status = h.out.status;
@@ -769,7 +816,18 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
         if (blocks > cap)
             blocks = cap;
         k.grid = dim3((unsigned)blocks);
-        launch_feat(inst, k, a);
+        if (ROX_WAVE_TICKETS == 2 && wave_ticketed(a.opts.out_mode)) {
+            StreamCtx *wx = ctx_for(sys, st);
+            if (!wx)
+                return fail(ROX_E_NOMEM, "out of host memory");
+            std::lock_guard<std::mutex> wg(wx->wt_mu);
+            int rcw = assign_wave_tickets(wx, &a, 1, st);
+            if (rcw)
+                return rcw;
+            launch_feat(inst, k, a);
+        } else {
+            launch_feat(inst, k, a);
+        }
     }
     a.n_rays = total;
     a.out = out0;
@@ -1371,11 +1429,11 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
     if (!cx)
         return fail(ROX_E_NOMEM, "out of host memory");
     std::lock_guard<std::mutex> lock(cx->batch_mu);
-    k.small = want_small(sys, (int64_t)n_grids * R);
+    k.small = want_small(sys, (int64_t)n_grids * R, opts[0].out_mode, kInstances[inst], n_grids);
     const int bs = block_of(opts[0].out_mode, kInstances[inst], k.small);
     int64_t blocks = (R + bs - 1) / bs;
-    if (compact || wave_ticketed(opts[0].out_mode)) {
-        // per-item tickets (HITS_COMPACT tiles / the wave tickets of the reduced-output modes)
+    if (compact) {
+        // per-item tickets
         if ((int64_t)n_grids > cx->btickets_cap) {
             if (cx->d_btickets)
                 HIP_TRY(hipFree(cx->d_btickets));
@@ -1385,11 +1443,6 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
             HIP_TRY(hipMemsetAsync(cx->d_btickets, 0, sizeof(uint32_t) * 2 * (size_t)n_grids, st));
             cx->btickets_cap = n_grids;
         }
-        if (!compact)
-            for (int32_t i = 0; i < n_grids; ++i)
-                items[i].ticket = cx->d_btickets + 2 * (size_t)i;
-    }
-    if (compact) {
         // per-item look-back states; small tiles when the whole batch is small
         const int32_t small = ((int64_t)n_grids * R <= (int64_t)sys->num_cus * kSmallTile)
                                   ? compact_small_want(sys, R) : 0;
@@ -1424,6 +1477,11 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
     const int64_t cap = (int64_t)sys->num_cus * (compact ? compact_blocks_per_cu() : blocks_per_cu(bs));
     if (blocks > cap)
         blocks = cap;
+    if (ROX_WAVE_TICKETS == 2 && wave_ticketed(opts[0].out_mode)) {
+        std::lock_guard<std::mutex> wg(cx->wt_mu);      // (batch_mu keeps the enqueue order)
+        if ((rc = assign_wave_tickets(cx, items.data(), n_grids, st)))
+            return rc;
+    }
     // items -> pinned slot -> device, in stream order
     if (n_grids > cx->items_cap) {
         if (cx->d_items)

@@ -551,6 +551,54 @@ class TraceEngine:
         return res
 
     @_in_flight
+    def trace_pupil_grids_host(self, flds, wvl_idxs, grid, opts_list):
+        """FULL (or LAST) packets of several small pupil grids by ONE launch whose stores go
+        straight into one pinned host block -- no copy-engine transfer, one synchronise --
+        for figure-sized batches (the chief rays of every field and wavelength of a model,
+        trace.trace_chief_ray).  Returns one host result per item (``seg`` [n_seg, 10, R],
+        ``op``, ``status``, ``fail_surf``, ``pupil``: NumPy views of the block; segments past
+        a failure are NaN)."""
+        R = grid_rays(grid)
+        n = len(flds)
+        mode = opts_list[0].out_mode
+        rows = (self.num_segments(opts_list[0].flags) if mode == abi.OUT_FULL else 1) * abi.SEG_DOUBLES
+        b_seg, b_op, b_pu = 8 * rows * R, 8 * R, 16 * R
+        b_st, b_fs = (R + 15) // 16 * 16, (2 * R + 15) // 16 * 16
+        per = b_seg + b_op + b_pu + b_st + b_fs
+        lease = _pool.take(self.torch, per * n)
+        whole = lease.array((per * n // 8,), np.float64)
+        whole.fill(np.nan)
+        outs, views = [], []
+        for i in range(n):
+            base = lease.ptr + i * per
+            o = abi.Out()
+            o.seg, o.op, o.pupil = base, base + b_seg, base + b_seg + b_op
+            o.status = base + b_seg + b_op + b_pu
+            o.fail_surf = o.status + b_st
+            o.ld = R
+            outs.append(o)
+            off = i * per
+
+            class _H:
+                pass
+            h = _H()
+            h.R, h.out_mode = R, mode
+            h.seg = lease.array((rows // abi.SEG_DOUBLES, abi.SEG_DOUBLES, R) if mode == abi.OUT_FULL
+                                else (abi.SEG_DOUBLES, R), np.float64, off)
+            h.op = lease.array((R,), np.float64, off + b_seg)
+            h.pupil = lease.array((2, R), np.float64, off + b_seg + b_op)
+            h.status = lease.array((R,), np.uint8, off + b_seg + b_op + b_pu)
+            h.fail_surf = lease.array((R,), np.int16, off + b_seg + b_op + b_pu + b_st)
+            views.append(h)
+        n, f_arr, w_arr, o_arr, out_arr = self._batch_args(flds, wvl_idxs, opts_list, outs)
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_trace_pupil_grids(self._handle, n, f_arr, w_arr, C.byref(grid),
+                                                  o_arr, out_arr, self._stream()),
+                   'rox_trace_pupil_grids')
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return views
+
+    @_in_flight
     def trace_pupil_grids_hits(self, flds, wvl_idxs, grid, opts_list):
         """ROX_OUT_HITS_COMPACT for several (field, wavelength) pairs in one launch: a list of
         (R_ok, 2) arrays, each a view of the pinned block the kernel packed that item's

@@ -73,6 +73,9 @@ def install(fallback='raise'):
              (rtrace, 'trace_astigmatism', _t.trace_astigmatism),
              # trace_field / trace_all_fields: a field's list of rays as one launch
              (rtrace, 'trace_ray_list_at_field', _t.trace_ray_list_at_field),
+             # setup_pupil_coords -> get_chief_ray_pkg -> trace_chief_ray (bare module globals of
+             # rayoptics.raytr.trace): the chief rays of all fields x wavelengths in one launch
+             (rtrace, 'trace_chief_ray', _t.trace_chief_ray),
              (rtrace, 'aim_chief_ray', _t.aim_chief_ray),
              (ropticalspec, 'aim_chief_ray', _t.aim_chief_ray),
              # the wide-angle pupil search behind aim_chief_ray (trace.py:634-635) and

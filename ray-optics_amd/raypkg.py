@@ -25,21 +25,36 @@ except Exception:
 
 
 class LazyRay:
-    """sequence of ray segments of one ray; segment k is built on access"""
-    __slots__ = ('_seg', '_r', '_n', '_named')
+    """sequence of ray segments of one ray; segment k is built on access.  The first segment
+    asked for is gathered alone (a spot diagram reads ray[-1] of a million rays and nothing
+    else); a second request gathers the ray's whole [n, 10] block once and every segment after
+    that is three views of it (vigcalc.max_aperture_at_surf walks every segment of every
+    boundary ray: 370 segments per model update)."""
+    __slots__ = ('_seg', '_r', '_n', '_named', '_blk', '_asked')
 
     def __init__(self, seg, r, nseg, named=False):
         self._seg = seg         # numpy [K, 10, R] (FULL) or [1, 10, R]
         self._r = r
         self._n = nseg
         self._named = named
+        self._blk = None
+        self._asked = False
 
     def __len__(self):
         return self._n
 
     def _make(self, k):
-        s = self._seg[k, :, self._r]
-        item = [s[0:3].copy(), s[3:6].copy(), float(s[6]), s[7:10].copy()]
+        if self._blk is not None:
+            s = self._blk[k]
+            item = [s[0:3], s[3:6], float(s[6]), s[7:10]]
+        elif self._asked and self._n > 1:
+            self._blk = np.ascontiguousarray(self._seg[:self._n, :, self._r])
+            s = self._blk[k]
+            item = [s[0:3], s[3:6], float(s[6]), s[7:10]]
+        else:
+            self._asked = True
+            s = self._seg[k, :, self._r]        # (fancy-free gather: a fresh 10-vector)
+            item = [s[0:3].copy(), s[3:6].copy(), float(s[6]), s[7:10].copy()]
         return RaySeg(*item) if self._named else item
 
     def __getitem__(self, k):
@@ -51,12 +66,14 @@ class LazyRay:
             raise IndexError('ray segment index out of range')
         return self._make(k)
 
+    def to_list(self):
+        self._asked = True
+        return [self._make(k) for k in range(self._n)]
+
     def __iter__(self):
+        self._asked = True
         for k in range(self._n):
             yield self._make(k)
-
-    def to_list(self):
-        return [self._make(k) for k in range(self._n)]
 
     def __repr__(self):
         return f'LazyRay({self._n} segments, ray {self._r})'

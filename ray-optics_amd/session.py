@@ -104,7 +104,54 @@ def _evict():
         _cache.pop(key).engine.close()
 
 
+_held = threading.local()       # .models: {id(seq_model): [depth, engine, memo dict]}
+
+
+class hold:
+    """``with session.hold(opt_model):`` -- for the duration of ONE drop-in call that asks for
+    the model's engine many times (a fan figure's chief rays and launches: 7 requests per fan),
+    validate the model once and answer the rest from that: the fingerprint walk over the
+    interfaces costs ~25 us a time.  Per thread; the model is not expected to change inside
+    one call of the reference's API (the reference's own ``path()`` cache assumes as much).
+    ``memo`` is a scratch dict for values that are constant over the same span
+    (table.field_from_model)."""
+
+    def __init__(self, opt_model):
+        self._key = id(opt_model['seq_model'])
+        self._model = opt_model
+
+    def __enter__(self):
+        models = _held.__dict__.setdefault('models', {})
+        ent = models.get(self._key)
+        if ent is None:
+            models[self._key] = ent = [0, engine_for(self._model), {}]
+        ent[0] += 1
+        return ent[1]
+
+    def __exit__(self, *exc):
+        models = _held.models
+        ent = models[self._key]
+        ent[0] -= 1
+        if ent[0] == 0:
+            del models[self._key]
+        return False
+
+
+def held_memo(opt_model):
+    """the scratch dict of the innermost ``hold`` on this model in this thread, or None"""
+    models = getattr(_held, 'models', None)
+    if not models:
+        return None
+    ent = models.get(id(opt_model['seq_model']))
+    return ent[2] if ent is not None else None
+
+
 def engine_for(opt_model):
+    models = getattr(_held, 'models', None)
+    if models:
+        ent = models.get(id(opt_model['seq_model']))
+        if ent is not None:
+            return ent[1]
     with _lock:
         return _engine_for(opt_model)
 

@@ -418,6 +418,23 @@ def field_from_model(opt_model, fld, pupil_type='rel pupil', cache=None):
     pre = getattr(fld, 'rox_field', None)
     if pre is not None and pupil_type == 'rel pupil':
         return pre
+    # inside one drop-in call (session.hold) the same field is asked for several times: the
+    # constants depend, beyond the held model state, on what a chief-ray request may change
+    # in between -- the aim and the vignetting factors
+    from . import session
+    memo = session.held_memo(opt_model)
+    if memo is not None:
+        ai = getattr(fld, 'aim_info', None)
+        mkey = ('field', id(fld), pupil_type, None if ai is None else tuple(np.ravel(ai).tolist()),
+                fld.vlx, fld.vux, fld.vly, fld.vuy)
+        hit = memo.get(mkey)
+        if hit is None:
+            hit = memo[mkey] = _field_from_model(opt_model, fld, pupil_type, cache)
+        return hit
+    return _field_from_model(opt_model, fld, pupil_type, cache)
+
+
+def _field_from_model(opt_model, fld, pupil_type, cache):
     osp = opt_model['optical_spec']
     fod = opt_model['analysis_results']['parax_data'].fod
     pupil_oi_key, pupil_value_key = osp['pupil'].key

@@ -185,6 +185,88 @@ def iterate_ray_raw(pthlist, ifcx, xy_target, pt0, d0, obj2pup_dist, eprad, wvl,
     return start_coords, rr
 
 
+def _chief_rays(opt_model, eng):
+    """Chief-ray packets of EVERY (field, wavelength) of the model's current state in one
+    launch (``TraceEngine.trace_pupil_grids_host``: FULL packets of a 2 x 2 pupil grid whose
+    first ray is pupil (0, 0), written straight into pinned host memory), kept on the engine
+    -- a model edit makes a new engine -- under the field's ray-start constants: a re-aimed
+    field simply misses.  {(field constants, wavelength index): (seg [N, 10], op) | None}"""
+    cache = eng.__dict__.setdefault('_chief_cache', {})
+    osp = opt_model['optical_spec']
+    tbl = eng.table
+    oc = eng.__dict__.setdefault('_obj_coords_cache', {})
+    kw = {'apply_vignetting': True}                 # trace_base's default; (0, 0) is its fixed point
+    flds, wis, optl, keys = [], [], [], []
+    for fld in osp['fov'].fields:
+        try:
+            f = field_from_model(opt_model, fld, 'rel pupil', cache=oc)
+        except Exception:                           # noqa: BLE001  (that field goes the one-ray way)
+            continue
+        opts = opts_from_kwargs(tbl.n_ifcs, kw, abi.OUT_FULL)
+        if f.kind == abi.FLD_EPD_WIDE or f.z_dir0 == 0.0:
+            opts.flags &= ~abi.INTERSECT_OBJ        # trace.py:302-303
+        fb = bytes(f)
+        for wi in range(len(tbl.wvls)):
+            if (fb, wi) in cache:
+                continue
+            flds.append(f)
+            wis.append(wi)
+            optl.append(opts)
+            keys.append((fb, wi))
+    if flds:
+        res = eng.trace_pupil_grids_host(flds, wis, make_grid((0., 0.), (1., 1.), 2), optl)
+        for key, h in zip(keys, res):
+            if int(h.status[0]) == abi.OK:
+                cache[key] = (np.array(h.seg[:, :, 0]), float(h.op[0]))
+            else:
+                cache[key] = None                   # a failing chief ray: the reference's own path
+        if len(cache) > 4096:                       # (a session that re-aims for ever)
+            for k in list(cache)[:len(cache) - 2048]:
+                del cache[k]
+    return cache
+
+
+def trace_chief_ray(opt_model, fld, wvl, foc):
+    """rayoptics/raytr/trace.py:513-535 ``trace_chief_ray``: the chief ray of ``fld`` at ``wvl``
+    and its exit-pupil segment.  Every analysis reaches it through ``setup_pupil_coords`` ->
+    ``get_chief_ray_pkg`` (trace.py:608-624, 660-687; both stay the reference's own code, as
+    does ``calculate_reference_sphere``) -- per (field, wavelength[, fan]) of a figure, each
+    time one ray through the one-ray seam.  Here the first request of a model state traces
+    the chief rays of ALL fields and wavelengths in one launch; the others are served from
+    that batch.  The packet is the one ``trace_safe(opt_model, [0., 0.], fld, wvl,
+    output_filter=None, rayerr_filter='full')`` returns; ``transfer_to_exit_pupil`` is the
+    reference's own.  A wavelength outside the spectral list, a field this layer cannot
+    express or a failing chief ray go to the reference's function."""
+    import rayoptics.raytr.trace as rtrace
+    from rayoptics.raytr import RayPkg as RefRayPkg
+    pkg = None
+    eng = session.engine_for(opt_model)
+    try:
+        wi = eng.table.wvl_index(wvl)
+        f = field_from_model(opt_model, fld, 'rel pupil',
+                             cache=eng.__dict__.setdefault('_obj_coords_cache', {}))
+        key = (bytes(f), wi)
+        cache = eng.__dict__.get('_chief_cache')
+        if cache is None or key not in cache:
+            cache = _chief_rays(opt_model, eng)
+        pkg = cache.get(key)
+    except (ValueError, KeyError):
+        pkg = None
+    if pkg is None:
+        from . import install
+        theirs = install._saved.get((rtrace, 'trace_chief_ray'))
+        if theirs is None:
+            raise RuntimeError('trace_chief_ray: not installed over the reference')
+        return theirs(opt_model, fld, wvl, foc)
+    seg, op = pkg
+    blk = seg.copy()            # this call's own block: the segments view it (as raytrace_trace's do)
+    cr = RefRayPkg([[s[0:3], s[3:6], float(s[6]), s[7:10]] for s in blk], op, wvl)
+    fod = opt_model['analysis_results']['parax_data'].fod
+    cr_exp_seg = rtrace.transfer_to_exit_pupil(opt_model.seq_model.ifcs[-2],
+                                               (cr.ray[-2][0], cr.ray[-2][1]), fod.exp_dist)
+    return cr, cr_exp_seg
+
+
 def trace_ray_list_at_field(opt_model, ray_list, fld, wvl, foc, **kwargs):
     """rayoptics/raytr/trace.py:478-486: a list of ray DataFrames for the pupil points of
     ``ray_list`` at ``fld`` -- one ``trace_ray`` per point in the reference (``trace_field`` /
@@ -380,6 +462,12 @@ def _is_spot_filter(fct):
 
 def seq_trace_grid(self, fct, fi, wl=None, num_rays=21, form='grid',
                    append_if_none=True, **kwargs):
+    with session.hold(self.opt_model):      # one validation of the model for the whole call
+        return _seq_trace_grid(self, fct, fi, wl, num_rays, form, append_if_none, **kwargs)
+
+
+def _seq_trace_grid(self, fct, fi, wl=None, num_rays=21, form='grid',
+                    append_if_none=True, **kwargs):
     """rayoptics/seq/sequential.py:1058-1085, as a replacement *method* of
     SequentialModel.  Chief-ray / reference-sphere setup stays the reference's
     (a handful of iterated single rays); the num_rays**2 loop goes to the GPU.
@@ -430,6 +518,11 @@ def _fan_figure_callback(fct):
 
 
 def seq_trace_fan(self, fct, fi, xy, num_rays=21, **kwargs):
+    with session.hold(self.opt_model):      # one validation of the model for the whole call
+        return _seq_trace_fan(self, fct, fi, xy, num_rays, **kwargs)
+
+
+def _seq_trace_fan(self, fct, fi, xy, num_rays=21, **kwargs):
     """rayoptics/seq/sequential.py:1006-1056, as a replacement *method* of SequentialModel:
     the x or y fan of field ``fi`` at every wavelength.  Chief ray and reference sphere per
     wavelength stay the reference's; for RayFanFigure's own callbacks (transverse aberration,

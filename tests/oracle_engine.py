@@ -144,6 +144,9 @@ class OracleEngine:
     def trace_pupil_grids(self, flds, wvl_idxs, grid, opts_list, **kw):
         return [self.trace_pupil_grid(f, grid, w, o) for f, w, o in zip(flds, wvl_idxs, opts_list)]
 
+    def trace_pupil_grids_host(self, flds, wvl_idxs, grid, opts_list):
+        return [self.trace_pupil_grid(f, grid, w, o).to_host() for f, w, o in zip(flds, wvl_idxs, opts_list)]
+
     def trace_pupil_list_hits(self, fld, px, py, wvl_idx, opts):
         return oracle.trace_pupil_list(self.table, fld, px, py, wvl_idx, opts).hits.copy()
 

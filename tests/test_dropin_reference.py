@@ -1622,3 +1622,103 @@ def test_trace_grid_fails_where_the_reference_fails(ref, installed):
         assert ours == theirs, (kw['form'], kw['append_if_none'], ours, theirs)
         seen.add(ours[0])
     assert seen == {'raised', 'returned'}       # both endings occur under this NumPy
+
+
+def _same_tree(a, b):
+    """nested tuples / lists / arrays / floats / None / objects: equal values, equal zero signs"""
+    if a is None or b is None:
+        assert a is None and b is None
+    elif isinstance(a, (list, tuple)):
+        assert isinstance(b, (list, tuple)) and len(a) == len(b)
+        for x, y in zip(a, b):
+            _same_tree(x, y)
+    elif isinstance(a, (np.ndarray, float, int, np.floating, np.integer)):
+        x, y = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+        np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(np.signbit(x), np.signbit(y))
+    else:
+        assert a is b or type(a) is type(b)         # the exiting Interface object
+
+
+@pytest.mark.parametrize('model', ['dblgauss', 'singlet', 'rc_telescope', 'nikkor', 'cell_phone',
+                                   'tilted_singlet', 'toroid_lens'])
+def test_setup_pupil_coords_from_the_chief_ray_batch(ref, installed, model):
+    """trace.setup_pupil_coords for every field and wavelength, with a defocus, a given image
+    point and an image delta: chief-ray package (every segment, with zero signs), exit-pupil
+    segment and reference sphere are the reference's -- served from ONE launch per model state
+    (trace.trace_chief_ray rebound; get_chief_ray_pkg / calculate_reference_sphere untouched)"""
+    import rayoptics.raytr.trace as trace
+    from rayoptics_amd import session
+    build = getattr(ref, model)
+    calls = []
+
+    def run_all(opm):
+        out = []
+        osp = opm['osp']
+        for fld in osp['fov'].fields:
+            for wvl in osp['wvls'].wavelengths:
+                for kw in (dict(), dict(image_pt=np.array([0.01, -0.02, 0.0])),
+                           dict(image_delta=np.array([0.001, 0.002]))):
+                    rs, cr = trace.setup_pupil_coords(opm, fld, wvl, 0.05, **kw)
+                    out.append((rs[:3], rs[3], cr[0][0], cr[0][1], cr[0][2], cr[1]))
+        return out
+    opm_o = build()
+    eng = session.engine_for(opm_o)
+    eng.__dict__.pop('_chief_cache', None)      # (building the model has already asked for some)
+    real = eng.trace_pupil_grids_host
+
+    def counting(*a, **k):
+        calls.append(len(a[0]))
+        return real(*a, **k)
+    eng.trace_pupil_grids_host = counting
+    ours = run_all(opm_o)
+    installed.uninstall()
+    theirs = run_all(build())
+    installed.install()
+    assert len(ours) == len(theirs) and len(ours) >= 3
+    for a, b in zip(ours, theirs):
+        _same_tree(a, b)
+    n_f, n_w = len(opm_o['osp']['fov'].fields), len(opm_o['osp']['wvls'].wavelengths)
+    # every chief ray of the model state in ONE launch (none at all where the field's own
+    # cached package -- get_chief_ray_pkg, trace.py:680-687 -- already answers every request)
+    # (a model whose fields carry no chief ray re-aims per request, get_chief_ray_pkg
+    # trace.py:680-682: every new aim is a new ray start and misses)
+    assert len(calls) <= n_f * n_w
+    if model == 'dblgauss':
+        assert calls == [n_f * n_w], calls
+
+
+def test_chief_ray_batch_follows_the_model(ref, installed):
+    """re-aiming a field, a wavelength that is not in the spectral list, and a model edit: the
+    cached batch is never served stale"""
+    import rayoptics.raytr.trace as trace
+    opm = ref.dblgauss()
+    osp, sm = opm['osp'], opm['seq_model']
+    fld = osp['fov'].fields[2]
+    # (not the wavelength of the package the field itself caches: get_chief_ray_pkg would
+    # return that one, stale aim and all, in the reference as here)
+    wvl = [w for w in osp['wvls'].wavelengths if w != fld.chief_ray[0][2]][0]
+
+    def snap():
+        rs, cr = trace.setup_pupil_coords(opm, fld, wvl, 0.0)
+        return (rs[:3], cr[0][0], cr[0][1], cr[1][:3])
+    a = snap()
+    fld.aim_info = np.array([fld.aim_info[0], fld.aim_info[1] + 0.01])    # re-aimed by hand
+    b = snap()
+    installed.uninstall()
+    b_ref = snap()
+    installed.install()
+    _same_tree(b, b_ref)
+    assert not np.array_equal(np.asarray(a[1][3][0]), np.asarray(b[1][3][0]))
+    sm.ifcs[3].profile.cv *= 1.001                                         # an edit without update_model
+    c = snap()
+    installed.uninstall()
+    c_ref = snap()
+    installed.install()
+    _same_tree(c, c_ref)
+    with pytest.raises(ValueError):
+        trace.setup_pupil_coords(opm, fld, 600.0, 0.0)
+    installed.uninstall()
+    with pytest.raises(ValueError):
+        trace.setup_pupil_coords(opm, fld, 600.0, 0.0)
+    installed.install()

@@ -117,13 +117,14 @@ def main():
     ap.add_argument('--inst', default='lean', help='feature instance (csrc/inst_<name>.hip)')
     ap.add_argument('--mode', type=int, default=2, help='ROX_OUT_* of the kernel (2 = HITS, 0 = FULL)')
     ap.add_argument('--feat', type=int, default=0, help='FEAT template value of the instance (lean 0, even 1, radial 2)')
+    ap.add_argument('--workload', default=None, help='PMC record to quote beside the static count')
     args = ap.parse_args()
     src = os.path.join(ROOT, 'ray-optics_amd', 'csrc', f'inst_{args.inst}.hip')
     with tempfile.TemporaryDirectory() as td:
         subprocess.check_call(['hipcc'] + FLAGS + ['-I', os.path.join(ROOT, 'include'), '-S', '--cuda-device-only',
                                                    src, '-o', os.path.join(td, 'k.s')])
         asm = open(os.path.join(td, 'k.s')).read()
-    mangled = f'_ZN3rox12trace_kernelILi{args.mode}ELi1ELb0ELi{args.feat}EEEvNS_9TraceArgsE'
+    mangled = f'_ZN3rox12trace_kernelILi{args.mode}ELi1ELb0ELi{args.feat}ELb0EEEvNS_9TraceArgsE'
     ins = instructions(kernel_body(asm, mangled))
     total = sum(1 for _l, op, _t in ins if op)
     (n, j, i, tgt), outer, all_loops = surface_loop(ins)
@@ -136,7 +137,7 @@ def main():
     p = os.path.join(ROOT, 'profiles', 'valu_per_intersection.json')
     if os.path.exists(p):
         j_ = json.load(open(p))
-        wl = {'lean': 'dblgauss_c2', 'radial': 'cell_phone', 'even': 'nikkor_c3'}.get(args.inst)
+        wl = args.workload or {'lean': 'dblgauss_c2', 'radial': 'cell_phone', 'even': 'nikkor_c3'}.get(args.inst)
         if wl in j_:
             key = 'valu_wave_insts_per_intersection' if args.mode == 2 else 'full_valu_wave_insts_per_intersection'
             pmc = {'workload': wl, 'valu_wave_insts_per_lane_intersection': j_[wl][key],
