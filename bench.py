@@ -22,7 +22,7 @@ cold_ms_per_step  the same K launches issued right after an idle second, before 
 roofline      HBM-bound kernel: algorithmic bytes = what one launch must write
               (80 B per appended segment + 8 B op + 3 B status, +16 B pupil)
               divided by the trace kernel's mean duration from HIP events on the
-              launch stream; `traffic` is a committed PMC figure (traffic_source says
+              launch stream; `traffic` is a committed PMC figure (traffic_committed_from says
               from which library build) -- null when the library has changed since
 roofline_hits the HITS kernel behind spot diagrams / OPD / refocus is fp64-VALU
               bound: TFLOP/s by SURVEY 8(d)'s 130 flop per intersection against the
@@ -351,7 +351,7 @@ def main():
             'rays_per_s': rays_all / dt * args.steps,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic,
-                         'traffic_source': traffic_source,
+                         'traffic_committed_from': traffic_source,
                          'kernel': 'trace_kernel<FULL,PUPIL>', 'kernel_ms': kern_ms,
                          'algorithmic_bytes_per_launch': alg_bytes,
                          'frac_of_measured_copy_peak_6290': achieved / 6290.0},
@@ -461,6 +461,12 @@ def main():
                     'sharding': f'pupil-row blocks over {world} ranks', 'pairs_to_host': head['pairs'],
                     'pieces_per_rank': head['pieces_per_rank'], 'stages': head['stages']}
                 line['predicted_ms'] = head['predicted_ms']
+                line.update(scaling_keys(head.get('one_gpu_same_problem_ms'), head['ms_per_step'], world))
+                line['one_gpu_same_problem'] = (
+                    'rank 0 alone, same problem, same exchange code (' + head['exchange'] + '), same run'
+                    + ('' if not head.get('one_gpu_error') else ' -- FAILED: ' + head['one_gpu_error']))
+                if head.get('configs3_by_field'):
+                    line['configs3_by_field'] = head['configs3_by_field']
                 line['strong_headline'] = {k: head[k] for k in ('exchange', 'ms_per_step_by_exchange', 'errors',
                                                                   'last_pass_phases_ms_rank0', 'grids_delivered')}
 
@@ -471,6 +477,21 @@ def main():
                                                                    fence, ranks_seen))
         if rank == 0:
             line['strong_scaling'] = strong
+            if world == 1 and isinstance(strong, dict) and isinstance(strong.get('c5'), dict):
+                # the N = 1 point of the N > 1 headline's curve: the same strong problem, best
+                # exchange, end to end -- same field names as a `--gpus N` line carries
+                c5 = strong['c5']
+                legs = {k: c5[k]['end_to_end_ms'] for k in ('rccl', 'host')
+                        if isinstance(c5.get(k), dict) and 'end_to_end_ms' in c5[k]}
+                if legs:
+                    bestx = min(legs, key=legs.get)
+                    line['strong_equiv'] = dict(
+                        scaling_keys(legs[bestx], legs[bestx], 1), ms_per_step=legs[bestx], exchange=bestx,
+                        ms_per_step_by_exchange=legs, workload=c5['workload'] + ' (BASELINE.json configs[4])',
+                        intersections_per_step=c5['intersections'],
+                        value=c5['intersections'] / (legs[bestx] * 1e-3),
+                        what='what a `--gpus N` line reports under value / ms_per_step, at N = 1: draw the '
+                             'scaling curve from this and the N > 1 lines, not from this line\'s `value`')
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(wl, fld, wi, opts, num, args.cpu_sample_rows,
@@ -750,8 +771,10 @@ class SpotProblem:
     """one fixed-size spot-diagram problem (every (field, wavelength) grid of a workload) cut
     over the ranks: the engine, the plan, and the intersections one pass actually performs"""
 
-    def __init__(self, torch, dist, multi, world, rank, name, num, by, field_idx=None, n_wvls=None):
+    def __init__(self, torch, dist, multi, world, rank, name, num, by, field_idx=None, n_wvls=None,
+                 group=None):
         from rayoptics_amd import abi, workloads
+        self.group = group      # None = the default group; a one-rank group = rank 0 on its own
         from rayoptics_amd import dist as rdist
         from rayoptics_amd.engine import TraceEngine, make_opts, make_grid, DeviceResult
         self.torch, self.dist, self.multi, self.world, self.rank = torch, dist, multi, world, rank
@@ -813,7 +836,7 @@ class SpotProblem:
         wl = self.wl
         return rdist.trace_spot_sharded(self.eng, self.fields, self.image_pts, self.nw, self.num, wl.foc,
                                         by=self.by, exchange=exchange, segment=segment, timings=timings,
-                                        pipeline=pipeline, result_on=result_on)
+                                        pipeline=pipeline, result_on=result_on, group=self.group)
 
     def kernel_ms(self):
         """this rank's launches alone (packed hits appended into HBM), events on the launch stream"""
@@ -860,6 +883,46 @@ class SpotProblem:
         self.torch.cuda.empty_cache()
 
 
+def scaling_keys(one_gpu_same_problem_ms, ms_per_step, world):
+    """the keys that make a `--gpus N` line readable on its own: what ONE GPU needs for the same
+    fixed-size problem through the same code (measured in the same run, on rank 0, while the
+    other ranks wait), and what the N ranks made of it.  speedup = one_gpu_same_problem_ms /
+    ms_per_step; efficiency = speedup / n_gpus.  The curve over N is drawn from `ms_per_step`
+    (or `value`) of the strong-scaled lines and these keys -- never across the N = 1 line's own
+    `value`, which is a different workload (README, "Reading the bench line")."""
+    if not one_gpu_same_problem_ms or not ms_per_step:
+        return {'one_gpu_same_problem_ms': one_gpu_same_problem_ms, 'speedup': None, 'efficiency': None}
+    sp = one_gpu_same_problem_ms / ms_per_step
+    return {'one_gpu_same_problem_ms': one_gpu_same_problem_ms, 'speedup': sp, 'efficiency': sp / world}
+
+
+def solo_same_problem(args, torch, dist, multi, rank, fence, solo_group, name, num, by, exchange, steps):
+    """rank 0 alone on the SAME strong problem (all pieces on its GPU, same exchange code, world
+    = 1 through a one-rank group) while the other ranks wait at the fence: ms per pass"""
+    ms, err = None, None
+    if rank == 0:
+        prob = None
+        try:
+            prob = SpotProblem(torch, dist, False, 1, 0, name, num, by, group=solo_group)
+            lf = torch.cuda.synchronize
+            seg = prob.segment('solo', lf) if exchange == 'host' else None
+            try:
+                ms = prob.timed(lf, steps, 1, exchange=exchange, segment=seg)[0]
+            finally:
+                if seg is not None:
+                    LIVE_SEGMENTS.discard(seg.path)
+                    seg.close(unlink=True)
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            err = repr(e)
+        finally:
+            if prob is not None:
+                prob.close()
+    fence()
+    return ms, err
+
+
 def strong_headline(args, torch, dist, multi, world, rank, fence):
     """N > 1: BASELINE configs[4]'s spot problem cut by pupil rows over the ranks and delivered to
     rank 0 as host arrays -- K passes between two fences, the exchange inside the timed region
@@ -889,7 +952,26 @@ def strong_headline(args, torch, dist, multi, world, rank, fence):
         ms, tm = legs[best]
         pairs = tm['pairs_total']
         phases = ('trace_ms', 'stage_sync_ms', 'gather_ms', 'd2h_ms', 'reassembly_ms')
+        # the same problem on ONE GPU in the same run (collective: every rank makes the group)
+        solo_group = dist.new_group(ranks=[0]) if multi else None
+        one_ms, one_err = solo_same_problem(args, torch, dist, multi, rank, fence, solo_group, 'litho_c5',
+                                            args.strong_num, 'rows', best, max(2, min(args.steps, 5)))
+        c4 = None
+        if world == 4:
+            # BASELINE configs[3] as north_star words it: shard-by-field over 4 GPUs
+            c4p = SpotProblem(torch, dist, multi, world, rank, 'rc_telescope_c4', 256, 'field')
+            try:
+                c4_ms, c4_tm = c4p.timed(fence, max(args.steps, 5), max(args.warmup, 2), exchange='rccl')
+                c4_one, c4_err = solo_same_problem(args, torch, dist, multi, rank, fence, solo_group,
+                                                   'rc_telescope_c4', 256, 'field', 'rccl', max(args.steps, 5))
+                c4 = dict(scaling_keys(c4_one, c4_ms, world), ms_per_step=c4_ms, exchange='rccl',
+                          workload=c4p.what + ' (BASELINE.json configs[3], one field per rank, rank 0 two)',
+                          intersections_per_step=c4p.intersections, pairs=c4_tm['pairs_total'],
+                          one_gpu_error=c4_err)
+            finally:
+                c4p.close()
         return {'ms_per_step': ms, 'exchange': best, 'intersections_per_step': prob.intersections,
+                'one_gpu_same_problem_ms': one_ms, 'one_gpu_error': one_err, 'configs3_by_field': c4,
                 'rays_per_step': sum(prob.caps), 'workload': prob.what, 'pairs': pairs,
                 'stages': tm.get('stages'), 'pieces_per_rank': tm.get('pieces'),
                 'ms_per_step_by_exchange': {k: v[0] for k, v in legs.items()},

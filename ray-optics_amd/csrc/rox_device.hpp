@@ -100,11 +100,13 @@
 #endif
 // FULL mode of the instances that carry Newton code (aspheres, toroids): the iteration counts
 // differ per wave, so a 1024-thread workgroup (the only one its CU holds at 99-125 VGPRs) waits
-// at every surface for its slowest wave with nothing else to run.  Smaller workgroups -- four
-// per CU, out of step with each other -- win there (phone lens 319 -> 290 us, Nikkor 485 -> 452,
-// .zmx zoom 210 -> 196; 512 threads: 292 / 463 / 204; 128: 299 / 465 / 201).
+// at every surface for its slowest wave with nothing else to run; four 256-thread workgroups
+// per CU, out of step with each other, avoid that (round 3, when these instances always ran
+// 256: phone lens 319 -> 290 us).  Since round 5 the choice is made per SYSTEM at launch
+// (roxtrace.hip want_small(): by the share of Newton interfaces): the large workgroup is the
+// regular one here too and the ROX_BLOCK_SMALL kernels are the alternative.
 #ifndef ROX_BLOCK_FULL_POLY
-#define ROX_BLOCK_FULL_POLY 256
+#define ROX_BLOCK_FULL_POLY 1024
 #endif
 #ifndef ROX_WG_SYNC_POLY     // barrier per surface also there (off: 286 / 483 / 195 -- within the noise)
 #define ROX_WG_SYNC_POLY 1
@@ -121,11 +123,11 @@
 #ifndef ROX_NEWTON_SLIM_DIV   // 1: the Spencer-Murty quotient f / dot(d, df) through slim_div()
 #define ROX_NEWTON_SLIM_DIV 1
 #endif
-#ifndef ROX_NEWTON_UNROLL     // Spencer-Murty steps spelled straight-line before the residual loop
-#define ROX_NEWTON_UNROLL 4
-#endif
-#ifndef ROX_COSI_SLIM         // 1: cosI = dot(d, n) / |n| of refract() / mirror() through slim_div()
-#define ROX_COSI_SLIM 1
+#ifndef ROX_NEWTON_UNROLL     // Spencer-Murty steps spelled straight-line before the residual loop.  Rounds 1-4
+#define ROX_NEWTON_UNROLL 0    // shipped 4 (six inlined evaluations per asphere site); the plain loop -- two --
+#endif                         // is a third of the code and faster: Nikkor HITS 329 -> 314 us, .zmx 143.2 -> 141.5
+#ifndef ROX_COSI_SLIM         // 1: cosI = dot(d, n) / |n| of refract() / mirror() through slim_div():
+#define ROX_COSI_SLIM 0        //    measured, nothing (lean HITS 109.8 us without, 111.4 with): off
 #endif
 #ifndef ROX_IDENT_RT_FULL_POLY   // 1: the identity-rotation short cut also in the FULL mode of those
 #define ROX_IDENT_RT_FULL_POLY 1 //    instances, which are closer to their VALU bound (283 / 473 / 187 us)
@@ -251,6 +253,10 @@ struct TraceArgs {
     int32_t axis_kind;         // AXIS_LIST: px[r],py[r]; AXIS_PRODUCT: px[r/num], py[r%num]
     int32_t axis_num;
     int32_t row_begin;         // AXIS_PRODUCT: first pupil row of this launch
+    // AXIS_PRODUCT, reduced-output modes of the Newton instances: a wave takes an 8 x 8 patch of
+    // the pupil grid instead of 64 consecutive rays of a row (trace_tiles; set by the host when
+    // the grid divides into such tiles)
+    int32_t patch8;
     // HITS_COMPACT: decoupled look-back state of this launch
     uint64_t *tile_state;      // [tiles] (epoch << 32 | flag << 30 | count)
     uint32_t *ticket;          // [0] next tile, [1] workgroups done
@@ -741,8 +747,8 @@ __device__ __forceinline__ bool newton_hit(int kind, double cv, double cc1, doub
         ++iter;
     };
     // measured on the reference's even-asphere zoom: 2 steps 20 %, 3 steps 73 %,
-    // 4 steps 6 %, more < 1 % -- four steps straight-line and
-    // predicated per lane, then the residual loop (cap 1000 as in the reference)
+    // 4 steps 6 %, more < 1 %.  ROX_NEWTON_UNROLL steps straight-line and
+    // predicated per lane (0 since round 5), then the loop (cap 1000 as in the reference)
 #pragma unroll
     for (int u = 0; u < ROX_NEWTON_UNROLL; ++u)
         if (delta > eps)
@@ -1583,6 +1589,8 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     c.probe_surf = -1;
     const int64_t ld = a.out.ld;
     constexpr bool kWaveTick = wave_ticketed(OUT_MODE);
+    constexpr bool kPatch = GEN == GEN_PUPIL && !kCompact && !kWaveTick && OUT_MODE != ROX_OUT_FULL &&
+                            (FEAT & F_POLY) != 0;
     const int64_t n_small = kCompact ? compact_small_tiles(a.n_rays, a.small_tiles) : 0;
     const int64_t n_tiles = kCompact ? compact_tiles(a.n_rays, a.small_tiles, kB)
                           : kWaveTick ? (a.n_rays + 63) / 64 : (a.n_rays + kB - 1) / kB;
@@ -1635,6 +1643,18 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
         if (tile >= n_tiles)
             break;
         int64_t r = kWaveTick ? tile * 64 + lane : tile * kB + threadIdx.x;
+        // 8 x 8 pupil patches per wave: at an asphere a wave executes Spencer-Murty steps until its
+        // slowest lane has converged, and the step count follows the ray height -- a patch spans
+        // a narrower range of heights than 64 rays of one row (8-12 % fewer wave-steps on the
+        // .zmx zoom and the phone lens, profiles/r04_newton_wave_steps.json).  A tile is 8 rows x
+        // kB / 8 columns, wave w its columns 8w .. 8w + 7; rays keep their index, so every output
+        // lands where it did.
+        if (kPatch && a.patch8) {
+            constexpr int cols = kB / 8;
+            const int64_t per_band = a.axis_num / cols;
+            const int64_t band = tile / per_band, cb = tile - band * per_band;
+            r = (band * 8 + (lane >> 3)) * (int64_t)a.axis_num + cb * cols + (wave * 8 + (lane & 7));
+        }
         bool active = r < a.n_rays;
         if (kCompact) {
             const bool small = tile < n_small;

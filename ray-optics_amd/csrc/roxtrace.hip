@@ -252,6 +252,7 @@ struct rox_system {
     int32_t n_seg[2] = {0, 0};
     int num_cus = 256;
     int features = 0;                   // F_* of the table
+    int n_newton = 0;                   // interfaces intersected by Newton iteration
     std::mutex mu;                      // guards ctxs
     std::vector<StreamCtx *> ctxs;
     // the small synchronous search entries (aiming, pupil search, vignetting, pupil
@@ -475,7 +476,15 @@ bool want_small(const rox_system *sys, int64_t total_rays, int out_mode, int fea
     if (out_mode == ROX_OUT_FULL) {
         const int64_t big = block_of(ROX_OUT_FULL, feat, false);
         if (big <= ROX_BLOCK_SMALL)
-            return false;                   // (the Newton instances: already small)
+            return false;
+        // Newton instances: a workgroup waits at every surface for its slowest wave, and the
+        // iteration counts differ per wave.  Where aspheres are a minority of the interfaces
+        // the large workgroup's packet rows still win (the .zmx zoom, one asphere in 12: 209
+        // -> 192 us per 2^20 rays; Nikkor, 4 in 28: 471 -> 445); where they are most of the
+        // system small workgroups out of step with each other do (phone lens, 8 in 12: 263
+        // against 288 us).  profiles/r05_full_block_newton.txt.
+        if ((feat & kFeatNewton) && sys->n_newton * 4 > sys->n_ifcs - 1)
+            return true;
         const int64_t per_item = (total_rays / n_items + big - 1) / big;
         const int64_t wgs = per_item * n_items, cus = sys->num_cus;
         const int64_t rounds = (wgs + cus - 1) / cus;
@@ -483,6 +492,26 @@ bool want_small(const rox_system *sys, int64_t total_rays, int out_mode, int fea
         return rounds <= 4 && idle * 10 >= 3 * rounds * cus;
     }
     return (total_rays + 63) / 64 <= (int64_t)sys->num_cus * per_cu;
+}
+
+// 8 x 8 pupil patches per wave (rox_device.hpp trace_tiles): product grids traced by a Newton
+// instance in a reduced-output mode, when the launch is whole tiles of 8 rows x bs / 8 columns.
+// OFF unless ROX_PATCH8=1 (read per call: the parity test flips it): built as the round-4
+// verdict asked and measured SLOWER -- .zmx zoom HITS 146.8 -> 157.3 us, phone lens 233.0 ->
+// 245.9, Nikkor 321.2 -> 328.7 per 2^20 rays (profiles/r05_patch8.txt): the 8-12 % of
+// Spencer-Murty wave-steps it saves are 2-5 % of a kernel, and a wave's outputs become eight
+// 64-byte pieces of eight different rows instead of one 512-byte run.
+int32_t want_patch8(int gen, const TraceArgs &a, int out_mode, int feat, int bs, int64_t n_rays)
+{
+    const char *e = getenv("ROX_PATCH8");
+    const int env = (e && *e) ? atoi(e) : 0;
+    if (!env || gen != GEN_PUPIL || a.axis_kind != AXIS_PRODUCT || !(feat & F_POLY) ||
+        out_mode == ROX_OUT_FULL || out_mode == ROX_OUT_HITS_COMPACT || a.axis_num < 8)
+        return 0;
+    const int64_t num = a.axis_num, cols = bs / 8;
+    if (num % cols != 0 || n_rays % (8 * num) != 0)
+        return 0;
+    return 1;
 }
 
 // ---- the search kernels (csrc/rox_search.hpp): the leanest instance of kSearchInstances that
@@ -782,6 +811,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
             int64_t hblocks = (a.n_rays + hb - 1) / hb;
             const int64_t hcap = (int64_t)sys->num_cus * blocks_per_cu(hb);
             kh.grid = dim3((unsigned)(hblocks > hcap ? hcap : hblocks));
+            h.patch8 = total <= chunk_max ? want_patch8(gen, h, ROX_OUT_HITS, kInstances[inst], hb, a.n_rays) : 0;
             if (ROX_WAVE_TICKETS == 2) {
                 std::lock_guard<std::mutex> wg(cx->wt_mu);
                 int rcw = assign_wave_tickets(cx, &h, 1, st);
@@ -816,6 +846,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
         if (blocks > cap)
             blocks = cap;
         k.grid = dim3((unsigned)blocks);
+        a.patch8 = total <= chunk_max ? want_patch8(gen, a, a.opts.out_mode, kInstances[inst], bs, a.n_rays) : 0;
         if (ROX_WAVE_TICKETS == 2 && wave_ticketed(a.opts.out_mode)) {
             StreamCtx *wx = ctx_for(sys, st);
             if (!wx)
@@ -1167,9 +1198,11 @@ int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_t
 {
     if (!rows || !n_table || !out_sys || n_ifcs < 2 || n_wvls < 1)
         return fail(ROX_E_ARG, "rox_system_create: bad argument");
-    int features = 0;
+    int features = 0, n_newton = 0;
     for (int i = 0; i < n_ifcs; ++i) {
         const rox_surface &s = rows[i];
+        if (s.profile >= ROX_EVENPOLY && s.profile <= ROX_XTOROID)
+            ++n_newton;
         if (s.mode < ROX_TRANSMIT || s.mode > ROX_PHANTOM || s.profile < ROX_SPHERICAL ||
             s.profile > ROX_THINLENS || s.ncoef < 0 || s.ncoef > ROX_MAX_COEF || s.n_ap < 0 ||
             s.n_ap > ROX_MAX_AP || s.ph.kind < ROX_PH_NONE || s.ph.kind > ROX_PH_HOLOGRAM ||
@@ -1196,6 +1229,7 @@ int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_t
     sys->n_ifcs = n_ifcs;
     sys->n_wvls = n_wvls;
     sys->features = features;
+    sys->n_newton = n_newton;
     sys->rows.assign(rows, rows + n_ifcs);
     hipError_t e = hipGetDevice(&sys->device);
     if (e != hipSuccess) {
@@ -1477,6 +1511,8 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
     const int64_t cap = (int64_t)sys->num_cus * (compact ? compact_blocks_per_cu() : blocks_per_cu(bs));
     if (blocks > cap)
         blocks = cap;
+    for (int32_t i = 0; i < n_grids; ++i)
+        items[i].patch8 = want_patch8(GEN_PUPIL, items[i], opts[0].out_mode, kInstances[inst], bs, R);
     if (ROX_WAVE_TICKETS == 2 && wave_ticketed(opts[0].out_mode)) {
         std::lock_guard<std::mutex> wg(cx->wt_mu);      // (batch_mu keeps the enqueue order)
         if ((rc = assign_wave_tickets(cx, items.data(), n_grids, st)))

@@ -117,3 +117,20 @@ def test_product_never_touches_the_oracle():
             'assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules), '
             '[m for m in sys.modules if m.startswith("oracle")]' % ROOT)
     subprocess.check_call([sys.executable, '-c', code])
+
+
+def test_bench_scaling_keys_are_what_they_say():
+    """bench.py's self-description of a `--gpus N` line: speedup = one_gpu_same_problem_ms /
+    ms_per_step and efficiency = speedup / n_gpus (no GPU needed: the helper is arithmetic)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('rox_bench', os.path.join(root, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    k = b.scaling_keys(77.0, 11.0, 8)
+    assert k['one_gpu_same_problem_ms'] == 77.0
+    assert k['speedup'] == 77.0 / 11.0 and k['efficiency'] == k['speedup'] / 8
+    k1 = b.scaling_keys(77.0, 77.0, 1)
+    assert k1['speedup'] == 1.0 and k1['efficiency'] == 1.0
+    assert b.scaling_keys(None, 11.0, 4)['speedup'] is None

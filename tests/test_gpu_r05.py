@@ -188,3 +188,50 @@ def test_eight_threads_over_twenty_models_with_sixteen_handles():
     assert not errors, errors[:3]
     assert min(counts) > 20, counts
     assert len(session._cache) == 0
+
+
+@pytest.mark.parametrize('name', ['zmx_evenasph_c3', 'cell_phone', 'nikkor_c3'])
+def test_patch_lane_mapping_leaves_every_ray_where_it_was(name, monkeypatch):
+    """ROX_PATCH8=1 (an experiment switch, read per call; off in the product because it measured
+    slower): reduced-output launches of the Newton instances give a wave an 8 x 8 pupil patch
+    when the grid divides into such tiles (512, 192: yes -- with 512- and 256-thread workgroups;
+    200, a 24-row block of 512: no / yes): HITS, LAST and a batched HITS launch against the
+    oracle, ray for ray"""
+    monkeypatch.setenv('ROX_PATCH8', '1')
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    wl = workloads.load(name)
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    wi = wl.ref_wvl_idx
+    fi = len(wl.fields) - 1
+    for mode in (abi.OUT_HITS, abi.OUT_LAST):
+        for gkw in (dict(num=512), dict(num=192), dict(num=200), dict(num=512, row_begin=40, row_count=24),
+                    dict(num=512, row_begin=3, row_count=13)):
+            o = make_opts(flags=SPOT, out_mode=mode, first_surf=1, last_surf=N - 2, foc=wl.foc,
+                          image_pt=wl.image_pts[fi])
+            dev = eng.trace_pupil_grid(wl.fields[fi], make_grid((-1., -1.), (1., 1.), **gkw), wi, o,
+                                       nan_fill=True).to_host()
+            oo = oracle.make_opts(flags=SPOT, out_mode=mode, first_surf=1, last_surf=N - 2, foc=wl.foc,
+                                  image_pt=wl.image_pts[fi])
+            orc = oracle.trace_pupil_grid(wl.table, wl.fields[fi], oracle.make_grid((-1., -1.), (1., 1.), **gkw),
+                                          wi, oo)
+            assert np.array_equal(dev.status, orc.status), (mode, gkw)
+            assert np.array_equal(dev.seg, orc.seg, equal_nan=True), (mode, gkw)
+            assert np.array_equal(dev.op, orc.op, equal_nan=True)
+            assert np.array_equal(dev.pupil, orc.pupil)
+    # batched: every field in one launch
+    fis = list(range(len(wl.fields)))
+    optl = [make_opts(flags=SPOT, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2, foc=wl.foc,
+                      image_pt=wl.image_pts[f]) for f in fis]
+    res = eng.trace_pupil_grids([wl.fields[f] for f in fis], [wi] * len(fis),
+                                make_grid((-1., -1.), (1., 1.), 256), optl, nan_fill=True)
+    for f, r in zip(fis, res):
+        h = r.to_host()
+        oo = oracle.make_opts(flags=SPOT, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2, foc=wl.foc,
+                              image_pt=wl.image_pts[f])
+        orc = oracle.trace_pupil_grid(wl.table, wl.fields[f], oracle.make_grid((-1., -1.), (1., 1.), 256), wi, oo)
+        assert np.array_equal(h.status, orc.status)
+        assert np.array_equal(h.seg, orc.seg, equal_nan=True)
+    eng.close()

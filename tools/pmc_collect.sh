@@ -20,6 +20,10 @@ pass() {   # name counters...
 }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM
 pass sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE
+# instruction supply and scalar side of the Newton instances (round 5 audit); a pass whose
+# counter names this ROCm does not know fails on its own and leaves the others alone
+pass sq3 SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES
+pass sq4 SQ_IFETCH SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 find $OUT -name "*.csv" | head -20
