@@ -2058,7 +2058,7 @@ struct VigArgs {
 
 // the feature instances the search kernels are compiled for (csrc/search_*.hip, rox_search.hpp);
 // the host launches the first one that covers the system's features
-constexpr int kSearchInstances[] = {0, F_EVEN, F_RADIAL, F_APLIST, F_ALL};
+constexpr int kSearchInstances[] = {0, F_EVEN, F_RADIAL, F_APLIST, F_EVEN | F_APLIST, F_ALL};
 #define ROX_SEARCH_DECL(name)                                          \
     void launch_aim_##name(const AimArgs &, size_t lds, hipStream_t); \
     void launch_enp_##name(const EnpArgs &, size_t lds, hipStream_t); \
@@ -2067,6 +2067,7 @@ ROX_SEARCH_DECL(lean)
 ROX_SEARCH_DECL(even)
 ROX_SEARCH_DECL(radial)
 ROX_SEARCH_DECL(aplist)
+ROX_SEARCH_DECL(evenap)
 ROX_SEARCH_DECL(general)
 #undef ROX_SEARCH_DECL
 

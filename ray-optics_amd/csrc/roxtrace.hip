@@ -541,6 +541,7 @@ size_t search_lds_bytes(size_t N, size_t W)
         case 1: launch_##kind##_even(a, lds, st); break;                             \
         case 2: launch_##kind##_radial(a, lds, st); break;                           \
         case 3: launch_##kind##_aplist(a, lds, st); break;                           \
+        case 4: launch_##kind##_evenap(a, lds, st); break;                           \
         default: launch_##kind##_general(a, lds, st); break;                         \
         }                                                                            \
     }
