@@ -69,6 +69,9 @@
 #ifndef ROX_MIN_WAVES_POLY   // waves per SIMD the reduced-output modes of those instances are compiled for
 #define ROX_MIN_WAVES_POLY ROX_MIN_WAVES
 #endif
+#ifndef ROX_STAGED_RCP        // 1: refract()'s three quotients by n_out use the refined reciprocal of n_out
+#define ROX_STAGED_RCP 0       //    that the workgroup formed once per (wavelength, interface) at staging:
+#endif                         //    8 VALU fewer per refraction, measured HITS -1 % (111.4 -> 110.3 us), FULL +2 %: off
 #ifndef ROX_KERNEL_ALIGN     // alignment of the trace kernels' code (0: the compiler's 256 bytes)
 #define ROX_KERNEL_ALIGN 0
 #endif
@@ -257,6 +260,7 @@ struct TraceArgs {
     // the pupil grid instead of 64 consecutive rays of a row (trace_tiles; set by the host when
     // the grid divides into such tiles)
     int32_t patch8;
+    int32_t n_band_ok;         // every entry of n_table lies in the slim band (rox_system_create)
     // HITS_COMPACT: decoupled look-back state of this launch
     uint64_t *tile_state;      // [tiles] (epoch << 32 | flag << 30 | count)
     uint32_t *ticket;          // [0] next tile, [1] workgroups done
@@ -475,8 +479,11 @@ __device__ __forceinline__ v3 unit(const v3 &v)
 }
 
 // raytrace.py:19-30.  false = TIR (math.sqrt ValueError)
+// r_ok: r_out = rcp_band(n_out), formed at staging with the very instruction sequence
+// slim_div3 would execute per lane (every index of the table lies in the band, checked on the
+// host): the divisor's band test and the five reciprocal instructions leave the per-ray path.
 __device__ __forceinline__ bool refract(const v3 &d, const v3 &nrm, double n_in,
-                                        double n_out, v3 &out)
+                                        double n_out, v3 &out, double r_out = 0.0, bool r_ok = false)
 {
     const double nlen = slim_sqrt(dot3(nrm, nrm));
 #if ROX_COSI_SLIM
@@ -490,8 +497,14 @@ __device__ __forceinline__ bool refract(const v3 &d, const v3 &nrm, double n_in,
         return false;
     const double n_cosIp = copysign(slim_sqrt(rad), cosI);
     const double alpha = n_cosIp - n_in * cosI;
-    out = slim_div3(v3{n_in * d.x + alpha * nrm.x, n_in * d.y + alpha * nrm.y,
-                       n_in * d.z + alpha * nrm.z}, n_out);
+    const v3 num{n_in * d.x + alpha * nrm.x, n_in * d.y + alpha * nrm.y, n_in * d.z + alpha * nrm.z};
+#if ROX_STAGED_RCP && ROX_SLIM_FP64
+    if (r_ok && wave_all(in_band_or_zero(num.x) && in_band_or_zero(num.y) && in_band_or_zero(num.z))) {
+        out = v3{div_band(num.x, n_out, r_out), div_band(num.y, n_out, r_out), div_band(num.z, n_out, r_out)};
+        return true;
+    }
+#endif
+    out = slim_div3(num, n_out);
     return true;
 }
 
@@ -1082,6 +1095,8 @@ struct Ctx {
     tblp wvls;              // [W]
     tbli slot, nslots_before;
     tblp apthr;             // [N] sqrt_le_threshold(max_aperture + fuzz)
+    tblp rcpn;              // rcp_band(ntab), same shape as ntab; nullptr where not staged (search kernels)
+    bool rcpn_ok;           // every index in the slim band: rcpn may be used
     int N;
     bool check_ap, intersect_obj, filter_ph;
     int first_surf, last_surf;
@@ -1122,6 +1137,7 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
     const int N = c.N;
     tblp tbl = c.tbl;
     tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
+    tblp rnw = PER_RAY_WVL ? c.rcpn + (size_t)wi * N : c.rcpn;      // (read only when c.rcpn_ok)
 #define SLOT(s) ((FEAT & F_PHFILT) ? c.slot[s] : (s))
 #define NSLOTS_BEFORE(s) ((FEAT & F_PHFILT) ? c.nslots_before[s] : (s))
     // without phantom filtering segment k of a packet is interface k
@@ -1305,7 +1321,7 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
             } else if (mode == ROX_REFLECT) {
                 ad = mirror(b4d, nrm);
             } else if (mode == ROX_TRANSMIT) {
-                if (!refract(b4d, nrm, nwl[surf - 1], nwl[surf], ad))
+                if (!refract(b4d, nrm, nwl[surf - 1], nwl[surf], ad, c.rcpn_ok ? rnw[surf] : 0.0, c.rcpn_ok))
                     status = ROX_TIR;               // :239-245
             } else {
                 ad = b4d;
@@ -1548,17 +1564,23 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     double *wvls_w = phc_w + ((FEAT & F_PHASE) ? (size_t)nw_rows * N * kPhaseConsts : 0);
     double *apthr_w = wvls_w + a.n_wvls;                // [N]
     int32_t *slot_w = reinterpret_cast<int32_t *>(apthr_w + N);
-    // HITS_COMPACT: two tiles' worth of packed (x, y) pairs behind the slot map
+    // refined reciprocals of the indices (refract()), behind the slot map
+    double *rcpn_w = reinterpret_cast<double *>(
+        (reinterpret_cast<uintptr_t>(slot_w + 2 * N) + 7) & ~uintptr_t(7));
+    // HITS_COMPACT: two tiles' worth of packed (x, y) pairs behind them
     d2 *stash_w = reinterpret_cast<d2 *>(
-        (reinterpret_cast<uintptr_t>(slot_w + 2 * N) + 15) & ~uintptr_t(15));
+        (reinterpret_cast<uintptr_t>(rcpn_w + (size_t)nw_rows * N) + 15) & ~uintptr_t(15));
 
     // stage the surface table once per workgroup
     for (int i = threadIdx.x; i < N * kRowDoubles; i += kB)
         tbl_w[i] = a.rows[i];
     {
         const size_t w0 = PER_RAY_WVL ? 0 : (size_t)a.wvl_idx_all * N;
-        for (int i = threadIdx.x; i < nw_rows * N; i += kB)
-            ntab_w[i] = a.n_table[w0 + i];
+        for (int i = threadIdx.x; i < nw_rows * N; i += kB) {
+            const double n_i = a.n_table[w0 + i];
+            ntab_w[i] = n_i;
+            rcpn_w[i] = a.n_band_ok ? rcp_band(n_i) : 0.0;
+        }
         if (FEAT & F_PHASE)
             for (int i = threadIdx.x; i < nw_rows * N * kPhaseConsts; i += kB)
                 phc_w[i] = a.ph_consts[w0 * kPhaseConsts + i];
@@ -1578,6 +1600,7 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
 
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w; c.apthr = apthr_w;
+    c.rcpn = rcpn_w; c.rcpn_ok = ROX_STAGED_RCP && a.n_band_ok != 0;
     c.slot = slot_w; c.nslots_before = slot_w + N;
     c.N = N;
     const uint32_t flags = a.opts.flags;

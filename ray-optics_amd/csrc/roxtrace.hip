@@ -209,6 +209,7 @@ struct StreamCtx {
     static constexpr int kItemSlots = 4;
     rox::TraceArgs *d_items = nullptr, *h_items = nullptr;
     int32_t items_cap = 0;
+    std::vector<char> items_last;       // the bytes d_items holds (or is about to, in stream order)
     hipEvent_t item_ev[kItemSlots] = {nullptr, nullptr, nullptr, nullptr};
     bool item_ev_live[kItemSlots] = {false, false, false, false};
     uint32_t item_slot = 0;
@@ -253,6 +254,7 @@ struct rox_system {
     int num_cus = 256;
     int features = 0;                   // F_* of the table
     int n_newton = 0;                   // interfaces intersected by Newton iteration
+    int n_band_ok = 0;                  // every refractive index in the slim-fp64 band
     std::mutex mu;                      // guards ctxs
     std::vector<StreamCtx *> ctxs;
     // the small synchronous search entries (aiming, pupil search, vignetting, pupil
@@ -330,6 +332,7 @@ size_t lds_bytes(const rox_system *s, bool per_ray_wvl, bool phase)
     size_t b = N * sizeof(dev_surface) + Wn * N * sizeof(double) +
                (phase ? Wn * N * kPhaseConsts * sizeof(double) : 0) +
                ((size_t)s->n_wvls + N) * sizeof(double) + 2 * N * sizeof(int32_t);
+    b = ((b + 7) & ~size_t(7)) + Wn * N * sizeof(double);      // the indices' reciprocals
     return (b + 15) & ~size_t(15);
 }
 
@@ -691,6 +694,7 @@ int launch_setup(rox_system *sys, TraceArgs &a, int gen, bool prw, hipStream_t s
     a.slots = sys->d_slots[(a.opts.flags & ROX_FILTER_PHANTOMS) ? 1 : 0];
     a.n_ifcs = sys->n_ifcs;
     a.n_wvls = sys->n_wvls;
+    a.n_band_ok = sys->n_band_ok;
     int need = sys->features;
     if ((a.opts.flags & ROX_FILTER_PHANTOMS) && sys->n_seg[1] != sys->n_seg[0])
         need |= F_PHFILT;
@@ -1231,6 +1235,17 @@ int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_t
     sys->n_wvls = n_wvls;
     sys->features = features;
     sys->n_newton = n_newton;
+    {
+        // (rox_device.hpp in_band: biased exponent in [640, 1408))
+        bool ok = true;
+        for (size_t i = 0; i < (size_t)n_wvls * (size_t)n_ifcs; ++i) {
+            uint64_t u;
+            memcpy(&u, &n_table[i], sizeof u);
+            const uint32_t h = (uint32_t)(u >> 32) & 0x7fffffffu;
+            ok = ok && (h - 0x28000000u) < 0x30000000u;
+        }
+        sys->n_band_ok = ok ? 1 : 0;
+    }
     sys->rows.assign(rows, rows + n_ifcs);
     hipError_t e = hipGetDevice(&sys->device);
     if (e != hipSuccess) {
@@ -1532,19 +1547,31 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
         HIP_TRY(hipHostMalloc(&cx->h_items, sizeof(TraceArgs) * (size_t)want * StreamCtx::kItemSlots,
                               hipHostMallocDefault));
         cx->items_cap = want;
+        cx->items_last.clear();
         for (bool &live : cx->item_ev_live)
             live = false;
     }
-    const uint32_t slot = cx->item_slot++ % StreamCtx::kItemSlots;
-    if (!cx->item_ev[slot])
-        HIP_TRY(hipEventCreateWithFlags(&cx->item_ev[slot], hipEventDisableTiming));
-    if (cx->item_ev_live[slot])
-        HIP_TRY(hipEventSynchronize(cx->item_ev[slot]));
-    TraceArgs *h = cx->h_items + (size_t)slot * cx->items_cap;
-    memcpy(h, items.data(), sizeof(TraceArgs) * (size_t)n_grids);
-    HIP_TRY(hipMemcpyAsync(cx->d_items, h, sizeof(TraceArgs) * (size_t)n_grids, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(cx->item_ev[slot], st));
-    cx->item_ev_live[slot] = true;
+    // The items of a batch that repeats the previous one of this stream byte for byte (a figure
+    // refreshed with unchanged arguments, a timing loop) are already in d_items: the upload -- a
+    // copy-engine transfer in front of the kernel, ~6 us of a 24 us configs[3] pass -- is skipped.
+    const size_t items_bytes = sizeof(TraceArgs) * (size_t)n_grids;
+    const bool same_items = cx->items_last.size() == items_bytes &&
+                            memcmp(cx->items_last.data(), items.data(), items_bytes) == 0;
+    if (!same_items) {
+        const uint32_t slot = cx->item_slot++ % StreamCtx::kItemSlots;
+        if (!cx->item_ev[slot])
+            HIP_TRY(hipEventCreateWithFlags(&cx->item_ev[slot], hipEventDisableTiming));
+        if (cx->item_ev_live[slot])
+            HIP_TRY(hipEventSynchronize(cx->item_ev[slot]));
+        TraceArgs *h = cx->h_items + (size_t)slot * cx->items_cap;
+        memcpy(h, items.data(), items_bytes);
+        cx->items_last.clear();                     // (not valid until the copy is enqueued)
+        HIP_TRY(hipMemcpyAsync(cx->d_items, h, items_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(cx->item_ev[slot], st));
+        cx->item_ev_live[slot] = true;
+        cx->items_last.assign(reinterpret_cast<const char *>(items.data()),
+                              reinterpret_cast<const char *>(items.data()) + items_bytes);
+    }
     k.grid = dim3((unsigned)blocks, (unsigned)n_grids);
     launch_feat_batch(inst, k, cx->d_items);
     HIP_TRY(hipGetLastError());
