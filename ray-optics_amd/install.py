@@ -76,6 +76,7 @@ def install(fallback='raise'):
              # setup_pupil_coords -> get_chief_ray_pkg -> trace_chief_ray (bare module globals of
              # rayoptics.raytr.trace): the chief rays of all fields x wavelengths in one launch
              (rtrace, 'trace_chief_ray', _t.trace_chief_ray),
+             (rtrace, 'trace_astigmatism_coddington_fan', _t.trace_astigmatism_coddington_fan),
              (rtrace, 'aim_chief_ray', _t.aim_chief_ray),
              (ropticalspec, 'aim_chief_ray', _t.aim_chief_ray),
              # the wide-angle pupil search behind aim_chief_ray (trace.py:634-635) and
@@ -90,7 +91,9 @@ def install(fallback='raise'):
              # vigcalc.set_pupil's marginal-ray iteration (set_pupil / set_stop_aperture call
              # iterate_pupil_ray, set_vig and set_clear_apertures through these module globals)
              (rvigcalc, 'iterate_pupil_ray', _v.iterate_pupil_ray),
-             (rtrace, 'trace_boundary_rays_at_field', _v.trace_boundary_rays_at_field)]
+             (rtrace, 'trace_boundary_rays_at_field', _v.trace_boundary_rays_at_field),
+             # ... of every field in one launch (set_clear_apertures, every model update)
+             (rtrace, 'trace_boundary_rays', _v.trace_boundary_rays)]
     for owner, name, ours in seams:
         theirs = getattr(owner, name)
         _saved[(owner, name)] = theirs

@@ -14,6 +14,8 @@ the per-ray Python loop replaced by one device launch.
                      a field's boundary rays in one launch)
   trace_astigmatism <- rayoptics/raytr/trace.py:823-863 (five rays, one launch; the field loop
                      of trace_astigmatism_curve calls it)
+  trace_chief_ray, trace_astigmatism_coddington_fan <- rayoptics/raytr/trace.py:513-535, 708-712
+                     (the chief rays of every field x wavelength of a model state in one launch)
   iterate_ray_raw <- rayoptics/raytr/trace.py:866-961 (the reverse chief ray of
                      wideangle.eval_real_image_ht: the whole iteration in one launch)
   osp_update_optical_properties <- rayoptics/raytr/opticalspec.py:263-281 (method; all
@@ -239,19 +241,7 @@ def trace_chief_ray(opt_model, fld, wvl, foc):
     express or a failing chief ray go to the reference's function."""
     import rayoptics.raytr.trace as rtrace
     from rayoptics.raytr import RayPkg as RefRayPkg
-    pkg = None
-    eng = session.engine_for(opt_model)
-    try:
-        wi = eng.table.wvl_index(wvl)
-        f = field_from_model(opt_model, fld, 'rel pupil',
-                             cache=eng.__dict__.setdefault('_obj_coords_cache', {}))
-        key = (bytes(f), wi)
-        cache = eng.__dict__.get('_chief_cache')
-        if cache is None or key not in cache:
-            cache = _chief_rays(opt_model, eng)
-        pkg = cache.get(key)
-    except (ValueError, KeyError):
-        pkg = None
+    pkg = _chief_ray_packet(opt_model, fld, wvl)
     if pkg is None:
         from . import install
         theirs = install._saved.get((rtrace, 'trace_chief_ray'))
@@ -265,6 +255,43 @@ def trace_chief_ray(opt_model, fld, wvl, foc):
     cr_exp_seg = rtrace.transfer_to_exit_pupil(opt_model.seq_model.ifcs[-2],
                                                (cr.ray[-2][0], cr.ray[-2][1]), fod.exp_dist)
     return cr, cr_exp_seg
+
+
+def _chief_ray_packet(opt_model, fld, wvl):
+    """(seg [N, 10], op) of the chief ray of (fld, wvl) from the model state's batch
+    (:func:`_chief_rays`), or None where the reference's own path must answer"""
+    eng = session.engine_for(opt_model)
+    try:
+        wi = eng.table.wvl_index(wvl)
+        f = field_from_model(opt_model, fld, 'rel pupil',
+                             cache=eng.__dict__.setdefault('_obj_coords_cache', {}))
+        key = (bytes(f), wi)
+        cache = eng.__dict__.get('_chief_cache')
+        if cache is None or key not in cache:
+            cache = _chief_rays(opt_model, eng)
+        return cache.get(key)
+    except (ValueError, KeyError):
+        return None
+
+
+def trace_astigmatism_coddington_fan(opt_model, fld, wvl, foc):
+    """rayoptics/raytr/trace.py:708-712: astigmatism by a Coddington trace along the chief ray
+    of ``fld`` -- ``trace_ray(opt_model, [0., 0.], fld, wvl)`` (named tuples) followed by
+    ``trace_coddington_fan``, which is packet algebra and stays the reference's own.  The chief
+    ray comes from the model state's one-launch batch instead of the one-ray seam."""
+    import rayoptics.raytr.trace as rtrace
+    from rayoptics.raytr import RayPkg as RefRayPkg, RaySeg as RefRaySeg
+    pkg = _chief_ray_packet(opt_model, fld, wvl)
+    if pkg is None:
+        from . import install
+        theirs = install._saved.get((rtrace, 'trace_astigmatism_coddington_fan'))
+        if theirs is None:
+            raise RuntimeError('trace_astigmatism_coddington_fan: not installed over the reference')
+        return theirs(opt_model, fld, wvl, foc)
+    seg, op = pkg
+    blk = seg.copy()
+    cr = RefRayPkg([RefRaySeg(s[0:3], s[3:6], float(s[6]), s[7:10]) for s in blk], op, wvl)
+    return rtrace.trace_coddington_fan(opt_model, cr, foc=foc)
 
 
 def trace_ray_list_at_field(opt_model, ray_list, fld, wvl, foc, **kwargs):

@@ -109,3 +109,66 @@ def trace_boundary_rays_at_field(opt_model, fld, wvl, use_named_tuples=False, **
     ifcs = opt_model['seq_model'].ifcs
     return [emit(pk, r, output_filter, rayerr_filter, use_named_tuples, ifcs)[0]
             for r in range(len(pupil_rays))]
+
+
+_RIM = ((0., 0.), (1., 0.), (-1., 0.), (0., 1.), (0., -1.))    # PupilSpec.default_pupil_rays
+_RIM_IN_3X3 = (4, 7, 1, 5, 3)                                     # ray r = i * 3 + j of x = -1 + i, y = -1 + j
+
+
+def trace_boundary_rays(opt_model, **kwargs):
+    """rayoptics/raytr/trace.py:467-475: the boundary rays of EVERY field at the central
+    wavelength (``set_clear_apertures`` asks for them on every model update,
+    vigcalc.py:68).  The reference traces five single rays per field; the per-field drop-in
+    (:func:`trace_boundary_rays_at_field`) made that one launch per field; here all fields are
+    ONE launch: the five standard pupil points are points of the 3 x 3 product grid over
+    [-1, 1]^2 (whose accumulated coordinates -1, -1 + 1, -1 + 1 + 1 are exactly -1, 0, 1), so
+    the batch is ``trace_pupil_grids_host`` of that grid for every field -- FULL packets
+    straight into pinned host memory -- and rays 4, 7, 1, 5, 3 of each item are the rim rays.
+    Anything else (other pupil rays, extra keywords) takes the per-field route."""
+    import rayoptics.raytr.trace as rtrace
+    from . import abi
+    from .analyses import _setup_pupil_coords
+    from .engine import make_grid
+    from .raypkg import HostPackets
+    from .table import field_from_model
+    from .trace import emit, opts_from_kwargs
+    osp = opt_model.optical_spec
+    fov = osp.field_of_view
+    wvl = opt_model.seq_model.central_wavelength()
+    pupil_rays = osp.pupil.pupil_rays
+    std = (len(pupil_rays) == 5 and
+           all(float(p[0]) == q[0] and float(p[1]) == q[1] for p, q in zip(pupil_rays, _RIM)))
+    if not std or (set(kwargs) - {'use_named_tuples', 'rayerr_filter'}):
+        rayset = []
+        for fld in fov.fields:
+            rim_rays = rtrace.trace_boundary_rays_at_field(opt_model, fld, wvl, **kwargs)
+            fld.pupil_rays = rtrace.boundary_ray_dict(opt_model, rim_rays)
+            rayset.append(rim_rays)
+        return rayset
+    named = kwargs.get('use_named_tuples', False)
+    rayerr_filter = kwargs.get('rayerr_filter', 'full')
+    with session.hold(opt_model) as eng:
+        for fld in fov.fields:                  # (may aim a field that has no chief ray yet)
+            ref_sphere, cr_pkg = _setup_pupil_coords(opt_model, fld, wvl, 0.0)
+            fld.chief_ray = cr_pkg
+            fld.ref_sphere = ref_sphere
+        tbl = eng.table
+        wi = tbl.wvl_index(wvl)
+        oc = eng.__dict__.setdefault('_obj_coords_cache', {})
+        flds, optl = [], []
+        for fld in fov.fields:
+            f = field_from_model(opt_model, fld, 'rel pupil', cache=oc)
+            opts = opts_from_kwargs(tbl.n_ifcs, {'apply_vignetting': True}, abi.OUT_FULL)
+            if f.kind == abi.FLD_EPD_WIDE or f.z_dir0 == 0.0:
+                opts.flags &= ~abi.INTERSECT_OBJ        # trace.py:302-303
+            flds.append(f)
+            optl.append(opts)
+        res = eng.trace_pupil_grids_host(flds, [wi] * len(flds), make_grid((-1., -1.), (1., 1.), 3), optl)
+        ifcs = opt_model['seq_model'].ifcs
+        rayset = []
+        for fld, opts, h in zip(fov.fields, optl, res):
+            pk = HostPackets(h, tbl, opts.flags, abi.OUT_FULL, wvl)
+            rim_rays = [emit(pk, r, None, rayerr_filter, named, ifcs)[0] for r in _RIM_IN_3X3]
+            fld.pupil_rays = rtrace.boundary_ray_dict(opt_model, rim_rays)
+            rayset.append(rim_rays)
+    return rayset

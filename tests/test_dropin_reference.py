@@ -1722,3 +1722,71 @@ def test_chief_ray_batch_follows_the_model(ref, installed):
     with pytest.raises(ValueError):
         trace.setup_pupil_coords(opm, fld, 600.0, 0.0)
     installed.install()
+
+
+@pytest.mark.parametrize('model', ['dblgauss', 'singlet'])
+def test_coddington_astigmatism_along_the_batched_chief_ray(ref, installed, model):
+    """trace.trace_astigmatism_coddington_fan (trace.py:708-712): the Coddington recursion is the
+    reference's own on a chief ray taken from the model state's one-launch batch; every field
+    and wavelength, with and without a focus shift"""
+    import rayoptics.raytr.trace as trace
+    opm = getattr(ref, model)()
+    osp = opm['osp']
+
+    def run():
+        out = []
+        for fld in osp['fov'].fields:
+            for wvl in osp['wvls'].wavelengths:
+                for foc in (None, 0.0, 0.03):
+                    out.append(trace.trace_astigmatism_coddington_fan(opm, fld, wvl, foc))
+        return out
+    ours, theirs = both(installed, run)
+    assert len(ours) == len(theirs) >= 3
+    for a, b in zip(ours, theirs):
+        _same_tree(list(a), list(b))
+
+
+@pytest.mark.parametrize('model', ['dblgauss', 'singlet', 'rc_telescope', 'nikkor', 'cell_phone', 'tilted_singlet'])
+def test_boundary_rays_of_every_field_in_one_launch(ref, installed, model):
+    """trace.trace_boundary_rays (trace.py:467-475; set_clear_apertures calls it on every model
+    update): five rim rays per field, all fields one launch -- every packet (named tuples and
+    plain), the fields' pupil_rays dictionaries, chief rays and reference spheres are the
+    reference's; so is a run with the vignetting factors pushed until rim rays fail"""
+    import rayoptics.raytr.trace as trace
+    from rayoptics_amd import session
+
+    def snapshot(opm, **kw):
+        rs = trace.trace_boundary_rays(opm, **kw)
+        flds = opm['osp']['fov'].fields
+        return ([[None if p is None else (list(p[0]), p[1], p[2]) for p in f] for f in rs],
+                [sorted(f.pupil_rays) for f in flds],
+                [(f.ref_sphere[:3], f.chief_ray[0][1], f.chief_ray[1][:3]) for f in flds])
+    for kw in (dict(use_named_tuples=True), dict()):
+        opm = getattr(ref, model)()
+        launches = []
+        eng = session.engine_for(opm)
+        real = eng.trace_pupil_grids_host
+
+        def counting(flds, *a, **k):
+            launches.append(len(flds))
+            return real(flds, *a, **k)
+        eng.trace_pupil_grids_host = counting
+        ours = snapshot(opm, **kw)
+        n_f = len(opm['osp']['fov'].fields)
+        assert n_f in launches                      # the rim rays of all fields: one launch
+        installed.uninstall()
+        theirs = snapshot(getattr(ref, model)(), **kw)
+        installed.install()
+        _same_tree(ours[0], theirs[0])
+        assert ours[1] == theirs[1]
+        _same_tree(ours[2], theirs[2])
+    # rim rays that fail (the vignetting opened far beyond the apertures): partial packets
+    def wide(opm):
+        for f in opm['osp']['fov'].fields:
+            f.vux = f.vlx = f.vuy = f.vly = -0.9
+        return snapshot(opm, use_named_tuples=True)
+    ours = wide(getattr(ref, model)())
+    installed.uninstall()
+    theirs = wide(getattr(ref, model)())
+    installed.install()
+    _same_tree(ours[0], theirs[0])
