@@ -733,7 +733,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
     // lane byte offsets are 32-bit: at most 2^28 rays per launch
     const int64_t total = a.n_rays;
     int64_t chunk_max = rays_per_launch();
-    k.small = want_small(sys, total, a.opts.out_mode, kInstances[inst]);
+    k.small = !prw && want_small(sys, total, a.opts.out_mode, kInstances[inst]);   // (per-ray-wavelength lists keep the regular kernels)
     const bool compact = a.opts.out_mode == ROX_OUT_HITS_COMPACT;
     StreamCtx *cx = nullptr;
     bool two_pass = false;

@@ -111,6 +111,19 @@ def trace_boundary_rays_at_field(opt_model, fld, wvl, use_named_tuples=False, **
             for r in range(len(pupil_rays))]
 
 
+def _materialised(pkg):
+    """a boundary-ray package with its segments as a real list, as the reference returns it:
+    ``max_aperture_at_surf`` (vigcalc.py:31-42) indexes every segment of every rim ray for every
+    interface -- 370 lazy segment builds per model update otherwise"""
+    if pkg is None:
+        return None
+    ray = pkg[0]
+    if hasattr(ray, 'to_list'):
+        ray = ray.to_list()
+        return pkg._replace(ray=ray) if hasattr(pkg, '_replace') else (ray,) + tuple(pkg[1:])
+    return pkg
+
+
 _RIM = ((0., 0.), (1., 0.), (-1., 0.), (0., 1.), (0., -1.))    # PupilSpec.default_pupil_rays
 _RIM_IN_3X3 = (4, 7, 1, 5, 3)                                     # ray r = i * 3 + j of x = -1 + i, y = -1 + j
 
@@ -168,7 +181,7 @@ def trace_boundary_rays(opt_model, **kwargs):
         rayset = []
         for fld, opts, h in zip(fov.fields, optl, res):
             pk = HostPackets(h, tbl, opts.flags, abi.OUT_FULL, wvl)
-            rim_rays = [emit(pk, r, None, rayerr_filter, named, ifcs)[0] for r in _RIM_IN_3X3]
+            rim_rays = [_materialised(emit(pk, r, None, rayerr_filter, named, ifcs)[0]) for r in _RIM_IN_3X3]
             fld.pupil_rays = rtrace.boundary_ray_dict(opt_model, rim_rays)
             rayset.append(rim_rays)
     return rayset
