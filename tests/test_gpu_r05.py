@@ -235,3 +235,84 @@ def test_patch_lane_mapping_leaves_every_ray_where_it_was(name, monkeypatch):
         assert np.array_equal(h.status, orc.status)
         assert np.array_equal(h.seg, orc.seg, equal_nan=True)
     eng.close()
+
+
+def _flat_table(aps, max_aperture=50.0):
+    """object plane, one flat dummy carrying the clear apertures `aps`, image plane"""
+    from rayoptics_amd import SurfaceTable
+    rows = (abi.Surface * 3)()
+    for i, r in enumerate(rows):
+        r.mode, r.profile, r.ec = abi.DUMMY, abi.SPHERICAL, 1.0
+        for k in range(3):
+            r.rt[4 * k] = 1.0
+        r.t[2] = 5.0 if i < 2 else 0.0
+        r.z_dir = 1.0
+        r.max_aperture = 1e12
+    rows[1].max_aperture = max_aperture
+    rows[1].n_ap = len(aps)
+    for k, (kind, obsc, ox, oy, a, b) in enumerate(aps):
+        ap = rows[1].ap[k]
+        ap.kind, ap.is_obscuration, ap.x_offset, ap.y_offset, ap.a, ap.b = kind, obsc, ox, oy, a, b
+    return SurfaceTable(rows, np.ones((1, 3)), [550.0])
+
+
+@pytest.mark.parametrize('aps', [
+    [],                                                                     # max_aperture alone
+    [(abi.AP_CIRCULAR, 0, 0.0, 0.0, 3.7, 0.0)],
+    [(abi.AP_CIRCULAR, 0, 0.31, -0.77, 2.9, 0.0)],
+    [(abi.AP_CIRCULAR, 1, -0.4, 0.2, 1.3, 0.0)],                            # an obscuration
+    [(abi.AP_CIRCULAR, 0, 0.1, 0.1, 4.1, 0.0), (abi.AP_CIRCULAR, 1, 0.0, 0.3, 0.9, 0.0),
+     (abi.AP_RECTANGULAR, 0, 0.2, 0.0, 3.0, 2.5)],
+])
+def test_aperture_edges_decided_as_the_square_root_decides_them(aps):
+    """the aperture tests compare x^2 + y^2 with a staged threshold instead of taking the square
+    root (rox_device.hpp sqrt_le_threshold / stage_aperture_thresholds).  Rays parallel to the
+    axis land on a flat surface exactly where they start, so their start points are laid within
+    +-6 ulp of every circular edge (radius + fuzz, along 97 directions) and of the rectangular
+    ones: blocked / passed must be the oracle's -- which takes the square root, like the
+    reference -- for every one of them, with two fuzz values"""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine
+    max_ap = 6.3
+    tbl = _flat_table(aps, max_ap)
+    eng = TraceEngine(tbl)
+    n_edge = 0
+    for fuzz in (1e-5, 1e-4):
+        pts = []
+        circles = [(0.0, 0.0, max_ap)] if not aps else [(ox, oy, a) for k, _o, ox, oy, a, _b in aps
+                                                         if k == abi.AP_CIRCULAR]
+        for ox, oy, rad in circles:
+            t = rad + fuzz
+            for ang in np.linspace(0.0, 2 * np.pi, 97):
+                c, s_ = np.cos(ang), np.sin(ang)
+                for scale in (1.0, np.nextafter(1.0, 2.0), np.nextafter(1.0, 0.0)):
+                    x, y = ox + t * scale * c, oy + t * scale * s_
+                    for kx in range(-6, 7, 3):
+                        xx = x
+                        for _ in range(abs(kx)):
+                            xx = np.nextafter(xx, np.inf if kx > 0 else -np.inf)
+                        pts.append((xx, y))
+        for k, _o, ox, oy, a, b in aps:
+            if k == abi.AP_RECTANGULAR:
+                for sx in (-1, 1):
+                    e = ox + sx * (a + fuzz)
+                    for kx in range(-4, 5):
+                        xx = e
+                        for _ in range(abs(kx)):
+                            xx = np.nextafter(xx, np.inf if kx > 0 else -np.inf)
+                        pts.append((xx, oy + 0.3))
+        pts = np.array(pts)
+        R = len(pts)
+        pt0 = np.stack([pts[:, 0], pts[:, 1], np.zeros(R)])
+        d = np.stack([np.zeros(R), np.zeros(R), np.ones(R)])
+        for mode in (abi.OUT_FULL, abi.OUT_HITS):
+            opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES, out_mode=mode, first_surf=1,
+                                    last_surf=1, fuzz=fuzz, image_pt=(0.0, 0.0))
+            orc = oracle.trace_rays(tbl, pt0, d, 0, opts)
+            dev = eng.trace_rays(pt0, d, 0, opts, nan_fill=True).to_host()
+            assert np.array_equal(dev.status, orc.status), (fuzz, mode, int((dev.status != orc.status).sum()))
+            assert np.array_equal(dev.fail_surf, orc.fail_surf)
+        n_edge += int((orc.status == abi.BLOCKED).sum())
+        assert 0 < int((orc.status == abi.BLOCKED).sum()) < R       # the points really straddle the edges
+    eng.close()
+    assert n_edge > 0
