@@ -745,7 +745,7 @@ def drop_segments():
 atexit.register(drop_segments)
 
 
-PRED = {'c5_kernels_ms_one_gpu': 75.2, 'pcie_GBps': 55.0, 'xgmi_link_GBps': 153.0,
+PRED = {'c5_kernels_ms_one_gpu': 68.2, 'pcie_GBps': 55.0, 'xgmi_link_GBps': 153.0,
         'piece_tail_ms': 0.3, 'stage_sync_ms_per_stage': 0.06}
 
 

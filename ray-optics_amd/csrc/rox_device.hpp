@@ -83,6 +83,13 @@
 #ifndef ROX_WAVE_TICKETS     // 1: the reduced-output modes (HITS, LAST, OPD, FAN) run as resident waves that
 #define ROX_WAVE_TICKETS 0    //    stride over 64-ray tiles (wave_ticketed() below): measured slower, off
 #endif
+#ifndef ROX_MIN_WAVES_APLIST_REDUCED  // waves per SIMD the HITS kernels of the aperture-list instance
+#define ROX_MIN_WAVES_APLIST_REDUCED 8 // (spherical tables with clear-aperture lists: every Zemax import without
+#endif                                 // aspheres -- BASELINE configs[3], configs[4]) are compiled for.  At the
+                                       // default 4 hipcc takes 79 VGPRs; held to 64 (56 B of scratch per lane) or 72
+                                       // the same source is 8 % faster: lithography lens HITS 421 -> 386 us per 2^20
+                                       // rays, RC telescope 46.6 -> 42.9 (7: 389 / 42.9); the lean instance gains
+                                       // nothing from it (111.0 -> 113.6) and FULL loses 7-12 %.  profiles/r05_min_waves.txt
 #ifndef ROX_BLOCK_SMALL      // workgroup size of launches that do not fill the chip (block_of() below)
 #define ROX_BLOCK_SMALL 256
 #endif
@@ -181,9 +188,12 @@ constexpr bool has_small(int out_mode, int feat)
 {
     return block_of(out_mode, feat, true) != block_of(out_mode, feat, false);
 }
-constexpr int min_waves_of(int out_mode, int feat)
+constexpr int min_waves_of(int out_mode, int feat, bool small = false)
 {
-    return (out_mode == ROX_OUT_FULL && (feat & kFeatNewton)) ? ROX_MIN_WAVES_FULL_POLY
+    // (the small-workgroup kernels serve launches that fit the chip once: latency, where the
+    // scratch of the tighter budget costs -- configs[3] HITS 18 -> 20 us -- instead of paying)
+    return (feat == 8 /* F_APLIST */ && out_mode == ROX_OUT_HITS && !small) ? ROX_MIN_WAVES_APLIST_REDUCED
+         : (out_mode == ROX_OUT_FULL && (feat & kFeatNewton)) ? ROX_MIN_WAVES_FULL_POLY
          : (out_mode == ROX_OUT_HITS_COMPACT && !(feat & ~8)) ? ROX_MIN_WAVES_COMPACT_LEAN
          : (out_mode != ROX_OUT_FULL && out_mode != ROX_OUT_HITS_COMPACT && (feat & kFeatNewton))
                ? ROX_MIN_WAVES_POLY
@@ -1824,7 +1834,7 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
 }
 
 template <int OUT_MODE, int GEN, bool PER_RAY_WVL, int FEAT, bool SMALL = false>
-__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT, SMALL), min_waves_of(OUT_MODE, FEAT))
+__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT, SMALL), min_waves_of(OUT_MODE, FEAT, SMALL))
 ROX_KERNEL_ALIGNED trace_kernel(const TraceArgs a)
 {
     trace_tiles<OUT_MODE, GEN, PER_RAY_WVL, FEAT, SMALL>(a);
@@ -1837,7 +1847,7 @@ ROX_KERNEL_ALIGNED trace_kernel(const TraceArgs a)
 // address space, i.e. with the same scalar loads that read a kernel argument.
 typedef const __attribute__((address_space(4))) TraceArgs *ConstTraceArgs;
 template <int OUT_MODE, int FEAT, bool SMALL = false>
-__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT, SMALL), min_waves_of(OUT_MODE, FEAT))
+__global__ void __launch_bounds__(block_of(OUT_MODE, FEAT, SMALL), min_waves_of(OUT_MODE, FEAT, SMALL))
 ROX_KERNEL_ALIGNED trace_kernel_batch(const TraceArgs *items)
 {
     trace_tiles<OUT_MODE, GEN_PUPIL, false, FEAT, SMALL>(*(ConstTraceArgs)(items + blockIdx.y));
