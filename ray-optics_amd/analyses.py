@@ -48,8 +48,13 @@ def trace_list_of_rays(opt_model, rays, output_filter=None, rayerr_filter=None,
     out_mode = (abi.OUT_LAST if output_filter == 'last' and rayerr_filter != 'full'
                 else abi.OUT_FULL)
     opts = opts_from_kwargs(tbl.n_ifcs, kwargs, out_mode)
-    res = eng.trace_rays(pt0, dir0, wi, opts)
-    pk = HostPackets(res.to_host(), tbl, opts.flags, out_mode, wvls)
+    from .engine import HOST_DIRECT_BYTES
+    per_ray = 8 * (abi.SEG_DOUBLES * (tbl.n_ifcs if out_mode == abi.OUT_FULL else 1) + 8)
+    if R * per_ray <= HOST_DIRECT_BYTES and hasattr(eng, 'trace_rays_np'):
+        host = eng.trace_rays_np(pt0, dir0, wi, opts)       # (small lists: no device-to-host copies)
+    else:
+        host = eng.trace_rays(pt0, dir0, wi, opts).to_host()
+    pk = HostPackets(host, tbl, opts.flags, out_mode, wvls)
     ifcs = opt_model['seq_model'].ifcs
     named = True        # trace.trace() wraps in RayPkg (trace.py:250)
     ray_list = []

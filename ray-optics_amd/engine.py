@@ -274,6 +274,10 @@ class _View:
 
 _pool = PinnedPool()
 
+# pupil launches whose outputs are at most this many bytes go through ROX_HOST_POINTERS
+# (TraceEngine.trace_pupil_np); the library bounces up to 4 MiB through its mapped block
+HOST_DIRECT_BYTES = 1 << 20
+
 
 class DeviceResult:
     """SoA trace results resident in HBM (torch tensors on the engine's device).
@@ -552,16 +556,19 @@ class TraceEngine:
 
     @_in_flight
     def trace_pupil_grids_host(self, flds, wvl_idxs, grid, opts_list):
-        """FULL (or LAST) packets of several small pupil grids by ONE launch whose stores go
-        straight into one pinned host block -- no copy-engine transfer, one synchronise --
-        for figure-sized batches (the chief rays of every field and wavelength of a model,
-        trace.trace_chief_ray).  Returns one host result per item (``seg`` [n_seg, 10, R],
+        """FULL / LAST packets (or the FAN / OPD / HITS rows) of several small pupil grids by ONE
+        launch whose stores go straight into one pinned host block -- no copy-engine transfer,
+        one synchronise -- for figure-sized batches (the chief rays of every field and
+        wavelength of a model, trace.trace_chief_ray; the fans of a RayFanFigure).  Returns one host result per item (``seg`` [n_seg, 10, R],
         ``op``, ``status``, ``fail_surf``, ``pupil``: NumPy views of the block; segments past
         a failure are NaN)."""
         R = grid_rays(grid)
         n = len(flds)
         mode = opts_list[0].out_mode
-        rows = (self.num_segments(opts_list[0].flags) if mode == abi.OUT_FULL else 1) * abi.SEG_DOUBLES
+        if mode == abi.OUT_FULL:
+            rows = self.num_segments(opts_list[0].flags) * abi.SEG_DOUBLES
+        else:
+            rows = {abi.OUT_LAST: abi.SEG_DOUBLES, abi.OUT_OPD: 1, abi.OUT_FAN: 3, abi.OUT_HITS: 2}[mode]
         b_seg, b_op, b_pu = 8 * rows * R, 8 * R, 16 * R
         b_st, b_fs = (R + 15) // 16 * 16, (2 * R + 15) // 16 * 16
         per = b_seg + b_op + b_pu + b_st + b_fs
@@ -584,7 +591,7 @@ class TraceEngine:
             h = _H()
             h.R, h.out_mode = R, mode
             h.seg = lease.array((rows // abi.SEG_DOUBLES, abi.SEG_DOUBLES, R) if mode == abi.OUT_FULL
-                                else (abi.SEG_DOUBLES, R), np.float64, off)
+                                else (rows, R), np.float64, off)
             h.op = lease.array((R,), np.float64, off + b_seg)
             h.pupil = lease.array((2, R), np.float64, off + b_seg + b_op)
             h.status = lease.array((R,), np.uint8, off + b_seg + b_op + b_pu)
@@ -635,6 +642,101 @@ class TraceEngine:
                    'rox_trace_pupil_list')
         res._keep = (px, py)
         return res
+
+    @_in_flight
+    def trace_pupil_np(self, fld, wvl_idx, opts, grid=None, px=None, py=None):
+        """A SMALL pupil launch (a fan, a handful of rays, a figure-sized grid) with plain NumPy
+        buffers through the library's ROX_HOST_POINTERS path: inputs and results cross in one
+        device-mapped pinned block that the kernel reads and writes directly -- one launch, one
+        synchronise, no torch tensors, no copy-engine transfers (a DeviceResult + to_host costs
+        five device-to-host copies: ~1.2 ms of a RayFanFigure refresh went there).  Returns the
+        host result (``seg`` [n_seg, 10, R] or [rows, R], ``op``, ``status``, ``fail_surf``,
+        ``pupil``; slots the trace does not produce are NaN).  Callers keep it to batches of
+        at most HOST_DIRECT_BYTES."""
+        mode = opts.out_mode
+        if grid is not None:
+            R = grid_rays(grid)
+        else:
+            px = np.ascontiguousarray(px, dtype=np.float64)
+            py = np.ascontiguousarray(py, dtype=np.float64)
+            R = px.shape[0]
+        if mode == abi.OUT_FULL:
+            key = opts.flags & abi.FILTER_PHANTOMS
+            nseg = self._nseg.get(key)
+            if nseg is None:
+                nseg = self._nseg[key] = self.num_segments(opts.flags)
+            shape = (nseg, abi.SEG_DOUBLES, R)
+        else:
+            shape = ({abi.OUT_LAST: abi.SEG_DOUBLES, abi.OUT_OPD: 1, abi.OUT_FAN: 3, abi.OUT_HITS: 2}[mode], R)
+
+        class _H:
+            pass
+        h = _H()
+        h.R, h.out_mode = R, mode
+        h.seg = np.empty(shape)
+        h.op = np.empty(R)
+        h.status = np.empty(R, dtype=np.uint8)
+        h.fail_surf = np.empty(R, dtype=np.int16)
+        h.pupil = np.empty((2, R))
+        o = abi.Out()
+        o.seg, o.op, o.status = h.seg.ctypes.data, h.op.ctypes.data, h.status.ctypes.data
+        o.fail_surf, o.pupil, o.ld = h.fail_surf.ctypes.data, h.pupil.ctypes.data, R
+        saved = opts.flags
+        opts.flags = saved | abi.HOST_POINTERS
+        try:
+            with self.torch.cuda.device(self.device):
+                if grid is not None:
+                    rc = self.lib.rox_trace_pupil_grid(self._handle, C.byref(fld), C.byref(grid), int(wvl_idx),
+                                                       C.byref(opts), C.byref(o), self._stream())
+                else:
+                    rc = self.lib.rox_trace_pupil_list(self._handle, C.byref(fld), R, px.ctypes.data,
+                                                       py.ctypes.data, int(wvl_idx), C.byref(opts),
+                                                       C.byref(o), self._stream())
+        finally:
+            opts.flags = saved
+        _check(rc, 'rox_trace_pupil_grid' if grid is not None else 'rox_trace_pupil_list')
+        return h
+
+    @_in_flight
+    def trace_rays_np(self, pt0, dir0, wvl_idx, opts):
+        """explicit rays ([3, R] arrays, one wavelength index or R of them) with plain NumPy
+        buffers through ROX_HOST_POINTERS -- the small-batch form of :meth:`trace_rays`, see
+        :meth:`trace_pupil_np`"""
+        pt0 = np.ascontiguousarray(pt0, dtype=np.float64)
+        dir0 = np.ascontiguousarray(dir0, dtype=np.float64)
+        R = pt0.shape[1]
+        mode = opts.out_mode
+        if mode == abi.OUT_FULL:
+            shape = (self.num_segments(opts.flags), abi.SEG_DOUBLES, R)
+        else:
+            shape = ({abi.OUT_LAST: abi.SEG_DOUBLES, abi.OUT_HITS: 2}[mode], R)
+        if np.ndim(wvl_idx) == 0:
+            wi, wi_ptr, wi_all = None, None, int(wvl_idx)
+        else:
+            wi = np.ascontiguousarray(wvl_idx, dtype=np.int32)
+            wi_ptr, wi_all = wi.ctypes.data, 0
+
+        class _H:
+            pass
+        h = _H()
+        h.R, h.out_mode, h.pupil = R, mode, None
+        h.seg = np.empty(shape)
+        h.op = np.empty(R)
+        h.status = np.empty(R, dtype=np.uint8)
+        h.fail_surf = np.empty(R, dtype=np.int16)
+        o = abi.Out()
+        o.seg, o.op, o.status = h.seg.ctypes.data, h.op.ctypes.data, h.status.ctypes.data
+        o.fail_surf, o.ld = h.fail_surf.ctypes.data, R
+        saved = opts.flags
+        opts.flags = saved | abi.HOST_POINTERS
+        try:
+            with self.torch.cuda.device(self.device):
+                rc = self.lib.rox_trace_rays(self._handle, R, pt0.ctypes.data, dir0.ctypes.data, wi_ptr,
+                                             wi_all, C.byref(opts), C.byref(o), self._stream())
+        finally:
+            opts.flags = saved
+        _check(rc, 'rox_trace_rays')
+        return h
 
     # -- spot diagram: hits compacted on the device, written to pinned memory ----
     def _hits_out(self, R, want_status=False):

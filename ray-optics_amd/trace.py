@@ -375,6 +375,17 @@ def _trace_pupil(opt_model, fld, wvl, kwargs, output_filter, rayerr_filter, grid
         out_mode = (abi.OUT_LAST if output_filter == 'last' and rayerr_filter != 'full'
                     else abi.OUT_FULL)
     eng, f, wi, opts = _launch_setup(opt_model, fld, wvl, kwargs, out_mode, foc, image_pt, wf)
+    # small launches (fans, rim rays, ray lists, figure-sized grids): NumPy buffers through the
+    # library's host-pointer path -- one launch, one synchronise, no device-to-host copies
+    from .engine import HOST_DIRECT_BYTES, grid_rays
+    R = grid_rays(grid) if grid is not None else len(pupil_list[0])
+    per_ray = 8 * (abi.SEG_DOUBLES * (eng.table.n_ifcs if out_mode == abi.OUT_FULL else 1) + 4)
+    if R * per_ray <= HOST_DIRECT_BYTES and hasattr(eng, 'trace_pupil_np'):
+        if grid is not None:
+            h = eng.trace_pupil_np(f, wi, opts, grid=grid)
+        else:
+            h = eng.trace_pupil_np(f, wi, opts, px=pupil_list[0], py=pupil_list[1])
+        return HostPackets(h, eng.table, opts.flags, out_mode, wvl)
     if grid is not None:
         res = eng.trace_pupil_grid(f, grid, wi, opts)
     else:
@@ -605,10 +616,11 @@ def _seq_trace_fan(self, fct, fi, xy, num_rays=21, **kwargs):
             flds.append(f)
             wis.append(widx)
             optl.append(opts)
-        res = eng.trace_pupil_grids(flds, wis, make_grid(fan_def[0], fan_def[1], num_rays, abi.GRID_FAN),
-                                    optl)
-        for (w, _rs, _cr, _wf), r in zip(setups, res):
-            h = r.to_host(want=('seg', 'status', 'pupil'))
+        # (every wavelength's fan in one launch, written by the kernel straight into pinned host
+        # memory: one synchronise instead of three device-to-host copies per wavelength)
+        res = eng.trace_pupil_grids_host(flds, wis, make_grid(fan_def[0], fan_def[1], num_rays, abi.GRID_FAN),
+                                         optl)
+        for (w, _rs, _cr, _wf), h in zip(setups, res):
             seg = h.seg if h.seg.ndim == 2 else h.seg[0]       # [3][num_rays]: dx, dy, OPD
             if kind == 'opd':
                 # convert_to_waves = 1/self.wvl_to_sys_units(wvl) of the figure (:126)

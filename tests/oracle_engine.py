@@ -144,6 +144,11 @@ class OracleEngine:
     def trace_pupil_grids(self, flds, wvl_idxs, grid, opts_list, **kw):
         return [self.trace_pupil_grid(f, grid, w, o) for f, w, o in zip(flds, wvl_idxs, opts_list)]
 
+    def trace_pupil_np(self, fld, wvl_idx, opts, grid=None, px=None, py=None):
+        if grid is not None:
+            return self.trace_pupil_grid(fld, grid, wvl_idx, opts).to_host()
+        return self.trace_pupil_list(fld, px, py, wvl_idx, opts).to_host()
+
     def trace_pupil_grids_host(self, flds, wvl_idxs, grid, opts_list):
         return [self.trace_pupil_grid(f, grid, w, o).to_host() for f, w, o in zip(flds, wvl_idxs, opts_list)]
 
