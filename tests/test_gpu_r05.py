@@ -316,3 +316,49 @@ def test_aperture_edges_decided_as_the_square_root_decides_them(aps):
         assert 0 < int((orc.status == abi.BLOCKED).sum()) < R       # the points really straddle the edges
     eng.close()
     assert n_edge > 0
+
+
+@pytest.mark.parametrize('name', ['dblgauss_c2', 'cell_phone', 'rc_telescope_c4'])
+def test_host_pointer_small_launches_equal_the_device_results(name):
+    """TraceEngine.trace_pupil_np / trace_rays_np (NumPy buffers through ROX_HOST_POINTERS: what
+    the drop-ins use for launches of <= 1 MiB) against the DeviceResult path of the same
+    launch: FULL / LAST / HITS, a vignetted grid with failing rays, a fan, a row block, a pupil
+    list, explicit rays with per-ray wavelengths -- every array equal, NaN where nothing is
+    produced"""
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    wl = workloads.load(name)
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    fi = len(wl.fields) - 1
+    fld = wl.fields[fi]
+    wi = wl.ref_wvl_idx
+
+    def same(h, d):
+        assert np.array_equal(h.status, d.status) and np.array_equal(h.fail_surf, d.fail_surf)
+        assert np.array_equal(h.op, d.op, equal_nan=True)
+        ok = d.status == abi.OK
+        hs, ds = (h.seg, d.seg) if h.seg.ndim == 3 else (h.seg[None], d.seg[None])
+        assert np.array_equal(hs[:, :, ok], ds[:, :, ok])
+        assert np.isnan(hs[-1][:, ~ok]).all()            # nothing produced there: NaN
+        if getattr(h, 'pupil', None) is not None and d.pupil is not None:
+            assert np.array_equal(h.pupil, d.pupil)
+    rng = np.random.default_rng(11)
+    for mode in (abi.OUT_FULL, abi.OUT_LAST, abi.OUT_HITS):
+        o = make_opts(flags=SPOT, out_mode=mode, first_surf=1, last_surf=N - 2, foc=wl.foc,
+                      image_pt=wl.image_pts[fi])
+        for g in (make_grid((-1.2, -1.2), (1.2, 1.2), 23), make_grid((0., -1.), (0., 1.), 21, abi.GRID_FAN),
+                  make_grid((-1., -1.), (1., 1.), 40, row_begin=5, row_count=7)):
+            same(eng.trace_pupil_np(fld, wi, o, grid=g),
+                 eng.trace_pupil_grid(fld, g, wi, o, nan_fill=True).to_host())
+        px, py = rng.uniform(-1.3, 1.3, 57), rng.uniform(-1.3, 1.3, 57)
+        same(eng.trace_pupil_np(fld, wi, o, px=px, py=py),
+             eng.trace_pupil_list(fld, px, py, wi, o, nan_fill=True).to_host())
+        R = 41
+        pt0 = np.stack([rng.uniform(-1, 1, R), rng.uniform(-1, 1, R), np.full(R, -30.0)])
+        d = np.stack([rng.uniform(-.05, .05, R), rng.uniform(-.05, .05, R), np.ones(R)])
+        d /= np.sqrt((d * d).sum(0))
+        o2 = make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES, out_mode=mode, first_surf=1, last_surf=N - 2)
+        for w in (wi, rng.integers(0, len(wl.table.wvls), R).astype(np.int32)):
+            same(eng.trace_rays_np(pt0, d, w, o2), eng.trace_rays(pt0, d, w, o2, nan_fill=True).to_host())
+    eng.close()
