@@ -126,6 +126,10 @@ def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
+    # the BASELINE configurations are timed as a call whose fields or outputs changed: the library's
+    # short cut for a batch that repeats the stream's previous one byte for byte (no item upload,
+    # ~6 us of a ~24 us configs[3] pass) is switched off for this process (read once by the library)
+    os.environ.setdefault('ROX_BATCH_ALWAYS_UPLOAD', '1')
     import torch
     import torch.distributed as dist
     import rayoptics_amd  # noqa: F401
@@ -250,7 +254,15 @@ def main():
     hits = DeviceResult(torch, eng.device, 0, R, abi.OUT_HITS, want_pupil=False, nan_fill=False)
     hits_kern_ms = eng.time_pupil_grid_sustained(fld, grid, wi, o_hits, hits,
                                                  max(min(args.steps, 50), 10))
-    del hits
+    # ... and its tolerance-mode twin (ROX_FAST_FP64: <= 1e-10 from the reference instead of its
+    # bits, tests/test_gpu_fast.py), with the deviation of this very launch from the exact one
+    o_fast = make_opts(flags=flags | abi.FAST_FP64, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2,
+                       foc=wl.foc, image_pt=wl.image_pts[fi])
+    hits_f = DeviceResult(torch, eng.device, 0, R, abi.OUT_HITS, want_pupil=False, nan_fill=False)
+    hits_fast_ms = eng.time_pupil_grid_sustained(fld, grid, wi, o_fast, hits_f,
+                                                 max(min(args.steps, 50), 10))
+    fast_check = fast_vs_exact(torch, abi, hits, hits_f)
+    del hits, hits_f
 
     # spot-diagram wall-clock at the product boundary: the function the reference's
     # SpotDiagramFigure reaches through SequentialModel.trace_grid, on a table-backed
@@ -356,6 +368,11 @@ def main():
                          'algorithmic_bytes_per_launch': alg_bytes,
                          'frac_of_measured_copy_peak_6290': achieved / 6290.0},
             'roofline_hits': roofline_hits(inters, R, hits_kern_ms),
+            'roofline_hits_fast': dict(roofline_hits(inters, R, hits_fast_ms, workload='dblgauss_c2_fast'),
+                                       kernel='trace_kernel<HITS,PUPIL,F_FAST> (ROX_FAST_FP64: <= 1e-10 '
+                                              'from the reference, not bit-exact; opt-in)',
+                                       vs_exact_same_launch=fast_check,
+                                       speedup_over_exact=hits_kern_ms / hits_fast_ms),
             'spot_diagram': {'wallclock_ms': float(np.median(spot_ms)),
                              'wallclock_min_ms': float(np.min(spot_ms)), 'rays': R,
                              'rays_through': n_through, 'kernel_hits_ms': hits_kern_ms,
@@ -367,6 +384,7 @@ def main():
                                      'straight into pinned host memory; 13 MB over PCIe at ~55 GB/s '
                                      'is the floor)'},
             'configs': configs,
+            'configs_batch_items_uploaded_every_pass': os.environ.get('ROX_BATCH_ALWAYS_UPLOAD') == '1',
             'psf': psf,
             'cpu_baseline': None,
             'strong_scaling': None,
@@ -592,6 +610,18 @@ def psf_leg(torch):
     return out
 
 
+def fast_vs_exact(torch, abi, exact, fast):
+    """the tolerance-mode HITS launch against the bit-exact one of the same grid: status flips
+    and the worst scaled deviation max |a - b| / max(1, |a|) over the rays both carry through"""
+    st_e, st_f = exact.status, fast.status
+    flips = int((st_e != st_f).sum().item())
+    ok = (st_e == abi.OK) & (st_f == abi.OK)
+    a, b = exact.seg[:, ok], fast.seg[:, ok]
+    dev = float(((a - b).abs() / a.abs().clamp(min=1.0)).max().item()) if int(ok.sum().item()) else 0.0
+    return {'status_flips': flips, 'rays_through': int(ok.sum().item()), 'max_scaled_deviation': dev,
+            'tolerance': 1e-10}
+
+
 def roofline_hits(inters, R, kern_ms, workload='dblgauss_c2'):
     """the VALU-bound HITS kernel: achieved fp64 TFLOP/s by SURVEY 8(d)'s count of
     130 flop per spherical refracting intersection (5 sqrt + 8 div counted as one
@@ -650,14 +680,15 @@ def configs_leg(torch, abi, workloads):
         pairs = [(f, w) for f in fis for w in wis]
         rec = {'what': what, 'workload': name, 'interfaces': N, 'grids': len(pairs),
                'rays': R * len(pairs)}
-        for mode, label in ((abi.OUT_HITS, 'hits'), (abi.OUT_FULL, 'full')):
+        for mode, label in ((abi.OUT_HITS, 'hits'), (abi.OUT_HITS, 'hits_fast'), (abi.OUT_FULL, 'full')):
             if mode == abi.OUT_FULL and not do_full:
                 continue
+            fast = abi.FAST_FP64 if label == 'hits_fast' else 0
             # every grid of the configuration has its own output buffers (a pass leaves the
             # whole configuration's result in HBM)
             ress = [DeviceResult(torch, eng.device, eng.num_segments(0), R, mode,
                                  want_pupil=(mode == abi.OUT_FULL), nan_fill=False) for _ in pairs]
-            optl = [make_opts(flags=(SPOT_FLAGS & ~abi.INTERSECT_OBJ) | wide[f], out_mode=mode,
+            optl = [make_opts(flags=(SPOT_FLAGS & ~abi.INTERSECT_OBJ) | wide[f] | fast, out_mode=mode,
                               first_surf=1, last_surf=N - 2, foc=wl.foc, image_pt=wl.image_pts[f])
                     for f, _w in pairs]
             fldl = [wl.fields[f] for f, _w in pairs]
@@ -713,7 +744,7 @@ def configs_leg(torch, abi, workloads):
                           'frac_of_8000': gbps / 8000.0, 'frac_of_measured_copy_peak_6290': gbps / 6290.0})
             else:
                 r.update({'bound': 'fp64 valu', 'tflops_130_per_intersection': 130.0 * inters / (ms * 1e-3) / 1e12})
-                pmc = committed_pmc(name)
+                pmc = committed_pmc(name + ('_fast' if fast else ''))
                 if pmc:
                     r['valu_issue_frac'] = (pmc['valu_wave_insts_per_intersection'] * inters * 4 /
                                             (256 * 4 * 2.4e9 * ms * 1e-3))

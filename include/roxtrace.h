@@ -55,15 +55,24 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libroxtrace.so is built with -fvisibility=hidden: the entry points declared between this
+ * push and the pop at the end of the header are the library's whole dynamic symbol table
+ * (tests/test_abi.py compares `nm -D` with the declarations). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ABI history: 4 = packed hits appended over launches (ROX_HITS_APPEND), rox_pin_host_memory,
  * rox_aim carries both branches of iterate_ray;  5 = rox_trace_pupil_grids (several grids, one
  * launch), rox_find_real_enp / rox_enp (the wide-angle pupil search);  6 = rox_out.ld is the
  * capacity of seg in pairs for ROX_OUT_HITS_COMPACT (overflow: n_hits < 0), rox_copy_async,
  * rox_iterate_ray_raw, rox_iterate_pupil_rays;  7 = rox_synchronize (a binding without the
- * HIP runtime can wait for the asynchronous entries).
+ * HIP runtime can wait for the asynchronous entries);  8 = ROX_FAST_FP64 (tolerance-mode
+ * kernels for the reduced-output modes), rox_surface.flags validated by rox_system_create,
+ * the dynamic symbol table is exactly this header's (+ roxtrace_diag.h's) functions and
+ * DT_SONAME is libroxtrace.so.8.
  * rox_abi_version() of the library must equal the header a binding was written against. */
-#define ROX_ABI_VERSION 7
+#define ROX_ABI_VERSION 8
 #define ROX_MAX_COEF 10   /* EvenPolynomial r^2..r^20 / RadialPolynomial r^1..r^10 */
 #define ROX_MAX_AP 4      /* clear apertures per surface carried in the table */
 #define ROX_SEG_DOUBLES 10 /* p[3], d[3], dst, nrml[3]  (model_constants.py:31) */
@@ -139,6 +148,19 @@ enum { ROX_CHECK_APERTURES = 1u,     /* raytrace.py:198-202                    *
  * call that needed more room leaves the NEGATED pair count it needed in n_hits (later
  * appending calls keep it negative).                                          */
 #define ROX_HITS_APPEND 32u
+/* ROX_FAST_FP64: tolerance mode.  The default kernels reproduce the reference's NumPy path bit
+ * for bit; with this flag the caller accepts ray intercepts, directions, optical paths and OPDs
+ * within 1e-10 * max(1, |reference value|) of it -- the tolerance ray-optics users compare ray
+ * traces at -- and the reduced-output modes (LAST, HITS, HITS_COMPACT, OPD, FAN), which are bound
+ * by instruction issue, run on kernels that are still IEEE binary64 but use reciprocal /
+ * reciprocal-square-root seeds with Newton-Raphson refinement, fused multiply-adds and Horner
+ * series instead of NumPy's operation order (csrc/rox_device.hpp, "tolerance mode"; observed
+ * deviation <= 1e-12).  A ray whose miss / total-internal-reflection radicand or aperture margin
+ * lies within rounding of zero may be classified the other way.  ROX_OUT_FULL ignores the flag
+ * (FULL packets are bound by their stores and stay bit-exact), as do the search entries
+ * (rox_aim_chief_rays, rox_find_real_enp, rox_calc_vignetting, rox_iterate_*).  In a
+ * rox_trace_pupil_grids call every item must carry the same setting.             */
+#define ROX_FAST_FP64 64u
 /* rox_surface.rt_order: NumPy hands `rt.dot(v)` to OpenBLAS dgemv, whose FMA
  * chain runs over the columns in a different order for an F-ordered rt (the
  * transpose view compute_local_transforms makes, rayoptics/elem/transform.py:86)
@@ -541,6 +563,9 @@ typedef struct rox_enp {
 int rox_find_real_enp(rox_system *sys, int32_t n, const rox_enp *probs,
                       double eps, double *z_out, int32_t *result, void *stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* runs `launches` back-to-back launches of the pupil-grid kernel on `stream`,
  * bracketed by HIP events recorded on that same stream, and returns the mean
@@ -34,6 +37,9 @@ int rox_selftest_fp64(uint64_t n, uint64_t seed, uint64_t counts[4]);
  * ROX_PACK_TWO_PASS=1).  Tests use it to see which form a call took. */
 int rox_diag_pack_launches(uint64_t counts[2]);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ by :mod:`rayoptics_amd.engine`, which fails loudly when it is missing.
 """
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_COEF = 10
 MAX_AP = 4
 SEG_DOUBLES = 10
@@ -34,6 +34,7 @@ FILTER_PHANTOMS = 4
 APPLY_VIGNETTING = 8
 HOST_POINTERS = 16
 HITS_APPEND = 32
+FAST_FP64 = 64            # tolerance mode (include/roxtrace.h ROX_FAST_FP64): reduced-output modes only
 # summation order of rt.dot(v) (see include/roxtrace.h)
 RT_F_ORDER, RT_C_ORDER = 0, 1
 # grid kinds

@@ -25,7 +25,39 @@ LIB = os.path.join(HERE, 'libroxtrace.so')
 OBJ_ROOT = os.path.join(HERE, '..', 'build', 'obj')
 
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
-         '-ffp-contract=off', '-fno-fast-math', '-Wall', '-Wno-unused-function']
+         '-ffp-contract=off', '-fno-fast-math', '-Wall', '-Wno-unused-function',
+         # the dynamic symbol table is the C ABI and nothing else: the entry points get default
+         # visibility from the `#pragma GCC visibility push(default)` of include/roxtrace*.h
+         '-fvisibility=hidden', '-fvisibility-inlines-hidden']
+# DT_SONAME = libroxtrace.so.<ROX_ABI_VERSION>; build() keeps a link of that name beside the library
+# for executables linked with -lroxtrace (examples/spot_diagram.c)
+SONAME_FMT = 'libroxtrace.so.%d'
+
+
+def abi_version():
+    import re
+    with open(os.path.join(INC, 'roxtrace.h')) as f:
+        return int(re.search(r'#define\s+ROX_ABI_VERSION\s+(\d+)', f.read()).group(1))
+
+
+def ensure_soname_link(lib=None):
+    """libroxtrace.so.<abi> -> libroxtrace.so next to the library (idempotent)"""
+    lib = lib or LIB
+    if os.path.basename(lib) != 'libroxtrace.so' or not os.path.isdir(INC):
+        return None
+    link = os.path.join(os.path.dirname(lib), SONAME_FMT % abi_version())
+    for old in glob.glob(os.path.join(os.path.dirname(lib), 'libroxtrace.so.[0-9]*')):
+        if old != link and not old.endswith('.srchash'):
+            os.remove(old)                      # the link of an earlier ABI version
+    try:
+        if os.path.islink(link) and os.readlink(link) == 'libroxtrace.so':
+            return link
+        if os.path.lexists(link):
+            os.remove(link)
+        os.symlink('libroxtrace.so', link)
+    except OSError:
+        shutil.copyfile(lib, link)
+    return link
 
 
 def hipcc():
@@ -46,7 +78,7 @@ def headers():
 def source_hash(extra=()):
     """digest of every input of the build: sources, headers, flags, this file"""
     h = hashlib.sha256()
-    for p in sources() + headers() + [os.path.abspath(__file__)]:
+    for p in sources() + headers() + [os.path.join(CSRC, 'libroxtrace.map'), os.path.abspath(__file__)]:
         with open(p, 'rb') as f:
             h.update(os.path.basename(p).encode() + b'\0' + f.read())
     h.update(' '.join(FLAGS + list(extra)).encode())
@@ -75,6 +107,7 @@ def build(force=False, extra=(), out=None):
     lib = out or LIB
     extra = list(extra)
     if not force and not stale(lib, extra):
+        ensure_soname_link(lib)
         return lib
     digest = source_hash(extra)
     objdir = os.path.join(OBJ_ROOT, digest[:16])
@@ -92,8 +125,12 @@ def build(force=False, extra=(), out=None):
     with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         objs = list(ex.map(compile_one, sources()))
     tmp = lib + f'.tmp{os.getpid()}'
-    subprocess.check_call([cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp, *objs])
+    subprocess.check_call([cc, '--offload-arch=gfx950', '-shared', '-fPIC',
+                           '-Wl,-soname,' + SONAME_FMT % abi_version(),
+                           '-Wl,--version-script=' + os.path.join(CSRC, 'libroxtrace.map'),
+                           '-o', tmp, *objs])
     os.replace(tmp, lib)
+    ensure_soname_link(lib)
     with open(_stamp(lib), 'w') as f:
         f.write(digest + '\n')
     # keep the object cache small (it travels with the tree): the three newest digests

@@ -1,0 +1,12 @@
+// fast_general.hip -- the tolerance-mode (ROX_FAST_FP64) trace kernels of feature instance
+// F_ALL (rox_device.hpp, "tolerance mode"): reduced-output modes only.  One translation unit per
+// instance so that the instances compile in parallel.
+#include "rox_device.hpp"
+
+namespace rox {
+void launch_general_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_ALL) | F_FAST>(k, a); }
+void launch_general_fast_batch(const LaunchCfg &k, const TraceArgs *items)
+{
+    launch_instance_batch<(F_ALL) | F_FAST>(k, items);
+}
+}  // namespace rox

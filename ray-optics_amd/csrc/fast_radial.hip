@@ -1,0 +1,12 @@
+// fast_radial.hip -- the tolerance-mode (ROX_FAST_FP64) trace kernels of feature instance
+// F_RADIAL (rox_device.hpp, "tolerance mode"): reduced-output modes only.  One translation unit per
+// instance so that the instances compile in parallel.
+#include "rox_device.hpp"
+
+namespace rox {
+void launch_radial_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_RADIAL) | F_FAST>(k, a); }
+void launch_radial_fast_batch(const LaunchCfg &k, const TraceArgs *items)
+{
+    launch_instance_batch<(F_RADIAL) | F_FAST>(k, items);
+}
+}  // namespace rox

@@ -36,8 +36,6 @@
 
 #include <cstddef>
 #include <cstdint>
-#include <cstdlib>
-#include <mutex>
 
 #include "../../include/roxtrace.h"
 
@@ -69,9 +67,6 @@
 #ifndef ROX_MIN_WAVES_POLY   // waves per SIMD the reduced-output modes of those instances are compiled for
 #define ROX_MIN_WAVES_POLY ROX_MIN_WAVES
 #endif
-#ifndef ROX_STAGED_RCP        // 1: refract()'s three quotients by n_out use the refined reciprocal of n_out
-#define ROX_STAGED_RCP 0       //    that the workgroup formed once per (wavelength, interface) at staging:
-#endif                         //    8 VALU fewer per refraction, measured HITS -1 % (111.4 -> 110.3 us), FULL +2 %: off
 #ifndef ROX_KERNEL_ALIGN     // alignment of the trace kernels' code (0: the compiler's 256 bytes)
 #define ROX_KERNEL_ALIGN 0
 #endif
@@ -80,9 +75,6 @@
 #else
 #define ROX_KERNEL_ALIGNED
 #endif
-#ifndef ROX_WAVE_TICKETS     // 1: the reduced-output modes (HITS, LAST, OPD, FAN) run as resident waves that
-#define ROX_WAVE_TICKETS 0    //    stride over 64-ray tiles (wave_ticketed() below): measured slower, off
-#endif
 #ifndef ROX_MIN_WAVES_APLIST_REDUCED  // waves per SIMD the HITS kernels of the aperture-list instance
 #define ROX_MIN_WAVES_APLIST_REDUCED 8 // (spherical tables with clear-aperture lists: every Zemax import without
 #endif                                 // aspheres -- BASELINE configs[3], configs[4]) are compiled for.  At the
@@ -90,6 +82,9 @@
                                        // the same source is 8 % faster: lithography lens HITS 421 -> 386 us per 2^20
                                        // rays, RC telescope 46.6 -> 42.9 (7: 389 / 42.9); the lean instance gains
                                        // nothing from it (111.0 -> 113.6) and FULL loses 7-12 %.  profiles/r05_min_waves.txt
+#ifndef ROX_MIN_WAVES_FAST   // waves per SIMD the tolerance-mode (F_FAST) instances are compiled for
+#define ROX_MIN_WAVES_FAST ROX_MIN_WAVES
+#endif
 #ifndef ROX_BLOCK_SMALL      // workgroup size of launches that do not fill the chip (block_of() below)
 #define ROX_BLOCK_SMALL 256
 #endif
@@ -150,6 +145,7 @@ constexpr int kWaves = kBlock / 64;
 // threads per workgroup (= rays per tile) of an output mode of a feature instance
 // (feat & kFeatNewton: the instance carries Newton code -- F_EVEN | F_RADIAL | F_TOROID)
 constexpr int kFeatNewton = 1 | 2 | 4;
+constexpr int kFeatFast = 64;       // F_FAST: a tolerance-mode instance (ROX_FAST_FP64; reduced-output modes only)
 // `small`: the launch does not fill the chip several times over (roxtrace.hip want_small()): it
 // runs in workgroups of ROX_BLOCK_SMALL threads, which spread over the CUs wave by wave instead
 // of sixteen (FULL) or eight waves at a time.  A CU holds 5 waves per SIMD of the lean FULL
@@ -163,26 +159,6 @@ constexpr int block_of(int out_mode, int feat, bool small = false)
          : out_mode == ROX_OUT_FULL ? ((feat & kFeatNewton) ? ROX_BLOCK_FULL_POLY : ROX_BLOCK_FULL)
          : ((feat & kFeatNewton) ? ROX_BLOCK_POLY : ROX_BLOCK);
 }
-// EXPERIMENT (ROX_WAVE_TICKETS=1, off): the reduced-output modes as one chip-load of resident
-// workgroups whose WAVES stride over the 64-ray tiles of the batch -- wave w takes tiles w,
-// w + W, w + 2W ... -- so that the table is staged once per resident workgroup and no wave slot
-// waits for a workgroup launch.  Round 4's counters had put the average occupancy of the
-// one-tile-per-workgroup form at 2.7 of 4 waves per SIMD on the 13-interface asphere models
-// (4.1 of 6 on the double Gauss) and VALU utilisation tracks it.  Measured (profiles/
-// r05_wave_striding.txt): the hardware dispatcher handing out four times as many workgroups as
-// fit IS the better balancer -- static striding over exactly the resident waves is 3-10 % slower
-// (double Gauss HITS 112 -> 115 us, .zmx zoom 160 -> 174, Nikkor 328 -> 355), and drawing tiles
-// dynamically by an atomic ticket per wave three times slower: a device-scope atomic on one
-// address is performed at the memory side of the eight L2s, 15-35 ns each, serialised
-// (profiles/r05_wave_tickets.txt).  What the low average is made of is the drain of a single
-// launch (the last workgroups' lifetime with the chip emptying), which a batch of grids in one
-// launch pays once.
-constexpr int kWtShards = 32, kWtStride = 64;      // 32 counters, 256 B apart
-constexpr bool wave_ticketed(int out_mode)
-{
-    return ROX_WAVE_TICKETS && out_mode != ROX_OUT_FULL && out_mode != ROX_OUT_HITS_COMPACT &&
-           out_mode != 100 /* MODE_PROBE */;
-}
 // whether a distinct small-workgroup kernel exists for (mode, instance)
 constexpr bool has_small(int out_mode, int feat)
 {
@@ -192,7 +168,8 @@ constexpr int min_waves_of(int out_mode, int feat, bool small = false)
 {
     // (the small-workgroup kernels serve launches that fit the chip once: latency, where the
     // scratch of the tighter budget costs -- configs[3] HITS 18 -> 20 us -- instead of paying)
-    return (feat == 8 /* F_APLIST */ && out_mode == ROX_OUT_HITS && !small) ? ROX_MIN_WAVES_APLIST_REDUCED
+    return (feat & kFeatFast) ? ROX_MIN_WAVES_FAST
+         : (feat == 8 /* F_APLIST */ && out_mode == ROX_OUT_HITS && !small) ? ROX_MIN_WAVES_APLIST_REDUCED
          : (out_mode == ROX_OUT_FULL && (feat & kFeatNewton)) ? ROX_MIN_WAVES_FULL_POLY
          : (out_mode == ROX_OUT_HITS_COMPACT && !(feat & ~8)) ? ROX_MIN_WAVES_COMPACT_LEAN
          : (out_mode != ROX_OUT_FULL && out_mode != ROX_OUT_HITS_COMPACT && (feat & kFeatNewton))
@@ -266,17 +243,9 @@ struct TraceArgs {
     int32_t axis_kind;         // AXIS_LIST: px[r],py[r]; AXIS_PRODUCT: px[r/num], py[r%num]
     int32_t axis_num;
     int32_t row_begin;         // AXIS_PRODUCT: first pupil row of this launch
-    // AXIS_PRODUCT, reduced-output modes of the Newton instances: a wave takes an 8 x 8 patch of
-    // the pupil grid instead of 64 consecutive rays of a row (trace_tiles; set by the host when
-    // the grid divides into such tiles)
-    int32_t patch8;
-    int32_t n_band_ok;         // every entry of n_table lies in the slim band (rox_system_create)
     // HITS_COMPACT: decoupled look-back state of this launch
     uint64_t *tile_state;      // [tiles] (epoch << 32 | flag << 30 | count)
     uint32_t *ticket;          // [0] next tile, [1] workgroups done
-    // ROX_WAVE_TICKETS == 2: this launch's sharded tile counters (kWtShards words, kWtStride
-    // apart) and the set the NEXT launch of the stream will use, which this one zeroes
-    uint32_t *wt_cur, *wt_next;
     // pairs already in out.seg when this launch starts (earlier launches of a chunked
     // call; earlier calls with ROX_HITS_APPEND) -- nullptr = none -- and where the running
     // total goes.  Never the same word: a tile may still be reading the base while the
@@ -489,11 +458,8 @@ __device__ __forceinline__ v3 unit(const v3 &v)
 }
 
 // raytrace.py:19-30.  false = TIR (math.sqrt ValueError)
-// r_ok: r_out = rcp_band(n_out), formed at staging with the very instruction sequence
-// slim_div3 would execute per lane (every index of the table lies in the band, checked on the
-// host): the divisor's band test and the five reciprocal instructions leave the per-ray path.
 __device__ __forceinline__ bool refract(const v3 &d, const v3 &nrm, double n_in,
-                                        double n_out, v3 &out, double r_out = 0.0, bool r_ok = false)
+                                        double n_out, v3 &out)
 {
     const double nlen = slim_sqrt(dot3(nrm, nrm));
 #if ROX_COSI_SLIM
@@ -508,12 +474,6 @@ __device__ __forceinline__ bool refract(const v3 &d, const v3 &nrm, double n_in,
     const double n_cosIp = copysign(slim_sqrt(rad), cosI);
     const double alpha = n_cosIp - n_in * cosI;
     const v3 num{n_in * d.x + alpha * nrm.x, n_in * d.y + alpha * nrm.y, n_in * d.z + alpha * nrm.z};
-#if ROX_STAGED_RCP && ROX_SLIM_FP64
-    if (r_ok && wave_all(in_band_or_zero(num.x) && in_band_or_zero(num.y) && in_band_or_zero(num.z))) {
-        out = v3{div_band(num.x, n_out, r_out), div_band(num.y, n_out, r_out), div_band(num.z, n_out, r_out)};
-        return true;
-    }
-#endif
     out = slim_div3(num, n_out);
     return true;
 }
@@ -782,6 +742,254 @@ __device__ __forceinline__ bool newton_hit(int kind, double cv, double cc1, doub
         return false;
     s = s1;
     hit = p;        // df already holds df(hit): normal() re-evaluates the same expression
+    return true;
+}
+
+// ================================================================ tolerance mode
+// ROX_FAST_FP64 (rox_opts.flags, include/roxtrace.h): the caller accepts results within the
+// tolerance BASELINE's north star states -- 1e-10 on ray intercepts, scaled by max(1, |ref|) --
+// instead of the reference's bits.  The reduced-output modes (HITS, HITS_COMPACT, LAST, OPD, FAN)
+// are bound by VALU issue, and 2.4 x their algorithmic flop count is the price of bit parity:
+// every `/` and `sqrt` a 10-25-instruction correctly rounded expansion behind an exponent-band
+// test, every product and sum separately rounded in NumPy's order, |n| re-measured where it is
+// 1 by construction.  The F_FAST instances below are still IEEE binary64 throughout, with
+//   * v_rcp_f64 / v_rsq_f64 (2^-23 .. 2^-24 relative) + two Newton-Raphson steps (<= ~1.5 ulp)
+//     instead of the correctly rounded expansions, no band tests, no fall-back paths;
+//   * fused multiply-adds wherever the formula has a*b + c;
+//   * refraction through mu = n_in / n_out staged per (wavelength, interface): no division
+//     per ray; the surface normal is taken as the unit vector it is (raytrace.py:19-30 divides
+//     by its length again), and a sphere's gradient (-cv x, -cv y, 1 - cv z) is not normalised
+//     at all: its squared length is 1 + cv F(hit) with F the surface function, i.e. 1 up to
+//     the residual of the intersection;
+//   * Horner evaluation of the asphere series (profiles.py:849-885, 1070-1113 accumulate
+//     powers forward), 1/sqrt from the same iteration that gives the sqrt;
+//   * the Spencer-Murty iteration itself as the reference runs it (same start, same
+//     convergence test, the penultimate iterate returned): the iterates differ from the
+//     reference's by rounding only, so both stop within eps of the same point.
+// Ray-failure decisions (miss, TIR, aperture) are taken on values that differ from the
+// reference's in the last bits: a ray whose radicand / aperture margin is within rounding of
+// zero may be decided the other way (tests/test_gpu_fast.py counts such rays and shows each
+// of them on its boundary).  Degenerate operands keep the reference's outcomes where those are
+// defined (den == 0 in Spherical.intersect, r == 0 in RadialPolynomial.df, a zero-length
+// gradient); NaN and infinity propagate as NaN.
+constexpr int F_FAST = 64;
+#ifndef ROX_FAST_NR          // Newton-Raphson steps after v_rcp_f64 / v_rsq_f64: 2 = ~1 ulp,
+#define ROX_FAST_NR 2         // 1 = ~2^-45 relative (measured difference: see EXPERIMENTS.md)
+#endif
+
+// 1 / b, b != 0 and finite
+__device__ __forceinline__ double rcp_f(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(r, fma(-b, r, 1.0), r);
+#if ROX_FAST_NR >= 2
+    r = fma(r, fma(-b, r, 1.0), r);
+#endif
+    return r;
+}
+
+// s = sqrt(x), h = 0.5 / sqrt(x) by the coupled iteration on (x y, y / 2), y = v_rsq_f64(x).
+// The seed is taken of max(x, 2^-1000): x = 0 gives s = 0 (a finite y times 0) instead of the
+// NaN of 0 * inf -- an on-axis ray has r^2 = 0 exactly -- and NaN stays NaN (x * y).
+__device__ __forceinline__ void sqrt_half_rsqrt_f(double x, double &s, double &h)
+{
+    const double y = __builtin_amdgcn_rsq(fmax(x, 0x1p-1000));
+    s = x * y;
+    h = 0.5 * y;
+    const double e = fma(-h, s, 0.5);
+    s = fma(s, e, s);
+    h = fma(h, e, h);
+#if ROX_FAST_NR >= 2
+    const double e1 = fma(-h, s, 0.5);
+    s = fma(s, e1, s);
+    h = fma(h, e1, h);
+#endif
+}
+
+__device__ __forceinline__ double sqrt_f(double x)
+{
+    const double y = __builtin_amdgcn_rsq(fmax(x, 0x1p-1000));
+    double s = x * y;
+    const double h = 0.5 * y;
+    s = fma(s, fma(-h, s, 0.5), s);
+#if ROX_FAST_NR >= 2
+    s = fma(fma(-s, s, x), h, s);       // (the residual form: h need not be refined for it)
+#endif
+    return s;
+}
+
+__device__ __forceinline__ double dot3_f(const v3 &a, const v3 &b)
+{
+    return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+}
+
+// v / |v|; the zero vector stays the zero vector (misc_math.py:48-54)
+__device__ __forceinline__ v3 unit_f(const v3 &v)
+{
+    double s, h;
+    sqrt_half_rsqrt_f(dot3_f(v, v), s, h);
+    const double y = h + h;
+    return v3{v.x * y, v.y * y, v.z * y};
+}
+
+template <class P>
+__device__ __forceinline__ v3 rotate_f(P rt, const v3 &v)
+{
+    return v3{fma(rt[2], v.z, fma(rt[1], v.y, rt[0] * v.x)),
+              fma(rt[5], v.z, fma(rt[4], v.y, rt[3] * v.x)),
+              fma(rt[8], v.z, fma(rt[7], v.y, rt[6] * v.x))};
+}
+
+// raytrace.py:19-30 with mu = n_in / n_out, mu2 = mu^2 and a unit normal:
+//   d_out = mu d + (sign(cosI) sqrt(1 - mu^2 (1 - cosI^2)) - mu cosI) n
+__device__ __forceinline__ bool refract_f(const v3 &d, const v3 &n, double mu, double mu2, v3 &out)
+{
+    const double c = dot3_f(d, n);
+    const double rad = fma(mu2, fma(c, c, -1.0), 1.0);
+    if (rad < 0.0)
+        return false;
+    const double alpha = fma(-mu, c, copysign(sqrt_f(rad), c));
+    out = v3{fma(alpha, n.x, mu * d.x), fma(alpha, n.y, mu * d.y), fma(alpha, n.z, mu * d.z)};
+    return true;
+}
+
+// raytrace.py:33-38 with a unit normal
+__device__ __forceinline__ v3 mirror_f(const v3 &d, const v3 &n)
+{
+    const double k = -2.0 * dot3_f(d, n);
+    return v3{fma(k, n.x, d.x), fma(k, n.y, d.y), fma(k, n.z, d.z)};
+}
+
+// profiles.py:321-336 / 580-593.  The reference's outcomes for a vanishing denominator
+// (FloatingPointError -> s = 0 for a finite non-zero numerator, NaN for 0/0 unless all three
+// coefficients vanish) are kept by one wave-uniform test.
+__device__ __forceinline__ bool quadric_hit_f(bool conic, double cv, double cc, double ec,
+                                              const v3 &p, const v3 &d, double z_dir,
+                                              double &s, v3 &hit)
+{
+    double ax2, cx2, b;
+    if (!conic) {
+        ax2 = cv;
+        cx2 = fma(cv, dot3_f(p, p), -(p.z + p.z));
+        b = fma(cv, dot3_f(d, p), -d.z);
+    } else {
+        ax2 = cv * fma(cc * d.z, d.z, 1.0);
+        const double ez = ec * p.z;
+        cx2 = fma(cv, fma(ez, p.z, fma(p.y, p.y, p.x * p.x)), -(p.z + p.z));
+        b = fma(cv, fma(ez, d.z, fma(d.y, p.y, d.x * p.x)), -d.z);
+    }
+    const double rad = fma(-ax2, cx2, b * b);
+    if (rad < 0.0)
+        return false;                           // TraceMissedSurfaceError
+    const double den = fma(z_dir, sqrt_f(rad), -b);
+    s = cx2 * rcp_f(den);
+    if (__builtin_amdgcn_ballot_w64(den == 0.0) != 0) {
+        if (den == 0.0) {
+            if (cx2 != 0.0 && isfinite(cx2))
+                s = 0.0;
+            else if (b == 0.0 && cx2 == 0.0 && ax2 == 0.0)
+                s = 0.0;
+            else
+                s = __builtin_nan("");
+        }
+    }
+    hit = v3{fma(s, d.x, p.x), fma(s, d.y, p.y), fma(s, d.z, p.z)};
+    return true;
+}
+
+// f(p), df(p) of EvenPolynomial / RadialPolynomial (profiles.py:849-885, 1070-1113), Horner
+// form.  Toroids keep the exact evaluation (poly_eval): no workload of BASELINE carries one.
+template <int FEAT>
+__device__ __forceinline__ bool poly_eval_f(int kind, double cv, double cc1, double ec, double cR,
+                                            int ncoef, tblp coefs, const v3 &p, double &f, v3 &df)
+{
+    if ((FEAT & F_TOROID) && kind >= ROX_YTOROID)
+        return poly_eval<FEAT & ~F_FAST, true>(kind, cv, cc1, ec, cR, ncoef, coefs, p, f, df);
+    const d2 *cd = reinterpret_cast<const d2 *>(
+        coefs + (offsetof(dev_surface, cd) - offsetof(rox_surface, coefs)) / 8);
+    const bool radial = (FEAT & F_RADIAL) && (!(FEAT & F_EVEN) || kind == ROX_RADIALPOLY);
+    const double r2 = fma(p.y, p.y, p.x * p.x);
+    const double cv2 = cv * cv;
+    double z_asp = 0.0, e_asp = 0.0, e_tot;
+    if (!radial) {
+        // sag: z = cv r2 / (1 + sqrt(1 - (cc+1) cv^2 r2)) + sum coef_i r2^(i+1)
+        // df:  e = cv / sqrt(1 - ec cv^2 r2)               + sum 2(i+1) coef_i r2^i
+        const double rad = fma(-cc1 * cv2, r2, 1.0);
+        if (rad < 0.0)
+            return false;
+        double srad, hrad;
+        sqrt_half_rsqrt_f(rad, srad, hrad);
+        double he = hrad;                       // 0.5 / sqrt(rad_e)
+        if (cc1 != ec) {                        // (wave-uniform; equal unless a caller fills ec otherwise)
+            double se;
+            const double rad_e = fma(-ec * cv2, r2, 1.0);
+            sqrt_half_rsqrt_f(rad_e, se, he);
+            if (rad_e < 0.0)
+                he = __builtin_nan("");         // np.sqrt of a negative: NaN, no exception
+        }
+        for (int i = ncoef - 1; i >= 0; --i) {
+            const d2 c = cd[i];
+            z_asp = fma(z_asp, r2, c.x);
+            e_asp = fma(e_asp, r2, c.y);
+        }
+        const double z = (cv * r2) * rcp_f(1.0 + srad);
+        f = p.z - fma(z_asp, r2, z);
+        e_tot = fma(cv + cv, he, e_asp);
+    } else {
+        // sag: z = cv r2 / (1 + sqrt(1 - ec cv^2 r2)) + sum coef_i r^(i+1)
+        // df:  e = cv / sqrt(.)                         + sum (i+1) coef_i r^(i-1)
+        const double rad = fma(-ec * cv2, r2, 1.0);
+        if (rad < 0.0)
+            return false;
+        double srad, hrad, r, hr;
+        sqrt_half_rsqrt_f(rad, srad, hrad);
+        sqrt_half_rsqrt_f(r2, r, hr);
+        const double rinv = (r2 == 0.0) ? 1.0 : hr + hr;    // profiles.py:1104: r_pow = 1 at r = 0
+        for (int i = ncoef - 1; i >= 1; --i) {
+            const d2 c = cd[i];
+            z_asp = fma(z_asp, r, c.x);
+            e_asp = fma(e_asp, r, c.y);
+        }
+        const d2 c0 = cd[0];
+        z_asp = fma(z_asp, r, ncoef > 0 ? c0.x : 0.0);
+        e_asp = fma(ncoef > 0 ? c0.y : 0.0, rinv, e_asp);
+        const double z = (cv * r2) * rcp_f(1.0 + srad);
+        f = p.z - fma(z_asp, r, z);
+        e_tot = fma(cv + cv, hrad, e_asp);
+    }
+    df = v3{-e_tot * p.x, -e_tot * p.y, 1.0};
+    return true;
+}
+
+// profiles.py:155-186, as newton_hit() runs it
+template <int FEAT>
+__device__ __forceinline__ bool newton_hit_f(int kind, double cv, double cc1, double ec, double cR,
+                                             int ncoef, tblp coefs, const v3 &p0, const v3 &d,
+                                             double eps, double &s, v3 &hit, v3 &df)
+{
+    v3 p = p0;
+    double f;
+    if (!poly_eval_f<FEAT>(kind, cv, cc1, ec, cR, ncoef, coefs, p, f, df))
+        return false;
+    double s1 = -f * rcp_f(dot3_f(d, df));
+    double delta = fabs(s1);
+    int iter = 0;
+    bool ok = true;
+    while (delta > eps && iter < 1000) {
+        p = v3{fma(s1, d.x, p0.x), fma(s1, d.y, p0.y), fma(s1, d.z, p0.z)};
+        if (!poly_eval_f<FEAT>(kind, cv, cc1, ec, cR, ncoef, coefs, p, f, df)) {
+            ok = false;
+            break;
+        }
+        const double s2 = fma(-f, rcp_f(dot3_f(d, df)), s1);
+        delta = fabs(s2 - s1);
+        s1 = s2;
+        ++iter;
+    }
+    if (!ok)
+        return false;
+    s = s1;
+    hit = p;
     return true;
 }
 
@@ -1105,8 +1313,7 @@ struct Ctx {
     tblp wvls;              // [W]
     tbli slot, nslots_before;
     tblp apthr;             // [N] sqrt_le_threshold(max_aperture + fuzz)
-    tblp rcpn;              // rcp_band(ntab), same shape as ntab; nullptr where not staged (search kernels)
-    bool rcpn_ok;           // every index in the slim band: rcpn may be used
+    tblp mu;                // F_FAST only: per wavelength row [N] n_in / n_out, [N] its square
     int N;
     bool check_ap, intersect_obj, filter_ph;
     int first_surf, last_surf;
@@ -1147,7 +1354,6 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
     const int N = c.N;
     tblp tbl = c.tbl;
     tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
-    tblp rnw = PER_RAY_WVL ? c.rcpn + (size_t)wi * N : c.rcpn;      // (read only when c.rcpn_ok)
 #define SLOT(s) ((FEAT & F_PHFILT) ? c.slot[s] : (s))
 #define NSLOTS_BEFORE(s) ((FEAT & F_PHFILT) ? c.nslots_before[s] : (s))
     // without phantom filtering segment k of a packet is interface k
@@ -1211,12 +1417,7 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         }
         tblp prow = tbl + (size_t)(surf - 1) * kRowDoubles;     // `before`
         tblp row = tbl + (size_t)surf * kRowDoubles;             // `after`
-#ifdef ROX_SPEC_EXPERIMENT  // (tools only: what compile-time knowledge of a spherical, centred
-        // table would be worth to the lean instance -- the per-system specialisation question)
-        const int mode = ((tbli)row)[0], prof = (FEAT == 0) ? (int)ROX_SPHERICAL : ((tbli)row)[1];
-#else
         const int mode = ((tbli)row)[0], prof = ((tbli)row)[1];
-#endif
         const double cv = row[O_CV];
         const bool thin = (FEAT & F_PHASE) && prof == ROX_THINLENS;
 
@@ -1231,13 +1432,8 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         // every active lane's six components are finite (their sum is: a conservative test).
         // (reduced-output modes only: in FULL mode, which is bound by its packet stores, the
         // extra branch measured 2 % slower)
-#ifdef ROX_SPEC_EXPERIMENT
-        if (FEAT == 0 || (kIdentRt && (((tbli)prow)[5] & 2) != 0 &&
-            wave_all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((bd.x + bd.y) + bd.z))))) {
-#else
         if (kIdentRt && (((tbli)prow)[5] & 2) != 0 &&
             wave_all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((bd.x + bd.y) + bd.z)))) {
-#endif
             b4p = v3{dp.x + 0.0, dp.y + 0.0, dp.z + 0.0};
             b4d = v3{bd.x + 0.0, bd.y + 0.0, bd.z + 0.0};
         } else {
@@ -1331,7 +1527,7 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
             } else if (mode == ROX_REFLECT) {
                 ad = mirror(b4d, nrm);
             } else if (mode == ROX_TRANSMIT) {
-                if (!refract(b4d, nrm, nwl[surf - 1], nwl[surf], ad, c.rcpn_ok ? rnw[surf] : 0.0, c.rcpn_ok))
+                if (!refract(b4d, nrm, nwl[surf - 1], nwl[surf], ad))
                     status = ROX_TIR;               // :239-245
             } else {
                 ad = b4d;
@@ -1375,6 +1571,169 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
 #undef SLOT
 #undef NSLOTS_BEFORE
 #undef ROX_LEAVE
+    e.status = status;
+    e.fail_surf = fail_surf;
+    e.opl = opl;
+    e.phs = phs;
+    e.inc = inc; e.ad = ad; e.nrm = nrm;
+}
+
+// ------------------------------------------------------------------ one ray, tolerance mode
+// trace_ray() for the F_FAST instances: the same loop (raytrace.py:83-264) over the same table,
+// reduced-output modes only -- no packet stores, hence no segment bookkeeping -- with the
+// arithmetic of the section "tolerance mode" above.  c.mu / c.mu2 = n_in / n_out and its square
+// per interface, staged by the workgroup.
+template <int OUT_MODE, bool PER_RAY_WVL, int FEAT>
+__device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, const v3 &dir0, int wi,
+                                               bool live, RayEnd &e)
+{
+    static_assert(OUT_MODE != ROX_OUT_FULL && OUT_MODE != MODE_PROBE, "reduced-output modes only");
+    constexpr int O_CV = offsetof(rox_surface, cv) / 8, O_CC = offsetof(rox_surface, cc) / 8,
+                  O_EC = offsetof(rox_surface, ec) / 8, O_CR = offsetof(rox_surface, cR) / 8,
+                  O_COEF = offsetof(rox_surface, coefs) / 8,
+                  O_RT = offsetof(rox_surface, rt) / 8, O_T = offsetof(rox_surface, t) / 8,
+                  O_ZDIR = offsetof(rox_surface, z_dir) / 8,
+                  O_PH = offsetof(rox_surface, ph) / 8;
+    constexpr bool kPoly = (FEAT & F_POLY) != 0;
+    const int N = c.N;
+    tblp tbl = c.tbl;
+    tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
+    tblp muw = PER_RAY_WVL ? c.mu + (size_t)wi * 2 * N : c.mu;      // [N] mu, [N] mu^2
+
+    int status = live ? ROX_OK : 255, fail_surf = -1;
+    v3 bp = pt0, bd = dir0;
+    if (live && c.intersect_obj) {              // raytrace.py:145-158 (the normal is not needed)
+        tblp row = tbl;
+        const int prof = ((tbli)row)[1];
+        double s_;
+        v3 df;
+        bool ok;
+        if ((FEAT & F_PHASE) && prof == ROX_THINLENS) {
+            s_ = -pt0.z * rcp_f(dir0.z);
+            bp = v3{fma(s_, dir0.x, pt0.x), fma(s_, dir0.y, pt0.y), fma(s_, dir0.z, pt0.z)};
+            ok = true;
+        } else if (!kPoly || prof <= ROX_CONIC) {
+            ok = quadric_hit_f(prof == ROX_CONIC, row[O_CV], row[O_CC], row[O_EC], pt0, dir0,
+                               row[O_ZDIR], s_, bp);
+        } else {
+            ok = newton_hit_f<FEAT>(prof, row[O_CV], row[O_CC] + 1.0, row[O_EC], row[O_CR],
+                                    ((tbli)row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
+        }
+        if (!ok) {
+            status = ROX_MISSED_SURFACE;
+            fail_surf = 0;
+        }
+    }
+    double z_dir_before = tbl[O_ZDIR];
+    double opl = 0.0, phs = 0.0;
+    v3 inc{0, 0, 0}, nrm{0, 0, 0}, ad = dir0;
+    e.ray1_p = e.rayk_p = e.rayk_d = e.probe_p = v3{0, 0, 0};
+
+    for (int surf = 1; surf < N && status == ROX_OK; ++surf) {
+        tblp prow = tbl + (size_t)(surf - 1) * kRowDoubles;
+        tblp row = tbl + (size_t)surf * kRowDoubles;
+        const int mode = ((tbli)row)[0], prof = ((tbli)row)[1];
+        const double cv = row[O_CV];
+        const bool thin = (FEAT & F_PHASE) && prof == ROX_THINLENS;
+
+        // :170-174 transform to the new vertex frame, closest approach to its origin
+        const v3 dp{bp.x - prow[O_T], bp.y - prow[O_T + 1], bp.z - prow[O_T + 2]};
+        v3 b4p = dp, b4d = bd;
+        if ((((tbli)prow)[5] & 2) == 0) {       // (identity rotations are flagged on the device row)
+            b4p = rotate_f(prow + O_RT, dp);
+            b4d = rotate_f(prow + O_RT, bd);
+        }
+        const double pp_dst = -dot3_f(b4p, b4d);
+        const v3 pp{fma(pp_dst, b4d.x, b4p.x), fma(pp_dst, b4d.y, b4p.y), fma(pp_dst, b4d.z, b4p.z)};
+
+        // :181-183 intersect
+        double s;
+        v3 df;
+        bool ok;
+        if (thin) {
+            s = -pp.z * rcp_f(b4d.z);
+            inc = v3{fma(s, b4d.x, pp.x), fma(s, b4d.y, pp.y), fma(s, b4d.z, pp.z)};
+            ok = true;
+        } else if (!kPoly || prof <= ROX_CONIC) {
+            ok = quadric_hit_f(prof == ROX_CONIC, cv, row[O_CC], row[O_EC], pp, b4d, z_dir_before, s, inc);
+        } else {
+            ok = newton_hit_f<FEAT>(prof, cv, row[O_CC] + 1.0, row[O_EC], row[O_CR],
+                                    ((tbli)row)[2], row + O_COEF, pp, b4d, c.eps, s, inc, df);
+        }
+        if (!ok) {                                  // :231-237
+            status = ROX_MISSED_SURFACE;
+            fail_surf = surf;
+            break;
+        }
+        // :193-194 (in_gap_range, :123-132)
+        {
+            const int g = surf - 1;
+            const bool in_gap = !(c.last_surf >= 0 && c.first_surf == c.last_surf) &&
+                                g >= c.first_surf && (c.last_surf < 0 || g < c.last_surf);
+            if (in_gap)
+                opl = fma(nwl[surf - 1], pp_dst + s, opl);
+        }
+
+        // :196 normal = normalize(df(inc_pt)); a sphere's gradient has unit length on the sphere
+        if (thin) {
+            nrm = v3{0., 0., 1.};
+        } else if (!kPoly || prof <= ROX_CONIC) {
+            if (prof == ROX_CONIC) {
+                const double k = (row[O_CC] + 1.0) * cv;
+                nrm = unit_f(v3{-cv * inc.x, -cv * inc.y, fma(-k, inc.z, 1.0)});
+            } else {
+                nrm = v3{-cv * inc.x, -cv * inc.y, fma(-cv, inc.z, 1.0)};
+            }
+        } else {
+            nrm = unit_f(df);
+        }
+
+        // :198-202 aperture test (in_surface_range, :134-142)
+        if (c.check_ap && surf >= c.first_surf && (c.last_surf < 0 || surf <= c.last_surf) &&
+            mode != ROX_PHANTOM) {
+            const int n_ap = (FEAT & F_APLIST) ? ((tbli)row)[3] : 0;
+            const bool in = n_ap > 0
+                ? inside_aperture_list(row, n_ap, inc.x, inc.y, c.fuzz)
+                : fma(inc.y, inc.y, inc.x * inc.x) <= c.apthr[surf];
+            if (!in)
+                status = ROX_BLOCKED;               // :247-251
+        }
+
+        // :205-221 phase element (the exact code: rare), or refract / reflect / pass through
+        if (status == ROX_OK) {
+            if ((FEAT & F_PHASE) && ((tbli)(row + O_PH))[0] != ROX_PH_NONE) {
+                double dW = 0.0;
+                tblp pc = c.phc + ((PER_RAY_WVL ? (size_t)wi * N : 0) + surf) * kPhaseConsts;
+                const int rc = apply_phase(row + O_PH, pc, inc, b4d, nrm, z_dir_before,
+                                           c.wvls[wi], nwl[surf - 1], nwl[surf], mode, ad, dW);
+                if (rc == PHASE_OK)
+                    phs += dW;
+                else
+                    status = (rc == PHASE_TIR) ? ROX_TIR : ROX_EVANESCENT;    // :253-257
+            } else if (mode == ROX_REFLECT) {
+                ad = mirror_f(b4d, nrm);
+            } else if (mode == ROX_TRANSMIT) {
+                if (!refract_f(b4d, nrm, muw[surf], muw[N + surf], ad))
+                    status = ROX_TIR;               // :239-245
+            } else {
+                ad = b4d;
+            }
+        }
+        if (status != ROX_OK) {
+            fail_surf = surf;
+            break;
+        }
+        if (OUT_MODE == ROX_OUT_OPD || OUT_MODE == ROX_OUT_FAN) {
+            if (surf == 1)
+                e.ray1_p = inc;
+            if (surf == N - 2) {
+                e.rayk_p = inc;
+                e.rayk_d = ad;
+            }
+        }
+        bp = inc; bd = ad;
+        z_dir_before = row[O_ZDIR];
+    }
     e.status = status;
     e.fail_surf = fail_surf;
     e.opl = opl;
@@ -1574,23 +1933,28 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     double *wvls_w = phc_w + ((FEAT & F_PHASE) ? (size_t)nw_rows * N * kPhaseConsts : 0);
     double *apthr_w = wvls_w + a.n_wvls;                // [N]
     int32_t *slot_w = reinterpret_cast<int32_t *>(apthr_w + N);
-    // refined reciprocals of the indices (refract()), behind the slot map
-    double *rcpn_w = reinterpret_cast<double *>(
+    // F_FAST: mu = n_in / n_out and mu^2 per (wavelength row, interface), behind the slot map
+    constexpr bool kFast = (FEAT & F_FAST) != 0;
+    double *mu_w = reinterpret_cast<double *>(
         (reinterpret_cast<uintptr_t>(slot_w + 2 * N) + 7) & ~uintptr_t(7));
     // HITS_COMPACT: two tiles' worth of packed (x, y) pairs behind them
     d2 *stash_w = reinterpret_cast<d2 *>(
-        (reinterpret_cast<uintptr_t>(rcpn_w + (size_t)nw_rows * N) + 15) & ~uintptr_t(15));
+        (reinterpret_cast<uintptr_t>(mu_w + (kFast ? (size_t)nw_rows * 2 * N : 0)) + 15) & ~uintptr_t(15));
 
     // stage the surface table once per workgroup
     for (int i = threadIdx.x; i < N * kRowDoubles; i += kB)
         tbl_w[i] = a.rows[i];
     {
         const size_t w0 = PER_RAY_WVL ? 0 : (size_t)a.wvl_idx_all * N;
-        for (int i = threadIdx.x; i < nw_rows * N; i += kB) {
-            const double n_i = a.n_table[w0 + i];
-            ntab_w[i] = n_i;
-            rcpn_w[i] = a.n_band_ok ? rcp_band(n_i) : 0.0;
-        }
+        for (int i = threadIdx.x; i < nw_rows * N; i += kB)
+            ntab_w[i] = a.n_table[w0 + i];
+        if (kFast)
+            for (int i = threadIdx.x; i < nw_rows * N; i += kB) {
+                const int w = i / N, sf = i - w * N;
+                const double m = sf > 0 ? a.n_table[w0 + i - 1] / a.n_table[w0 + i] : 1.0;
+                mu_w[(size_t)w * 2 * N + sf] = m;
+                mu_w[(size_t)w * 2 * N + N + sf] = m * m;
+            }
         if (FEAT & F_PHASE)
             for (int i = threadIdx.x; i < nw_rows * N * kPhaseConsts; i += kB)
                 phc_w[i] = a.ph_consts[w0 * kPhaseConsts + i];
@@ -1610,8 +1974,8 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
 
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w; c.apthr = apthr_w;
-    c.rcpn = rcpn_w; c.rcpn_ok = ROX_STAGED_RCP && a.n_band_ok != 0;
     c.slot = slot_w; c.nslots_before = slot_w + N;
+    c.mu = mu_w;
     c.N = N;
     const uint32_t flags = a.opts.flags;
     c.check_ap = flags & ROX_CHECK_APERTURES;
@@ -1621,12 +1985,9 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     c.eps = a.opts.eps; c.fuzz = a.opts.fuzz;
     c.probe_surf = -1;
     const int64_t ld = a.out.ld;
-    constexpr bool kWaveTick = wave_ticketed(OUT_MODE);
-    constexpr bool kPatch = GEN == GEN_PUPIL && !kCompact && !kWaveTick && OUT_MODE != ROX_OUT_FULL &&
-                            (FEAT & F_POLY) != 0;
     const int64_t n_small = kCompact ? compact_small_tiles(a.n_rays, a.small_tiles) : 0;
     const int64_t n_tiles = kCompact ? compact_tiles(a.n_rays, a.small_tiles, kB)
-                          : kWaveTick ? (a.n_rays + 63) / 64 : (a.n_rays + kB - 1) / kB;
+                          : (a.n_rays + kB - 1) / kB;
 
     // HITS_COMPACT: tiles are handed out by ticket, so that the tile a workgroup
     // waits for in the look-back is always held by a running workgroup
@@ -1638,24 +1999,6 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     int64_t pend_tile = -1, pend_it = 0;    // HITS_COMPACT: the tile whose finish is deferred
     int pend_total = 0;
 
-    // wave striding: this wave's first tile and the stride (all waves of the launch)
-    const int64_t wv_first = (int64_t)blockIdx.x * (kB / 64) + __builtin_amdgcn_readfirstlane(wave);
-    const int64_t wv_stride = (int64_t)gridDim.x * (kB / 64);
-    // sharded tickets (ROX_WAVE_TICKETS == 2): the workgroups with blockIdx.x = s (mod shards)
-    // draw the tiles = s (mod shards) from counter s -- dynamic within a shard, every shard the
-    // same interleaved sample of the batch.  One word takes ~90 returning device-scope atomics
-    // per microsecond; 32 words on 32 lines take them side by side.  Lane 0 holds the wave's
-    // next draw, made one tile ahead.
-    const int wt_shards = (int)gridDim.x < kWtShards ? (int)gridDim.x : kWtShards;
-    const int wt_shard = (int)(blockIdx.x % (unsigned)wt_shards);
-    uint32_t tk = 0;
-    if (kWaveTick && ROX_WAVE_TICKETS == 2) {
-        if (blockIdx.x == 0 && threadIdx.x < kWtShards)
-            __hip_atomic_store(&a.wt_next[threadIdx.x * kWtStride], 0u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0)
-            tk = atomicAdd(&a.wt_cur[wt_shard * kWtStride], 1u);
-    }
     for (int64_t it = 0;; ++it) {
         int64_t tile;
         if (kCompact) {
@@ -1664,30 +2007,12 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
             __syncthreads();
             // (wave-uniform by construction: keep it in scalar registers across the trace)
             tile = (int64_t)__builtin_amdgcn_readfirstlane((int)s_tile);
-        } else if (kWaveTick && ROX_WAVE_TICKETS == 2) {
-            tile = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk) * wt_shards + wt_shard;
-            if (tile < n_tiles && lane == 0)
-                tk = atomicAdd(&a.wt_cur[wt_shard * kWtStride], 1u);
-        } else if (kWaveTick) {
-            tile = wv_first + it * wv_stride;
         } else {
             tile = (int64_t)blockIdx.x + it * gridDim.x;
         }
         if (tile >= n_tiles)
             break;
-        int64_t r = kWaveTick ? tile * 64 + lane : tile * kB + threadIdx.x;
-        // 8 x 8 pupil patches per wave: at an asphere a wave executes Spencer-Murty steps until its
-        // slowest lane has converged, and the step count follows the ray height -- a patch spans
-        // a narrower range of heights than 64 rays of one row (8-12 % fewer wave-steps on the
-        // .zmx zoom and the phone lens, profiles/r04_newton_wave_steps.json).  A tile is 8 rows x
-        // kB / 8 columns, wave w its columns 8w .. 8w + 7; rays keep their index, so every output
-        // lands where it did.
-        if (kPatch && a.patch8) {
-            constexpr int cols = kB / 8;
-            const int64_t per_band = a.axis_num / cols;
-            const int64_t band = tile / per_band, cb = tile - band * per_band;
-            r = (band * 8 + (lane >> 3)) * (int64_t)a.axis_num + cb * cols + (wave * 8 + (lane & 7));
-        }
+        int64_t r = tile * kB + threadIdx.x;
         bool active = r < a.n_rays;
         if (kCompact) {
             const bool small = tile < n_small;
@@ -1730,7 +2055,10 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
                     wi = 0;
             }
         }
-        trace_ray<OUT_MODE, PER_RAY_WVL, FEAT>(c, so, pt0, dir0, wi, active, e);
+        if constexpr (kFast)
+            trace_ray_fast<OUT_MODE, PER_RAY_WVL, FEAT>(c, pt0, dir0, wi, active, e);
+        else
+            trace_ray<OUT_MODE, PER_RAY_WVL, FEAT>(c, so, pt0, dir0, wi, active, e);
         if (active) {
             if (PER_RAY_WVL && !wi_ok) {
                 // reported as a miss at the object surface; no packet
@@ -1757,7 +2085,7 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
                         so.put(0, 1, (e.inc.y + dist * e.ad.y) - a.opts.image_pt[1]);
                     }
                 } else if (OUT_MODE == ROX_OUT_HITS) {      // axisarrayfigure.py:229-238
-                    const double dist = a.opts.foc / e.ad.z;
+                    const double dist = kFast ? a.opts.foc * rcp_f(e.ad.z) : a.opts.foc / e.ad.z;
                     so.put(0, 0, (e.inc.x + dist * e.ad.x) - a.opts.image_pt[0]);
                     so.put(0, 1, (e.inc.y + dist * e.ad.y) - a.opts.image_pt[1]);
                 }
@@ -1794,7 +2122,7 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
             total = __builtin_amdgcn_readfirstlane(total);
             d2 *stash = stash_w + (size_t)(it & 1) * kB;
             if (ok) {
-                const double dist = a.opts.foc / e.ad.z;
+                const double dist = kFast ? a.opts.foc * rcp_f(e.ad.z) : a.opts.foc / e.ad.z;
                 d2 xy;
                 xy.x = (e.inc.x + dist * e.ad.x) - a.opts.image_pt[0];
                 xy.y = (e.inc.y + dist * e.ad.y) - a.opts.image_pt[1];
@@ -1858,7 +2186,7 @@ struct LaunchCfg {
     int gen;            // GEN_*
     bool per_ray_wvl;
     bool small;         // workgroups of ROX_BLOCK_SMALL threads (pupil launches; see block_of())
-    int num_cus;        // wave-ticketed modes: the grid is clamped to the workgroups the chip holds
+    bool fast;          // the tolerance-mode instance (ROX_FAST_FP64 on a reduced-output mode)
     int out_mode;       // ROX_OUT_*
     dim3 grid;
     size_t lds;
@@ -1878,76 +2206,32 @@ inline void launch_with_lds(K kernel, const dim3 &grid, const dim3 &block, size_
     hipLaunchKernelGGL(kernel, grid, block, lds, st, a);
 }
 
-// Wave-strided modes: no more workgroups than the chip holds at once.  The runtime's occupancy
-// figure for (kernel, workgroup size, dynamic LDS) is cached per kernel instantiation and capped
-// at six waves per SIMD (every trace kernel uses 106 SGPRs: 800 / (112 + 16) waves; the API has
-// been seen one workgroup per CU high near such limits -- a surplus workgroup would run its
-// share of the tiles alone after everyone else).  ROX_TICKET_BLOCKS_PER_CU overrides it.
-struct OccCache {
-    std::mutex mu;
-    size_t lds = ~size_t(0);
-    int per_cu = 0;
-};
-template <class K>
-inline dim3 ticket_grid(OccCache &oc, K kernel, const LaunchCfg &k, int block)
-{
-    static const int forced = [] {
-        const char *e = getenv("ROX_TICKET_BLOCKS_PER_CU");
-        return (e && *e) ? atoi(e) : 0;
-    }();
-    int per_cu;
-    {
-        std::lock_guard<std::mutex> g(oc.mu);
-        if (oc.lds != k.lds) {
-            if (k.lds > kDefaultDynLds)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds);
-            int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, k.lds) != hipSuccess || n < 1) {
-                (void)hipGetLastError();
-                n = 1;
-            }
-            const int sgpr_cap = 6 * 4 * 64 / block;        // six waves per SIMD
-            oc.per_cu = n > sgpr_cap && sgpr_cap >= 1 ? sgpr_cap : n;
-            oc.lds = k.lds;
-        }
-        per_cu = oc.per_cu;
-    }
-    if (forced > 0)
-        per_cu = forced;
-    const unsigned cap = (unsigned)per_cu * (unsigned)(k.num_cus > 0 ? k.num_cus : 256);
-    dim3 g = k.grid;
-    if (g.x > cap)
-        g.x = cap;
-    return g;
-}
-
 // the small-workgroup kernels exist for the modes whose regular workgroup is larger
 // (per-ray-wavelength lists keep to the regular one)
 template <int OUT_MODE, int GEN, bool PRW, int FEAT>
 inline void launch_one(const LaunchCfg &k, const TraceArgs &a)
 {
-    static OccCache oc[2];
     if constexpr (!PRW && has_small(OUT_MODE, FEAT)) {
         if (k.small) {
             constexpr int bs = block_of(OUT_MODE, FEAT, true);
             auto kern = trace_kernel<OUT_MODE, GEN, PRW, FEAT, true>;
-            launch_with_lds(kern, wave_ticketed(OUT_MODE) ? ticket_grid(oc[1], kern, k, bs) : k.grid,
-                            dim3(bs), k.lds, k.stream, a);
+            launch_with_lds(kern, k.grid, dim3(bs), k.lds, k.stream, a);
             return;
         }
     }
     constexpr int bs = block_of(OUT_MODE, FEAT);
     auto kern = trace_kernel<OUT_MODE, GEN, PRW, FEAT, false>;
-    launch_with_lds(kern, wave_ticketed(OUT_MODE) ? ticket_grid(oc[0], kern, k, bs) : k.grid, dim3(bs),
-                    k.lds, k.stream, a);
+    launch_with_lds(kern, k.grid, dim3(bs), k.lds, k.stream, a);
 }
 
 template <int GEN, bool PRW, int FEAT>
 inline void launch_mode(const LaunchCfg &k, const TraceArgs &a)
 {
     switch (k.out_mode) {
-    case ROX_OUT_FULL: launch_one<ROX_OUT_FULL, GEN, PRW, FEAT>(k, a); break;
+    case ROX_OUT_FULL:
+        if constexpr (!(FEAT & F_FAST))     // (the host never sends FULL to a tolerance-mode instance)
+            launch_one<ROX_OUT_FULL, GEN, PRW, FEAT>(k, a);
+        break;
     case ROX_OUT_LAST: launch_one<ROX_OUT_LAST, GEN, PRW, FEAT>(k, a); break;
     case ROX_OUT_OPD: launch_one<ROX_OUT_OPD, GEN, PRW, FEAT>(k, a); break;
     case ROX_OUT_HITS_COMPACT: launch_one<ROX_OUT_HITS_COMPACT, GEN, PRW, FEAT>(k, a); break;
@@ -1982,27 +2266,27 @@ inline void launch_batch_with_lds(K kernel, const dim3 &grid, const dim3 &block,
 template <int OUT_MODE, int FEAT>
 inline void launch_one_batch(const LaunchCfg &k, const TraceArgs *items)
 {
-    static OccCache oc[2];
     if constexpr (has_small(OUT_MODE, FEAT)) {
         if (k.small) {
             constexpr int bs = block_of(OUT_MODE, FEAT, true);
             auto kern = trace_kernel_batch<OUT_MODE, FEAT, true>;
-            launch_batch_with_lds(kern, wave_ticketed(OUT_MODE) ? ticket_grid(oc[1], kern, k, bs) : k.grid,
-                                  dim3(bs), k.lds, k.stream, items);
+            launch_batch_with_lds(kern, k.grid, dim3(bs), k.lds, k.stream, items);
             return;
         }
     }
     constexpr int bs = block_of(OUT_MODE, FEAT);
     auto kern = trace_kernel_batch<OUT_MODE, FEAT, false>;
-    launch_batch_with_lds(kern, wave_ticketed(OUT_MODE) ? ticket_grid(oc[0], kern, k, bs) : k.grid,
-                          dim3(bs), k.lds, k.stream, items);
+    launch_batch_with_lds(kern, k.grid, dim3(bs), k.lds, k.stream, items);
 }
 
 template <int FEAT>
 inline void launch_instance_batch(const LaunchCfg &k, const TraceArgs *items)
 {
     switch (k.out_mode) {
-    case ROX_OUT_FULL: launch_one_batch<ROX_OUT_FULL, FEAT>(k, items); break;
+    case ROX_OUT_FULL:
+        if constexpr (!(FEAT & F_FAST))
+            launch_one_batch<ROX_OUT_FULL, FEAT>(k, items);
+        break;
     case ROX_OUT_LAST: launch_one_batch<ROX_OUT_LAST, FEAT>(k, items); break;
     case ROX_OUT_OPD: launch_one_batch<ROX_OUT_OPD, FEAT>(k, items); break;
     case ROX_OUT_HITS_COMPACT: launch_one_batch<ROX_OUT_HITS_COMPACT, FEAT>(k, items); break;
@@ -2031,6 +2315,21 @@ void launch_poly_batch(const LaunchCfg &, const TraceArgs *);
 void launch_aplist_batch(const LaunchCfg &, const TraceArgs *);
 void launch_evenap_batch(const LaunchCfg &, const TraceArgs *);
 void launch_general_batch(const LaunchCfg &, const TraceArgs *);
+// ... and their tolerance-mode twins (csrc/fast_*.hip: kInstances[i] | F_FAST, reduced-output modes)
+void launch_lean_fast(const LaunchCfg &, const TraceArgs &);
+void launch_even_fast(const LaunchCfg &, const TraceArgs &);
+void launch_radial_fast(const LaunchCfg &, const TraceArgs &);
+void launch_poly_fast(const LaunchCfg &, const TraceArgs &);
+void launch_aplist_fast(const LaunchCfg &, const TraceArgs &);
+void launch_evenap_fast(const LaunchCfg &, const TraceArgs &);
+void launch_general_fast(const LaunchCfg &, const TraceArgs &);
+void launch_lean_fast_batch(const LaunchCfg &, const TraceArgs *);
+void launch_even_fast_batch(const LaunchCfg &, const TraceArgs *);
+void launch_radial_fast_batch(const LaunchCfg &, const TraceArgs *);
+void launch_poly_fast_batch(const LaunchCfg &, const TraceArgs *);
+void launch_aplist_fast_batch(const LaunchCfg &, const TraceArgs *);
+void launch_evenap_fast_batch(const LaunchCfg &, const TraceArgs *);
+void launch_general_fast_batch(const LaunchCfg &, const TraceArgs *);
 
 // the pack pass of two-pass packed hits (csrc/pack.hip): a plain ROX_OUT_HITS launch has left
 // (x, y)[2][ld] and status[n_rays]; survivors go to dst in ray order, exactly where the fused

@@ -51,7 +51,6 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
 
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
-    c.rcpn = nullptr; c.rcpn_ok = false;
     c.slot = slot_w; c.nslots_before = slot_w + N;
     c.apthr = nullptr;          // (the trial rays of the aiming never test apertures)
     c.N = N;
@@ -343,7 +342,6 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
 
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
-    c.rcpn = nullptr; c.rcpn_ok = false;
     c.slot = slot_w; c.nslots_before = slot_w + N;
     c.apthr = apthr_w;          // (checked trace only)
     c.N = N;
@@ -612,7 +610,6 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
 
     Ctx c;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
-    c.rcpn = nullptr; c.rcpn_ok = false;
     c.slot = slot_w; c.nslots_before = slot_w + N;
     c.apthr = nullptr;
     c.N = N;

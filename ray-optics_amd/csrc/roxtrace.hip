@@ -226,12 +226,6 @@ struct StreamCtx {
     std::mutex stage_mu;                // one ROX_HOST_POINTERS call at a time per stream
     std::mutex compact_mu;              // epoch / ticket state: one HITS_COMPACT enqueue at a time
     std::mutex ticket_mu;               // first allocation of d_ticket / d_hits_base
-    // ROX_WAVE_TICKETS == 2 (experiment): two sets of [items][kWtShards] sharded tile counters;
-    // launch n of the stream draws from set n & 1 and zeroes the other for launch n + 1
-    uint32_t *d_wt = nullptr;
-    int64_t wt_items_cap = 0;
-    uint32_t wt_parity = 0;
-    std::mutex wt_mu;
 };
 
 }  // namespace
@@ -254,7 +248,6 @@ struct rox_system {
     int num_cus = 256;
     int features = 0;                   // F_* of the table
     int n_newton = 0;                   // interfaces intersected by Newton iteration
-    int n_band_ok = 0;                  // every refractive index in the slim-fp64 band
     std::mutex mu;                      // guards ctxs
     std::vector<StreamCtx *> ctxs;
     // the small synchronous search entries (aiming, pupil search, vignetting, pupil
@@ -326,14 +319,28 @@ void slot_map(const rox_system *s, bool filter, std::vector<int32_t> &m, int32_t
     n_seg = next;
 }
 
-size_t lds_bytes(const rox_system *s, bool per_ray_wvl, bool phase)
+size_t lds_bytes(const rox_system *s, bool per_ray_wvl, bool phase, bool fast)
 {
     const size_t N = s->n_ifcs, Wn = per_ray_wvl ? (size_t)s->n_wvls : 1;
     size_t b = N * sizeof(dev_surface) + Wn * N * sizeof(double) +
                (phase ? Wn * N * kPhaseConsts * sizeof(double) : 0) +
                ((size_t)s->n_wvls + N) * sizeof(double) + 2 * N * sizeof(int32_t);
-    b = ((b + 7) & ~size_t(7)) + Wn * N * sizeof(double);      // the indices' reciprocals
+    if (fast)       // mu and mu^2 per (wavelength row, interface) behind the slot map
+        b = ((b + 7) & ~size_t(7)) + Wn * 2 * N * sizeof(double);
     return (b + 15) & ~size_t(15);
+}
+
+// ROX_FAST_FP64 is a permission, taken where it buys something: the reduced-output modes (bound
+// by VALU issue).  FULL packets are bound by their stores and stay bit-exact.
+// ROX_FAST_FP64_DISABLE=1 (read once) ignores the flag everywhere: an A/B switch for callers
+// that set it by default.
+bool use_fast(const rox_opts &o)
+{
+    static const bool off = [] {
+        const char *e = getenv("ROX_FAST_FP64_DISABLE");
+        return e && *e && atoi(e) != 0;
+    }();
+    return (o.flags & ROX_FAST_FP64) != 0 && o.out_mode != ROX_OUT_FULL && !off;
 }
 
 int check_opts(const rox_system *sys, const rox_opts *o, const rox_out *out, int64_t n_rays)
@@ -497,26 +504,6 @@ bool want_small(const rox_system *sys, int64_t total_rays, int out_mode, int fea
     return (total_rays + 63) / 64 <= (int64_t)sys->num_cus * per_cu;
 }
 
-// 8 x 8 pupil patches per wave (rox_device.hpp trace_tiles): product grids traced by a Newton
-// instance in a reduced-output mode, when the launch is whole tiles of 8 rows x bs / 8 columns.
-// OFF unless ROX_PATCH8=1 (read per call: the parity test flips it): built as the round-4
-// verdict asked and measured SLOWER -- .zmx zoom HITS 146.8 -> 157.3 us, phone lens 233.0 ->
-// 245.9, Nikkor 321.2 -> 328.7 per 2^20 rays (profiles/r05_patch8.txt): the 8-12 % of
-// Spencer-Murty wave-steps it saves are 2-5 % of a kernel, and a wave's outputs become eight
-// 64-byte pieces of eight different rows instead of one 512-byte run.
-int32_t want_patch8(int gen, const TraceArgs &a, int out_mode, int feat, int bs, int64_t n_rays)
-{
-    const char *e = getenv("ROX_PATCH8");
-    const int env = (e && *e) ? atoi(e) : 0;
-    if (!env || gen != GEN_PUPIL || a.axis_kind != AXIS_PRODUCT || !(feat & F_POLY) ||
-        out_mode == ROX_OUT_FULL || out_mode == ROX_OUT_HITS_COMPACT || a.axis_num < 8)
-        return 0;
-    const int64_t num = a.axis_num, cols = bs / 8;
-    if (num % cols != 0 || n_rays % (8 * num) != 0)
-        return 0;
-    return 1;
-}
-
 // ---- the search kernels (csrc/rox_search.hpp): the leanest instance of kSearchInstances that
 // covers the system's features -- their trial rays never filter phantoms
 int pick_search_instance(const rox_system *sys)
@@ -558,7 +545,9 @@ void launch_feat(int inst, const LaunchCfg &k, const TraceArgs &a)
     typedef void (*fn)(const LaunchCfg &, const TraceArgs &);
     static const fn fns[] = {launch_lean, launch_even, launch_radial, launch_poly,
                              launch_aplist, launch_evenap, launch_general};
-    fns[inst](k, a);
+    static const fn fast[] = {launch_lean_fast, launch_even_fast, launch_radial_fast, launch_poly_fast,
+                              launch_aplist_fast, launch_evenap_fast, launch_general_fast};
+    (k.fast ? fast : fns)[inst](k, a);
 }
 
 void launch_feat_batch(int inst, const LaunchCfg &k, const TraceArgs *items)
@@ -567,7 +556,10 @@ void launch_feat_batch(int inst, const LaunchCfg &k, const TraceArgs *items)
     static const fn fns[] = {launch_lean_batch, launch_even_batch, launch_radial_batch,
                              launch_poly_batch, launch_aplist_batch, launch_evenap_batch,
                              launch_general_batch};
-    fns[inst](k, items);
+    static const fn fast[] = {launch_lean_fast_batch, launch_even_fast_batch, launch_radial_fast_batch,
+                              launch_poly_fast_batch, launch_aplist_fast_batch, launch_evenap_fast_batch,
+                              launch_general_fast_batch};
+    (k.fast ? fast : fns)[inst](k, items);
 }
 
 // (initialisations are enqueued on the launch stream itself: a stream created with
@@ -587,31 +579,6 @@ int ensure_ticket(StreamCtx *cx, hipStream_t st)
         cx->d_hits_base = b;
         cx->d_ticket = t;
     }
-    return 0;
-}
-
-// sharded wave tickets of a launch of n_items items: items[i].wt_cur / wt_next
-int assign_wave_tickets(StreamCtx *cx, TraceArgs *items, int64_t n_items, hipStream_t st)
-{
-    const size_t per_item = (size_t)kWtShards * kWtStride;
-    if (n_items > cx->wt_items_cap) {
-        if (cx->d_wt)
-            HIP_TRY(hipFree(cx->d_wt));         // synchronises with the launches using it
-        cx->d_wt = nullptr;
-        cx->wt_items_cap = 0;
-        const int64_t cap = n_items < 16 ? 16 : n_items;
-        HIP_TRY(hipMalloc(&cx->d_wt, sizeof(uint32_t) * 2 * per_item * (size_t)cap));
-        HIP_TRY(hipMemsetAsync(cx->d_wt, 0, sizeof(uint32_t) * 2 * per_item * (size_t)cap, st));
-        cx->wt_items_cap = cap;
-        cx->wt_parity = 0;
-    }
-    uint32_t *cur = cx->d_wt + (size_t)(cx->wt_parity & 1) * per_item * (size_t)cx->wt_items_cap;
-    uint32_t *nxt = cx->d_wt + (size_t)((cx->wt_parity & 1) ^ 1) * per_item * (size_t)cx->wt_items_cap;
-    for (int64_t i = 0; i < n_items; ++i) {
-        items[i].wt_cur = cur + (size_t)i * per_item;
-        items[i].wt_next = nxt + (size_t)i * per_item;
-    }
-    ++cx->wt_parity;
     return 0;
 }
 
@@ -694,19 +661,18 @@ int launch_setup(rox_system *sys, TraceArgs &a, int gen, bool prw, hipStream_t s
     a.slots = sys->d_slots[(a.opts.flags & ROX_FILTER_PHANTOMS) ? 1 : 0];
     a.n_ifcs = sys->n_ifcs;
     a.n_wvls = sys->n_wvls;
-    a.n_band_ok = sys->n_band_ok;
     int need = sys->features;
     if ((a.opts.flags & ROX_FILTER_PHANTOMS) && sys->n_seg[1] != sys->n_seg[0])
         need |= F_PHFILT;
     k.gen = gen;
     k.per_ray_wvl = prw;
     k.small = false;
-    k.num_cus = sys->num_cus;
+    k.fast = use_fast(a.opts);
     k.out_mode = a.opts.out_mode;
     k.stream = st;
     inst = pick_instance(need);
     // (an instance compiled with F_PHASE stages the phase constants, needed or not)
-    k.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0);
+    k.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0, k.fast);
     if (a.opts.out_mode == ROX_OUT_HITS_COMPACT)    // two tiles of packed pairs (rox_device.hpp)
         k.lds += 16 + 2 * 16 * (size_t)block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]);
     if (k.lds > 160 * 1024 - 64)
@@ -811,21 +777,12 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
             h.out.status = out0.status ? out0.status + base : cx->d_pack_status;
             LaunchCfg kh = k;
             kh.out_mode = ROX_OUT_HITS;
-            kh.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0);
+            kh.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0, kh.fast);
             const int hb = block_of(ROX_OUT_HITS, kInstances[inst], kh.small);
             int64_t hblocks = (a.n_rays + hb - 1) / hb;
             const int64_t hcap = (int64_t)sys->num_cus * blocks_per_cu(hb);
             kh.grid = dim3((unsigned)(hblocks > hcap ? hcap : hblocks));
-            h.patch8 = total <= chunk_max ? want_patch8(gen, h, ROX_OUT_HITS, kInstances[inst], hb, a.n_rays) : 0;
-            if (ROX_WAVE_TICKETS == 2) {
-                std::lock_guard<std::mutex> wg(cx->wt_mu);
-                int rcw = assign_wave_tickets(cx, &h, 1, st);
-                if (rcw)
-                    return rcw;
-                launch_feat(inst, kh, h);
-            } else {
-                launch_feat(inst, kh, h);
-            }
+            launch_feat(inst, kh, h);
             // pass 2: survivors to their final place, in ray order
             PackArgs p;
             p.status = h.out.status;
@@ -851,19 +808,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
         if (blocks > cap)
             blocks = cap;
         k.grid = dim3((unsigned)blocks);
-        a.patch8 = total <= chunk_max ? want_patch8(gen, a, a.opts.out_mode, kInstances[inst], bs, a.n_rays) : 0;
-        if (ROX_WAVE_TICKETS == 2 && wave_ticketed(a.opts.out_mode)) {
-            StreamCtx *wx = ctx_for(sys, st);
-            if (!wx)
-                return fail(ROX_E_NOMEM, "out of host memory");
-            std::lock_guard<std::mutex> wg(wx->wt_mu);
-            int rcw = assign_wave_tickets(wx, &a, 1, st);
-            if (rcw)
-                return rcw;
-            launch_feat(inst, k, a);
-        } else {
-            launch_feat(inst, k, a);
-        }
+        launch_feat(inst, k, a);
     }
     a.n_rays = total;
     a.out = out0;
@@ -1213,6 +1158,16 @@ int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_t
             s.n_ap > ROX_MAX_AP || s.ph.kind < ROX_PH_NONE || s.ph.kind > ROX_PH_HOLOGRAM ||
             s.ph.ncoef < 0 || s.ph.ncoef > ROX_MAX_COEF)
             return fail(ROX_E_ARG, "rox_system_create: row %d is malformed", i);
+        // rox_surface.flags: ROX_SURF_CV_INT_ZERO says "the curvature is the INTEGER 0" (its
+        // only effect: the zero signs of Spherical / Conic df).  It means nothing on any other
+        // row, and a caller that left the field uninitialised must not get flat normals on a
+        // curved surface: refused, as are bits this version does not define.
+        if ((s.flags & ~ROX_SURF_CV_INT_ZERO) != 0)
+            return fail(ROX_E_ARG, "rox_system_create: row %d: unknown bits in rox_surface.flags (%#x)", i,
+                        (unsigned)s.flags);
+        if ((s.flags & ROX_SURF_CV_INT_ZERO) && !(s.profile <= ROX_CONIC && s.cv == 0.0))
+            return fail(ROX_E_ARG, "rox_system_create: row %d: ROX_SURF_CV_INT_ZERO on a surface that is not "
+                                   "a Spherical / Conic of zero curvature", i);
         if (s.profile == ROX_EVENPOLY)
             features |= F_EVEN;
         else if (s.profile == ROX_RADIALPOLY)
@@ -1235,17 +1190,6 @@ int rox_system_create(const rox_surface *rows, int32_t n_ifcs, const double *n_t
     sys->n_wvls = n_wvls;
     sys->features = features;
     sys->n_newton = n_newton;
-    {
-        // (rox_device.hpp in_band: biased exponent in [640, 1408))
-        bool ok = true;
-        for (size_t i = 0; i < (size_t)n_wvls * (size_t)n_ifcs; ++i) {
-            uint64_t u;
-            memcpy(&u, &n_table[i], sizeof u);
-            const uint32_t h = (uint32_t)(u >> 32) & 0x7fffffffu;
-            ok = ok && (h - 0x28000000u) < 0x30000000u;
-        }
-        sys->n_band_ok = ok ? 1 : 0;
-    }
     sys->rows.assign(rows, rows + n_ifcs);
     hipError_t e = hipGetDevice(&sys->device);
     if (e != hipSuccess) {
@@ -1447,9 +1391,9 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
             return fail(ROX_E_UNSUPPORTED, "rox_trace_pupil_grids: device pointers only, no ROX_HITS_APPEND "
                                            "(item %d)", i);
         if (opts[i].out_mode != opts[0].out_mode ||
-            ((opts[i].flags ^ opts[0].flags) & ROX_FILTER_PHANTOMS))
-            return fail(ROX_E_ARG, "rox_trace_pupil_grids: out_mode and ROX_FILTER_PHANTOMS must be the "
-                                   "same for every item (item %d)", i);
+            ((opts[i].flags ^ opts[0].flags) & (ROX_FILTER_PHANTOMS | ROX_FAST_FP64)))
+            return fail(ROX_E_ARG, "rox_trace_pupil_grids: out_mode, ROX_FILTER_PHANTOMS and ROX_FAST_FP64 "
+                                   "must be the same for every item (item %d)", i);
     }
     // the items, validated one by one exactly as single launches are
     auto enq = enqueue_lock(sys, st);
@@ -1527,13 +1471,6 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
     const int64_t cap = (int64_t)sys->num_cus * (compact ? compact_blocks_per_cu() : blocks_per_cu(bs));
     if (blocks > cap)
         blocks = cap;
-    for (int32_t i = 0; i < n_grids; ++i)
-        items[i].patch8 = want_patch8(GEN_PUPIL, items[i], opts[0].out_mode, kInstances[inst], bs, R);
-    if (ROX_WAVE_TICKETS == 2 && wave_ticketed(opts[0].out_mode)) {
-        std::lock_guard<std::mutex> wg(cx->wt_mu);      // (batch_mu keeps the enqueue order)
-        if ((rc = assign_wave_tickets(cx, items.data(), n_grids, st)))
-            return rc;
-    }
     // items -> pinned slot -> device, in stream order
     if (n_grids > cx->items_cap) {
         if (cx->d_items)
@@ -1555,7 +1492,14 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
     // refreshed with unchanged arguments, a timing loop) are already in d_items: the upload -- a
     // copy-engine transfer in front of the kernel, ~6 us of a 24 us configs[3] pass -- is skipped.
     const size_t items_bytes = sizeof(TraceArgs) * (size_t)n_grids;
-    const bool same_items = cx->items_last.size() == items_bytes &&
+    // ROX_BATCH_ALWAYS_UPLOAD=1 (read once) switches the short cut off: bench.py times the
+    // BASELINE configurations that way, so that its figures are those of a call whose fields or
+    // outputs changed.  (TraceArgs is value-initialised, padding included, before it is filled.)
+    static const bool always_upload = [] {
+        const char *e = getenv("ROX_BATCH_ALWAYS_UPLOAD");
+        return e && *e && atoi(e) != 0;
+    }();
+    const bool same_items = !always_upload && cx->items_last.size() == items_bytes &&
                             memcmp(cx->items_last.data(), items.data(), items_bytes) == 0;
     if (!same_items) {
         const uint32_t slot = cx->item_slot++ % StreamCtx::kItemSlots;

@@ -391,6 +391,31 @@ def _in_flight(fn):
     return guarded
 
 
+class ModelMemo:
+    """What the drop-in layer remembers per MODEL STATE -- i.e. per engine: a model edit makes a
+    new engine (session.engine_for), so nothing here outlives the state it was computed from.
+
+    ``chief_rays``  {(bytes(rox_field), wavelength index): (seg [N, 10], op) | None}: the
+                    one-launch chief-ray batch of trace.trace_chief_ray
+    ``obj_coords``  the memo of ``osp.obj_coords(fld)`` (table._obj_coords: the reverse
+                    chief-ray iteration of real-image-height fields, once per launch
+                    instead of once per ray)
+
+    session.engine_for hands one engine to every thread that traces the same model: writers
+    hold ``lock``."""
+    __slots__ = ('lock', 'chief_rays', 'obj_coords')
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.chief_rays = {}
+        self.obj_coords = {}
+
+    def clear(self):
+        with self.lock:
+            self.chief_rays.clear()
+            self.obj_coords.clear()
+
+
 class TraceEngine:
     """one immutable surface table on one GPU.
 
@@ -407,6 +432,7 @@ class TraceEngine:
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None
                                    else torch.device(device).index or 0)
         self.table = table
+        self.memo = ModelMemo()         # cleared by close()
         self._nseg = {}
         self._handle = C.c_void_p()
         # lifetime of the device handle under threads (session.engine_for hands one engine to
@@ -454,6 +480,7 @@ class TraceEngine:
     def close(self):
         """destroy the device handle -- at once, or, with calls in flight on other threads,
         when the last of them returns.  A later call re-creates it."""
+        self.memo.clear()
         with self._life:
             if self._calls > 0:
                 self._close_pending = True
@@ -565,6 +592,17 @@ class TraceEngine:
         R = grid_rays(grid)
         n = len(flds)
         mode = opts_list[0].out_mode
+        # every item's slice of the pinned block is sized from the first item's output mode and
+        # segment count: the library takes per-item options, so a list that mixes them would
+        # have the kernel write past a slice (the library checks the same for a batched launch,
+        # but falls back to per-item launches for a single item)
+        ph = opts_list[0].flags & abi.FILTER_PHANTOMS
+        for o in opts_list:
+            if o.out_mode != mode or (o.flags & abi.FILTER_PHANTOMS) != ph:
+                raise EngineError('trace_pupil_grids_host: out_mode and FILTER_PHANTOMS must be the '
+                                  'same for every item')
+        if len(opts_list) != n or len(wvl_idxs) != n:
+            raise EngineError('trace_pupil_grids_host: one wavelength index and one rox_opts per field')
         if mode == abi.OUT_FULL:
             rows = self.num_segments(opts_list[0].flags) * abi.SEG_DOUBLES
         else:

@@ -414,7 +414,15 @@ def field_from_model(opt_model, fld, pupil_type='rel pupil', cache=None):
     (plain, wide-angle, 'aim pt'), angular pupils ('NA', 'f/#', 'aim dir').
     The per-ray part of each branch runs on the device (``rox_field.kind``).
     Fields that carry prebuilt constants (``fld.rox_field``: table-backed
-    models, :mod:`~.workloads`) use them as is."""
+    models, :mod:`~.workloads`) use them as is.
+
+    Raises, for a field this layer cannot express: :class:`UnsupportedModelError` (a pupil
+    specification without a device branch), the reference's ``TraceError`` classes (the
+    reverse chief-ray iteration of a real-image-height field, ``osp.obj_coords``), and what
+    the reference's own arithmetic raises on degenerate specifications (``TypeError`` for an
+    angular pupil with neither chief-ray direction nor aim point, ``ValueError``,
+    ``ZeroDivisionError``, ``FloatingPointError``).  The drop-ins answer such a field through the
+    reference's own function (``trace._FIELD_ERRORS``)."""
     pre = getattr(fld, 'rox_field', None)
     if pre is not None and pupil_type == 'rel pupil':
         return pre

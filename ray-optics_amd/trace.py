@@ -27,7 +27,14 @@ import numpy as np
 from . import abi, session
 from .engine import make_opts, make_grid
 from .raypkg import HostPackets, RayPkg, RaySeg
-from .table import field_from_model
+from .table import field_from_model, UnsupportedModelError
+from .traceerror import TraceError
+
+# what table.field_from_model raises for a field this layer cannot express (its docstring): such
+# a field is answered by the reference's own function.  Anything else -- an AttributeError, a
+# NameError: a programming error -- propagates.
+_FIELD_ERRORS = (UnsupportedModelError, TraceError, TypeError, ValueError, ZeroDivisionError,
+                 FloatingPointError)
 
 
 def opts_from_kwargs(n_ifcs, kwargs, out_mode, foc=0.0, image_pt=(0., 0.), wf=None):
@@ -193,16 +200,17 @@ def _chief_rays(opt_model, eng):
     first ray is pupil (0, 0), written straight into pinned host memory), kept on the engine
     -- a model edit makes a new engine -- under the field's ray-start constants: a re-aimed
     field simply misses.  {(field constants, wavelength index): (seg [N, 10], op) | None}"""
-    cache = eng.__dict__.setdefault('_chief_cache', {})
+    memo = eng.memo                                  # engine.ModelMemo, cleared by eng.close()
+    cache = memo.chief_rays
     osp = opt_model['optical_spec']
     tbl = eng.table
-    oc = eng.__dict__.setdefault('_obj_coords_cache', {})
+    oc = memo.obj_coords
     kw = {'apply_vignetting': True}                 # trace_base's default; (0, 0) is its fixed point
     flds, wis, optl, keys = [], [], [], []
     for fld in osp['fov'].fields:
         try:
             f = field_from_model(opt_model, fld, 'rel pupil', cache=oc)
-        except Exception:                           # noqa: BLE001  (that field goes the one-ray way)
+        except _FIELD_ERRORS:                       # (that field goes the reference's own way)
             continue
         opts = opts_from_kwargs(tbl.n_ifcs, kw, abi.OUT_FULL)
         if f.kind == abi.FLD_EPD_WIDE or f.z_dir0 == 0.0:
@@ -217,14 +225,15 @@ def _chief_rays(opt_model, eng):
             keys.append((fb, wi))
     if flds:
         res = eng.trace_pupil_grids_host(flds, wis, make_grid((0., 0.), (1., 1.), 2), optl)
-        for key, h in zip(keys, res):
-            if int(h.status[0]) == abi.OK:
-                cache[key] = (np.array(h.seg[:, :, 0]), float(h.op[0]))
-            else:
-                cache[key] = None                   # a failing chief ray: the reference's own path
-        if len(cache) > 4096:                       # (a session that re-aims for ever)
-            for k in list(cache)[:len(cache) - 2048]:
-                del cache[k]
+        with memo.lock:
+            for key, h in zip(keys, res):
+                if int(h.status[0]) == abi.OK:
+                    cache[key] = (np.array(h.seg[:, :, 0]), float(h.op[0]))
+                else:
+                    cache[key] = None               # a failing chief ray: the reference's own path
+            if len(cache) > 4096:                   # (a session that re-aims for ever)
+                for k in list(cache)[:len(cache) - 2048]:
+                    cache.pop(k, None)
     return cache
 
 
@@ -263,15 +272,14 @@ def _chief_ray_packet(opt_model, fld, wvl):
     eng = session.engine_for(opt_model)
     try:
         wi = eng.table.wvl_index(wvl)
-        f = field_from_model(opt_model, fld, 'rel pupil',
-                             cache=eng.__dict__.setdefault('_obj_coords_cache', {}))
-        key = (bytes(f), wi)
-        cache = eng.__dict__.get('_chief_cache')
-        if cache is None or key not in cache:
-            cache = _chief_rays(opt_model, eng)
-        return cache.get(key)
-    except (ValueError, KeyError):
+        f = field_from_model(opt_model, fld, 'rel pupil', cache=eng.memo.obj_coords)
+    except _FIELD_ERRORS + (KeyError,):             # (KeyError: a wavelength outside the spectral list)
         return None
+    key = (bytes(f), wi)
+    cache = eng.memo.chief_rays
+    if key not in cache:
+        cache = _chief_rays(opt_model, eng)
+    return cache.get(key)
 
 
 def trace_astigmatism_coddington_fan(opt_model, fld, wvl, foc):
@@ -359,7 +367,7 @@ def _launch_setup(opt_model, fld, wvl, kwargs, out_mode, foc=0.0, image_pt=(0., 
     eng = session.engine_for(opt_model)
     tbl = eng.table
     opts = opts_from_kwargs(tbl.n_ifcs, kwargs, out_mode, foc, image_pt, wf)
-    f = field_from_model(opt_model, fld, pupil_type, cache=eng.__dict__.setdefault('_obj_coords_cache', {}))
+    f = field_from_model(opt_model, fld, pupil_type, cache=eng.memo.obj_coords)
     if pupil_type != 'rel pupil':
         opts.flags &= ~abi.APPLY_VIGNETTING             # trace.py:291-295
     if f.kind == abi.FLD_EPD_WIDE or f.z_dir0 == 0.0:

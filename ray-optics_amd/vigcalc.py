@@ -167,7 +167,7 @@ def trace_boundary_rays(opt_model, **kwargs):
             fld.ref_sphere = ref_sphere
         tbl = eng.table
         wi = tbl.wvl_index(wvl)
-        oc = eng.__dict__.setdefault('_obj_coords_cache', {})
+        oc = eng.memo.obj_coords
         flds, optl = [], []
         for fld in fov.fields:
             f = field_from_model(opt_model, fld, 'rel pupil', cache=oc)

@@ -63,8 +63,10 @@ class _Pack:
 
 class OracleEngine:
     def __init__(self, table, device=None):
+        from rayoptics_amd.engine import ModelMemo
         self.table = table
         self.device = 'cpu'
+        self.memo = ModelMemo()
 
     def hits_pack(self, cap, max_launches, dest=None):
         return _Pack(cap, max_launches, dest)

@@ -40,6 +40,21 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f'{name} not exported'
 
 
+def test_dynamic_symbol_table_is_the_c_abi_and_nothing_else(lib):
+    """`nm -D` of libroxtrace.so == the functions the two headers declare: no rox:: internals,
+    kernel host stubs or template instantiations (-fvisibility=hidden + csrc/libroxtrace.map),
+    and DT_SONAME carries the ABI version"""
+    import subprocess
+    path = lib._name
+    out = subprocess.check_output(['nm', '-D', '--defined-only', path], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == sorted(header_symbols() + header_symbols('roxtrace_diag.h'))
+    dyn = subprocess.check_output(['readelf', '-d', path], text=True)
+    assert f'[libroxtrace.so.{abi.ABI_VERSION}]' in dyn
+    link = os.path.join(os.path.dirname(path), f'libroxtrace.so.{abi.ABI_VERSION}')
+    assert os.path.exists(link)
+
+
 def test_abi_version_and_error_string(lib):
     abi.declare(lib)
     assert lib.rox_abi_version() == abi.ABI_VERSION

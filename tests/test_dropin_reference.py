@@ -1664,7 +1664,7 @@ def test_setup_pupil_coords_from_the_chief_ray_batch(ref, installed, model):
         return out
     opm_o = build()
     eng = session.engine_for(opm_o)
-    eng.__dict__.pop('_chief_cache', None)      # (building the model has already asked for some)
+    eng.memo.chief_rays.clear()      # (building the model has already asked for some)
     real = eng.trace_pupil_grids_host
 
     def counting(*a, **k):

@@ -1,0 +1,272 @@
+"""-m gpu: ROX_FAST_FP64, the tolerance mode of the reduced-output modes (include/roxtrace.h;
+csrc/rox_device.hpp "tolerance mode").  north_star's bar is 1e-10 on ray intercepts against the
+reference's NumPy path; the default kernels are bit-exact, these are not, so here the bar is
+asserted directly:
+
+  * every fixture system and every BASELINE configuration, HITS / LAST / OPD / FAN / packed
+    hits: fast vs the oracle (small grids) and vs the bit-exact device path (full-size grids)
+    <= 1e-10 * max(1, |ref|) on every value (TOL below; observed <= ~1e-12, printed);
+  * a ray's status may differ only where its decision margin is within rounding of zero: flips
+    are counted, and every flipped ray must lie within 1e-10 (scaled) of the aperture edge /
+    TIR limit / miss boundary it was decided at (helpers.boundary_margin, computed from the
+    ORACLE's FULL packet of that ray); rays laid within a few ulp of aperture edges and of the
+    critical angle make sure the accounting is exercised;
+  * ROX_OUT_FULL ignores the flag (bit-exact), a batch must agree on it."""
+import numpy as np
+import pytest
+
+from rayoptics_amd import abi
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+SPOT = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+WORKLOADS = ['singlet_c1', 'dblgauss_c2', 'zmx_evenasph_c3', 'nikkor_c3', 'rc_telescope_c4', 'litho_c5',
+             'cell_phone', 'tt_cassegrain', 'tt_landscape', 'tt_paraboloid', 'tt_singlet_seq',
+             'tt_triplet', 'tt_two_mirrors_conic', 'tt_two_sph_mirrors']
+
+
+def _flags(wl, fi):
+    f = wl.fields[fi]
+    wide = f.kind == abi.FLD_EPD_WIDE or f.z_dir0 == 0.0
+    return (SPOT & ~abi.INTERSECT_OBJ) | (0 if wide else abi.INTERSECT_OBJ)
+
+
+def _opts(wl, fi, mode, fast, **kw):
+    from rayoptics_amd.engine import make_opts
+    return make_opts(flags=_flags(wl, fi) | (abi.FAST_FP64 if fast else 0), out_mode=mode, first_surf=1,
+                     last_surf=wl.n_ifcs - 2, foc=wl.foc, image_pt=wl.image_pts[fi], **kw)
+
+
+def check_flips(tbl, wi, opts, ref, got, full_of, what):
+    """ref / got: exact and tolerance-mode results of the same rays.  Returns (n_flips, worst
+    scaled error of the rays both paths treat alike).  full_of(r) -> the oracle's FULL packet
+    [n_seg, 10] of ray r."""
+    flip = (ref.status != got.status) | (ref.fail_surf != got.fail_surf)
+    same = ~flip
+    ok = same & (ref.status == abi.OK)
+    err = 0.0
+    if ok.any():
+        err = max(err, H.scaled_err(ref.seg[..., ok], got.seg[..., ok]))
+    if same.any():
+        err = max(err, H.scaled_err(ref.op[same], got.op[same]))
+    assert err <= TOL, f'{what}: scaled error {err:.3e} > {TOL}'
+    for r in np.flatnonzero(flip):
+        # decided differently: at the first interface either path stopped at
+        surfs = [int(s) for s in (ref.fail_surf[r], got.fail_surf[r]) if s >= 0]
+        assert surfs, (what, r)
+        k = min(surfs)
+        m = H.boundary_margin(tbl, wi, opts, full_of(int(r)), k)
+        assert m and min(m.values()) <= TOL, f'{what}: ray {r} flipped at interface {k}, margins {m}'
+    return int(flip.sum()), err
+
+
+def _full_packet_fn(wl, fi, wi, grid_def, opts):
+    """oracle FULL packet of ray r of a product grid (traces the one pupil row that holds it)"""
+    from oracle import oracle
+    start, stop, num = grid_def
+
+    def full_of(r):
+        g = oracle.make_grid(start, stop, num, row_begin=r // num, row_count=1)
+        o = oracle.make_opts(flags=opts.flags & ~abi.FAST_FP64, out_mode=abi.OUT_FULL,
+                             first_surf=opts.first_surf, last_surf=opts.last_surf, eps=opts.eps, fuzz=opts.fuzz)
+        res = oracle.trace_pupil_grid(wl.table, wl.fields[fi], g, wi, o)
+        return res.seg[:, :, r % num]
+    return full_of
+
+
+@pytest.mark.parametrize('name', WORKLOADS)
+def test_fast_modes_against_the_oracle(name):
+    """64 x 64 grids of every field (first and last wavelength): HITS, LAST and packed hits in
+    tolerance mode against oracle/rox_oracle.c"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_grid
+    wl = workloads.load(name)
+    eng = TraceEngine(wl.table)
+    num = 64
+    gdef = ((-1., -1.), (1., 1.), num)
+    grid = make_grid(*gdef)
+    W = len(wl.table.wvls)
+    worst, flips, n_ok = 0.0, 0, 0
+    for fi in range(len(wl.fields)):
+        for wi in sorted({0, W - 1}):
+            for mode in (abi.OUT_HITS, abi.OUT_LAST):
+                o = _opts(wl, fi, mode, True)
+                orc = oracle.trace_pupil_grid(wl.table, wl.fields[fi], grid, wi, o)
+                dev = eng.trace_pupil_grid(wl.fields[fi], grid, wi, o, nan_fill=True).to_host()
+                f, e = check_flips(wl.table, wi, o, orc, dev, _full_packet_fn(wl, fi, wi, gdef, o),
+                                   f'{name} f{fi} w{wi} mode {mode}')
+                flips += f
+                worst = max(worst, e)
+                n_ok += int((orc.status == abi.OK).sum())
+            oc = _opts(wl, fi, abi.OUT_HITS_COMPACT, True)
+            xy = eng.trace_pupil_grid_hits(wl.fields[fi], grid, wi, oc)
+            orc_c = oracle.trace_pupil_grid(wl.table, wl.fields[fi], grid, wi, oc)
+            if f == 0:
+                assert xy.shape == orc_c.hits.shape
+                assert H.scaled_err(orc_c.hits, xy) <= TOL
+    eng.close()
+    assert n_ok > 500
+    print(f'[fast] {name}: worst scaled error {worst:.2e}, {flips} status flips')
+
+
+FULL_SIZE = [('dblgauss_c2', 1024, [0, 1, 2]), ('zmx_evenasph_c3', 512, [0, 1, 2]), ('nikkor_c3', 512, [0, 2]),
+             ('rc_telescope_c4', 256, [0, 2, 4]), ('litho_c5', 512, [0, 4, 8]), ('cell_phone', 512, [0, 2])]
+
+
+@pytest.mark.parametrize('name,num,fields', FULL_SIZE)
+def test_fast_hits_at_baseline_sizes_against_the_exact_device_path(name, num, fields):
+    """the BASELINE configurations' own grids: tolerance-mode HITS vs the bit-exact HITS of the same
+    launch (itself equal to the oracle bit for bit: tests/test_gpu_timed_launch.py,
+    test_gpu_configs.py), every ray"""
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_grid
+    wl = workloads.load(name)
+    eng = TraceEngine(wl.table)
+    gdef = ((-1., -1.), (1., 1.), num)
+    grid = make_grid(*gdef)
+    worst, flips, rays = 0.0, 0, 0
+    for fi in fields:
+        wi = wl.ref_wvl_idx
+        ox, of = _opts(wl, fi, abi.OUT_HITS, False), _opts(wl, fi, abi.OUT_HITS, True)
+        ex = eng.trace_pupil_grid(wl.fields[fi], grid, wi, ox, nan_fill=True).to_host()
+        fa = eng.trace_pupil_grid(wl.fields[fi], grid, wi, of, nan_fill=True).to_host()
+        f, e = check_flips(wl.table, wi, of, ex, fa, _full_packet_fn(wl, fi, wi, gdef, of), f'{name} f{fi}')
+        flips += f
+        worst = max(worst, e)
+        rays += num * num
+        assert (ex.status == abi.OK).sum() > num
+    eng.close()
+    print(f'[fast] {name} {num}^2 x {len(fields)} fields: worst scaled error {worst:.2e}, '
+          f'{flips} status flips in {rays} rays')
+    assert flips <= rays // 10000
+
+
+from test_oracle_golden import OPD_CASES, opd_opts  # noqa: E402
+
+
+@pytest.mark.parametrize('name,case', OPD_CASES)
+def test_fast_opd_and_fan(name, case):
+    """ROX_OUT_OPD grids and ROX_OUT_FAN fans in tolerance mode against the oracle: OPD within
+    1e-10 system units of optical path (~2e-7 waves), finite and infinite reference spheres"""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine
+    fx = H.fixture(name)
+    c = fx[case]
+    eng = TraceEngine(fx.table)
+    fld = H.field_from_arr(c['field'])
+    wi = int(c['wvl_idx'])
+    o = opd_opts(c)
+    o.flags |= abi.FAST_FP64
+    grid = oracle.make_grid(c['start'], c['stop'], 96)
+    orc = oracle.trace_pupil_grid(fx.table, fld, grid, wi, o)
+    dev = eng.trace_pupil_grid(fld, grid, wi, o, nan_fill=True).to_host()
+    same = (orc.status == dev.status)
+    assert (~same).sum() <= 2, int((~same).sum())
+    ok = same & (orc.status == abi.OK)
+    assert ok.sum() > 100
+    worst = H.scaled_err(orc.seg[..., ok], dev.seg[..., ok])
+    assert worst <= TOL, worst
+    for xy in (0, 1):
+        start, stop = np.zeros(2), np.zeros(2)
+        start[xy], stop[xy] = -1.0, 1.0
+        g = oracle.make_grid(start, stop, 33, abi.GRID_FAN)
+        of = opd_opts(c)
+        of.out_mode = abi.OUT_FAN
+        of.flags |= abi.APPLY_VIGNETTING | abi.FAST_FP64
+        of.foc, of.image_pt[0], of.image_pt[1] = 0.02, 0.01, -0.03
+        orc = oracle.trace_pupil_grid(fx.table, fld, g, wi, of)
+        dev = eng.trace_pupil_grid(fld, g, wi, of, nan_fill=True).to_host()
+        np.testing.assert_array_equal(dev.status, orc.status)
+        okf = orc.status == abi.OK
+        worst = max(worst, H.scaled_err(orc.seg[..., okf], dev.seg[..., okf]))
+    assert worst <= TOL, worst
+    eng.close()
+    print(f'[fast] OPD/FAN {name}/{case}: worst scaled error {worst:.2e}')
+
+
+def test_full_packets_ignore_the_flag_and_batches_must_agree():
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_grid, EngineError
+    wl = workloads.load('dblgauss_c2')
+    eng = TraceEngine(wl.table)
+    grid = make_grid((-1., -1.), (1., 1.), 96)
+    o = _opts(wl, 1, abi.OUT_FULL, True)
+    dev = eng.trace_pupil_grid(wl.fields[1], grid, 1, o, nan_fill=True).to_host()
+    orc = oracle.trace_pupil_grid(wl.table, wl.fields[1], grid, 1, o)
+    np.testing.assert_array_equal(dev.status, orc.status)
+    H.bit_equal(dev.seg, orc.seg, 'FULL with ROX_FAST_FP64')
+    H.bit_equal(dev.op, orc.op, 'op')
+    with pytest.raises(EngineError, match='ROX_FAST_FP64'):
+        eng.trace_pupil_grids([wl.fields[0], wl.fields[1]], [0, 0], grid,
+                              [_opts(wl, 0, abi.OUT_HITS, True), _opts(wl, 1, abi.OUT_HITS, False)])
+    # a batch in tolerance mode == the single launches in tolerance mode (same kernels' arithmetic)
+    pairs = [(fi, wi) for fi in range(3) for wi in range(len(wl.table.wvls))]
+    ol = [_opts(wl, fi, abi.OUT_HITS, True) for fi, _ in pairs]
+    res = eng.trace_pupil_grids([wl.fields[fi] for fi, _ in pairs], [wi for _, wi in pairs], grid, ol,
+                                nan_fill=True)
+    for (fi, wi), oo, r in zip(pairs, ol, res):
+        one = eng.trace_pupil_grid(wl.fields[fi], grid, wi, oo, nan_fill=True).to_host()
+        b = r.to_host()
+        np.testing.assert_array_equal(one.status, b.status)
+        H.bit_equal(one.seg, b.seg, f'batched fast f{fi} w{wi}')
+    eng.close()
+
+
+def _edge_table(n_glass, max_ap):
+    """object | flat glass-to-air interface 2 mm behind it | image: rays parallel to the axis land
+    where they start (aperture edges), tilted rays meet the critical angle"""
+    from rayoptics_amd import SurfaceTable
+    return SurfaceTable.from_prescription(
+        [dict(cv=0., thi=2., n=n_glass, max_aperture=1e12),
+         dict(cv=0., thi=3., n=1.0, max_aperture=max_ap),
+         dict(cv=0., thi=0., n=1.0, max_aperture=1e12)], wvls=(550.,))
+
+
+def _ulps(x, k):
+    for _ in range(abs(k)):
+        x = np.nextafter(x, np.inf if k > 0 else -np.inf)
+    return x
+
+
+def test_flipped_rays_lie_on_their_boundaries():
+    """rays laid within +-8 ulp of an aperture edge and of the critical angle: tolerance mode may
+    decide them the other way (it forms x^2 + y^2 with one rounding and the TIR radicand from
+    mu = n_in / n_out); every such ray is shown to sit on the boundary it was decided at, the
+    others agree to 1e-10"""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine
+    n_glass, max_ap, fuzz = 1.5, 4.3, 1e-5
+    tbl = _edge_table(n_glass, max_ap)
+    eng = TraceEngine(tbl)
+    pts, dirs = [], []
+    t = max_ap + fuzz
+    for ang in np.linspace(0.0, 2 * np.pi, 181):            # the aperture edge
+        for k in range(-8, 9):
+            pts.append((_ulps(t * np.cos(ang), k), t * np.sin(ang), 0.0))
+            dirs.append((0.0, 0.0, 1.0))
+    sc = 1.0 / n_glass                                       # sin of the critical angle
+    for ang in np.linspace(0.0, 2 * np.pi, 181):            # the TIR limit
+        for k in range(-8, 9):
+            s_ = _ulps(sc, k)
+            dirs.append((s_ * np.cos(ang), s_ * np.sin(ang), np.sqrt(1.0 - s_ * s_)))
+            pts.append((0.1 * np.cos(ang), 0.05, 0.0))
+    pt0, d = np.array(pts).T.copy(), np.array(dirs).T.copy()
+    R = pt0.shape[1]
+    flags = abi.INTERSECT_OBJ | abi.CHECK_APERTURES
+    o_full = oracle.make_opts(flags=flags, out_mode=abi.OUT_FULL, first_surf=1, last_surf=1, fuzz=fuzz)
+    full = oracle.trace_rays(tbl, pt0, d, 0, o_full)
+    total_flips = 0
+    for mode in (abi.OUT_HITS, abi.OUT_LAST):
+        o = oracle.make_opts(flags=flags | abi.FAST_FP64, out_mode=mode, first_surf=1, last_surf=1, fuzz=fuzz)
+        orc = oracle.trace_rays(tbl, pt0, d, 0, o)
+        dev = eng.trace_rays(pt0, d, 0, o, nan_fill=True).to_host()
+        f, e = check_flips(tbl, 0, o, orc, dev, lambda r: full.seg[:, :, r], f'edge rays mode {mode}')
+        total_flips += f
+        assert 0 < int((orc.status == abi.BLOCKED).sum()) < R // 2
+        assert 0 < int((orc.status == abi.TIR).sum()) < R // 2
+    eng.close()
+    print(f'[fast] edge rays: {total_flips} flips of {2 * R}, each on its boundary')

@@ -196,7 +196,7 @@ def test_phase_elements(kind):
     <= 8.4e-14; the north star allows 1e-10), >= 99 % of every array bit-identical."""
     from oracle import oracle
     from rayoptics_amd.engine import TraceEngine
-    n_ok = n_evan = 0
+    n_ok = 0
     for seed in range(6):
         rng = np.random.default_rng(4200 + 10 * seed + len(kind))
         tbl, k_phase = H.phase_table(rng, kind)
@@ -224,11 +224,44 @@ def test_phase_elements(kind):
                 f2 = H.assert_soa_close(orc.op, dev.op, f'{kind} op', atol=1e-12)
                 assert min(f1, f2) > 0.99, (kind, f1, f2)
         n_ok += int((orc.status == abi.OK).sum())
-        n_evan += int((orc.status == abi.EVANESCENT).sum())
         eng.close()
     assert n_ok > 1000
-    if kind in ('grating', 'doe', 'hologram'):
-        assert n_evan >= 0
+
+
+@pytest.mark.parametrize('kind', sorted(H.PHASE_LIMIT_CASES))
+def test_phase_elements_at_their_limits(kind):
+    """ROX_EVANESCENT (DiffractiveElement / HolographicElement: a negative radicand in
+    phase() -> TraceEvanescentRayError, raytrace.py:41-48), ROX_TIR out of the rt.bend inside
+    DiffractiveElement.phase (doe.py:296-297: TraceTIRError is not a ValueError, so it passes
+    through phase()'s handler) and the grating's np.sqrt NaN that is NOT an error (doe.py:150)
+    are REACHED on the device: counts asserted, equal to the oracle's, partial packets
+    included.  (The same constructions against the live reference:
+    tests/test_oracle_phase_reference.py::test_phase_limits_oracle_equals_reference.)"""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine
+    tbl, pt0, d, wi = H.phase_limit_case(kind)
+    eng = TraceEngine(tbl)
+    for mode in (abi.OUT_FULL, abi.OUT_HITS, abi.OUT_LAST):
+        opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES, out_mode=mode,
+                                first_surf=1, last_surf=tbl.n_ifcs - 2, foc=0.01)
+        with np.errstate(all='ignore'):
+            orc = oracle.trace_rays(tbl, pt0, d, wi, opts)
+        dev = eng.trace_rays(pt0, d, wi, opts, nan_fill=True).to_host()
+        np.testing.assert_array_equal(dev.status, orc.status)
+        np.testing.assert_array_equal(dev.fail_surf, orc.fail_surf)
+        if kind == 'hologram_evanescent':
+            bit_equal(dev.seg, orc.seg, f'{kind} seg')
+            bit_equal(dev.op, orc.op, f'{kind} op')
+        else:
+            H.assert_soa_close(orc.seg, dev.seg, f'{kind} seg', atol=1e-12)
+            H.assert_soa_close(orc.op, dev.op, f'{kind} op', atol=1e-12)
+        if mode == abi.OUT_FULL:
+            n_ok, n_limit = H.phase_limit_expect(kind, dev.status, dev.seg)
+            assert n_limit >= 30 and n_ok >= 30, (kind, n_ok, n_limit)
+            assert (n_ok, n_limit) == H.phase_limit_expect(kind, orc.status, orc.seg)
+            if kind != 'grating_nan':       # every failure is at the phase element
+                assert set(np.unique(dev.fail_surf)) == {-1, 1}
+    eng.close()
 
 
 # ---------------------------------------------------------------- ray starts

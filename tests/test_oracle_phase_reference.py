@@ -131,3 +131,73 @@ def test_phase_elements_oracle_equals_reference(kind, seed):
         n_checked += 1
         n_ok += st == abi.OK
     assert n_checked > R // 2 and n_ok > 0
+
+
+def limit_case_paths(kind):
+    """tests/helpers.py phase_limit_case() built from the reference's own classes"""
+    import helpers as H
+    from rayoptics.elem import surface
+    from rayoptics.oprops import doe
+    n_obj = H.PHASE_LIMIT_CASES[kind][0]
+    p = H.phase_limit_params(kind)
+    s0, s1, s2 = (surface.Surface(interact_mode=m) for m in ('dummy', 'transmit', 'dummy'))
+    s0.max_aperture, s1.max_aperture, s2.max_aperture = 1e12, 1e3, 1e12
+    if kind == 'grating_nan':
+        s1.phase_element = doe.DiffractionGrating(order=p['order'], grating_normal=np.array(p['normal']),
+                                                  grating_lpmm=p['lpmm'], interact_mode='transmit')
+    elif kind.startswith('doe'):
+        s1.phase_element = doe.DiffractiveElement(coefficients=list(p['coefs']), ref_wl=p['ref_wl'],
+                                                  order=p['order'], phase_fct=doe.radial_phase_fct)
+    else:
+        s1.phase_element = doe.HolographicElement(ref_pt=np.array(p['ref_pt']), ref_virtual=False,
+                                                  obj_pt=np.array(p['obj_pt']), obj_virtual=False,
+                                                  ref_wl=p['ref_wl'])
+    return [[[s0, None, (np.identity(3), np.array([0., 0., 5.])), n_obj[w], 1],
+             [s1, None, (np.identity(3), np.array([0., 0., 5.])), 1.0, 1],
+             [s2, None, (np.identity(3), np.array([0., 0., 0.])), 1.0, 1]]
+            for w in range(len(H.PHASE_LIMIT_WVLS))]
+
+
+@pytest.mark.parametrize('kind', ['grating_nan', 'doe_tir', 'doe_evanescent', 'hologram_evanescent'])
+def test_phase_limits_oracle_equals_reference(kind):
+    """the constructions of tests/test_gpu_r02.py::test_phase_elements_at_their_limits against the
+    live reference: TraceEvanescentRayError, the TraceTIRError out of DiffractiveElement.phase's
+    rt.bend, and the grating's NaN-without-an-error are reached (counted) and the oracle's
+    status, failing surface, partial packet and op equal the reference's bit for bit"""
+    import warnings
+    import helpers as H
+    from oracle import oracle, refshim
+    refshim.install()
+    from rayoptics.raytr.raytrace import trace_raw
+    from rayoptics.raytr import traceerror as terr
+    from rayoptics_amd import SurfaceTable, abi
+    tbl, pt0, d, wi = H.phase_limit_case(kind)
+    paths = limit_case_paths(kind)
+    tbl_ref = SurfaceTable.from_paths(paths, list(H.PHASE_LIMIT_WVLS))
+    assert bytes(tbl_ref.rows) == bytes(tbl.rows) and np.array_equal(tbl_ref.n_table, tbl.n_table)
+    N = tbl.n_ifcs
+    opts = oracle.make_opts(flags=abi.INTERSECT_OBJ | abi.CHECK_APERTURES, first_surf=1, last_surf=N - 2)
+    with np.errstate(all='ignore'):
+        res = oracle.trace_rays(tbl, pt0, d, wi, opts)
+    n_ok, n_limit = H.phase_limit_expect(kind, res.status, res.seg)
+    assert n_ok >= 30 and n_limit >= 30, (kind, n_ok, n_limit)
+    kinds = {terr.TraceMissedSurfaceError: abi.MISSED_SURFACE, terr.TraceTIRError: abi.TIR,
+             terr.TraceRayBlockedError: abi.BLOCKED, terr.TraceEvanescentRayError: abi.EVANESCENT}
+    kw = dict(first_surf=1, last_surf=N - 2, check_apertures=True)
+    seen = set()
+    for r in range(0, pt0.shape[1], 4):
+        try:
+            with np.errstate(all='ignore'), warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                ray, op, _ = trace_raw(iter(paths[wi[r]]), pt0[:, r].copy(), d[:, r].copy(),
+                                       H.PHASE_LIMIT_WVLS[wi[r]], **kw)
+            st, surf = abi.OK, -1
+        except terr.TraceError as e:
+            st, surf = kinds[type(e)], e.surf
+            ray, op, _ = e.ray_pkg
+        assert res.status[r] == st and res.fail_surf[r] == surf, (kind, r, st, surf, res.status[r])
+        ref = np.array([np.concatenate([s[0], s[1], [s[2]], s[3]]) for s in ray]).reshape(-1, 10)
+        assert np.array_equal(ref, res.seg[:len(ray), :, r], equal_nan=True), (kind, r)
+        assert op == res.op[r] or (np.isnan(op) and np.isnan(res.op[r])), (kind, r, op, res.op[r])
+        seen.add(st)
+    assert len(seen) == (1 if kind == 'grating_nan' else 2), seen

@@ -118,8 +118,12 @@ def main():
     ap.add_argument('--mode', type=int, default=2, help='ROX_OUT_* of the kernel (2 = HITS, 0 = FULL)')
     ap.add_argument('--feat', type=int, default=0, help='FEAT template value of the instance (lean 0, even 1, radial 2)')
     ap.add_argument('--workload', default=None, help='PMC record to quote beside the static count')
+    ap.add_argument('--fast', action='store_true',
+                    help='the tolerance-mode twin (csrc/fast_<name>.hip, FEAT | 64)')
     args = ap.parse_args()
-    src = os.path.join(ROOT, 'ray-optics_amd', 'csrc', f'inst_{args.inst}.hip')
+    if args.fast:
+        args.feat |= 64
+    src = os.path.join(ROOT, 'ray-optics_amd', 'csrc', f"{'fast' if args.fast else 'inst'}_{args.inst}.hip")
     with tempfile.TemporaryDirectory() as td:
         subprocess.check_call(['hipcc'] + FLAGS + ['-I', os.path.join(ROOT, 'include'), '-S', '--cuda-device-only',
                                                    src, '-o', os.path.join(td, 'k.s')])
