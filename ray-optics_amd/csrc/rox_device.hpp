@@ -1600,29 +1600,44 @@ __device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, cons
     tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
     tblp muw = PER_RAY_WVL ? c.mu + (size_t)wi * 2 * N : c.mu;      // [N] mu, [N] mu^2
 
+    // The object surface and the transfer to interface 1 keep the REFERENCE's arithmetic
+    // (trace_ray()'s operations in its order, correctly rounded): an object at infinity sits
+    // 1e10 system units away (rayoptics' convention), so `before_pt - t`, `-dot(b4_pt, b4_dir)`
+    // and `b4_pt + pp_dst * b4_dir` cancel numbers of that size down to the lens' own, and what
+    // is left carries ~1e-6 of rounding that depends on the operation order.  That noise is part
+    // of the reference's answer; any other order lands 1e-7 away from it.  Once per ray.
     int status = live ? ROX_OK : 255, fail_surf = -1;
     v3 bp = pt0, bd = dir0;
-    if (live && c.intersect_obj) {              // raytrace.py:145-158 (the normal is not needed)
+    v3 pp1{0, 0, 0}, b4d1 = dir0;
+    double pp_dst1 = 0.0;
+    if (live) {
         tblp row = tbl;
-        const int prof = ((tbli)row)[1];
-        double s_;
-        v3 df;
-        bool ok;
-        if ((FEAT & F_PHASE) && prof == ROX_THINLENS) {
-            s_ = -pt0.z * rcp_f(dir0.z);
-            bp = v3{fma(s_, dir0.x, pt0.x), fma(s_, dir0.y, pt0.y), fma(s_, dir0.z, pt0.z)};
-            ok = true;
-        } else if (!kPoly || prof <= ROX_CONIC) {
-            ok = quadric_hit_f(prof == ROX_CONIC, row[O_CV], row[O_CC], row[O_EC], pt0, dir0,
-                               row[O_ZDIR], s_, bp);
-        } else {
-            ok = newton_hit_f<FEAT>(prof, row[O_CV], row[O_CC] + 1.0, row[O_EC], row[O_CR],
-                                    ((tbli)row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
+        if (c.intersect_obj) {                  // raytrace.py:145-158 (the normal is not needed)
+            const int prof = ((tbli)row)[1];
+            double s_;
+            v3 df;
+            bool ok;
+            if ((FEAT & F_PHASE) && prof == ROX_THINLENS) {
+                s_ = -pt0.z / dir0.z;
+                bp = v3{pt0.x + s_ * dir0.x, pt0.y + s_ * dir0.y, pt0.z + s_ * dir0.z};
+                ok = true;
+            } else if (!kPoly || prof <= ROX_CONIC) {
+                ok = quadric_hit(prof == ROX_CONIC, row[O_CV], row[O_CC], row[O_EC], pt0, dir0,
+                                 row[O_ZDIR], s_, bp);
+            } else {
+                ok = newton_hit<FEAT & ~F_FAST>(prof, row[O_CV], row[O_CC] + 1.0, row[O_EC], row[O_CR],
+                                                ((tbli)row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
+            }
+            if (!ok) {
+                status = ROX_MISSED_SURFACE;
+                fail_surf = 0;
+            }
         }
-        if (!ok) {
-            status = ROX_MISSED_SURFACE;
-            fail_surf = 0;
-        }
+        const v3 dp{bp.x - row[O_T], bp.y - row[O_T + 1], bp.z - row[O_T + 2]};
+        const v3 b4p = rotate(row + O_RT, ((tbli)row)[4], dp);
+        b4d1 = rotate(row + O_RT, ((tbli)row)[4], bd);
+        pp_dst1 = -dot3(b4p, b4d1);
+        pp1 = v3{b4p.x + pp_dst1 * b4d1.x, b4p.y + pp_dst1 * b4d1.y, b4p.z + pp_dst1 * b4d1.z};
     }
     double z_dir_before = tbl[O_ZDIR];
     double opl = 0.0, phs = 0.0;
@@ -1637,14 +1652,19 @@ __device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, cons
         const bool thin = (FEAT & F_PHASE) && prof == ROX_THINLENS;
 
         // :170-174 transform to the new vertex frame, closest approach to its origin
-        const v3 dp{bp.x - prow[O_T], bp.y - prow[O_T + 1], bp.z - prow[O_T + 2]};
-        v3 b4p = dp, b4d = bd;
-        if ((((tbli)prow)[5] & 2) == 0) {       // (identity rotations are flagged on the device row)
-            b4p = rotate_f(prow + O_RT, dp);
-            b4d = rotate_f(prow + O_RT, bd);
+        v3 pp = pp1, b4d = b4d1;
+        double pp_dst = pp_dst1;
+        if (surf > 1) {
+            const v3 dp{bp.x - prow[O_T], bp.y - prow[O_T + 1], bp.z - prow[O_T + 2]};
+            v3 b4p = dp;
+            b4d = bd;
+            if ((((tbli)prow)[5] & 2) == 0) {   // (identity rotations are flagged on the device row)
+                b4p = rotate_f(prow + O_RT, dp);
+                b4d = rotate_f(prow + O_RT, bd);
+            }
+            pp_dst = -dot3_f(b4p, b4d);
+            pp = v3{fma(pp_dst, b4d.x, b4p.x), fma(pp_dst, b4d.y, b4p.y), fma(pp_dst, b4d.z, b4p.z)};
         }
-        const double pp_dst = -dot3_f(b4p, b4d);
-        const v3 pp{fma(pp_dst, b4d.x, b4p.x), fma(pp_dst, b4d.y, b4p.y), fma(pp_dst, b4d.z, b4p.z)};
 
         // :181-183 intersect
         double s;

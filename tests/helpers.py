@@ -218,6 +218,17 @@ def phase_limit_expect(kind, status, seg):
     return n_ok, int((status == want).sum())
 
 
+def record(kind, **kw):
+    """append a measurement a test made to the file ROX_TEST_RECORDS names (tools/gpu_run.sh sets
+    it to gpurun_out/<tag>/test_records.jsonl): deviations and flip counts worth keeping beside
+    a green run (profiles/)"""
+    path = os.environ.get('ROX_TEST_RECORDS')
+    if not path:
+        return
+    with open(path, 'a') as f:
+        f.write(json.dumps(dict(kind=kind, **kw)) + '\n')
+
+
 # ---- tolerance mode (ROX_FAST_FP64): comparison and status-flip accounting -------------------
 def scaled_err(ref, got):
     """max |ref - got| / max(1, |ref|) over the entries finite in both; NaN patterns must agree"""

@@ -39,12 +39,17 @@ def _opts(wl, fi, mode, fast, **kw):
                      last_surf=wl.n_ifcs - 2, foc=wl.foc, image_pt=wl.image_pts[fi], **kw)
 
 
-def check_flips(tbl, wi, opts, ref, got, full_of, what):
+def check_flips(tbl, wi, opts, ref, got, full_of, what, on_boundary=None):
     """ref / got: exact and tolerance-mode results of the same rays.  Returns (n_flips, worst
     scaled error of the rays both paths treat alike).  full_of(r) -> the oracle's FULL packet
-    [n_seg, 10] of ray r."""
+    [n_seg, 10] of ray r.  on_boundary: rays known to sit within 1e-10 of a decision boundary
+    although both paths decide them alike (a ray AT the critical angle leaves along the
+    surface: its image intercept is ~1e8 and moves by 1e7 per ulp of the radicand) -- their
+    status is compared, their values are not."""
     flip = (ref.status != got.status) | (ref.fail_surf != got.fail_surf)
     same = ~flip
+    if on_boundary is not None:
+        same &= ~on_boundary
     ok = same & (ref.status == abi.OK)
     err = 0.0
     if ok.any():
@@ -109,7 +114,7 @@ def test_fast_modes_against_the_oracle(name):
                 assert H.scaled_err(orc_c.hits, xy) <= TOL
     eng.close()
     assert n_ok > 500
-    print(f'[fast] {name}: worst scaled error {worst:.2e}, {flips} status flips')
+    H.record('fast_vs_oracle', workload=name, grid=num, worst_scaled_error=worst, status_flips=flips, rays_through=n_ok)
 
 
 FULL_SIZE = [('dblgauss_c2', 1024, [0, 1, 2]), ('zmx_evenasph_c3', 512, [0, 1, 2]), ('nikkor_c3', 512, [0, 2]),
@@ -139,8 +144,8 @@ def test_fast_hits_at_baseline_sizes_against_the_exact_device_path(name, num, fi
         rays += num * num
         assert (ex.status == abi.OK).sum() > num
     eng.close()
-    print(f'[fast] {name} {num}^2 x {len(fields)} fields: worst scaled error {worst:.2e}, '
-          f'{flips} status flips in {rays} rays')
+    H.record('fast_vs_exact_device', workload=name, grid=num, fields=len(fields), rays=rays,
+             worst_scaled_error=worst, status_flips=flips)
     assert flips <= rays // 10000
 
 
@@ -184,7 +189,7 @@ def test_fast_opd_and_fan(name, case):
         worst = max(worst, H.scaled_err(orc.seg[..., okf], dev.seg[..., okf]))
     assert worst <= TOL, worst
     eng.close()
-    print(f'[fast] OPD/FAN {name}/{case}: worst scaled error {worst:.2e}')
+    H.record('fast_opd_fan_vs_oracle', fixture=name, case=case, worst_scaled_error=worst)
 
 
 def test_full_packets_ignore_the_flag_and_batches_must_agree():
@@ -259,14 +264,21 @@ def test_flipped_rays_lie_on_their_boundaries():
     flags = abi.INTERSECT_OBJ | abi.CHECK_APERTURES
     o_full = oracle.make_opts(flags=flags, out_mode=abi.OUT_FULL, first_surf=1, last_surf=1, fuzz=fuzz)
     full = oracle.trace_rays(tbl, pt0, d, 0, o_full)
+    # the rays of the second group graze the TIR limit by construction (margin ~1e-15): shown here
+    near = np.zeros(R, dtype=bool)
+    for r in range(R // 2, R):
+        m = H.boundary_margin(tbl, 0, o_full, full.seg[:, :, r], 1)
+        near[r] = m.get('tir', 1.0) <= TOL
+    assert near[R // 2:].all() and not near[:R // 2].any()
     total_flips = 0
     for mode in (abi.OUT_HITS, abi.OUT_LAST):
         o = oracle.make_opts(flags=flags | abi.FAST_FP64, out_mode=mode, first_surf=1, last_surf=1, fuzz=fuzz)
         orc = oracle.trace_rays(tbl, pt0, d, 0, o)
         dev = eng.trace_rays(pt0, d, 0, o, nan_fill=True).to_host()
-        f, e = check_flips(tbl, 0, o, orc, dev, lambda r: full.seg[:, :, r], f'edge rays mode {mode}')
+        f, e = check_flips(tbl, 0, o, orc, dev, lambda r: full.seg[:, :, r], f'edge rays mode {mode}',
+                           on_boundary=near)
         total_flips += f
         assert 0 < int((orc.status == abi.BLOCKED).sum()) < R // 2
         assert 0 < int((orc.status == abi.TIR).sum()) < R // 2
     eng.close()
-    print(f'[fast] edge rays: {total_flips} flips of {2 * R}, each on its boundary')
+    H.record('fast_edge_rays', rays=2 * R, status_flips=total_flips, every_flip_on_its_boundary=True)

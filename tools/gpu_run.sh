@@ -22,6 +22,7 @@ cd "${GRAFT_REPO_ROOT:-$PWD}"
 TAG=$1; shift
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
+export ROX_TEST_RECORDS="$PWD/$OUT/test_records.jsonl"
 for step in "$@"; do
   kind=${step%%:*}
   rest=""; [ "$step" != "$kind" ] && rest=${step#*:}
