@@ -789,11 +789,12 @@ __device__ __forceinline__ double rcp_f(double b)
 }
 
 // s = sqrt(x), h = 0.5 / sqrt(x) by the coupled iteration on (x y, y / 2), y = v_rsq_f64(x).
-// The seed is taken of max(x, 2^-1000): x = 0 gives s = 0 (a finite y times 0) instead of the
-// NaN of 0 * inf -- an on-axis ray has r^2 = 0 exactly -- and NaN stays NaN (x * y).
+// The seed is taken of x + 2^-1000 (= x for every x >= 2^-947): x = 0 gives s = 0 (a finite y
+// times 0) instead of the NaN of 0 * inf -- an on-axis ray has r^2 = 0 exactly -- and NaN stays
+// NaN.  (One v_add; fmax() costs two v_max in IEEE mode, the first to quiet a signalling NaN.)
 __device__ __forceinline__ void sqrt_half_rsqrt_f(double x, double &s, double &h)
 {
-    const double y = __builtin_amdgcn_rsq(fmax(x, 0x1p-1000));
+    const double y = __builtin_amdgcn_rsq(x + 0x1p-1000);
     s = x * y;
     h = 0.5 * y;
     const double e = fma(-h, s, 0.5);
@@ -808,7 +809,7 @@ __device__ __forceinline__ void sqrt_half_rsqrt_f(double x, double &s, double &h
 
 __device__ __forceinline__ double sqrt_f(double x)
 {
-    const double y = __builtin_amdgcn_rsq(fmax(x, 0x1p-1000));
+    const double y = __builtin_amdgcn_rsq(x + 0x1p-1000);
     double s = x * y;
     const double h = 0.5 * y;
     s = fma(s, fma(-h, s, 0.5), s);
@@ -1955,11 +1956,13 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     int32_t *slot_w = reinterpret_cast<int32_t *>(apthr_w + N);
     // F_FAST: mu = n_in / n_out and mu^2 per (wavelength row, interface), behind the slot map
     constexpr bool kFast = (FEAT & F_FAST) != 0;
-    double *mu_w = reinterpret_cast<double *>(
-        (reinterpret_cast<uintptr_t>(slot_w + 2 * N) + 7) & ~uintptr_t(7));
-    // HITS_COMPACT: two tiles' worth of packed (x, y) pairs behind them
-    d2 *stash_w = reinterpret_cast<d2 *>(
-        (reinterpret_cast<uintptr_t>(mu_w + (kFast ? (size_t)nw_rows * 2 * N : 0)) + 15) & ~uintptr_t(15));
+    // (2 N int32 = 8 N bytes behind an 8-byte aligned start: aligned as it stands -- a pointer
+    // rounded through an integer loses its LDS address space and is read with flat loads)
+    double *mu_w = reinterpret_cast<double *>(slot_w + 2 * N);
+    // HITS_COMPACT: two tiles' worth of packed (x, y) pairs behind them, 16-byte aligned: the
+    // offset is rounded in doubles (lds is 16-byte aligned, every region before is whole doubles)
+    double *end_w = mu_w + (kFast ? (size_t)nw_rows * 2 * N : 0);
+    d2 *stash_w = reinterpret_cast<d2 *>(lds + (((size_t)(end_w - lds) + 1) & ~size_t(1)));
 
     // stage the surface table once per workgroup
     for (int i = threadIdx.x; i < N * kRowDoubles; i += kB)

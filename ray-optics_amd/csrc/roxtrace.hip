@@ -326,7 +326,7 @@ size_t lds_bytes(const rox_system *s, bool per_ray_wvl, bool phase, bool fast)
                (phase ? Wn * N * kPhaseConsts * sizeof(double) : 0) +
                ((size_t)s->n_wvls + N) * sizeof(double) + 2 * N * sizeof(int32_t);
     if (fast)       // mu and mu^2 per (wavelength row, interface) behind the slot map
-        b = ((b + 7) & ~size_t(7)) + Wn * 2 * N * sizeof(double);
+        b += Wn * 2 * N * sizeof(double);
     return (b + 15) & ~size_t(15);
 }
 

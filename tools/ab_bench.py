@@ -59,8 +59,9 @@ def main():
                 m = ~(np.isnan(dev.seg) & np.isnan(orc.seg))
                 res[f'maxdiff_mode{mode}'] = float(np.nanmax(np.abs(dev.seg[m] - orc.seg[m])))
     outs = {}
-    for name, mode in (('full', abi.OUT_FULL), ('hits', abi.OUT_HITS)):
-        o = make_opts(flags=flags, out_mode=mode, first_surf=1, last_surf=N - 2,
+    for name, mode in (('full', abi.OUT_FULL), ('hits', abi.OUT_HITS), ('hits_fast', abi.OUT_HITS)):
+        o = make_opts(flags=flags | (abi.FAST_FP64 if name == 'hits_fast' else 0), out_mode=mode,
+                      first_surf=1, last_surf=N - 2,
                       foc=wl.foc, image_pt=wl.image_pts[args.field])
         out = DeviceResult(torch, eng.device, eng.num_segments(flags), R, mode,
                            want_pupil=(mode == abi.OUT_FULL), nan_fill=False,

@@ -48,6 +48,13 @@ def main(tag, dirs):
                'source': f'{d} ({tag}): SQ_INSTS_VALU of trace_kernel<HITS> / intersections of one launch'}
         out[ab['workload']] = rec
         print(ab['workload'], rec)
+        if 'HITS_FAST' in pm:       # the tolerance-mode twin (ROX_FAST_FP64), bench.py's roofline_hits_fast
+            fr = {'valu_wave_insts_per_intersection': pm['HITS_FAST']['SQ_INSTS_VALU'] / ab['intersections'],
+                  'salu_wave_insts_per_intersection': pm['HITS_FAST']['SQ_INSTS_SALU'] / ab['intersections'],
+                  'grid': rec['grid'], 'intersections': ab['intersections'], 'library_source_hash': lib,
+                  'source': f'{d} ({tag}): SQ_INSTS_VALU of trace_kernel<HITS, F_FAST> / intersections of one launch'}
+            out[ab['workload'] + '_fast'] = fr
+            print(ab['workload'] + '_fast', fr)
     with open(out_path, 'w') as f:
         json.dump(out, f, indent=1)
 

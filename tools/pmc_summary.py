@@ -5,6 +5,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -18,6 +19,10 @@ def main(d):
                 if 'trace_kernel' not in k:
                     continue
                 short = 'FULL' if 'trace_kernel<0' in k else ('HITS' if 'trace_kernel<2' in k else k[:40])
+                # trace_kernel<mode, gen, per-ray-wvl, FEAT, small>: FEAT & 64 = the tolerance-mode twin
+                m = re.search(r'trace_kernel<\d+, \d+, \w+, (\d+)', k)
+                if m and int(m.group(1)) & 64:
+                    short += '_FAST'
                 acc[short][row['Counter_Name']].append(float(row['Counter_Value']))
     out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
     for k, cs in acc.items():
