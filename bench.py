@@ -66,6 +66,7 @@ import json
 import os
 import socket
 import sys
+import tempfile
 import threading
 import time
 
@@ -95,7 +96,12 @@ def parse():
     ap.add_argument('--no-strong', action='store_true', help='skip the strong-scaling leg')
     ap.add_argument('--strong-timeout', type=float, default=300.0,
                     help='multi-rank runs: seconds after which the strong-scaling leg is given up')
+    ap.add_argument('--preflight-timeout', type=float, default=20.0,
+                    help='N > 1: seconds each collective of the exchange pre-flight may take')
     ap.add_argument('--no-configs', action='store_true', help='skip the per-config leg')
+    ap.add_argument('--ref-fan-seconds', type=float, default=20.0,
+                    help='cpu_baseline: seconds of reference tracing per process of the all-core leg')
+    ap.add_argument('--ref-worker', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--strong-num', type=int, default=2048,
                     help='pupil grid of the strong-scaling leg is num x num per (field, wvl)')
     return ap.parse_args()
@@ -124,6 +130,8 @@ def self_launch(args):
 def main():
     global SPOT_FLAGS
     args = parse()
+    if args.ref_worker:                 # a process of cpu_reference_fanned(): no torch, no GPU
+        return ref_worker(args.ref_worker)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
     # the BASELINE configurations are timed as a call whose fields or outputs changed: the library's
@@ -154,6 +162,11 @@ def main():
     if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
+        # what RCCL has to say about a failure goes to a file per rank (NCCL_DEBUG_FILE: %h host,
+        # %p pid); a failing leg's record carries its tail (nccl_debug_tail())
+        os.environ.setdefault('NCCL_DEBUG', 'WARN')
+        os.environ.setdefault('NCCL_DEBUG_FILE', os.path.join(
+            tempfile.gettempdir(), f"rox_nccl_{os.environ['MASTER_PORT']}_%h_%p.log"))
         # RCCL prints a version banner on stdout when its communicator is built; stdout
         # carries exactly one JSON line, so fd 1 points at stderr until that is over
         sys.stdout.flush()
@@ -202,6 +215,22 @@ def main():
         ones = torch.ones(1, device=eng.device)
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
+
+    # N > 1: the exchange's call pattern once, tiny, under a short watchdog, BEFORE anything is
+    # timed: if grouped isend / irecv or an all-gather on the side stream cannot complete on this
+    # node, the line says which one within seconds instead of a timed leg dying in its timeout
+    preflight = None
+    if multi:
+        preflight = exchange_preflight(torch, dist, world, rank, eng.device, args.preflight_timeout)
+        if not preflight.get('ok'):
+            if rank == 0:
+                print(json.dumps({'metric': 'ray-surface intersections/sec', 'value': None, 'ok': False,
+                                  'n_gpus': world, 'hung_in': 'preflight: ' + str(preflight.get('hung_in')),
+                                  'preflight': preflight, 'errors': {'nccl_debug': nccl_debug_tail()}}),
+                      file=os.fdopen(saved_stdout, 'w'), flush=True)
+            else:
+                time.sleep(2.0)
+            os._exit(3)
 
     # cold: the K launches as a caller meets them after an idle second (one launch first, so
     # that module load and allocation are not in it)
@@ -352,6 +381,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'ranks_seen_by_backend': ranks_seen,
+            'preflight': preflight,
             'config': {'workload': 'double-Gauss 13 interfaces (K=12), 1 field, 1 wvl, '
                                    f'{num}x{num} pupil grid per GPU, FULL ray packets, '
                                    'device-generated rays (BASELINE.json configs[1])',
@@ -419,6 +449,7 @@ def main():
         if rank == 0:
             line['ok'] = False
             line['hung_in'] = hung_in[0]
+            line.setdefault('errors', {})['nccl_debug'] = nccl_debug_tail()
             if not line.get('strong_scaling'):
                 line['strong_scaling'] = {'error': f'timed out after {args.strong_timeout} s in '
                                                    f'{hung_in[0]}: a rank hung in an exchange'}
@@ -439,7 +470,7 @@ def main():
         except Exception as e:
             import traceback
             traceback.print_exc(file=sys.stderr)
-            return {'error': repr(e)}
+            return {'error': repr(e), 'nccl_debug': nccl_debug_tail() if multi else None}
         finally:
             if dog:
                 dog.cancel()
@@ -485,6 +516,11 @@ def main():
                     + ('' if not head.get('one_gpu_error') else ' -- FAILED: ' + head['one_gpu_error']))
                 if head.get('configs3_by_field'):
                     line['configs3_by_field'] = head['configs3_by_field']
+                if head.get('configs3_by_rows'):
+                    line['configs3_by_rows'] = head['configs3_by_rows']
+                # north_star's own words -- "an RCCL gather over xGMI of the image-plane hits" -- are the
+                # rccl_device figure: the gather alone, result left in rank 0's HBM
+                line['rccl_gather_only_ms'] = head['ms_per_step_by_exchange'].get('rccl_device')
                 line['strong_headline'] = {k: head[k] for k in ('exchange', 'ms_per_step_by_exchange', 'errors',
                                                                   'last_pass_phases_ms_rank0', 'grids_delivered')}
 
@@ -914,6 +950,139 @@ class SpotProblem:
         self.torch.cuda.empty_cache()
 
 
+def nccl_debug_tail(max_bytes=4000):
+    """the tail of every NCCL_DEBUG_FILE this run's ranks wrote on this host (WARN level)"""
+    import glob
+    pat = os.environ.get('NCCL_DEBUG_FILE')
+    if not pat:
+        return None
+    out = {}
+    for path in sorted(glob.glob(pat.replace('%h', '*').replace('%p', '*'))):
+        try:
+            with open(path, 'rb') as f:
+                f.seek(0, os.SEEK_END)
+                n = f.tell()
+                f.seek(max(0, n - max_bytes))
+                txt = f.read().decode(errors='replace').strip()
+            if txt:
+                out[os.path.basename(path)] = txt
+        except OSError:
+            pass
+    return out or None
+
+
+def exchange_preflight(torch, dist, world, rank, device, timeout_s, skip=()):
+    """The collectives the sharded spot exchange is made of (dist.trace_spot_sharded), once and
+    tiny, each under its own watchdog: (1) an all-gather of one count word issued on a SIDE
+    stream that waits for an event of the launch stream, copied to pinned memory behind it;
+    (2) grouped isend / irecv of a row slice from every rank to rank 0 on that stream
+    (batch_isend_irecv: 7 peers -> 7 xGMI links at N = 8); (3) an all-reduce (the fence).
+    Returns {'ok', 'steps_ms': {...}} or {'ok': False, 'hung_in': step} -- a step that does not
+    return within `timeout_s` ends the run (exit status 3) with that record in the line.
+    device=None runs the same calls without streams (CPU, gloo: tests/test_dist_gloo.py, where
+    `skip` lets one rank stay away from a step to show what a hang looks like)."""
+    import contextlib
+    cuda = device is not None
+    done = {}
+    state = {'step': None}
+    failed = threading.Event()
+
+    def watchdog():
+        t_end = time.time() + timeout_s
+        while time.time() < t_end:
+            if state['step'] is None:
+                return
+            time.sleep(0.05)
+        failed.set()
+
+    def run(name, fn):
+        state['step'] = name
+        dog = threading.Thread(target=watchdog, daemon=True)
+        dog.start()
+        box = {}
+
+        def body():
+            try:
+                t0 = time.perf_counter()
+                if name not in skip:
+                    fn()
+                if cuda:
+                    torch.cuda.synchronize()
+                box['ms'] = (time.perf_counter() - t0) * 1e3
+            except Exception as e:      # noqa: BLE001
+                box['error'] = repr(e)
+        th = threading.Thread(target=body, daemon=True)
+        th.start()
+        while th.is_alive() and not failed.is_set():
+            th.join(0.05)
+        state['step'] = None
+        if failed.is_set() and th.is_alive():
+            return False
+        if 'error' in box:
+            done[name] = {'error': box['error']}
+            return False
+        done[name] = round(box['ms'], 3)
+        return True
+
+    side = None
+    if cuda:
+        torch.cuda.set_device(device)
+        side = torch.cuda.Stream(device=device)
+    on_side = (lambda: torch.cuda.stream(side)) if cuda else contextlib.nullcontext
+    # (gloo -- CPU tests, the one-GPU rehearsal -- carries host tensors, as dist._wire has it)
+    wire = device if (cuda and dist.get_backend() == 'nccl') else 'cpu'
+    word = torch.full((1,), float(rank + 1), dtype=torch.float64, device=wire)
+    words = torch.zeros(world, dtype=torch.float64, device=wire)
+    pinned = torch.zeros(world, dtype=torch.float64)
+    if cuda:
+        pinned = pinned.pin_memory()
+    rows = torch.full((2, 256), float(rank), dtype=torch.float64, device=wire)
+    inbox = torch.zeros(world, 2, 256, dtype=torch.float64, device=wire) if rank == 0 else None
+
+    def all_gather_on_side_stream():
+        if cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            side.wait_event(ev)
+        with on_side():
+            dist.all_gather_into_tensor(words, word)
+            pinned.copy_(words, non_blocking=True)
+        if cuda:
+            side.synchronize()
+        if [float(x) for x in pinned.tolist()] != [float(r + 1) for r in range(world)]:
+            raise RuntimeError(f'all-gather returned {pinned.tolist()}')
+
+    def grouped_p2p_to_rank0():
+        with on_side():
+            ops = []
+            if rank == 0:
+                ops = [dist.P2POp(dist.irecv, inbox[r], r) for r in range(1, world)]
+            else:
+                ops = [dist.P2POp(dist.isend, rows, 0)]
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        if cuda:
+            side.synchronize()
+        if rank == 0 and world > 1:
+            got = [float(inbox[r, 0, 0].item()) for r in range(1, world)]
+            if got != [float(r) for r in range(1, world)]:
+                raise RuntimeError(f'grouped recv delivered {got}')
+
+    def all_reduce_fence():
+        t = torch.ones(1, device=device if cuda else 'cpu')
+        dist.all_reduce(t)
+        if int(t.item()) != world:
+            raise RuntimeError(f'all-reduce of ones gave {t.item()} on {world} ranks')
+
+    for name, fn in (('all_gather_on_side_stream', all_gather_on_side_stream),
+                     ('grouped_isend_irecv_to_rank0', grouped_p2p_to_rank0),
+                     ('all_reduce_fence', all_reduce_fence)):
+        if not run(name, fn):
+            return {'ok': False, 'hung_in': name, 'steps_ms': done, 'timeout_s': timeout_s}
+    return {'ok': True, 'steps_ms': done, 'timeout_s': timeout_s}
+
+
 def scaling_keys(one_gpu_same_problem_ms, ms_per_step, world):
     """the keys that make a `--gpus N` line readable on its own: what ONE GPU needs for the same
     fixed-size problem through the same code (measured in the same run, on rank 0, while the
@@ -981,31 +1150,47 @@ def strong_headline(args, torch, dist, multi, world, rank, fence):
                 seg.close(unlink=(rank == 0))
         best = min(legs, key=lambda k: legs[k][0])      # (max-over-ranks times: the same on every rank)
         ms, tm = legs[best]
+        # the gather alone (pairs left in rank 0's HBM): beside the two, never the headline -- the
+        # consumer of a spot diagram is host code
+        by_exchange = {k: v[0] for k, v in legs.items()}
+        try:
+            by_exchange['rccl_device'] = prob.timed(fence, args.steps, 1, exchange='rccl', result_on='device')[0]
+        except Exception as e:
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            errors['rccl_device'] = repr(e)
         pairs = tm['pairs_total']
         phases = ('trace_ms', 'stage_sync_ms', 'gather_ms', 'd2h_ms', 'reassembly_ms')
         # the same problem on ONE GPU in the same run (collective: every rank makes the group)
         solo_group = dist.new_group(ranks=[0]) if multi else None
         one_ms, one_err = solo_same_problem(args, torch, dist, multi, rank, fence, solo_group, 'litho_c5',
                                             args.strong_num, 'rows', best, max(2, min(args.steps, 5)))
-        c4 = None
+        c4, c4r = None, None
         if world == 4:
-            # BASELINE configs[3] as north_star words it: shard-by-field over 4 GPUs
-            c4p = SpotProblem(torch, dist, multi, world, rank, 'rc_telescope_c4', 256, 'field')
-            try:
-                c4_ms, c4_tm = c4p.timed(fence, max(args.steps, 5), max(args.warmup, 2), exchange='rccl')
-                c4_one, c4_err = solo_same_problem(args, torch, dist, multi, rank, fence, solo_group,
-                                                   'rc_telescope_c4', 256, 'field', 'rccl', max(args.steps, 5))
-                c4 = dict(scaling_keys(c4_one, c4_ms, world), ms_per_step=c4_ms, exchange='rccl',
-                          workload=c4p.what + ' (BASELINE.json configs[3], one field per rank, rank 0 two)',
-                          intersections_per_step=c4p.intersections, pairs=c4_tm['pairs_total'],
-                          one_gpu_error=c4_err)
-            finally:
-                c4p.close()
+            # BASELINE configs[3] as north_star words it -- shard-by-field over 4 GPUs (5 fields:
+            # 2/1/1/1, at most 62.5 % efficient by construction) -- and, SURVEY 8(e)'s "or split
+            # rows for balance", the same five grids cut by pupil rows (320 rows per rank)
+            def c4_leg(by, note):
+                c4p = SpotProblem(torch, dist, multi, world, rank, 'rc_telescope_c4', 256, by)
+                try:
+                    c4_ms, c4_tm = c4p.timed(fence, max(args.steps, 5), max(args.warmup, 2), exchange='rccl')
+                    c4_one, c4_err = solo_same_problem(args, torch, dist, multi, rank, fence, solo_group,
+                                                       'rc_telescope_c4', 256, by, 'rccl', max(args.steps, 5))
+                    return dict(scaling_keys(c4_one, c4_ms, world), ms_per_step=c4_ms, exchange='rccl',
+                                workload=c4p.what + ' (BASELINE.json configs[3], ' + note + ')',
+                                rays_per_rank=c4p.caps,
+                                intersections_per_step=c4p.intersections, pairs=c4_tm['pairs_total'],
+                                one_gpu_error=c4_err)
+                finally:
+                    c4p.close()
+            c4 = c4_leg('field', 'one field per rank, rank 0 two')
+            c4r = c4_leg('rows', 'the five grids cut by pupil rows, the same share for every rank')
         return {'ms_per_step': ms, 'exchange': best, 'intersections_per_step': prob.intersections,
                 'one_gpu_same_problem_ms': one_ms, 'one_gpu_error': one_err, 'configs3_by_field': c4,
+                'configs3_by_rows': c4r,
                 'rays_per_step': sum(prob.caps), 'workload': prob.what, 'pairs': pairs,
                 'stages': tm.get('stages'), 'pieces_per_rank': tm.get('pieces'),
-                'ms_per_step_by_exchange': {k: v[0] for k, v in legs.items()},
+                'ms_per_step_by_exchange': by_exchange,
                 'errors': errors,
                 'last_pass_phases_ms_rank0': {k: {q: v[1].get(q) for q in phases} for k, v in legs.items()},
                 'grids_delivered': tm.get('grids_delivered'),
@@ -1145,6 +1330,7 @@ def cpu_baseline(wl, fld, wi, opts, num, rows, fi=0, dev_sample=None):
            'reference_build': live['reference_build'],
            'port': {k: port[k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'rays_per_s',
                                          'all_cores')},
+           'fanned': live.get('fanned'),
            'port_over_reference_this_host': port['value'] / live['raw_rt_trace']['intersections_per_s'],
            'reference_python_build_container': port.get('reference_python')}
     return out
@@ -1257,7 +1443,14 @@ def cpu_reference_live(wl, fi, wi, num, dev_sample):
                   'what': 'every packet rt.trace returned for these rays vs the same rays of the '
                           'timed HIP launch: 13 segments x 10 doubles + op_delta per surviving ray; '
                           'failure class and surface for the others'}
+    try:
+        fanned = cpu_reference_fanned(fi, wi, num, R / dt_raw)
+    except Exception as e:                      # noqa: BLE001  (the one-core figure stands)
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        fanned = {'error': repr(e)}
     return {
+        'fanned': fanned,
         'host': {'cpu': _cpu_model(), 'nproc': os.cpu_count(), 'python': platform.python_version(),
                  'numpy': np.__version__, 'blas': _blas_info()},
         'reference_build': {'where': 'oracle/_ref (sourceless byte code, oracle/stage_reference.py)'
@@ -1273,6 +1466,109 @@ def cpu_reference_live(wl, fi, wi, num, dev_sample):
                               'extrapolated_1M_ray_spot_s': dt_drv * (1024 * 1024) / (n_drv * n_drv),
                               'what': 'trace.trace_grid (trace.py:563-605), spot filter, 256x256, one core'},
         'parity_vs_timed_launch': parity}
+
+
+def _ref_grid_rows(opm, fi, wi, num, row0, rows):
+    """(sm, wvl, N, starts) of pupil rows [row0, row0 + rows) of the num x num grid of field fi:
+    pupil coordinates by repeated += (trace.py:563-605), ray starts by the reference's own
+    apply_vignetting / ray_start_from_osp"""
+    sm, osp = opm['seq_model'], opm['optical_spec']
+    fld = osp['fov'].fields[fi]
+    wvl = osp['wvls'].wavelengths[wi]
+    xs = np.empty(num)
+    step = 2.0 / (num - 1)
+    v = -1.0
+    for k in range(num):
+        xs[k] = v
+        v += step
+    starts = []
+    for i in range(row0, row0 + rows):
+        for j in range(num):
+            pupil = fld.apply_vignetting(np.array([xs[i], xs[j]]))
+            pt0, dir0 = osp.ray_start_from_osp(pupil, fld, 'rel pupil')
+            if dir0[2] * sm.z_dir[0] < 0:
+                dir0 = -dir0
+            starts.append((pt0, dir0))
+    return sm, wvl, len(sm.ifcs), starts
+
+
+def ref_worker(spec_json):
+    """one process of cpu_reference_fanned(): rt.trace over its own pupil rows of the timed grid,
+    started at a common wall-clock instant; prints one JSON line"""
+    spec = json.loads(spec_json)
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    if gold not in sys.path:
+        sys.path.insert(0, gold)
+    import refmodels as rm                      # installs the import shim
+    import rayoptics.raytr.raytrace as rt
+    from rayoptics.raytr.traceerror import TraceError
+    opm = rm.dblgauss()
+    sm, wvl, N, starts = _ref_grid_rows(opm, spec['fi'], spec['wi'], spec['num'], spec['row0'], spec['rows'])
+    late = time.time() - spec['t_start']
+    while time.time() < spec['t_start']:
+        time.sleep(0.002)
+    inters = 0
+    t0 = time.time()
+    for pt0, dir0 in starts:
+        try:
+            rt.trace(sm, pt0, dir0, wvl, check_apertures=True)
+            inters += N - 1
+        except TraceError as e:
+            inters += e.surf
+    t1 = time.time()
+    print(json.dumps({'rays': len(starts), 'intersections': inters, 't_begin': t0, 't_end': t1,
+                      'late_s': max(late, 0.0)}), flush=True)
+    return 0
+
+
+def cpu_reference_fanned(fi, wi, num, rays_per_s_one_core, budget_s=None):
+    """the reference over the cores of THIS host -- rt.trace fanned over
+    min(os.cpu_count(), 64) processes (the shape of rayoptics/raytr/tests/time_trace.py:37-45, one
+    Python process per core: the reference has no threading of its own), each on its own pupil
+    rows of the timed grid, all starting at one wall-clock instant; rate = everything traced /
+    (last finish - common start).  Bounded: ~budget_s seconds of tracing per process."""
+    import subprocess
+    if budget_s is None:
+        budget_s = float(os.environ.get('ROX_REF_FAN_SECONDS', '20'))
+    procs = max(1, min(os.cpu_count() or 1, 64))
+    rows_total = int(min(num, max(procs, budget_s * rays_per_s_one_core * procs / num)))
+    procs = min(procs, rows_total)
+    bounds = [(rows_total * k) // procs for k in range(procs + 1)]
+    row_base = (num - rows_total) // 2
+    # ray starts are made before the common start: the slowest start-up (import + model + the
+    # Python ray-start loop, ~0.2 ms per ray) decides how far ahead the instant must lie
+    per = max(b1 - b0 for b0, b1 in zip(bounds, bounds[1:])) * num
+    t_start = time.time() + 12.0 + per / 2500.0
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    children = []
+    for k in range(procs):
+        spec = {'fi': fi, 'wi': wi, 'num': num, 'row0': row_base + bounds[k], 'rows': bounds[k + 1] - bounds[k],
+                't_start': t_start}
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), '--ref-worker',
+                                          json.dumps(spec)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                         env=env, text=True))
+    recs = []
+    for c in children:
+        out, _ = c.communicate(timeout=600)
+        line = [ln for ln in out.splitlines() if ln.startswith('{')]
+        if c.returncode != 0 or not line:
+            raise RuntimeError(f'a reference worker failed (rc {c.returncode})')
+        recs.append(json.loads(line[-1]))
+    rays = sum(r['rays'] for r in recs)
+    inters = sum(r['intersections'] for r in recs)
+    t_begin = min(r['t_begin'] for r in recs)
+    t_end = max(r['t_end'] for r in recs)
+    wall = t_end - min(t_begin, t_start)
+    return {'processes': procs, 'rays': rays, 'intersections': inters, 'seconds': wall,
+            'rays_per_s': rays / wall, 'intersections_per_s': inters / wall,
+            'per_process_seconds_min_max': [min(r['t_end'] - r['t_begin'] for r in recs),
+                                            max(r['t_end'] - r['t_begin'] for r in recs)],
+            'started_late_s_max': max(r['late_s'] for r in recs),
+            'host': {'cpu': _cpu_model(), 'nproc': os.cpu_count()},
+            'speedup_over_one_core': (rays / wall) / rays_per_s_one_core,
+            'how': f'the reference\'s rt.trace in {procs} Python processes (one per core, OMP/BLAS threads = 1), '
+                   f'pupil rows {row_base}..{row_base + rows_total - 1} x {num} of the timed grid split between '
+                   'them, common start; rate = all rays / (last finish - start)'}
 
 
 def _cpu_model():

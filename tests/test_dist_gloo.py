@@ -351,3 +351,53 @@ def test_full_packets_stay_on_their_rank_and_are_fetched_lazily(world, dst):
     assert ok.any() and (~ok).any()
     np.testing.assert_array_equal(got['op'][ok], ref.op[idx][ok])
     np.testing.assert_array_equal(got['seg'][:, :, ok], ref.seg[:wl.n_ifcs][:, :, idx][:, :, ok])
+
+
+# ---------------------------------------------------------------- bench.py's exchange pre-flight
+def _preflight_worker(rank, world, port, q, skip_on_rank1):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import importlib.util
+    import torch
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location('rox_bench', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    skip = skip_on_rank1 if rank == 1 else ()
+    out = b.exchange_preflight(torch, dist, world, rank, None, 3.0, skip=skip)
+    q.put((rank, out))
+    q.close()
+    q.join_thread()     # (the feeder thread must have written the record before the exit below)
+    os._exit(0)         # (a rank left waiting in a collective never returns from it)
+
+
+def _preflight(world, skip_on_rank1, salt):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 7 + salt) % 2000
+    procs = [ctx.Process(target=_preflight_worker, args=(r, world, port, q, skip_on_rank1)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    return got
+
+
+def test_bench_exchange_preflight_on_three_ranks():
+    """bench.py --gpus N runs the exchange's collectives once, tiny, before anything is timed: all
+    three steps complete on a healthy group and are timed"""
+    got = _preflight(3, (), 901)
+    for r in range(3):
+        assert got[r]['ok'], got[r]
+        assert list(got[r]['steps_ms']) == ['all_gather_on_side_stream', 'grouped_isend_irecv_to_rank0',
+                                            'all_reduce_fence']
+
+
+def test_bench_exchange_preflight_names_the_collective_that_hangs():
+    """rank 1 stays away from the grouped send: rank 0, waiting for it, reports within the
+    watchdog's 3 s WHICH step hung instead of sitting in the backend's own timeout"""
+    got = _preflight(2, ('grouped_isend_irecv_to_rank0',), 902)
+    assert got[0]['ok'] is False and got[0]['hung_in'] == 'grouped_isend_irecv_to_rank0', got[0]
+    assert 'all_gather_on_side_stream' in got[0]['steps_ms']
