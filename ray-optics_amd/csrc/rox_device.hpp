@@ -36,6 +36,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <type_traits>
 
 #include "../../include/roxtrace.h"
 
@@ -216,12 +217,34 @@ enum { F_EVEN = 1,      // some interface is an EvenPolynomial (Newton code)
        F_PHASE = 32 };  // phase elements / thin lenses
 constexpr int F_POLY = F_EVEN | F_RADIAL | F_TOROID;
 constexpr int F_ALL = F_POLY | F_APLIST | F_PHFILT | F_PHASE;
+// instance flavours beside the feature bits: F_FAST = 64 (tolerance mode, declared with its
+// arithmetic below), F_GTAB = 128: the table stays in global memory and is read with scalar
+// loads (ctblp above) -- the instance of tables beyond the LDS (and, ROX_FAST_GTAB, of the
+// tolerance-mode kernels)
+constexpr int F_GTAB = 128;
+#ifndef ROX_FAST_GTAB
+#define ROX_FAST_GTAB 0
+#endif
 
 struct v3 { double x, y, z; };
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 typedef const double *tblp;     // LDS (generic pointer into __shared__)
 typedef const int32_t *tbli;
+// The same table left in GLOBAL memory and read through the constant address space (the F_GTAB
+// instances): a wave-uniform address in that space is a scalar load (s_load_dwordx2..x16 through
+// the scalar cache), the value lands in SGPRs and no LDS is involved -- so a table has no size
+// limit (SequentialModel has none: rayoptics/seq/sequential.py:167-202) and the tolerance-mode
+// kernels, which issue one LDS broadcast per five VALU instructions otherwise, keep the LDS
+// pipe out of their way.  Every function below that reads the table is a template over the
+// pointer type; ints_of() / pairs_of() reinterpret within the pointer's own address space.
+typedef const __attribute__((address_space(4))) double *ctblp;
+typedef const __attribute__((address_space(4))) int32_t *ctbli;
+typedef const __attribute__((address_space(4))) d2 *ctbl2;
+__device__ __forceinline__ tbli ints_of(tblp p) { return reinterpret_cast<tbli>(p); }
+__device__ __forceinline__ ctbli ints_of(ctblp p) { return (ctbli)p; }
+__device__ __forceinline__ const d2 *pairs_of(tblp p) { return reinterpret_cast<const d2 *>(p); }
+__device__ __forceinline__ ctbl2 pairs_of(ctblp p) { return (ctbl2)p; }
 
 // ---------------------------------------------------------------- kernel args
 struct TraceArgs {
@@ -557,8 +580,8 @@ __device__ __forceinline__ bool quadric_hit(bool conic, double cv, double cc, do
 // 1 * m * m ... and the sag loop's m * m ... are the same numbers one term apart (1 * m is m
 // exactly, and from there both chains multiply the same value by m), so one chain serves both --
 // five operations per term instead of six, every result the one the two loops produce.
-template <int FEAT, bool SHARED = false>
-__device__ __forceinline__ void series2(const d2 *cd, int ncoef, double m, double z_pow, double e_pow,
+template <int FEAT, bool SHARED = false, class CD>
+__device__ __forceinline__ void series2(CD cd, int ncoef, double m, double z_pow, double e_pow,
                                         double &z_asp, double &e_asp)
 {
     z_asp = 0.0;
@@ -597,14 +620,13 @@ __device__ __forceinline__ void series2(const d2 *cd, int ncoef, double m, doubl
 }
 
 // FEAT says which of the three families this kernel instance carries code for.
-template <int FEAT, bool WANT_F>
+template <int FEAT, bool WANT_F, class TP>
 __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, double ec, double cR,
-                                          int ncoef, tblp coefs,
+                                          int ncoef, TP coefs,
                                           const v3 &p, double &f, v3 &df)
 {
     // (coefs[i], dcoefs[i]) pairs of the device row
-    const d2 *cd = reinterpret_cast<const d2 *>(
-        coefs + (offsetof(dev_surface, cd) - offsetof(rox_surface, coefs)) / 8);
+    const auto cd = pairs_of(coefs + (offsetof(dev_surface, cd) - offsetof(rox_surface, coefs)) / 8);
     if ((FEAT & F_TOROID) && (!(FEAT & (F_EVEN | F_RADIAL)) || kind >= ROX_YTOROID)) {
         // profiles.py:1337-1377 YToroid.fY/f/df; XToroid swaps x and y (:1429-1434)
         const bool xt = (kind == ROX_XTOROID);
@@ -694,9 +716,9 @@ __device__ __forceinline__ bool poly_eval(int kind, double cv, double cc1, doubl
 
 // profiles.py:155-186 Spencer & Murty Newton iteration.  Returns the last
 // *evaluated* iterate as the hit point (p0 itself when |s1| <= eps at once).
-template <int FEAT>
+template <int FEAT, class TP>
 __device__ __forceinline__ bool newton_hit(int kind, double cv, double cc1, double ec, double cR,
-                                           int ncoef, tblp coefs,
+                                           int ncoef, TP coefs,
                                            const v3 &p0, const v3 &d, double eps,
                                            double &s, v3 &hit, v3 &df)
 {
@@ -900,14 +922,13 @@ __device__ __forceinline__ bool quadric_hit_f(bool conic, double cv, double cc, 
 
 // f(p), df(p) of EvenPolynomial / RadialPolynomial (profiles.py:849-885, 1070-1113), Horner
 // form.  Toroids keep the exact evaluation (poly_eval): no workload of BASELINE carries one.
-template <int FEAT>
+template <int FEAT, class TP>
 __device__ __forceinline__ bool poly_eval_f(int kind, double cv, double cc1, double ec, double cR,
-                                            int ncoef, tblp coefs, const v3 &p, double &f, v3 &df)
+                                            int ncoef, TP coefs, const v3 &p, double &f, v3 &df)
 {
     if ((FEAT & F_TOROID) && kind >= ROX_YTOROID)
         return poly_eval<FEAT & ~F_FAST, true>(kind, cv, cc1, ec, cR, ncoef, coefs, p, f, df);
-    const d2 *cd = reinterpret_cast<const d2 *>(
-        coefs + (offsetof(dev_surface, cd) - offsetof(rox_surface, coefs)) / 8);
+    const auto cd = pairs_of(coefs + (offsetof(dev_surface, cd) - offsetof(rox_surface, coefs)) / 8);
     const bool radial = (FEAT & F_RADIAL) && (!(FEAT & F_EVEN) || kind == ROX_RADIALPOLY);
     const double r2 = fma(p.y, p.y, p.x * p.x);
     const double cv2 = cv * cv;
@@ -963,9 +984,9 @@ __device__ __forceinline__ bool poly_eval_f(int kind, double cv, double cc1, dou
 }
 
 // profiles.py:155-186, as newton_hit() runs it
-template <int FEAT>
+template <int FEAT, class TP>
 __device__ __forceinline__ bool newton_hit_f(int kind, double cv, double cc1, double ec, double cR,
-                                             int ncoef, tblp coefs, const v3 &p0, const v3 &d,
+                                             int ncoef, TP coefs, const v3 &p0, const v3 &d,
                                              double eps, double &s, v3 &hit, v3 &df)
 {
     v3 p = p0;
@@ -999,16 +1020,20 @@ __device__ __forceinline__ bool newton_hit_f(int kind, double cv, double cc1, do
 // sqrt_le_threshold(radius + fuzz) (stage_aperture_thresholds() below), so that
 // `sqrt(xx*xx + yy*yy) <= radius + fuzz` is decided without the square root, outcome for
 // outcome; interfaces without a list take the max_aperture threshold (Ctx.apthr).
-__device__ __forceinline__ bool inside_aperture_list(tblp row, int n_ap, double x, double y, double fuzz)
+// thr != nullptr (the F_GTAB instances, whose table is read-only): the interface's circular
+// thresholds, staged in LDS beside the table instead of inside it.
+template <class TP>
+__device__ __forceinline__ bool inside_aperture_list(TP row, int n_ap, double x, double y, double fuzz,
+                                                     tblp thr = nullptr)
 {
-    tblp ap = row + (offsetof(rox_surface, ap) / sizeof(double));
+    auto ap = row + (offsetof(rox_surface, ap) / sizeof(double));
     for (int k = 0; k < n_ap; ++k, ap += sizeof(rox_aperture) / sizeof(double)) {
-        const int2 ki{((tbli)ap)[0], ((tbli)ap)[1]};            // kind, is_obscuration
+        const int2 ki{ints_of(ap)[0], ints_of(ap)[1]};            // kind, is_obscuration
         const double xx = x - ap[1];
         const double yy = y - ap[2];
         bool ans;
         if (ki.x == ROX_AP_CIRCULAR)
-            ans = (xx * xx + yy * yy) <= ap[3];                 // the staged threshold
+            ans = (xx * xx + yy * yy) <= (thr ? thr[k] : ap[3]);    // the staged threshold
         else if (ki.x == ROX_AP_RECTANGULAR)
             ans = (fabs(xx) <= ap[3] + fuzz) && (fabs(yy) <= ap[4] + fuzz);
         else
@@ -1066,7 +1091,8 @@ enum { PHASE_OK = 0, PHASE_EVANESCENT = 1, PHASE_TIR = 2 };
 // raytrace.py:41-48 phase() over the phase element of the row.  ph points at
 // rox_surface.ph of the row; pc at the (wavelength, interface) grating
 // constants.  Returns PHASE_*; `out` = after_dir, `dW` = phs.
-__device__ __forceinline__ int apply_phase(tblp ph, tblp pc, const v3 &pt, const v3 &in_dir,
+template <class TP>
+__device__ __forceinline__ int apply_phase(TP ph, TP pc, const v3 &pt, const v3 &in_dir,
                                            const v3 &srf_nrml, double z_dir, double wvl,
                                            double n_in, double n_out, int mode, v3 &out,
                                            double &dW)
@@ -1074,7 +1100,7 @@ __device__ __forceinline__ int apply_phase(tblp ph, tblp pc, const v3 &pt, const
     constexpr int O_ORDER = offsetof(rox_phase, order) / 8, O_REFWL = offsetof(rox_phase, ref_wl) / 8,
                   O_SPACING = offsetof(rox_phase, spacing_nm) / 8, O_A = offsetof(rox_phase, a) / 8,
                   O_B = offsetof(rox_phase, b) / 8, O_COEF = offsetof(rox_phase, coefs) / 8;
-    const int kind = ((tbli)ph)[0];
+    const int kind = ints_of(ph)[0];
     if (kind == ROX_PH_GRATING) {               // doe.py:124-175 phase_ludwig
         const double refl = (mode == ROX_REFLECT) ? -1.0 : 1.0;
         const v3 un = unit(srf_nrml);
@@ -1126,7 +1152,7 @@ __device__ __forceinline__ int apply_phase(tblp ph, tblp pc, const v3 &pt, const
         const double mu = wvl / ph[O_REFWL];
         const double r_sqr = pt.x * pt.x + pt.y * pt.y;
         double w = 0, dWdX = 0, dWdY = 0;
-        const int nc = ((tbli)ph)[1];
+        const int nc = ints_of(ph)[1];
         for (int i = 0; i < nc; ++i) {
             const double c = ph[O_COEF + i];
             w += c * pow_int(r_sqr, i + 1);
@@ -1156,7 +1182,7 @@ __device__ __forceinline__ int apply_phase(tblp ph, tblp pc, const v3 &pt, const
         return PHASE_OK;
     }
     // ROX_PH_HOLOGRAM, doe.py:375-397
-    const int flags = ((tbli)ph)[2];
+    const int flags = ints_of(ph)[2];
     const v3 normal = unit(srf_nrml);
     v3 ref_dir = unit(v3{pt.x - ph[O_A], pt.y - ph[O_A + 1], pt.z - ph[O_A + 2]});
     if (flags & 1)
@@ -1307,10 +1333,12 @@ struct SegOut {
 };
 
 // the workgroup's view of the surface table (LDS) + the launch options
-struct Ctx {
-    tblp tbl;               // [N][kRowDoubles]
+template <class TP>
+struct CtxT {
+    TP tbl;                 // [N][kRowDoubles]: LDS (tblp), or global through scalar loads (ctblp, F_GTAB)
     tblp ntab;              // [N] (one wavelength) or [W][N] (per-ray wavelengths)
-    tblp phc;               // [N][kPhaseConsts] or [W][N][kPhaseConsts]; FEAT & F_PHASE only
+    TP phc;                 // [N][kPhaseConsts] or [W][N][kPhaseConsts]; FEAT & F_PHASE only
+    tblp aplthr;            // F_GTAB: [N][ROX_MAX_AP] circular clear-aperture thresholds; else nullptr
     tblp wvls;              // [W]
     tbli slot, nslots_before;
     tblp apthr;             // [N] sqrt_le_threshold(max_aperture + fuzz)
@@ -1321,6 +1349,7 @@ struct Ctx {
     double eps, fuzz;
     int probe_surf;         // MODE_PROBE
 };
+typedef CtxT<tblp> Ctx;
 
 // what a traced ray leaves in registers for the epilogues
 struct RayEnd {
@@ -1339,8 +1368,8 @@ struct RayEnd {
 // every surface, so that the workgroup writes whole [segment] rows together;
 // every wave must then reach every barrier: failed lanes idle instead of leaving.
 #define ROX_LEAVE if (kSync) continue; else break
-template <int OUT_MODE, bool PER_RAY_WVL, int FEAT>
-__device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const v3 &pt0,
+template <int OUT_MODE, bool PER_RAY_WVL, int FEAT, class CTX>
+__device__ __forceinline__ void trace_ray(const CTX &c, const SegOut &so, const v3 &pt0,
                                           const v3 &dir0, int wi, bool live, RayEnd &e)
 {
     constexpr int O_CV = offsetof(rox_surface, cv) / 8, O_CC = offsetof(rox_surface, cc) / 8,
@@ -1353,7 +1382,7 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
     constexpr bool kSync = OUT_MODE == ROX_OUT_FULL && (kPoly ? ROX_WG_SYNC_POLY : ROX_WG_SYNC);
     constexpr bool kIdentRt = ROX_IDENT_RT && (OUT_MODE != ROX_OUT_FULL || (kPoly && ROX_IDENT_RT_FULL_POLY));
     const int N = c.N;
-    tblp tbl = c.tbl;
+    const auto tbl = c.tbl;
     tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
 #define SLOT(s) ((FEAT & F_PHFILT) ? c.slot[s] : (s))
 #define NSLOTS_BEFORE(s) ((FEAT & F_PHFILT) ? c.nslots_before[s] : (s))
@@ -1364,9 +1393,9 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
     v3 bp, bn, bd = dir0;               // before_pt, before_normal, before_dir
     int b4_mode = ROX_DUMMY;
     if (live) {
-        tblp row = tbl;
+        const auto row = tbl;
         if (c.intersect_obj) {
-            const int2 mp{((tbli)row)[0], ((tbli)row)[1]};      // mode, profile
+            const int2 mp{ints_of(row)[0], ints_of(row)[1]};      // mode, profile
             b4_mode = mp.x;
             double s_;
             v3 df;
@@ -1383,7 +1412,7 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
                 df = v3{ncv * bp.x, ncv * bp.y, 1.0 - k * bp.z};
             } else {
                 ok = newton_hit<FEAT>(mp.y, row[O_CV], row[O_CC] + 1.0, row[O_EC], row[O_CR],
-                                      ((tbli)row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
+                                      ints_of(row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
             }
             if (!ok) {              // raised outside the try block: no packet
                 status = ROX_MISSED_SURFACE;
@@ -1416,14 +1445,14 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
             if (status != ROX_OK)
                 continue;
         }
-        tblp prow = tbl + (size_t)(surf - 1) * kRowDoubles;     // `before`
-        tblp row = tbl + (size_t)surf * kRowDoubles;             // `after`
-        const int mode = ((tbli)row)[0], prof = ((tbli)row)[1];
+        const auto prow = tbl + (size_t)(surf - 1) * kRowDoubles;     // `before`
+        const auto row = tbl + (size_t)surf * kRowDoubles;             // `after`
+        const int mode = ints_of(row)[0], prof = ints_of(row)[1];
         const double cv = row[O_CV];
         const bool thin = (FEAT & F_PHASE) && prof == ROX_THINLENS;
 
         // :170-174 transform to the new vertex frame, closest approach
-        const int rt_order = ((tbli)prow)[4];
+        const int rt_order = ints_of(prow)[4];
         const v3 dp{bp.x - prow[O_T], bp.y - prow[O_T + 1], bp.z - prow[O_T + 2]};
         v3 b4p, b4d;
         // rt exactly the identity (flagged on the device row when the system is created): each
@@ -1433,7 +1462,7 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         // every active lane's six components are finite (their sum is: a conservative test).
         // (reduced-output modes only: in FULL mode, which is bound by its packet stores, the
         // extra branch measured 2 % slower)
-        if (kIdentRt && (((tbli)prow)[5] & 2) != 0 &&
+        if (kIdentRt && (ints_of(prow)[5] & 2) != 0 &&
             wave_all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((bd.x + bd.y) + bd.z)))) {
             b4p = v3{dp.x + 0.0, dp.y + 0.0, dp.z + 0.0};
             b4d = v3{bd.x + 0.0, bd.y + 0.0, bd.z + 0.0};
@@ -1457,7 +1486,7 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
                              z_dir_before, s, inc);
         } else {
             ok = newton_hit<FEAT>(prof, cv, row[O_CC] + 1.0, row[O_EC], row[O_CR],
-                                  ((tbli)row)[2], row + O_COEF, pp, b4d, c.eps, s, inc, df);
+                                  ints_of(row)[2], row + O_COEF, pp, b4d, c.eps, s, inc, df);
         }
         const bool b4_filtered = c.filter_ph && (b4_mode == ROX_PHANTOM);
         if (!ok) {                                  // :231-237
@@ -1506,9 +1535,10 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
         // :198-202 aperture test (in_surface_range, :134-142)
         if (c.check_ap && surf >= c.first_surf && (c.last_surf < 0 || surf <= c.last_surf) &&
             mode != ROX_PHANTOM) {
-            const int n_ap = (FEAT & F_APLIST) ? ((tbli)row)[3] : 0;
+            const int n_ap = (FEAT & F_APLIST) ? ints_of(row)[3] : 0;
             const bool in = n_ap > 0
-                ? inside_aperture_list(row, n_ap, inc.x, inc.y, c.fuzz)
+                ? inside_aperture_list(row, n_ap, inc.x, inc.y, c.fuzz,
+                                       c.aplthr ? c.aplthr + (size_t)surf * ROX_MAX_AP : nullptr)
                 : (inc.x * inc.x + inc.y * inc.y) <= c.apthr[surf];   // sqrt-free, see above
             if (!in)
                 status = ROX_BLOCKED;               // :247-251
@@ -1516,9 +1546,9 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
 
         // :205-221 phase element, or refract / reflect / pass through
         if (status == ROX_OK) {
-            if ((FEAT & F_PHASE) && ((tbli)(row + O_PH))[0] != ROX_PH_NONE) {
+            if ((FEAT & F_PHASE) && ints_of(row + O_PH)[0] != ROX_PH_NONE) {
                 double dW = 0.0;
-                tblp pc = c.phc + ((PER_RAY_WVL ? (size_t)wi * N : 0) + surf) * kPhaseConsts;
+                const auto pc = c.phc + ((PER_RAY_WVL ? (size_t)wi * N : 0) + surf) * kPhaseConsts;
                 const int rc = apply_phase(row + O_PH, pc, inc, b4d, nrm, z_dir_before,
                                            c.wvls[wi], nwl[surf - 1], nwl[surf], mode, ad, dW);
                 if (rc == PHASE_OK)
@@ -1584,8 +1614,8 @@ __device__ __forceinline__ void trace_ray(const Ctx &c, const SegOut &so, const 
 // reduced-output modes only -- no packet stores, hence no segment bookkeeping -- with the
 // arithmetic of the section "tolerance mode" above.  c.mu / c.mu2 = n_in / n_out and its square
 // per interface, staged by the workgroup.
-template <int OUT_MODE, bool PER_RAY_WVL, int FEAT>
-__device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, const v3 &dir0, int wi,
+template <int OUT_MODE, bool PER_RAY_WVL, int FEAT, class CTX>
+__device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, const v3 &dir0, int wi,
                                                bool live, RayEnd &e)
 {
     static_assert(OUT_MODE != ROX_OUT_FULL && OUT_MODE != MODE_PROBE, "reduced-output modes only");
@@ -1597,7 +1627,7 @@ __device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, cons
                   O_PH = offsetof(rox_surface, ph) / 8;
     constexpr bool kPoly = (FEAT & F_POLY) != 0;
     const int N = c.N;
-    tblp tbl = c.tbl;
+    const auto tbl = c.tbl;
     tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
     tblp muw = PER_RAY_WVL ? c.mu + (size_t)wi * 2 * N : c.mu;      // [N] mu, [N] mu^2
 
@@ -1612,9 +1642,9 @@ __device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, cons
     v3 pp1{0, 0, 0}, b4d1 = dir0;
     double pp_dst1 = 0.0;
     if (live) {
-        tblp row = tbl;
+        const auto row = tbl;
         if (c.intersect_obj) {                  // raytrace.py:145-158 (the normal is not needed)
-            const int prof = ((tbli)row)[1];
+            const int prof = ints_of(row)[1];
             double s_;
             v3 df;
             bool ok;
@@ -1627,7 +1657,7 @@ __device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, cons
                                  row[O_ZDIR], s_, bp);
             } else {
                 ok = newton_hit<FEAT & ~F_FAST>(prof, row[O_CV], row[O_CC] + 1.0, row[O_EC], row[O_CR],
-                                                ((tbli)row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
+                                                ints_of(row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
             }
             if (!ok) {
                 status = ROX_MISSED_SURFACE;
@@ -1635,8 +1665,8 @@ __device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, cons
             }
         }
         const v3 dp{bp.x - row[O_T], bp.y - row[O_T + 1], bp.z - row[O_T + 2]};
-        const v3 b4p = rotate(row + O_RT, ((tbli)row)[4], dp);
-        b4d1 = rotate(row + O_RT, ((tbli)row)[4], bd);
+        const v3 b4p = rotate(row + O_RT, ints_of(row)[4], dp);
+        b4d1 = rotate(row + O_RT, ints_of(row)[4], bd);
         pp_dst1 = -dot3(b4p, b4d1);
         pp1 = v3{b4p.x + pp_dst1 * b4d1.x, b4p.y + pp_dst1 * b4d1.y, b4p.z + pp_dst1 * b4d1.z};
     }
@@ -1646,9 +1676,9 @@ __device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, cons
     e.ray1_p = e.rayk_p = e.rayk_d = e.probe_p = v3{0, 0, 0};
 
     for (int surf = 1; surf < N && status == ROX_OK; ++surf) {
-        tblp prow = tbl + (size_t)(surf - 1) * kRowDoubles;
-        tblp row = tbl + (size_t)surf * kRowDoubles;
-        const int mode = ((tbli)row)[0], prof = ((tbli)row)[1];
+        const auto prow = tbl + (size_t)(surf - 1) * kRowDoubles;
+        const auto row = tbl + (size_t)surf * kRowDoubles;
+        const int mode = ints_of(row)[0], prof = ints_of(row)[1];
         const double cv = row[O_CV];
         const bool thin = (FEAT & F_PHASE) && prof == ROX_THINLENS;
 
@@ -1659,7 +1689,7 @@ __device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, cons
             const v3 dp{bp.x - prow[O_T], bp.y - prow[O_T + 1], bp.z - prow[O_T + 2]};
             v3 b4p = dp;
             b4d = bd;
-            if ((((tbli)prow)[5] & 2) == 0) {   // (identity rotations are flagged on the device row)
+            if ((ints_of(prow)[5] & 2) == 0) {   // (identity rotations are flagged on the device row)
                 b4p = rotate_f(prow + O_RT, dp);
                 b4d = rotate_f(prow + O_RT, bd);
             }
@@ -1679,7 +1709,7 @@ __device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, cons
             ok = quadric_hit_f(prof == ROX_CONIC, cv, row[O_CC], row[O_EC], pp, b4d, z_dir_before, s, inc);
         } else {
             ok = newton_hit_f<FEAT>(prof, cv, row[O_CC] + 1.0, row[O_EC], row[O_CR],
-                                    ((tbli)row)[2], row + O_COEF, pp, b4d, c.eps, s, inc, df);
+                                    ints_of(row)[2], row + O_COEF, pp, b4d, c.eps, s, inc, df);
         }
         if (!ok) {                                  // :231-237
             status = ROX_MISSED_SURFACE;
@@ -1712,9 +1742,10 @@ __device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, cons
         // :198-202 aperture test (in_surface_range, :134-142)
         if (c.check_ap && surf >= c.first_surf && (c.last_surf < 0 || surf <= c.last_surf) &&
             mode != ROX_PHANTOM) {
-            const int n_ap = (FEAT & F_APLIST) ? ((tbli)row)[3] : 0;
+            const int n_ap = (FEAT & F_APLIST) ? ints_of(row)[3] : 0;
             const bool in = n_ap > 0
-                ? inside_aperture_list(row, n_ap, inc.x, inc.y, c.fuzz)
+                ? inside_aperture_list(row, n_ap, inc.x, inc.y, c.fuzz,
+                                       c.aplthr ? c.aplthr + (size_t)surf * ROX_MAX_AP : nullptr)
                 : fma(inc.y, inc.y, inc.x * inc.x) <= c.apthr[surf];
             if (!in)
                 status = ROX_BLOCKED;               // :247-251
@@ -1722,9 +1753,9 @@ __device__ __forceinline__ void trace_ray_fast(const Ctx &c, const v3 &pt0, cons
 
         // :205-221 phase element (the exact code: rare), or refract / reflect / pass through
         if (status == ROX_OK) {
-            if ((FEAT & F_PHASE) && ((tbli)(row + O_PH))[0] != ROX_PH_NONE) {
+            if ((FEAT & F_PHASE) && ints_of(row + O_PH)[0] != ROX_PH_NONE) {
                 double dW = 0.0;
-                tblp pc = c.phc + ((PER_RAY_WVL ? (size_t)wi * N : 0) + surf) * kPhaseConsts;
+                const auto pc = c.phc + ((PER_RAY_WVL ? (size_t)wi * N : 0) + surf) * kPhaseConsts;
                 const int rc = apply_phase(row + O_PH, pc, inc, b4d, nrm, z_dir_before,
                                            c.wvls[wi], nwl[surf - 1], nwl[surf], mode, ad, dW);
                 if (rc == PHASE_OK)
@@ -1947,15 +1978,24 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
 
     const int N = a.n_ifcs;
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    // LDS of a workgroup: [the table: N rows]  the indices  [phase constants]  wavelengths
+    // max-aperture thresholds  [clear-aperture thresholds]  slot map  [mu, mu^2]  [stash].
+    // F_GTAB leaves the table and the phase constants in global memory and keeps the circular
+    // clear-aperture thresholds, which the LDS instances write into their copy of the table,
+    // in an array of their own.
+    constexpr bool kGtab = (FEAT & F_GTAB) != 0;
+    constexpr bool kFast = (FEAT & F_FAST) != 0;
+    typedef typename std::conditional<kGtab, ctblp, tblp>::type TP;
     double *tbl_w = lds;                               // [N][kRowDoubles]
     const int nw_rows = PER_RAY_WVL ? a.n_wvls : 1;
-    double *ntab_w = tbl_w + (size_t)N * kRowDoubles;  // [W][N] (or [N] for one wavelength)
+    double *ntab_w = tbl_w + (kGtab ? 0 : (size_t)N * kRowDoubles);    // [W][N] (or [N] for one wavelength)
     double *phc_w = ntab_w + (size_t)nw_rows * N;      // [W][N][4] (F_PHASE only)
-    double *wvls_w = phc_w + ((FEAT & F_PHASE) ? (size_t)nw_rows * N * kPhaseConsts : 0);
+    double *wvls_w = phc_w + (((FEAT & F_PHASE) && !kGtab) ? (size_t)nw_rows * N * kPhaseConsts : 0);
     double *apthr_w = wvls_w + a.n_wvls;                // [N]
-    int32_t *slot_w = reinterpret_cast<int32_t *>(apthr_w + N);
+    double *aplthr_w = apthr_w + N;                     // [N][ROX_MAX_AP] (F_GTAB with F_APLIST)
+    int32_t *slot_w = reinterpret_cast<int32_t *>(
+        aplthr_w + ((kGtab && (FEAT & F_APLIST)) ? (size_t)N * ROX_MAX_AP : 0));
     // F_FAST: mu = n_in / n_out and mu^2 per (wavelength row, interface), behind the slot map
-    constexpr bool kFast = (FEAT & F_FAST) != 0;
     // (2 N int32 = 8 N bytes behind an 8-byte aligned start: aligned as it stands -- a pointer
     // rounded through an integer loses its LDS address space and is read with flat loads)
     double *mu_w = reinterpret_cast<double *>(slot_w + 2 * N);
@@ -1965,10 +2005,11 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     d2 *stash_w = reinterpret_cast<d2 *>(lds + (((size_t)(end_w - lds) + 1) & ~size_t(1)));
 
     // stage the surface table once per workgroup
-    for (int i = threadIdx.x; i < N * kRowDoubles; i += kB)
-        tbl_w[i] = a.rows[i];
+    if (!kGtab)
+        for (int i = threadIdx.x; i < N * kRowDoubles; i += kB)
+            tbl_w[i] = a.rows[i];
+    const size_t w0 = PER_RAY_WVL ? 0 : (size_t)a.wvl_idx_all * N;
     {
-        const size_t w0 = PER_RAY_WVL ? 0 : (size_t)a.wvl_idx_all * N;
         for (int i = threadIdx.x; i < nw_rows * N; i += kB)
             ntab_w[i] = a.n_table[w0 + i];
         if (kFast)
@@ -1978,7 +2019,7 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
                 mu_w[(size_t)w * 2 * N + sf] = m;
                 mu_w[(size_t)w * 2 * N + N + sf] = m * m;
             }
-        if (FEAT & F_PHASE)
+        if ((FEAT & F_PHASE) && !kGtab)
             for (int i = threadIdx.x; i < nw_rows * N * kPhaseConsts; i += kB)
                 phc_w[i] = a.ph_consts[w0 * kPhaseConsts + i];
     }
@@ -1989,14 +2030,36 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     for (int i = threadIdx.x; i < N; i += kB)
         apthr_w[i] = sqrt_le_threshold(
             a.rows[(size_t)i * kRowDoubles + offsetof(rox_surface, max_aperture) / 8] + a.opts.fuzz);
+    if (kGtab && (FEAT & F_APLIST))
+        for (int i = threadIdx.x; i < N * ROX_MAX_AP; i += kB) {
+            const double *row = a.rows + (size_t)(i / ROX_MAX_AP) * kRowDoubles;
+            const int k = i % ROX_MAX_AP;
+            double t = 0.0;
+            if (k < reinterpret_cast<const int32_t *>(row)[3]) {
+                const double *ap = row + offsetof(rox_surface, ap) / sizeof(double) +
+                                   (size_t)k * (sizeof(rox_aperture) / sizeof(double));
+                if (reinterpret_cast<const int32_t *>(ap)[0] == ROX_AP_CIRCULAR)
+                    t = sqrt_le_threshold(ap[3] + a.opts.fuzz);
+            }
+            aplthr_w[i] = t;
+        }
     __syncthreads();
-    if (FEAT & F_APLIST) {
+    if ((FEAT & F_APLIST) && !kGtab) {
         stage_aperture_thresholds<FEAT>(tbl_w, N, a.opts.fuzz, threadIdx.x, kB);
         __syncthreads();
     }
 
-    Ctx c;
-    c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w; c.apthr = apthr_w;
+    CtxT<TP> c;
+    if constexpr (kGtab) {
+        c.tbl = (ctblp)a.rows;
+        c.phc = (ctblp)a.ph_consts + w0 * kPhaseConsts;
+        c.aplthr = (FEAT & F_APLIST) ? aplthr_w : nullptr;
+    } else {
+        c.tbl = tbl_w;
+        c.phc = phc_w;
+        c.aplthr = nullptr;
+    }
+    c.ntab = ntab_w; c.wvls = wvls_w; c.apthr = apthr_w;
     c.slot = slot_w; c.nslots_before = slot_w + N;
     c.mu = mu_w;
     c.N = N;
@@ -2210,6 +2273,7 @@ struct LaunchCfg {
     bool per_ray_wvl;
     bool small;         // workgroups of ROX_BLOCK_SMALL threads (pupil launches; see block_of())
     bool fast;          // the tolerance-mode instance (ROX_FAST_FP64 on a reduced-output mode)
+    bool gtab;          // the table does not fit the LDS: the general instance over global memory
     int out_mode;       // ROX_OUT_*
     dim3 grid;
     size_t lds;
@@ -2338,7 +2402,12 @@ void launch_poly_batch(const LaunchCfg &, const TraceArgs *);
 void launch_aplist_batch(const LaunchCfg &, const TraceArgs *);
 void launch_evenap_batch(const LaunchCfg &, const TraceArgs *);
 void launch_general_batch(const LaunchCfg &, const TraceArgs *);
-// ... and their tolerance-mode twins (csrc/fast_*.hip: kInstances[i] | F_FAST, reduced-output modes)
+// the general instance over a table left in global memory (csrc/gtab_general.hip)
+void launch_general_gtab(const LaunchCfg &, const TraceArgs &);
+void launch_general_gtab_batch(const LaunchCfg &, const TraceArgs *);
+// ... and their tolerance-mode twins (csrc/fast_*.hip: kInstances[i] | F_FAST, reduced-output modes;
+// ROX_FAST_GTAB: with the table read through scalar loads)
+constexpr int kFastFlavour = F_FAST | (ROX_FAST_GTAB ? F_GTAB : 0);
 void launch_lean_fast(const LaunchCfg &, const TraceArgs &);
 void launch_even_fast(const LaunchCfg &, const TraceArgs &);
 void launch_radial_fast(const LaunchCfg &, const TraceArgs &);

@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
     const rox_aim pb = a.probs[i];
 
     Ctx c;
+    c.aplthr = nullptr;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
     c.slot = slot_w; c.nslots_before = slot_w + N;
     c.apthr = nullptr;          // (the trial rays of the aiming never test apertures)
@@ -341,6 +342,7 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     const double start_xy = xy == 0 ? pb.start_dir[0] : pb.start_dir[1];
 
     Ctx c;
+    c.aplthr = nullptr;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
     c.slot = slot_w; c.nslots_before = slot_w + N;
     c.apthr = apthr_w;          // (checked trace only)
@@ -366,12 +368,12 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     // aperture test's thresholds, stage_aperture_thresholds())
     auto edge = [&](int s) -> double {
         tblp row = a.rows + (size_t)s * kRowDoubles;
-        const int n_ap = ((tbli)row)[3];
+        const int n_ap = ints_of(row)[3];
         tblp ap = row + (offsetof(rox_surface, ap) / sizeof(double));
         for (int k = 0; k < n_ap; ++k, ap += sizeof(rox_aperture) / sizeof(double)) {
-            if (((tbli)ap)[1])
+            if (ints_of(ap)[1])
                 continue;
-            if (((tbli)ap)[0] == ROX_AP_CIRCULAR)
+            if (ints_of(ap)[0] == ROX_AP_CIRCULAR)
                 return ap[3] * unit_xy;
             return (xy == 0 ? ap[3] : ap[4]) * unit_xy;
         }
@@ -609,6 +611,7 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
     __shared__ int s_st[64], s_fs[64];
 
     Ctx c;
+    c.aplthr = nullptr;
     c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
     c.slot = slot_w; c.nslots_before = slot_w + N;
     c.apthr = nullptr;

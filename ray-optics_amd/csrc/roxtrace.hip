@@ -319,11 +319,15 @@ void slot_map(const rox_system *s, bool filter, std::vector<int32_t> &m, int32_t
     n_seg = next;
 }
 
-size_t lds_bytes(const rox_system *s, bool per_ray_wvl, bool phase, bool fast)
+// (rox_device.hpp trace_tiles: the LDS layout of a workgroup; gtab = the table and the phase
+// constants stay in global memory, the circular clear-aperture thresholds get an array)
+size_t lds_bytes(const rox_system *s, bool per_ray_wvl, bool phase, bool fast, bool gtab = false,
+                 bool aplist = false)
 {
     const size_t N = s->n_ifcs, Wn = per_ray_wvl ? (size_t)s->n_wvls : 1;
-    size_t b = N * sizeof(dev_surface) + Wn * N * sizeof(double) +
-               (phase ? Wn * N * kPhaseConsts * sizeof(double) : 0) +
+    size_t b = (gtab ? 0 : N * sizeof(dev_surface)) + Wn * N * sizeof(double) +
+               ((phase && !gtab) ? Wn * N * kPhaseConsts * sizeof(double) : 0) +
+               ((gtab && aplist) ? N * ROX_MAX_AP * sizeof(double) : 0) +
                ((size_t)s->n_wvls + N) * sizeof(double) + 2 * N * sizeof(int32_t);
     if (fast)       // mu and mu^2 per (wavelength row, interface) behind the slot map
         b += Wn * 2 * N * sizeof(double);
@@ -547,7 +551,10 @@ void launch_feat(int inst, const LaunchCfg &k, const TraceArgs &a)
                              launch_aplist, launch_evenap, launch_general};
     static const fn fast[] = {launch_lean_fast, launch_even_fast, launch_radial_fast, launch_poly_fast,
                               launch_aplist_fast, launch_evenap_fast, launch_general_fast};
-    (k.fast ? fast : fns)[inst](k, a);
+    if (k.gtab)
+        launch_general_gtab(k, a);
+    else
+        (k.fast ? fast : fns)[inst](k, a);
 }
 
 void launch_feat_batch(int inst, const LaunchCfg &k, const TraceArgs *items)
@@ -559,7 +566,10 @@ void launch_feat_batch(int inst, const LaunchCfg &k, const TraceArgs *items)
     static const fn fast[] = {launch_lean_fast_batch, launch_even_fast_batch, launch_radial_fast_batch,
                               launch_poly_fast_batch, launch_aplist_fast_batch, launch_evenap_fast_batch,
                               launch_general_fast_batch};
-    (k.fast ? fast : fns)[inst](k, items);
+    if (k.gtab)
+        launch_general_gtab_batch(k, items);
+    else
+        (k.fast ? fast : fns)[inst](k, items);
 }
 
 // (initialisations are enqueued on the launch stream itself: a stream created with
@@ -649,6 +659,7 @@ int ensure_pack_scratch(StreamCtx *cx, int64_t rays, bool need_status)
     return 0;
 }
 
+constexpr size_t kLdsLimit = 160 * 1024 - 64;
 // the table pointers of a launch, the leanest kernel instance that covers this system and
 // these options, and its LDS need
 int launch_setup(rox_system *sys, TraceArgs &a, int gen, bool prw, hipStream_t st, LaunchCfg &k,
@@ -672,11 +683,32 @@ int launch_setup(rox_system *sys, TraceArgs &a, int gen, bool prw, hipStream_t s
     k.stream = st;
     inst = pick_instance(need);
     // (an instance compiled with F_PHASE stages the phase constants, needed or not)
-    k.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0, k.fast);
-    if (a.opts.out_mode == ROX_OUT_HITS_COMPACT)    // two tiles of packed pairs (rox_device.hpp)
-        k.lds += 16 + 2 * 16 * (size_t)block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]);
-    if (k.lds > 160 * 1024 - 64)
-        return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS (max 163776)", k.lds);
+    const size_t stash = a.opts.out_mode == ROX_OUT_HITS_COMPACT    // two tiles of packed pairs (rox_device.hpp)
+                             ? 16 + 2 * 16 * (size_t)block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]) : 0;
+    const bool fast_gtab = k.fast && ROX_FAST_GTAB;
+    k.gtab = false;
+    k.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0, k.fast, fast_gtab,
+                      (kInstances[inst] & F_APLIST) != 0) + stash;
+    // A table that does not fit the LDS of a workgroup (~220 interfaces at 736 B a row) is traced
+    // by the general instance that leaves it in global memory and reads it with scalar loads
+    // (F_GTAB; bit-identical, every output mode): SequentialModel has no size limit either.
+    // ROX_FORCE_GTAB=1 sends every launch there (tests; read once).
+    static const bool force_gtab = [] {
+        const char *e = getenv("ROX_FORCE_GTAB");
+        return e && *e && atoi(e) != 0;
+    }();
+    if (k.lds > kLdsLimit || force_gtab) {
+        inst = (int)(sizeof kInstances / sizeof kInstances[0]) - 1;
+        k.fast = false;
+        k.gtab = true;
+        k.lds = lds_bytes(sys, prw, true, false, true, true) +
+                (a.opts.out_mode == ROX_OUT_HITS_COMPACT
+                     ? 16 + 2 * 16 * (size_t)block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]) : 0);
+        if (k.lds > kLdsLimit)
+            return fail(ROX_E_UNSUPPORTED, "%d interfaces x %d wavelengths need %zu B of LDS for their "
+                                           "indices and thresholds alone (max %zu)",
+                        sys->n_ifcs, prw ? sys->n_wvls : 1, k.lds, kLdsLimit);
+    }
     return 0;
 }
 
@@ -777,7 +809,9 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
             h.out.status = out0.status ? out0.status + base : cx->d_pack_status;
             LaunchCfg kh = k;
             kh.out_mode = ROX_OUT_HITS;
-            kh.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0, kh.fast);
+            kh.lds = k.gtab ? lds_bytes(sys, prw, true, false, true, true)
+                            : lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0, kh.fast, kh.fast && ROX_FAST_GTAB,
+                                        (kInstances[inst] & F_APLIST) != 0);
             const int hb = block_of(ROX_OUT_HITS, kInstances[inst], kh.small);
             int64_t hblocks = (a.n_rays + hb - 1) / hb;
             const int64_t hcap = (int64_t)sys->num_cus * blocks_per_cu(hb);

@@ -1,0 +1,110 @@
+"""-m gpu, round 6: tables beyond the LDS of a workgroup (the general instance over a table left
+in global memory, read with scalar loads: rox_device.hpp F_GTAB) -- a SequentialModel has no
+size limit (rayoptics/seq/sequential.py:167-202), round 5 returned ROX_E_UNSUPPORTED beyond
+~220 interfaces -- and the same instance forced onto the regular fixtures."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from rayoptics_amd import SurfaceTable, abi
+from rayoptics_amd.table import field_struct
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPOT = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+
+
+def long_chain(n_lenses, rng):
+    """object at infinity, n_lenses weak singlets (every fifth a conic, every seventh an even
+    asphere, every ninth with a clear-aperture list, one mirror pair in the middle would fold
+    the axis -- left out: the chain stays on one axis), image surface: 2 n_lenses + 2 interfaces"""
+    surfs = [dict(cv=0.0, thi=1.0e10, n=1.0, max_aperture=1e12)]
+    for k in range(n_lenses):
+        front = dict(cv=1 / 103.0, thi=4.0, n=[1.5168, 1.5200, 1.5140], max_aperture=14.0)
+        if k % 5 == 1:
+            front.update(profile='Conic', cc=-0.6)
+        if k % 7 == 2:
+            front.update(profile='EvenPolynomial', cc=-0.2, coefs=[0.0, 1e-7, -2e-10])
+        surfs.append(front)
+        surfs.append(dict(cv=-1 / 103.0, thi=46.0, n=1.0, max_aperture=14.0))
+    surfs.append(dict(cv=0.0, thi=0.0, n=1.0, max_aperture=50.0))
+    tbl = SurfaceTable.from_prescription(surfs, wvls=(587.6, 486.1, 656.3), stop_idx=1)
+    for k in range(3, n_lenses, 9):             # clear-aperture lists (a circle and an obscuration)
+        row = tbl.rows[1 + 2 * k]
+        row.n_ap = 2
+        for ap, (obsc, ox, oy, rad) in zip(row.ap, ((0, 0.1, -0.05, 13.0), (1, 0.0, 0.2, 0.4))):
+            ap.kind, ap.is_obscuration, ap.x_offset, ap.y_offset, ap.a, ap.b = abi.AP_CIRCULAR, obsc, ox, oy, rad, 0.0
+    return tbl
+
+
+@pytest.mark.parametrize('n_lenses', [150, 400])
+def test_tables_beyond_the_lds(n_lenses):
+    """302 and 802 interfaces (222 KB and 590 KB of rows: more than the 160 KiB of LDS): FULL
+    packets, hits, LAST and packed hits of a pupil grid, explicit rays with per-ray wavelengths,
+    a batch of (field, wavelength) grids -- every one bit-identical to the oracle"""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid
+    rng = np.random.default_rng(n_lenses)
+    tbl = long_chain(n_lenses, rng)
+    N = tbl.n_ifcs
+    assert N == 2 * n_lenses + 2 and N * 736 > 160 * 1024
+    eng = TraceEngine(tbl)
+    flds = [field_struct([0.0, -1.0e10 * np.tan(np.deg2rad(t)), 0.0], (0., 0.), 9.0, 1.0e10)
+            for t in (0.0, 0.05)]
+    num = 40
+    grid = make_grid((-1., -1.), (1., 1.), num)
+    ogrid = oracle.make_grid((-1., -1.), (1., 1.), num)
+    n_ok = 0
+    for mode in (abi.OUT_FULL, abi.OUT_HITS, abi.OUT_LAST):
+        opts = make_opts(flags=SPOT, out_mode=mode, first_surf=1, last_surf=N - 2, foc=0.01)
+        dev = eng.trace_pupil_grid(flds[1], grid, 1, opts, nan_fill=True).to_host()
+        orc = oracle.trace_pupil_grid(tbl, flds[1], ogrid, 1, opts)
+        np.testing.assert_array_equal(dev.status, orc.status)
+        np.testing.assert_array_equal(dev.fail_surf, orc.fail_surf)
+        H.bit_equal(dev.seg, orc.seg, f'{N} interfaces mode {mode}')
+        H.bit_equal(dev.op, orc.op, 'op')
+        n_ok = int((orc.status == abi.OK).sum())
+        assert 100 < n_ok < num * num
+    oc = make_opts(flags=SPOT, out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2, foc=0.01)
+    xy = eng.trace_pupil_grid_hits(flds[1], grid, 1, oc)
+    H.bit_equal(xy, oracle.trace_pupil_grid(tbl, flds[1], ogrid, 1, oc).hits, 'packed hits')
+    # explicit rays, per-ray wavelengths
+    R = 900
+    pt0 = np.stack([rng.uniform(-8, 8, R), rng.uniform(-8, 8, R), np.full(R, -50.0)])
+    d = np.stack([rng.uniform(-.01, .01, R), rng.uniform(-.01, .01, R), np.ones(R)])
+    d /= np.linalg.norm(d, axis=0)
+    wi = rng.integers(0, 3, R).astype(np.int32)
+    opts = make_opts(flags=abi.CHECK_APERTURES, out_mode=abi.OUT_FULL, first_surf=1, last_surf=N - 2)
+    dev = eng.trace_rays(pt0, d, wi, opts, nan_fill=True).to_host()
+    orc = oracle.trace_rays(tbl, pt0, d, wi, opts)
+    np.testing.assert_array_equal(dev.status, orc.status)
+    H.bit_equal(dev.seg, orc.seg, 'explicit rays')
+    H.bit_equal(dev.op, orc.op, 'explicit rays op')
+    # the batched entry: two fields x three wavelengths in one launch
+    pairs = [(fi, w) for fi in range(2) for w in range(3)]
+    ol = [make_opts(flags=SPOT, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2, foc=0.01) for _ in pairs]
+    res = eng.trace_pupil_grids([flds[fi] for fi, _ in pairs], [w for _, w in pairs], grid, ol, nan_fill=True)
+    for (fi, w), o, r in zip(pairs, ol, res):
+        orc = oracle.trace_pupil_grid(tbl, flds[fi], ogrid, w, o)
+        b = r.to_host()
+        np.testing.assert_array_equal(b.status, orc.status)
+        H.bit_equal(b.seg, orc.seg, f'batched f{fi} w{w}')
+    eng.close()
+
+
+def test_the_global_table_instance_on_the_regular_fixtures():
+    """ROX_FORCE_GTAB=1 (read once by the library: a subprocess) sends every trace launch through
+    the general instance over the global table: the parity, configuration and batch tests --
+    every fixture, every output mode, phase elements, phantom filtering -- pass unchanged"""
+    env = dict(os.environ, ROX_FORCE_GTAB='1')
+    files = ['tests/test_gpu_parity.py', 'tests/test_gpu_configs.py', 'tests/test_gpu_batch.py',
+             'tests/test_gpu_r02.py']
+    p = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider'] + files,
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
+    assert ' passed' in p.stdout
