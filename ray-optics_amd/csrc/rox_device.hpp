@@ -863,29 +863,29 @@ __device__ __forceinline__ v3 rotate_f(P rt, const v3 &v)
               fma(rt[8], v.z, fma(rt[7], v.y, rt[6] * v.x))};
 }
 
-// raytrace.py:19-30 with mu = n_in / n_out, mu2 = mu^2 and a unit normal:
-//   d_out = mu d + (sign(cosI) sqrt(1 - mu^2 (1 - cosI^2)) - mu cosI) n
-__device__ __forceinline__ bool refract_f(const v3 &d, const v3 &n, double mu, double mu2, v3 &out)
+// raytrace.py:19-38 with a unit normal, ONE formula for every interact mode, straight-line:
+//   d_out = mu d + (sg sign(cosI) sqrt(1 - mu^2 (1 - cosI^2)) - mu cosI) n
+//   transmit  mu = n_in / n_out, sg = +1          (bend)
+//   reflect   mu = 1, sg = -1: the root is |cosI|, d_out = d - 2 cosI n   (reflect)
+//   dummy / phantom  mu = 1, sg = +1: the bracket is |cosI| sign(cosI) - cosI = 0, d_out = d
+// (mu, mu^2, sg) are staged per (wavelength, interface) by the workgroup.  Returns false where
+// the radicand is negative (total internal reflection; out is NaN there).
+__device__ __forceinline__ bool interact_f(const v3 &d, const v3 &n, double mu, double mu2, double sg,
+                                           v3 &out)
 {
     const double c = dot3_f(d, n);
     const double rad = fma(mu2, fma(c, c, -1.0), 1.0);
-    if (rad < 0.0)
-        return false;
-    const double alpha = fma(-mu, c, copysign(sqrt_f(rad), c));
+    const double alpha = fma(sg, copysign(sqrt_f(rad), c), -(mu * c));
     out = v3{fma(alpha, n.x, mu * d.x), fma(alpha, n.y, mu * d.y), fma(alpha, n.z, mu * d.z)};
-    return true;
-}
-
-// raytrace.py:33-38 with a unit normal
-__device__ __forceinline__ v3 mirror_f(const v3 &d, const v3 &n)
-{
-    const double k = -2.0 * dot3_f(d, n);
-    return v3{fma(k, n.x, d.x), fma(k, n.y, d.y), fma(k, n.z, d.z)};
+    return !(rad < 0.0);
 }
 
 // profiles.py:321-336 / 580-593.  The reference's outcomes for a vanishing denominator
 // (FloatingPointError -> s = 0 for a finite non-zero numerator, NaN for 0/0 unless all three
 // coefficients vanish) are kept by one wave-uniform test.
+// Straight-line: a negative radicand does not leave -- the lane's s and hit become NaN (the
+// seed of sqrt_f is NaN for it) and the caller reads the returned flag.  A branch here costs a
+// saved exec mask and, where the paths meet again, a register copy per live value.
 __device__ __forceinline__ bool quadric_hit_f(bool conic, double cv, double cc, double ec,
                                               const v3 &p, const v3 &d, double z_dir,
                                               double &s, v3 &hit)
@@ -902,8 +902,6 @@ __device__ __forceinline__ bool quadric_hit_f(bool conic, double cv, double cc, 
         b = fma(cv, fma(ez, d.z, fma(d.y, p.y, d.x * p.x)), -d.z);
     }
     const double rad = fma(-ax2, cx2, b * b);
-    if (rad < 0.0)
-        return false;                           // TraceMissedSurfaceError
     const double den = fma(z_dir, sqrt_f(rad), -b);
     s = cx2 * rcp_f(den);
     if (__builtin_amdgcn_ballot_w64(den == 0.0) != 0) {
@@ -917,7 +915,7 @@ __device__ __forceinline__ bool quadric_hit_f(bool conic, double cv, double cc, 
         }
     }
     hit = v3{fma(s, d.x, p.x), fma(s, d.y, p.y), fma(s, d.z, p.z)};
-    return true;
+    return !(rad < 0.0);                        // false: TraceMissedSurfaceError
 }
 
 // f(p), df(p) of EvenPolynomial / RadialPolynomial (profiles.py:849-885, 1070-1113), Horner
@@ -1342,7 +1340,7 @@ struct CtxT {
     tblp wvls;              // [W]
     tbli slot, nslots_before;
     tblp apthr;             // [N] sqrt_le_threshold(max_aperture + fuzz)
-    tblp mu;                // F_FAST only: per wavelength row [N] n_in / n_out, [N] its square
+    tblp mu;                // F_FAST only: per wavelength row [N] mu, [N] mu^2, [N] sg (interact_f)
     int N;
     bool check_ap, intersect_obj, filter_ph;
     int first_surf, last_surf;
@@ -1629,7 +1627,7 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
     const int N = c.N;
     const auto tbl = c.tbl;
     tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
-    tblp muw = PER_RAY_WVL ? c.mu + (size_t)wi * 2 * N : c.mu;      // [N] mu, [N] mu^2
+    tblp muw = PER_RAY_WVL ? c.mu + (size_t)wi * 3 * N : c.mu;      // [N] mu, [N] mu^2, [N] sg
 
     // The object surface and the transfer to interface 1 keep the REFERENCE's arithmetic
     // (trace_ray()'s operations in its order, correctly rounded): an object at infinity sits
@@ -1672,7 +1670,13 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
     }
     double z_dir_before = tbl[O_ZDIR];
     double opl = 0.0, phs = 0.0;
-    v3 inc{0, 0, 0}, nrm{0, 0, 0}, ad = dir0;
+    // The loop body is straight-line per lane: a missed surface, a blocked ray or a total
+    // internal reflection is a FLAG -- the arithmetic behind it runs on (NaN for a negative
+    // radicand), and the iteration ends with one status select and one exit test.  `inc` and
+    // `ad` are the loop-carried point and direction themselves (the reference's before_pt /
+    // before_dir): a lane that fails leaves with values nobody reads (every consumer asks its
+    // status first), so nothing has to be copied aside for it.
+    v3 inc = bp, nrm{0, 0, 0}, ad = dir0;
     e.ray1_p = e.rayk_p = e.rayk_d = e.probe_p = v3{0, 0, 0};
 
     for (int surf = 1; surf < N && status == ROX_OK; ++surf) {
@@ -1686,12 +1690,11 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
         v3 pp = pp1, b4d = b4d1;
         double pp_dst = pp_dst1;
         if (surf > 1) {
-            const v3 dp{bp.x - prow[O_T], bp.y - prow[O_T + 1], bp.z - prow[O_T + 2]};
-            v3 b4p = dp;
-            b4d = bd;
-            if ((ints_of(prow)[5] & 2) == 0) {   // (identity rotations are flagged on the device row)
-                b4p = rotate_f(prow + O_RT, dp);
-                b4d = rotate_f(prow + O_RT, bd);
+            v3 b4p{inc.x - prow[O_T], inc.y - prow[O_T + 1], inc.z - prow[O_T + 2]};
+            b4d = ad;
+            if ((ints_of(prow)[5] & 2) == 0) {  // (identity rotations are flagged on the device row)
+                b4p = rotate_f(prow + O_RT, b4p);
+                b4d = rotate_f(prow + O_RT, ad);
             }
             pp_dst = -dot3_f(b4p, b4d);
             pp = v3{fma(pp_dst, b4d.x, b4p.x), fma(pp_dst, b4d.y, b4p.y), fma(pp_dst, b4d.z, b4p.z)};
@@ -1700,78 +1703,76 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
         // :181-183 intersect
         double s;
         v3 df;
-        bool ok;
+        bool hit;
         if (thin) {
             s = -pp.z * rcp_f(b4d.z);
             inc = v3{fma(s, b4d.x, pp.x), fma(s, b4d.y, pp.y), fma(s, b4d.z, pp.z)};
-            ok = true;
+            hit = true;
         } else if (!kPoly || prof <= ROX_CONIC) {
-            ok = quadric_hit_f(prof == ROX_CONIC, cv, row[O_CC], row[O_EC], pp, b4d, z_dir_before, s, inc);
+            hit = quadric_hit_f(prof == ROX_CONIC, cv, row[O_CC], row[O_EC], pp, b4d, z_dir_before, s, inc);
         } else {
-            ok = newton_hit_f<FEAT>(prof, cv, row[O_CC] + 1.0, row[O_EC], row[O_CR],
-                                    ints_of(row)[2], row + O_COEF, pp, b4d, c.eps, s, inc, df);
+            hit = newton_hit_f<FEAT>(prof, cv, row[O_CC] + 1.0, row[O_EC], row[O_CR],
+                                     ints_of(row)[2], row + O_COEF, pp, b4d, c.eps, s, inc, df);
         }
-        if (!ok) {                                  // :231-237
-            status = ROX_MISSED_SURFACE;
-            fail_surf = surf;
-            break;
-        }
-        // :193-194 (in_gap_range, :123-132)
+        // :193-194 (in_gap_range, :123-132); a ray that missed keeps the path it had (:231-237)
         {
             const int g = surf - 1;
             const bool in_gap = !(c.last_surf >= 0 && c.first_surf == c.last_surf) &&
                                 g >= c.first_surf && (c.last_surf < 0 || g < c.last_surf);
-            if (in_gap)
-                opl = fma(nwl[surf - 1], pp_dst + s, opl);
+            if (in_gap) {
+                const double opl_new = fma(nwl[surf - 1], pp_dst + s, opl);
+                opl = hit ? opl_new : opl;
+            }
         }
 
         // :196 normal = normalize(df(inc_pt)); a sphere's gradient has unit length on the sphere
         if (thin) {
             nrm = v3{0., 0., 1.};
         } else if (!kPoly || prof <= ROX_CONIC) {
-            if (prof == ROX_CONIC) {
-                const double k = (row[O_CC] + 1.0) * cv;
-                nrm = unit_f(v3{-cv * inc.x, -cv * inc.y, fma(-k, inc.z, 1.0)});
-            } else {
-                nrm = v3{-cv * inc.x, -cv * inc.y, fma(-cv, inc.z, 1.0)};
-            }
+            const double k = (prof == ROX_CONIC) ? (row[O_CC] + 1.0) * cv : cv;     // (wave-uniform)
+            nrm = v3{-cv * inc.x, -cv * inc.y, fma(-k, inc.z, 1.0)};
+            if (prof == ROX_CONIC)
+                nrm = unit_f(nrm);
         } else {
             nrm = unit_f(df);
         }
 
         // :198-202 aperture test (in_surface_range, :134-142)
+        bool blocked = false;
         if (c.check_ap && surf >= c.first_surf && (c.last_surf < 0 || surf <= c.last_surf) &&
             mode != ROX_PHANTOM) {
             const int n_ap = (FEAT & F_APLIST) ? ints_of(row)[3] : 0;
-            const bool in = n_ap > 0
-                ? inside_aperture_list(row, n_ap, inc.x, inc.y, c.fuzz,
-                                       c.aplthr ? c.aplthr + (size_t)surf * ROX_MAX_AP : nullptr)
-                : fma(inc.y, inc.y, inc.x * inc.x) <= c.apthr[surf];
-            if (!in)
-                status = ROX_BLOCKED;               // :247-251
+            blocked = n_ap > 0
+                ? !inside_aperture_list(row, n_ap, inc.x, inc.y, c.fuzz,
+                                        c.aplthr ? c.aplthr + (size_t)surf * ROX_MAX_AP : nullptr)
+                : !(fma(inc.y, inc.y, inc.x * inc.x) <= c.apthr[surf]);
         }
 
         // :205-221 phase element (the exact code: rare), or refract / reflect / pass through
-        if (status == ROX_OK) {
-            if ((FEAT & F_PHASE) && ints_of(row + O_PH)[0] != ROX_PH_NONE) {
+        bool tir = false;
+        int ph_fail = ROX_OK;
+        if ((FEAT & F_PHASE) && ints_of(row + O_PH)[0] != ROX_PH_NONE) {
+            if (hit && !blocked) {
                 double dW = 0.0;
                 const auto pc = c.phc + ((PER_RAY_WVL ? (size_t)wi * N : 0) + surf) * kPhaseConsts;
+                v3 out = ad;
                 const int rc = apply_phase(row + O_PH, pc, inc, b4d, nrm, z_dir_before,
-                                           c.wvls[wi], nwl[surf - 1], nwl[surf], mode, ad, dW);
+                                           c.wvls[wi], nwl[surf - 1], nwl[surf], mode, out, dW);
+                ad = out;
                 if (rc == PHASE_OK)
                     phs += dW;
                 else
-                    status = (rc == PHASE_TIR) ? ROX_TIR : ROX_EVANESCENT;    // :253-257
-            } else if (mode == ROX_REFLECT) {
-                ad = mirror_f(b4d, nrm);
-            } else if (mode == ROX_TRANSMIT) {
-                if (!refract_f(b4d, nrm, muw[surf], muw[N + surf], ad))
-                    status = ROX_TIR;               // :239-245
-            } else {
-                ad = b4d;
+                    ph_fail = (rc == PHASE_TIR) ? ROX_TIR : ROX_EVANESCENT;       // :253-257
             }
+        } else {
+            tir = !interact_f(b4d, nrm, muw[surf], muw[N + surf], muw[2 * N + surf], ad);   // :239-245
         }
-        if (status != ROX_OK) {
+        // :231-257 the first failure in the reference's order: miss, blocked, TIR / evanescent
+        const int st = !hit ? (int)ROX_MISSED_SURFACE
+                     : blocked ? (int)ROX_BLOCKED
+                     : tir ? (int)ROX_TIR : ph_fail;
+        if (st != ROX_OK) {
+            status = st;
             fail_surf = surf;
             break;
         }
@@ -1783,7 +1784,6 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
                 e.rayk_d = ad;
             }
         }
-        bp = inc; bd = ad;
         z_dir_before = row[O_ZDIR];
     }
     e.status = status;
@@ -1995,13 +1995,13 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
     double *aplthr_w = apthr_w + N;                     // [N][ROX_MAX_AP] (F_GTAB with F_APLIST)
     int32_t *slot_w = reinterpret_cast<int32_t *>(
         aplthr_w + ((kGtab && (FEAT & F_APLIST)) ? (size_t)N * ROX_MAX_AP : 0));
-    // F_FAST: mu = n_in / n_out and mu^2 per (wavelength row, interface), behind the slot map
+    // F_FAST: (mu, mu^2, sg) of interact_f per (wavelength row, interface), behind the slot map
     // (2 N int32 = 8 N bytes behind an 8-byte aligned start: aligned as it stands -- a pointer
     // rounded through an integer loses its LDS address space and is read with flat loads)
     double *mu_w = reinterpret_cast<double *>(slot_w + 2 * N);
     // HITS_COMPACT: two tiles' worth of packed (x, y) pairs behind them, 16-byte aligned: the
     // offset is rounded in doubles (lds is 16-byte aligned, every region before is whole doubles)
-    double *end_w = mu_w + (kFast ? (size_t)nw_rows * 2 * N : 0);
+    double *end_w = mu_w + (kFast ? (size_t)nw_rows * 3 * N : 0);
     d2 *stash_w = reinterpret_cast<d2 *>(lds + (((size_t)(end_w - lds) + 1) & ~size_t(1)));
 
     // stage the surface table once per workgroup
@@ -2015,9 +2015,12 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
         if (kFast)
             for (int i = threadIdx.x; i < nw_rows * N; i += kB) {
                 const int w = i / N, sf = i - w * N;
-                const double m = sf > 0 ? a.n_table[w0 + i - 1] / a.n_table[w0 + i] : 1.0;
-                mu_w[(size_t)w * 2 * N + sf] = m;
-                mu_w[(size_t)w * 2 * N + N + sf] = m * m;
+                // (mode of the interface: rox_surface.mode is the row's first word)
+                const int md = reinterpret_cast<const int32_t *>(a.rows + (size_t)sf * kRowDoubles)[0];
+                const double m = (sf > 0 && md == ROX_TRANSMIT) ? a.n_table[w0 + i - 1] / a.n_table[w0 + i] : 1.0;
+                mu_w[(size_t)w * 3 * N + sf] = m;
+                mu_w[(size_t)w * 3 * N + N + sf] = m * m;
+                mu_w[(size_t)w * 3 * N + 2 * N + sf] = (md == ROX_REFLECT) ? -1.0 : 1.0;
             }
         if ((FEAT & F_PHASE) && !kGtab)
             for (int i = threadIdx.x; i < nw_rows * N * kPhaseConsts; i += kB)

@@ -329,8 +329,8 @@ size_t lds_bytes(const rox_system *s, bool per_ray_wvl, bool phase, bool fast, b
                ((phase && !gtab) ? Wn * N * kPhaseConsts * sizeof(double) : 0) +
                ((gtab && aplist) ? N * ROX_MAX_AP * sizeof(double) : 0) +
                ((size_t)s->n_wvls + N) * sizeof(double) + 2 * N * sizeof(int32_t);
-    if (fast)       // mu and mu^2 per (wavelength row, interface) behind the slot map
-        b += Wn * 2 * N * sizeof(double);
+    if (fast)       // (mu, mu^2, sg) per (wavelength row, interface) behind the slot map
+        b += Wn * 3 * N * sizeof(double);
     return (b + 15) & ~size_t(15);
 }
 
