@@ -1654,8 +1654,10 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
                 ok = quadric_hit(prof == ROX_CONIC, row[O_CV], row[O_CC], row[O_EC], pt0, dir0,
                                  row[O_ZDIR], s_, bp);
             } else {
-                ok = newton_hit<FEAT & ~F_FAST>(prof, row[O_CV], row[O_CC] + 1.0, row[O_EC], row[O_CR],
-                                                ints_of(row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
+                // (an aspheric OBJECT surface -- never at infinity -- takes the tolerance-mode
+                // iteration: the exact one would set the register budget of the whole kernel)
+                ok = newton_hit_f<FEAT>(prof, row[O_CV], row[O_CC] + 1.0, row[O_EC], row[O_CR],
+                                        ints_of(row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
             }
             if (!ok) {
                 status = ROX_MISSED_SURFACE;
@@ -1679,26 +1681,16 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
     v3 inc = bp, nrm{0, 0, 0}, ad = dir0;
     e.ray1_p = e.rayk_p = e.rayk_d = e.probe_p = v3{0, 0, 0};
 
-    for (int surf = 1; surf < N && status == ROX_OK; ++surf) {
-        const auto prow = tbl + (size_t)(surf - 1) * kRowDoubles;
+    // one interface, from the closest approach `pp` (at distance pp_dst along b4d from the previous
+    // intersection) on; false = the ray ends here.  Inlined twice: for interface 1, whose transfer
+    // was made above in the reference's arithmetic, and in the loop -- so that the three vectors of
+    // that first transfer are not carried, 14 registers wide, through every later interface.
+    auto interface = [&](const int surf, const v3 &pp, const v3 &b4d, const double pp_dst)
+        __attribute__((always_inline)) -> bool {
         const auto row = tbl + (size_t)surf * kRowDoubles;
         const int mode = ints_of(row)[0], prof = ints_of(row)[1];
         const double cv = row[O_CV];
         const bool thin = (FEAT & F_PHASE) && prof == ROX_THINLENS;
-
-        // :170-174 transform to the new vertex frame, closest approach to its origin
-        v3 pp = pp1, b4d = b4d1;
-        double pp_dst = pp_dst1;
-        if (surf > 1) {
-            v3 b4p{inc.x - prow[O_T], inc.y - prow[O_T + 1], inc.z - prow[O_T + 2]};
-            b4d = ad;
-            if ((ints_of(prow)[5] & 2) == 0) {  // (identity rotations are flagged on the device row)
-                b4p = rotate_f(prow + O_RT, b4p);
-                b4d = rotate_f(prow + O_RT, ad);
-            }
-            pp_dst = -dot3_f(b4p, b4d);
-            pp = v3{fma(pp_dst, b4d.x, b4p.x), fma(pp_dst, b4d.y, b4p.y), fma(pp_dst, b4d.z, b4p.z)};
-        }
 
         // :181-183 intersect
         double s;
@@ -1774,7 +1766,7 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
         if (st != ROX_OK) {
             status = st;
             fail_surf = surf;
-            break;
+            return false;
         }
         if (OUT_MODE == ROX_OUT_OPD || OUT_MODE == ROX_OUT_FAN) {
             if (surf == 1)
@@ -1785,6 +1777,24 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
             }
         }
         z_dir_before = row[O_ZDIR];
+        return true;
+    };
+
+    if (status == ROX_OK && N > 1 && interface(1, pp1, b4d1, pp_dst1)) {
+        for (int surf = 2; surf < N; ++surf) {
+            // :170-174 transform to the new vertex frame, closest approach to its origin
+            const auto prow = tbl + (size_t)(surf - 1) * kRowDoubles;
+            v3 b4p{inc.x - prow[O_T], inc.y - prow[O_T + 1], inc.z - prow[O_T + 2]};
+            v3 b4d = ad;
+            if ((ints_of(prow)[5] & 2) == 0) {  // (identity rotations are flagged on the device row)
+                b4p = rotate_f(prow + O_RT, b4p);
+                b4d = rotate_f(prow + O_RT, ad);
+            }
+            const double pp_dst = -dot3_f(b4p, b4d);
+            const v3 pp{fma(pp_dst, b4d.x, b4p.x), fma(pp_dst, b4d.y, b4p.y), fma(pp_dst, b4d.z, b4p.z)};
+            if (!interface(surf, pp, b4d, pp_dst))
+                break;
+        }
     }
     e.status = status;
     e.fail_surf = fail_surf;

@@ -263,8 +263,14 @@ def test_bench_launches_its_own_ranks():
     assert 'configs[4]' in b['config']['workload']
     # both exchanges are timed with the exchange inside the timed region; the headline is the faster
     h = b['strong_headline']
-    assert set(h['ms_per_step_by_exchange']) == {'rccl', 'host'} and not h['errors']
-    assert h['exchange'] == min(h['ms_per_step_by_exchange'], key=h['ms_per_step_by_exchange'].get)
+    # (+ the gather alone -- the pairs left in rank 0's HBM: north_star's "RCCL gather over xGMI" --
+    # beside them, never the headline)
+    assert set(h['ms_per_step_by_exchange']) == {'rccl', 'host', 'rccl_device'} and not h['errors']
+    to_host = {k: v for k, v in h['ms_per_step_by_exchange'].items() if k != 'rccl_device'}
+    assert h['exchange'] == min(to_host, key=to_host.get)
+    assert b['rccl_gather_only_ms'] == h['ms_per_step_by_exchange']['rccl_device']
+    assert b['preflight']['ok'] and list(b['preflight']['steps_ms']) == [
+        'all_gather_on_side_stream', 'grouped_isend_irecv_to_rank0', 'all_reduce_fence']
     assert b['config']['exchange'].startswith(h['exchange'])
     assert b['ms_per_step'] == pytest.approx(h['ms_per_step_by_exchange'][h['exchange']])
     assert b['config']['rays_per_step'] == 45 * 192 * 192
