@@ -32,7 +32,7 @@ def _guard(ours, theirs):
     return call
 
 
-def install(fallback='raise'):
+def install(fallback='raise', tolerance_mode=None):
     import rayoptics.raytr.raytrace as rraytrace
     import rayoptics.raytr.trace as rtrace
     import rayoptics.raytr.analyses as ranalyses
@@ -43,6 +43,8 @@ def install(fallback='raise'):
     if _saved:
         uninstall()
     session.FALLBACK = fallback
+    if tolerance_mode is not None:      # session.TOLERANCE_MODE: ROX_FAST_FP64 on every launch
+        session.set_tolerance_mode(tolerance_mode)
     seams = [(rraytrace, 'trace', _t.raytrace_trace),
              (rraytrace, 'trace_raw', _t.raytrace_trace_raw),
              (rtrace, 'trace_grid', _t.trace_grid), (rtrace, 'trace_fan', _t.trace_fan),

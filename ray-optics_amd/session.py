@@ -37,10 +37,24 @@ import weakref
 from .table import SurfaceTable
 
 FALLBACK = 'raise'
+# TOLERANCE_MODE = True: every launch the drop-in layer makes carries ROX_FAST_FP64
+# (include/roxtrace.h): the reduced-output modes -- spot diagrams, wavefront grids, ray fans,
+# 'last'-filtered traces -- run on the tolerance-mode kernels (results within 1e-10 of the
+# reference instead of bit-identical, about twice as fast); FULL ray packets stay bit-exact.
+# Set by ``rayoptics_amd.install(tolerance_mode=True)`` or :func:`set_tolerance_mode`.
+TOLERANCE_MODE = False
 MAX_ENGINES = 16            # device handles kept alive (least recently used out first)
 _cache = {}                 # id(seq_model) -> _Entry, in LRU order
 _lock = threading.RLock()
 _engine_factory = None      # None -> engine.TraceEngine (the HIP path)
+
+
+def set_tolerance_mode(on=True):
+    """opt in to (or out of) the tolerance-mode kernels for the reduced-output modes; returns the
+    previous setting"""
+    global TOLERANCE_MODE
+    was, TOLERANCE_MODE = TOLERANCE_MODE, bool(on)
+    return was
 
 
 def _set_engine_factory(factory):

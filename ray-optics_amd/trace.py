@@ -50,6 +50,8 @@ def opts_from_kwargs(n_ifcs, kwargs, out_mode, foc=0.0, image_pt=(0., 0.), wf=No
         flags |= abi.FILTER_PHANTOMS
     if kwargs.get('apply_vignetting', False):
         flags |= abi.APPLY_VIGNETTING
+    if session.TOLERANCE_MODE:                  # (the library takes it for reduced-output modes only)
+        flags |= abi.FAST_FP64
     last = kwargs.get('last_surf', n_ifcs - 2)
     fuzz = kwargs.get('pt_inside_fuzz', None)
     return make_opts(flags=flags, out_mode=out_mode,

@@ -122,3 +122,52 @@ def test_the_engine_behind_the_drop_ins_is_the_hip_library(ref, installed):
     with open('/proc/self/maps') as f:
         maps = f.read()
     assert 'libroxtrace.so' in maps
+
+
+# ---------------------------------------------------------------- tolerance mode through the drop-ins
+@pytest.mark.parametrize('model', ['dblgauss', 'nikkor', 'rc_telescope', 'zmx_evenasph_c3', 'cell_phone'])
+def test_tolerance_mode_figures_within_1e_10_of_the_reference(ref, installed, model):
+    """rayoptics_amd.install(tolerance_mode=True): the reference's own SpotDiagramFigure (packed
+    hits), Wavefront grid (OPD epilogue) and RayFanFigure data come from the ROX_FAST_FP64
+    kernels -- every number within 1e-10 * max(1, |reference|) of the un-installed reference's,
+    the survivor counts identical (north_star's tolerance; the default path is bit-exact)"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    from rayoptics.mpl.axisarrayfigure import SpotDiagramFigure, RayFanFigure
+    from rayoptics_amd import session
+    opm = getattr(ref, model)()
+
+    def run():
+        out = []
+        fig = plt.figure(FigureClass=SpotDiagramFigure, opt_model=opm, num_rays=24)
+        fig.update_data()
+        out += [np.array(g, dtype=float) for row in fig.axis_data_array for g in row[0][0]]
+        plt.close(fig)
+        for dt in ('Ray', 'OPD'):
+            fig = plt.figure(FigureClass=RayFanFigure, opt_model=opm, data_type=dt, num_rays=21)
+            fig.update_data()
+            for row in fig.axis_data_array:
+                for fan in row:
+                    for curve in fan[0]:
+                        out.append(np.array(curve[0], dtype=float))
+                        out.append(np.array(curve[1], dtype=float))
+            plt.close(fig)
+        return out
+    was = session.set_tolerance_mode(True)
+    try:
+        ours, theirs = both(installed, run)
+    finally:
+        session.set_tolerance_mode(was)
+    assert len(ours) == len(theirs) and len(ours) > 6
+    worst, n = 0.0, 0
+    for a, b in zip(ours, theirs):
+        assert a.shape == b.shape
+        m = np.isfinite(b)
+        assert np.array_equal(m, np.isfinite(a))
+        if m.any():
+            worst = max(worst, float((np.abs(a[m] - b[m]) / np.maximum(1.0, np.abs(b[m]))).max()))
+            n += int(m.sum())
+    assert n > 1000 and worst <= 1e-10, (model, worst)
+    import helpers as H
+    H.record('tolerance_mode_figures_vs_live_reference', model=model, values=n, worst_scaled_error=worst)
