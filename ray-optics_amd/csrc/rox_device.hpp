@@ -1607,6 +1607,232 @@ __device__ __forceinline__ void trace_ray(const CTX &c, const SegOut &so, const 
     e.inc = inc; e.ad = ad; e.nrm = nrm;
 }
 
+// ------------------------------------------------------------------ one ray, reduced outputs, exact
+// trace_ray() for the reduced-output modes (LAST, HITS, packed hits, OPD, FAN) in the loop shape
+// the tolerance-mode kernels showed to pay (trace_ray_fast below): the arithmetic is trace_ray()'s,
+// operation for operation -- so every bit of every output is the same -- but a missed surface, a
+// blocked ray or a total internal reflection is a FLAG the iteration ends on, not a way out of
+// the middle of it.  The operations behind a raised flag run on (on NaN where a radicand was
+// negative) in lanes nobody reads any more: no saved exec masks inside the iteration, no
+// register copies where paths meet, and the incidence point / direction are the loop-carried
+// before_pt / before_dir themselves.  FULL packets (segment stores, the late append of
+// raytrace.py:185-191, phantom filtering) and MODE_PROBE stay with trace_ray().
+#ifndef ROX_REDUCED_STRAIGHT     // 0: the reduced-output modes of the exact instances keep trace_ray()
+#define ROX_REDUCED_STRAIGHT 1
+#endif
+
+// profiles.py:321-336 / 580-593 as quadric_root() / quadric_hit() compute them, without the early exit
+__device__ __forceinline__ bool quadric_hit_sl(bool conic, double cv, double cc, double ec,
+                                               const v3 &p, const v3 &d, double z_dir,
+                                               double &s, v3 &hit)
+{
+    double ax2, cx2, b;
+    if (!conic) {
+        ax2 = cv;
+        cx2 = cv * dot3(p, p) - 2 * p.z;
+        b = cv * dot3(d, p) - d.z;
+    } else {
+        ax2 = cv * (1. + cc * d.z * d.z);
+        cx2 = cv * (p.x * p.x + p.y * p.y + ec * p.z * p.z) - 2.0 * p.z;
+        b = cv * (d.x * p.x + d.y * p.y + ec * d.z * p.z) - d.z;
+    }
+    const double rad = b * b - ax2 * cx2;
+    const double den = z_dir * slim_sqrt(rad) - b;      // (NaN where rad < 0: flagged below)
+    double sq = cx2 / den;
+    // np.errstate(divide='raise') -> FloatingPointError -> s = 0 only for a finite non-zero
+    // numerator; 0/0 and nan/0 stay NaN; all three coefficients zero: s = 0 without dividing
+    if (den == 0.0 && cx2 != 0.0 && isfinite(cx2))
+        sq = 0.0;
+    if (!((b != 0) || (cx2 != 0) || (ax2 != 0)))
+        sq = 0.0;
+    s = sq;
+    hit = v3{p.x + s * d.x, p.y + s * d.y, p.z + s * d.z};
+    return !(rad < 0.0) || !((b != 0) || (cx2 != 0) || (ax2 != 0));
+}
+
+// raytrace.py:19-30 as refract() computes it, without the early exit (false = TIR, out is NaN)
+__device__ __forceinline__ bool refract_sl(const v3 &d, const v3 &nrm, double n_in, double n_out, v3 &out)
+{
+    const double nlen = slim_sqrt(dot3(nrm, nrm));
+    const double cosI = dot3(d, nrm) / nlen;
+    const double sin2 = 1.0 - cosI * cosI;
+    const double rad = n_out * n_out - n_in * n_in * sin2;
+    const double n_cosIp = copysign(slim_sqrt(rad), cosI);
+    const double alpha = n_cosIp - n_in * cosI;
+    const v3 num{n_in * d.x + alpha * nrm.x, n_in * d.y + alpha * nrm.y, n_in * d.z + alpha * nrm.z};
+    out = slim_div3(num, n_out);
+    return !(rad < 0.0);
+}
+
+template <int OUT_MODE, bool PER_RAY_WVL, int FEAT, class CTX>
+__device__ __forceinline__ void trace_ray_reduced(const CTX &c, const v3 &pt0, const v3 &dir0, int wi,
+                                                  bool live, RayEnd &e)
+{
+    static_assert(OUT_MODE != ROX_OUT_FULL && OUT_MODE != MODE_PROBE, "reduced-output modes only");
+    constexpr int O_CV = offsetof(rox_surface, cv) / 8, O_CC = offsetof(rox_surface, cc) / 8,
+                  O_EC = offsetof(rox_surface, ec) / 8, O_CR = offsetof(rox_surface, cR) / 8,
+                  O_COEF = offsetof(rox_surface, coefs) / 8,
+                  O_RT = offsetof(rox_surface, rt) / 8, O_T = offsetof(rox_surface, t) / 8,
+                  O_ZDIR = offsetof(rox_surface, z_dir) / 8,
+                  O_PH = offsetof(rox_surface, ph) / 8;
+    constexpr bool kPoly = (FEAT & F_POLY) != 0;
+    const int N = c.N;
+    const auto tbl = c.tbl;
+    tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
+
+    // ---- object surface, raytrace.py:145-158 (before_normal is only ever stored: not needed)
+    int status = live ? ROX_OK : 255, fail_surf = -1;
+    v3 inc = pt0, ad = dir0, nrm{0, 0, 0};
+    if (live && c.intersect_obj) {
+        const auto row = tbl;
+        const int prof = ints_of(row)[1];
+        double s_;
+        v3 df, bp;
+        bool ok;
+        if ((FEAT & F_PHASE) && prof == ROX_THINLENS) {     // thinlens.py:131-134
+            s_ = -pt0.z / dir0.z;
+            bp = v3{pt0.x + s_ * dir0.x, pt0.y + s_ * dir0.y, pt0.z + s_ * dir0.z};
+            ok = true;
+        } else if (!kPoly || prof <= ROX_CONIC) {
+            ok = quadric_hit(prof == ROX_CONIC, row[O_CV], row[O_CC], row[O_EC], pt0, dir0,
+                             row[O_ZDIR], s_, bp);
+        } else {
+            ok = newton_hit<FEAT>(prof, row[O_CV], row[O_CC] + 1.0, row[O_EC], row[O_CR],
+                                  ints_of(row)[2], row + O_COEF, pt0, dir0, c.eps, s_, bp, df);
+        }
+        if (!ok) {                          // raised outside the try block: no packet
+            status = ROX_MISSED_SURFACE;
+            fail_surf = 0;
+        } else {
+            inc = bp;
+        }
+    }
+    double z_dir_before = tbl[O_ZDIR];
+    double opl = 0.0, phs = 0.0;
+    e.ray1_p = e.rayk_p = e.rayk_d = e.probe_p = v3{0, 0, 0};
+
+    // ---- remaining surfaces, raytrace.py:164-229
+    for (int surf = 1; surf < N && status == ROX_OK; ++surf) {
+        const auto prow = tbl + (size_t)(surf - 1) * kRowDoubles;     // `before`
+        const auto row = tbl + (size_t)surf * kRowDoubles;             // `after`
+        const int mode = ints_of(row)[0], prof = ints_of(row)[1];
+        const double cv = row[O_CV];
+        const bool thin = (FEAT & F_PHASE) && prof == ROX_THINLENS;
+
+        // :170-174 transform to the new vertex frame, closest approach (trace_ray(): the identity
+        // short cut under the same finiteness test, the dgemv chains otherwise)
+        const int rt_order = ints_of(prow)[4];
+        const v3 dp{inc.x - prow[O_T], inc.y - prow[O_T + 1], inc.z - prow[O_T + 2]};
+        v3 b4p, b4d;
+        if (ROX_IDENT_RT && (ints_of(prow)[5] & 2) != 0 &&
+            wave_all(__builtin_isfinite(((dp.x + dp.y) + dp.z) + ((ad.x + ad.y) + ad.z)))) {
+            b4p = v3{dp.x + 0.0, dp.y + 0.0, dp.z + 0.0};
+            b4d = v3{ad.x + 0.0, ad.y + 0.0, ad.z + 0.0};
+        } else {
+            b4p = rotate(prow + O_RT, rt_order, dp);
+            b4d = rotate(prow + O_RT, rt_order, ad);
+        }
+        const double pp_dst = -dot3(b4p, b4d);
+        const v3 pp{b4p.x + pp_dst * b4d.x, b4p.y + pp_dst * b4d.y, b4p.z + pp_dst * b4d.z};
+
+        // :181-183 intersect
+        double s;
+        v3 df;
+        bool hit;
+        if (thin) {
+            s = -pp.z / b4d.z;
+            inc = v3{pp.x + s * b4d.x, pp.y + s * b4d.y, pp.z + s * b4d.z};
+            hit = true;
+        } else if (!kPoly || prof <= ROX_CONIC) {
+            hit = quadric_hit_sl(prof == ROX_CONIC, cv, row[O_CC], row[O_EC], pp, b4d, z_dir_before, s, inc);
+        } else {
+            hit = newton_hit<FEAT>(prof, cv, row[O_CC] + 1.0, row[O_EC], row[O_CR],
+                                   ints_of(row)[2], row + O_COEF, pp, b4d, c.eps, s, inc, df);
+        }
+        // :193-194 (in_gap_range, :123-132); a ray that missed keeps the path it had (:231-237)
+        {
+            const int g = surf - 1;
+            const bool in_gap = !(c.last_surf >= 0 && c.first_surf == c.last_surf) &&
+                                g >= c.first_surf && (c.last_surf < 0 || g < c.last_surf);
+            if (in_gap) {
+                const double dst_b4 = pp_dst + s;
+                const double opl_new = opl + nwl[surf - 1] * dst_b4;
+                opl = hit ? opl_new : opl;
+            }
+        }
+
+        // :196 normal = normalize(df(inc_pt))
+        if (thin) {
+            nrm = v3{0., 0., 1.};
+        } else {
+            if (!kPoly || prof <= ROX_CONIC) {
+                const double k = (prof == ROX_CONIC) ? (row[O_CC] + 1.0) * cv : cv;
+                const double ncv = row[O_CR];       // -cv as df forms it (roxtrace.hip, device row)
+                df = v3{ncv * inc.x, ncv * inc.y, 1.0 - k * inc.z};
+            }
+            nrm = unit(df);
+        }
+
+        // :198-202 aperture test (in_surface_range, :134-142)
+        bool blocked = false;
+        if (c.check_ap && surf >= c.first_surf && (c.last_surf < 0 || surf <= c.last_surf) &&
+            mode != ROX_PHANTOM) {
+            const int n_ap = (FEAT & F_APLIST) ? ints_of(row)[3] : 0;
+            blocked = n_ap > 0
+                ? !inside_aperture_list(row, n_ap, inc.x, inc.y, c.fuzz,
+                                        c.aplthr ? c.aplthr + (size_t)surf * ROX_MAX_AP : nullptr)
+                : !((inc.x * inc.x + inc.y * inc.y) <= c.apthr[surf]);
+        }
+
+        // :205-221 phase element, or refract / reflect / pass through (wave-uniform branches)
+        bool tir = false;
+        int ph_fail = ROX_OK;
+        if ((FEAT & F_PHASE) && ints_of(row + O_PH)[0] != ROX_PH_NONE) {
+            if (hit && !blocked) {
+                double dW = 0.0;
+                const auto pc = c.phc + ((PER_RAY_WVL ? (size_t)wi * N : 0) + surf) * kPhaseConsts;
+                v3 out = ad;
+                const int rc = apply_phase(row + O_PH, pc, inc, b4d, nrm, z_dir_before,
+                                           c.wvls[wi], nwl[surf - 1], nwl[surf], mode, out, dW);
+                ad = out;
+                if (rc == PHASE_OK)
+                    phs += dW;
+                else
+                    ph_fail = (rc == PHASE_TIR) ? ROX_TIR : ROX_EVANESCENT;       // :253-257
+            }
+        } else if (mode == ROX_REFLECT) {
+            ad = mirror(b4d, nrm);
+        } else if (mode == ROX_TRANSMIT) {
+            tir = !refract_sl(b4d, nrm, nwl[surf - 1], nwl[surf], ad);              // :239-245
+        } else {
+            ad = b4d;
+        }
+        // :231-257 the first failure in the reference's order: miss, blocked, TIR / evanescent
+        const int st = !hit ? (int)ROX_MISSED_SURFACE
+                     : blocked ? (int)ROX_BLOCKED
+                     : tir ? (int)ROX_TIR : ph_fail;
+        if (st != ROX_OK) {
+            status = st;
+            fail_surf = surf;
+            break;
+        }
+        if (OUT_MODE == ROX_OUT_OPD || OUT_MODE == ROX_OUT_FAN) {
+            if (surf == 1)
+                e.ray1_p = inc;
+            if (surf == N - 2) {
+                e.rayk_p = inc;
+                e.rayk_d = ad;
+            }
+        }
+        z_dir_before = row[O_ZDIR];
+    }
+    e.status = status;
+    e.fail_surf = fail_surf;
+    e.opl = opl;
+    e.phs = phs;
+    e.inc = inc; e.ad = ad; e.nrm = nrm;
+}
+
 // ------------------------------------------------------------------ one ray, tolerance mode
 // trace_ray() for the F_FAST instances: the same loop (raytrace.py:83-264) over the same table,
 // reduced-output modes only -- no packet stores, hence no segment bookkeeping -- with the
@@ -2156,6 +2382,8 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
         }
         if constexpr (kFast)
             trace_ray_fast<OUT_MODE, PER_RAY_WVL, FEAT>(c, pt0, dir0, wi, active, e);
+        else if constexpr (ROX_REDUCED_STRAIGHT && OUT_MODE != ROX_OUT_FULL)
+            trace_ray_reduced<OUT_MODE, PER_RAY_WVL, FEAT>(c, pt0, dir0, wi, active, e);
         else
             trace_ray<OUT_MODE, PER_RAY_WVL, FEAT>(c, so, pt0, dir0, wi, active, e);
         if (active) {
