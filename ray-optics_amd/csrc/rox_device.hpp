@@ -2734,6 +2734,7 @@ ROX_SEARCH_DECL(radial)
 ROX_SEARCH_DECL(aplist)
 ROX_SEARCH_DECL(evenap)
 ROX_SEARCH_DECL(general)
+ROX_SEARCH_DECL(general_gtab)
 #undef ROX_SEARCH_DECL
 
 }  // namespace rox

@@ -19,27 +19,84 @@
 
 namespace rox {
 
-template <int FEAT>
-__global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
+// The table of a search kernel's workgroup (64 threads): staged in LDS -- every wavelength's
+// indices and phase constants, the trial rays carry their own wavelength index -- or, for the
+// F_GTAB instance (tables beyond the LDS), left in global memory and read with scalar loads,
+// with only the indices, the slot map and the aperture thresholds of the checked trace in LDS.
+// ap_fuzz < 0: the kernel's trial rays never test apertures (no thresholds staged).
+template <int FEAT, class ARGS>
+__device__ __forceinline__ auto search_ctx(const ARGS &a, double *lds, double ap_fuzz)
 {
+    constexpr bool kGtab = (FEAT & F_GTAB) != 0;
+    typedef typename std::conditional<kGtab, ctblp, tblp>::type TP;
     const int N = a.n_ifcs, W = a.n_wvls;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     double *tbl_w = lds;
-    double *ntab_w = tbl_w + (size_t)N * kRowDoubles;
+    double *ntab_w = tbl_w + (kGtab ? 0 : (size_t)N * kRowDoubles);
     double *phc_w = ntab_w + (size_t)W * N;
-    double *wvls_w = phc_w + (size_t)W * N * kPhaseConsts;
+    double *wvls_w = phc_w + (kGtab ? 0 : (size_t)W * N * kPhaseConsts);
     int32_t *slot_w = reinterpret_cast<int32_t *>(wvls_w + W);
-    for (int i = threadIdx.x; i < N * kRowDoubles; i += 64)
-        tbl_w[i] = a.rows[i];
+    double *apthr_w = reinterpret_cast<double *>(slot_w + 2 * N);      // [N]
+    double *aplthr_w = apthr_w + N;                                     // [N][ROX_MAX_AP] (F_GTAB)
+    if (!kGtab) {
+        for (int i = threadIdx.x; i < N * kRowDoubles; i += 64)
+            tbl_w[i] = a.rows[i];
+        for (int i = threadIdx.x; i < W * N * kPhaseConsts; i += 64)
+            phc_w[i] = a.ph_consts[i];
+    }
     for (int i = threadIdx.x; i < W * N; i += 64)
         ntab_w[i] = a.n_table[i];
-    for (int i = threadIdx.x; i < W * N * kPhaseConsts; i += 64)
-        phc_w[i] = a.ph_consts[i];
     for (int i = threadIdx.x; i < W; i += 64)
         wvls_w[i] = a.wvls[i];
     for (int i = threadIdx.x; i < 2 * N; i += 64)
         slot_w[i] = a.slots[i];
+    if (ap_fuzz >= 0.0) {
+        // the sqrt-free aperture thresholds of the checked trace, behind the slot map
+        for (int i = threadIdx.x; i < N; i += 64)
+            apthr_w[i] = sqrt_le_threshold(
+                a.rows[(size_t)i * kRowDoubles + offsetof(rox_surface, max_aperture) / 8] + ap_fuzz);
+        if (kGtab && (FEAT & F_APLIST))
+            for (int i = threadIdx.x; i < N * ROX_MAX_AP; i += 64) {
+                const double *row = a.rows + (size_t)(i / ROX_MAX_AP) * kRowDoubles;
+                const int k = i % ROX_MAX_AP;
+                double t = 0.0;
+                if (k < reinterpret_cast<const int32_t *>(row)[3]) {
+                    const double *ap = row + offsetof(rox_surface, ap) / sizeof(double) +
+                                       (size_t)k * (sizeof(rox_aperture) / sizeof(double));
+                    if (reinterpret_cast<const int32_t *>(ap)[0] == ROX_AP_CIRCULAR)
+                        t = sqrt_le_threshold(ap[3] + ap_fuzz);
+                }
+                aplthr_w[i] = t;
+            }
+    }
     __syncthreads();
+    if (!kGtab && (FEAT & F_APLIST) && ap_fuzz >= 0.0) {
+        stage_aperture_thresholds<FEAT>(tbl_w, N, ap_fuzz, threadIdx.x, 64);
+        __syncthreads();
+    }
+    CtxT<TP> c;
+    if constexpr (kGtab) {
+        c.tbl = (ctblp)a.rows;
+        c.phc = (ctblp)a.ph_consts;
+        c.aplthr = ((FEAT & F_APLIST) && ap_fuzz >= 0.0) ? aplthr_w : nullptr;
+    } else {
+        c.tbl = tbl_w;
+        c.phc = phc_w;
+        c.aplthr = nullptr;
+    }
+    c.ntab = ntab_w; c.wvls = wvls_w;
+    c.slot = slot_w; c.nslots_before = slot_w + N;
+    c.apthr = ap_fuzz >= 0.0 ? apthr_w : nullptr;
+    c.mu = nullptr;
+    c.N = N;
+    return c;
+}
+
+template <int FEAT>
+__global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
+{
+    const int N = a.n_ifcs;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    auto c = search_ctx<FEAT>(a, lds, -1.0);     // (the trial rays of the aiming never test apertures)
     // a.wave_per_problem (small batches: the fields of a model): every lane of the wave follows
     // the same problem -- problems in different phases of their iterations (the call sites of
     // the trace inside MINPACK's hybrd) then run side by side on different CUs instead of
@@ -49,12 +106,6 @@ __global__ void __launch_bounds__(64) aim_kernel(const AimArgs a)
         return;
     const rox_aim pb = a.probs[i];
 
-    Ctx c;
-    c.aplthr = nullptr;
-    c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
-    c.slot = slot_w; c.nslots_before = slot_w + N;
-    c.apthr = nullptr;          // (the trial rays of the aiming never test apertures)
-    c.N = N;
     c.check_ap = false; c.intersect_obj = true; c.filter_ph = false;    // raytrace.py:51-80, 83-99
     c.first_surf = 1; c.last_surf = N - 2;
     c.eps = a.eps; c.fuzz = 1e-5;
@@ -293,34 +344,10 @@ __device__ __forceinline__ double secant(F &f, F2 &f_two, double x0, double tol,
 template <int FEAT>
 __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
 {
-    const int N = a.n_ifcs, W = a.n_wvls;
+    const int N = a.n_ifcs;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *tbl_w = lds;
-    double *ntab_w = tbl_w + (size_t)N * kRowDoubles;
-    double *phc_w = ntab_w + (size_t)W * N;
-    double *wvls_w = phc_w + (size_t)W * N * kPhaseConsts;
-    int32_t *slot_w = reinterpret_cast<int32_t *>(wvls_w + W);
-    for (int i = threadIdx.x; i < N * kRowDoubles; i += 64)
-        tbl_w[i] = a.rows[i];
-    for (int i = threadIdx.x; i < W * N; i += 64)
-        ntab_w[i] = a.n_table[i];
-    for (int i = threadIdx.x; i < W * N * kPhaseConsts; i += 64)
-        phc_w[i] = a.ph_consts[i];
-    for (int i = threadIdx.x; i < W; i += 64)
-        wvls_w[i] = a.wvls[i];
-    for (int i = threadIdx.x; i < 2 * N; i += 64)
-        slot_w[i] = a.slots[i];
-    // the sqrt-free aperture thresholds of the checked trace
-    // (pt_inside_fuzz = 1e-4), behind the slot map
-    double *apthr_w = reinterpret_cast<double *>(slot_w + 2 * N);
-    for (int i = threadIdx.x; i < N; i += 64)
-        apthr_w[i] = sqrt_le_threshold(
-            a.rows[(size_t)i * kRowDoubles + offsetof(rox_surface, max_aperture) / 8] + 1e-4);
-    __syncthreads();
-    if (FEAT & F_APLIST) {      // (only the checked trace, fuzz 1e-4, tests apertures here)
-        stage_aperture_thresholds<FEAT>(tbl_w, N, 1e-4, threadIdx.x, 64);
-        __syncthreads();
-    }
+    // (only the checked trace, pt_inside_fuzz = 1e-4, tests apertures here)
+    auto c = search_ctx<FEAT>(a, lds, 1e-4);
     const int i = a.wave_per_problem ? (int)blockIdx.x : (int)(blockIdx.x * 64 + threadIdx.x);
     if (i >= a.n)
         return;
@@ -341,12 +368,6 @@ __global__ void __launch_bounds__(64) vig_kernel(const VigArgs a)
     const double unit_xy = xy == 0 ? pb.unit_dir[0] : pb.unit_dir[1];
     const double start_xy = xy == 0 ? pb.start_dir[0] : pb.start_dir[1];
 
-    Ctx c;
-    c.aplthr = nullptr;
-    c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
-    c.slot = slot_w; c.nslots_before = slot_w + N;
-    c.apthr = apthr_w;          // (checked trace only)
-    c.N = N;
     c.filter_ph = false;
     c.intersect_obj = pb.fld.kind != ROX_FLD_EPD_WIDE && pb.fld.z_dir0 != 0.0;     // trace.py:302-303
     c.first_surf = 1; c.last_surf = N - 2;
@@ -578,24 +599,9 @@ __device__ __forceinline__ double brentq(F &f, double xa, double xb, double xtol
 template <int FEAT>
 __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
 {
-    const int N = a.n_ifcs, W = a.n_wvls;
+    const int N = a.n_ifcs;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *tbl_w = lds;
-    double *ntab_w = tbl_w + (size_t)N * kRowDoubles;
-    double *phc_w = ntab_w + (size_t)W * N;
-    double *wvls_w = phc_w + (size_t)W * N * kPhaseConsts;
-    int32_t *slot_w = reinterpret_cast<int32_t *>(wvls_w + W);
-    for (int i = threadIdx.x; i < N * kRowDoubles; i += 64)
-        tbl_w[i] = a.rows[i];
-    for (int i = threadIdx.x; i < W * N; i += 64)
-        ntab_w[i] = a.n_table[i];
-    for (int i = threadIdx.x; i < W * N * kPhaseConsts; i += 64)
-        phc_w[i] = a.ph_consts[i];
-    for (int i = threadIdx.x; i < W; i += 64)
-        wvls_w[i] = a.wvls[i];
-    for (int i = threadIdx.x; i < 2 * N; i += 64)
-        slot_w[i] = a.slots[i];
-    __syncthreads();
+    auto c = search_ctx<FEAT>(a, lds, -1.0);
     // One WAVE per problem (round 4).  With one lane per problem the lanes of a wave sit in
     // different phases of the search -- the walk, find_edge, the secant iteration, brentq are
     // different call sites of the trace -- and the wave executes their union one after the
@@ -610,12 +616,6 @@ __global__ void __launch_bounds__(64) enp_kernel(const EnpArgs a)
     __shared__ double s_z[64], s_h[64];
     __shared__ int s_st[64], s_fs[64];
 
-    Ctx c;
-    c.aplthr = nullptr;
-    c.tbl = tbl_w; c.ntab = ntab_w; c.phc = phc_w; c.wvls = wvls_w;
-    c.slot = slot_w; c.nslots_before = slot_w + N;
-    c.apthr = nullptr;
-    c.N = N;
     c.check_ap = false; c.intersect_obj = false; c.filter_ph = false;   // intersect_obj=False
     c.first_surf = 1; c.last_surf = N - 2;
     c.eps = a.eps; c.fuzz = 1e-5;

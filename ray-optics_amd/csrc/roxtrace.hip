@@ -521,15 +521,44 @@ int pick_search_instance(const rox_system *sys)
 
 // surface table + index table + phase constants + wavelengths + slot map + the vignetting
 // search's aperture thresholds
-size_t search_lds_bytes(size_t N, size_t W)
+constexpr size_t kLdsLimit = 160 * 1024 - 64;
+// (rox_search.hpp search_ctx(); gtab: the table and the phase constants stay in global memory,
+// the circular clear-aperture thresholds of the checked trace get an array)
+size_t search_lds_bytes(size_t N, size_t W, bool gtab = false)
 {
-    return (N * sizeof(dev_surface) + W * N * sizeof(double) * (1 + kPhaseConsts) +
-            W * sizeof(double) + 2 * N * sizeof(int32_t) + N * sizeof(double) + 15) & ~size_t(15);
+    return ((gtab ? N * ROX_MAX_AP * sizeof(double)
+                  : N * sizeof(dev_surface) + W * N * sizeof(double) * kPhaseConsts) +
+            W * N * sizeof(double) + W * sizeof(double) + 2 * N * sizeof(int32_t) + N * sizeof(double) + 15) &
+           ~size_t(15);
+}
+
+// the LDS need of a search launch; gtab = the system's table does not fit the LDS of a
+// workgroup: the general instance over the table in global memory (search_general_gtab.hip)
+int search_lds(const rox_system *sys, size_t &lds, bool &gtab)
+{
+    const size_t N = sys->n_ifcs, W = sys->n_wvls;
+    static const bool force_gtab = [] {
+        const char *e = getenv("ROX_FORCE_GTAB");
+        return e && *e && atoi(e) != 0;
+    }();
+    lds = search_lds_bytes(N, W);
+    gtab = lds > kLdsLimit || force_gtab;
+    if (gtab) {
+        lds = search_lds_bytes(N, W, true);
+        if (lds > kLdsLimit)
+            return fail(ROX_E_UNSUPPORTED, "%zu interfaces x %zu wavelengths need %zu B of LDS for their "
+                                           "indices and thresholds alone (max %zu)", N, W, lds, kLdsLimit);
+    }
+    return 0;
 }
 
 #define ROX_SEARCH_DISPATCH(kind, Args)                                              \
-    void launch_##kind(const rox_system *sys, const Args &a, size_t lds, hipStream_t st) \
+    void launch_##kind(const rox_system *sys, const Args &a, size_t lds, bool gtab, hipStream_t st) \
     {                                                                                \
+        if (gtab) {                                                                  \
+            launch_##kind##_general_gtab(a, lds, st);                                \
+            return;                                                                  \
+        }                                                                            \
         switch (pick_search_instance(sys)) {                                         \
         case 0: launch_##kind##_lean(a, lds, st); break;                             \
         case 1: launch_##kind##_even(a, lds, st); break;                             \
@@ -659,7 +688,6 @@ int ensure_pack_scratch(StreamCtx *cx, int64_t rays, bool need_status)
     return 0;
 }
 
-constexpr size_t kLdsLimit = 160 * 1024 - 64;
 // the table pointers of a launch, the leanest kernel instance that covers this system and
 // these options, and its LDS need
 int launch_setup(rox_system *sys, TraceArgs &a, int gen, bool prw, hipStream_t st, LaunchCfg &k,
@@ -1620,10 +1648,10 @@ int rox_iterate_ray_raw(rox_system *sys, int32_t n, const rox_aim *probs, double
             return fail(ROX_E_ARG, "probs[%d].epsfcn %g", i, probs[i].epsfcn);
     }
     hipStream_t st = (hipStream_t)stream;
-    const size_t N = sys->n_ifcs, W = sys->n_wvls;
-    const size_t lds = search_lds_bytes(N, W);
-    if (lds > 160 * 1024 - 64)
-        return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
+    size_t lds;
+    bool gtab;
+    if (int rcl = search_lds(sys, lds, gtab))
+        return rcl;
     const size_t pb = up16(sizeof(rox_aim) * n), yb = up16(sizeof(double) * 2 * n), rb = up16(sizeof(int32_t) * n);
     std::lock_guard<std::mutex> lock(sys->search_mu);
     char *d = nullptr;
@@ -1642,7 +1670,7 @@ int rox_iterate_ray_raw(rox_system *sys, int32_t n, const rox_aim *probs, double
     a.last_status = last_xy ? (int32_t *)(d + pb + 2 * yb + rb) : nullptr;
     a.eps = eps;
     a.wave_per_problem = n <= kWavePerProblemMax;
-    launch_aim(sys, a, lds, st);
+    launch_aim(sys, a, lds, gtab, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
@@ -1679,10 +1707,10 @@ int rox_find_real_enp(rox_system *sys, int32_t n, const rox_enp *probs, double e
             return fail(ROX_E_ARG, "probs[%d].surf %d out of range", i, probs[i].surf);
     }
     hipStream_t st = (hipStream_t)stream;
-    const size_t N = sys->n_ifcs, W = sys->n_wvls;
-    const size_t lds = search_lds_bytes(N, W);
-    if (lds > 160 * 1024 - 64)
-        return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
+    size_t lds;
+    bool gtab;
+    if (int rcl = search_lds(sys, lds, gtab))
+        return rcl;
     const size_t pb = up16(sizeof(rox_enp) * n), zb = up16(sizeof(double) * 2 * n);
     std::lock_guard<std::mutex> lock(sys->search_mu);
     char *d = nullptr;
@@ -1698,7 +1726,7 @@ int rox_find_real_enp(rox_system *sys, int32_t n, const rox_enp *probs, double e
     a.z_out = (double *)(d + pb);
     a.result = (int32_t *)(d + pb + zb);
     a.eps = eps;
-    launch_enp(sys, a, lds, st);
+    launch_enp(sys, a, lds, gtab, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
@@ -1729,10 +1757,10 @@ int rox_iterate_pupil_rays(rox_system *sys, int32_t n, const rox_pupil_iter *pro
             return rc;
     }
     hipStream_t st = (hipStream_t)stream;
-    const size_t N = sys->n_ifcs, W = sys->n_wvls;
-    const size_t lds = search_lds_bytes(N, W);
-    if (lds > 160 * 1024 - 64)
-        return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
+    size_t lds;
+    bool gtab;
+    if (int rcl = search_lds(sys, lds, gtab))
+        return rcl;
     const size_t pb = up16(sizeof(rox_pupil_iter) * n);
     std::lock_guard<std::mutex> lock(sys->search_mu);
     char *d = nullptr;
@@ -1748,7 +1776,7 @@ int rox_iterate_pupil_rays(rox_system *sys, int32_t n, const rox_pupil_iter *pro
     a.vig = (double *)(d + pb);
     a.eps = eps;
     a.wave_per_problem = n <= kWavePerProblemMax;
-    launch_vig(sys, a, lds, st);
+    launch_vig(sys, a, lds, gtab, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);
@@ -1777,10 +1805,10 @@ int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs, double
             return rc;
     }
     hipStream_t st = (hipStream_t)stream;
-    const size_t N = sys->n_ifcs, W = sys->n_wvls;
-    const size_t lds = search_lds_bytes(N, W);
-    if (lds > 160 * 1024 - 64)
-        return fail(ROX_E_UNSUPPORTED, "surface table needs %zu B of LDS", lds);
+    size_t lds;
+    bool gtab;
+    if (int rcl = search_lds(sys, lds, gtab))
+        return rcl;
     const size_t pb = up16(sizeof(rox_vig) * n), vb = up16(sizeof(double) * n);
     std::lock_guard<std::mutex> lock(sys->search_mu);
     char *d = nullptr;
@@ -1797,7 +1825,7 @@ int rox_calc_vignetting(rox_system *sys, int32_t n, const rox_vig *probs, double
     a.clip = (int32_t *)(d + pb + vb);
     a.eps = eps;
     a.wave_per_problem = n <= kWavePerProblemMax;
-    launch_vig(sys, a, lds, st);
+    launch_vig(sys, a, lds, gtab, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);

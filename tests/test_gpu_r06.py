@@ -94,16 +94,28 @@ def test_tables_beyond_the_lds(n_lenses):
         b = r.to_host()
         np.testing.assert_array_equal(b.status, orc.status)
         H.bit_equal(b.seg, orc.seg, f'batched f{fi} w{w}')
+    # the search kernels over the same table (their trial rays read it through scalar loads too):
+    # chief-ray aiming at three wavelengths
+    probs = []
+    for w in range(3):
+        pa = abi.Aim()
+        pa.pt0[1] = -1.0e10 * np.tan(np.deg2rad(0.05))
+        pa.z_enp, pa.y_target, pa.z_dir0, pa.wvl_idx, pa.surf, pa.flip = 1.0e10, 0.0, 1.0, w, 1, 1
+        probs.append(pa)
+    y_dev, r_dev = eng.aim_chief_rays(probs)
+    y_orc, r_orc = oracle.aim_chief_rays(tbl, probs, 1e-12)
+    assert np.array_equal(r_dev, r_orc) and np.array_equal(y_dev, y_orc)
     eng.close()
 
 
 def test_the_global_table_instance_on_the_regular_fixtures():
     """ROX_FORCE_GTAB=1 (read once by the library: a subprocess) sends every trace launch through
-    the general instance over the global table: the parity, configuration and batch tests --
-    every fixture, every output mode, phase elements, phantom filtering -- pass unchanged"""
+    the general instance over the global table (the search kernels included): the parity,
+    configuration, batch, aiming / vignetting / wide-angle tests -- every fixture, every output
+    mode, phase elements, phantom filtering -- pass unchanged"""
     env = dict(os.environ, ROX_FORCE_GTAB='1')
     files = ['tests/test_gpu_parity.py', 'tests/test_gpu_configs.py', 'tests/test_gpu_batch.py',
-             'tests/test_gpu_r02.py']
+             'tests/test_gpu_r02.py', 'tests/test_gpu_r04.py']
     p = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider'] + files,
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1800)
     assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
