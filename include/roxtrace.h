@@ -70,7 +70,7 @@ extern "C" {
  * HIP runtime can wait for the asynchronous entries);  8 = ROX_FAST_FP64 (tolerance-mode
  * kernels for the reduced-output modes), rox_surface.flags validated by rox_system_create,
  * the dynamic symbol table is exactly this header's (+ roxtrace_diag.h's) functions and
- * DT_SONAME is libroxtrace.so.8.
+ * DT_SONAME is libroxtrace.so.8, rox_spot_stats.
  * rox_abi_version() of the library must equal the header a binding was written against. */
 #define ROX_ABI_VERSION 8
 #define ROX_MAX_COEF 10   /* EvenPolynomial r^2..r^20 / RadialPolynomial r^1..r^10 */
@@ -482,6 +482,29 @@ int rox_trace_pupil_list(rox_system *sys, const rox_field *fld,
                          int64_t n_rays, const double *px, const double *py,
                          int32_t wvl_idx, const rox_opts *opts,
                          const rox_out *out, void *stream);
+
+/* What a spot diagram's consumers reduce the image-plane hits to, computed on the device from
+ * the output of a ROX_OUT_HITS launch (layout ROX_SPOT_ROWS: seg = (x, y)[2][ld] + status, rays
+ * that did not reach the image skipped) or of a ROX_OUT_HITS_COMPACT launch (ROX_SPOT_PAIRS: seg
+ * = interleaved pairs, status NULL, the count read from n_hits on the device when given):
+ *   summary  count, sum x, sum y, sum x^2, sum y^2 (centroid, RMS spot radius), min / max of x and
+ *            y -- RayGeoPSF.ray_data_bounds (rayoptics/mpl/analysisfigure.py:237-248);
+ *   hist     optional [n_x_edges - 1][n_y_edges - 1] counts = numpy.histogram2d(x, y,
+ *            bins=[x_edges, y_edges]) as RayGeoPSF.plot's `ax.hist2d` calls it (:250-290):
+ *            edges[i] <= v < edges[i + 1], the last bin closed on the right, values outside
+ *            dropped.  x_edges / y_edges / summary / hist are HOST pointers; the call is
+ *            synchronous (two launches on `stream` + one synchronise).                      */
+enum { ROX_SPOT_ROWS = 0, ROX_SPOT_PAIRS = 1 };
+typedef struct rox_spot_summary {
+    int64_t n;               /* entries counted                                 */
+    double sum[2];           /* sum x, sum y                                    */
+    double sum_sq[2];        /* sum x^2, sum y^2                                */
+    double min[2], max[2];   /* +inf / -inf when n == 0                         */
+} rox_spot_summary;          /* 72 bytes */
+int rox_spot_stats(const double *seg, int64_t ld, const uint8_t *status, const int64_t *n_hits,
+                   int64_t n, int32_t layout, const double *x_edges, int32_t n_x_edges,
+                   const double *y_edges, int32_t n_y_edges, rox_spot_summary *summary,
+                   uint32_t *hist, void *stream);
 
 /* chief-ray aiming ------------------------------------------------------- */
 /* One problem per (field, wavelength): trace.iterate_ray

@@ -144,6 +144,15 @@ class Enp(C.Structure):
 ENP_FOUND, ENP_NO_CHIEF_RAY, ENP_REFERENCE_RAISES = 0, 1, 3
 
 
+class SpotSummary(C.Structure):
+    """rox_spot_summary: count, sums, sums of squares, min / max of the image-plane hits"""
+    _fields_ = [('n', C.c_int64), ('sum', C.c_double * 2), ('sum_sq', C.c_double * 2),
+                ('min', C.c_double * 2), ('max', C.c_double * 2)]
+
+
+SPOT_ROWS, SPOT_PAIRS = 0, 1
+
+
 class Vig(C.Structure):
     _fields_ = [('fld', Field), ('start_dir', C.c_double * 2), ('unit_dir', C.c_double * 2),
                 ('xy', C.c_int32), ('wvl_idx', C.c_int32), ('stop_surf', C.c_int32),
@@ -174,7 +183,8 @@ EXPORTS = ('rox_abi_version', 'rox_device_count', 'rox_set_device',
            'rox_trace_pupil_grid', 'rox_trace_pupil_grids', 'rox_trace_pupil_list',
            'rox_aim_chief_rays', 'rox_iterate_ray_raw', 'rox_find_real_enp', 'rox_calc_vignetting',
            'rox_iterate_pupil_rays', 'rox_calc_psf',
-           'rox_pin_host_memory', 'rox_unpin_host_memory', 'rox_copy_async', 'rox_synchronize')
+           'rox_pin_host_memory', 'rox_unpin_host_memory', 'rox_copy_async', 'rox_synchronize',
+           'rox_spot_stats')
 # ... and the measurement / self-test helpers of include/roxtrace_diag.h
 DIAG_EXPORTS = ('rox_time_pupil_grid', 'rox_selftest_fp64', 'rox_diag_pack_launches')
 
@@ -228,6 +238,8 @@ def declare(lib):
     lib.rox_copy_async.argtypes = [vp, vp, C.c_size_t, vp]
     lib.rox_synchronize.restype = C.c_int
     lib.rox_synchronize.argtypes = [vp]
+    lib.rox_spot_stats.restype = C.c_int
+    lib.rox_spot_stats.argtypes = [vp, i64, vp, vp, i64, i32, vp, i32, vp, i32, P(SpotSummary), vp, vp]
     lib.rox_time_pupil_grid.restype = C.c_int
     lib.rox_time_pupil_grid.argtypes = [vp, P(Field), P(Grid), i32, P(Opts),
                                         P(Out), vp, i32, P(dbl)]

@@ -812,6 +812,48 @@ class TraceEngine:
         return HitsPack(self.torch, self.device, cap, max_launches, dest)
 
     @_in_flight
+    def spot_stats(self, res, x_edges=None, y_edges=None):
+        """rox_spot_stats over the device-resident output of a ROX_OUT_HITS launch
+        (``res``: a DeviceResult of that mode -- rays that did not reach the image are skipped):
+        ``(summary, hist)`` with ``summary`` a dict (n, centroid, rms_radius about the centroid,
+        min / max per axis, the raw sums) and ``hist`` = numpy.histogram2d(x, y, bins=[x_edges,
+        y_edges])[0] as uint32 (None without edges).  Nothing but 72 bytes and the histogram
+        crosses PCIe (RayGeoPSF's 2-D histogram, rayoptics/mpl/analysisfigure.py:237-290)."""
+        if res.out_mode != abi.OUT_HITS:
+            raise EngineError('spot_stats reads the rows of a ROX_OUT_HITS launch')
+        return self._spot_stats(res.seg.data_ptr(), res.ld, res.status.data_ptr(), None, res.R,
+                                abi.SPOT_ROWS, x_edges, y_edges)
+
+    def _spot_stats(self, seg_ptr, ld, status_ptr, n_hits_ptr, n, layout, x_edges, y_edges):
+        summ = abi.SpotSummary()
+        hist = None
+        xe = ye = None
+        nxe = nye = 0
+        hp = None
+        if x_edges is not None:
+            xe = np.ascontiguousarray(x_edges, dtype=np.float64)
+            ye = np.ascontiguousarray(y_edges, dtype=np.float64)
+            nxe, nye = len(xe), len(ye)
+            hist = np.empty((nxe - 1, nye - 1), dtype=np.uint32)
+            hp = hist.ctypes.data
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.rox_spot_stats(seg_ptr, int(ld), status_ptr, n_hits_ptr, int(n), int(layout),
+                                           None if xe is None else xe.ctypes.data, nxe,
+                                           None if ye is None else ye.ctypes.data, nye,
+                                           C.byref(summ), hp, self._stream()), 'rox_spot_stats')
+        n_ok = int(summ.n)
+        out = {'n': n_ok, 'sum': (summ.sum[0], summ.sum[1]), 'sum_sq': (summ.sum_sq[0], summ.sum_sq[1]),
+               'min': (summ.min[0], summ.min[1]), 'max': (summ.max[0], summ.max[1])}
+        if n_ok:
+            cx, cy = summ.sum[0] / n_ok, summ.sum[1] / n_ok
+            var = (summ.sum_sq[0] + summ.sum_sq[1]) / n_ok - (cx * cx + cy * cy)
+            out['centroid'] = (cx, cy)
+            out['rms_radius'] = float(np.sqrt(max(var, 0.0)))
+        else:
+            out['centroid'], out['rms_radius'] = (float('nan'), float('nan')), float('nan')
+        return out, hist
+
+    @_in_flight
     def trace_pupil_grid_hits_append(self, fld, grid, wvl_idx, opts, pack):
         """enqueue one ROX_OUT_HITS_COMPACT | ROX_HITS_APPEND launch behind the pairs
         ``pack`` already holds; nothing is synchronised"""

@@ -482,6 +482,42 @@ def trace_grid_spot(opt_model, grid_rng, fld, wvl, foc, image_pt, **kwargs):
                                      wi, opts)
 
 
+def trace_grid_spot_stats(opt_model, grid_rng, fld, wvl, foc, image_pt, bins=None, **kwargs):
+    """What the consumers of a spot diagram reduce it to, without the spot leaving the device:
+    ``(summary, hist, x_edges, y_edges)`` of the transverse aberrations of the pupil grid --
+    ``summary``: n, centroid, rms_radius, min / max (RayGeoPSF.ray_data_bounds,
+    rayoptics/mpl/analysisfigure.py:237-248); ``hist``: ``numpy.histogram2d(x, y, bins=[x_edges,
+    y_edges])[0]`` as RayGeoPSF.plot's ``hist2d`` forms it (:250-290).  ``bins``: None (no
+    histogram), ``(x_edges, y_edges)``, or an int ``num`` -- RayGeoPSF's 'fit' scale: edges =
+    ``linspace`` over the larger half-extent of the data about (0, centre_y), ``num`` samples
+    per axis, made from the summary of a first pass (one launch, two tiny reductions).  A
+    ROX_OUT_HITS launch + rox_spot_stats: 72 bytes and the histogram cross PCIe."""
+    from .engine import DeviceResult
+    kwargs['check_apertures'] = True
+    kwargs['apply_vignetting'] = kwargs.get('apply_vignetting', True)
+    eng, f, wi, opts = _launch_setup(opt_model, fld, wvl, kwargs, abi.OUT_HITS, foc, image_pt[:2])
+    grid = make_grid(grid_rng[0], grid_rng[1], grid_rng[2])
+    R = grid_rng[2] * grid_rng[2]
+    res = DeviceResult(eng.torch, eng.device, 0, R, abi.OUT_HITS, want_pupil=False, nan_fill=False)
+    eng.trace_pupil_grid(f, grid, wi, opts, want_pupil=False, out=res)
+    if bins is None:
+        summ, _ = eng.spot_stats(res)
+        return summ, None, None, None
+    if isinstance(bins, int):
+        summ, _ = eng.spot_stats(res)
+        # analysisfigure.py:237-262 ('fit'): delta = (max - min) / 2, centre_y = (max_y + min_y) / 2
+        dx = (summ['max'][0] - summ['min'][0]) / 2
+        dy = (summ['max'][1] - summ['min'][1]) / 2
+        cy = (summ['max'][1] + summ['min'][1]) / 2
+        mv = dx if dx > dy else dy
+        x_edges = np.linspace(-mv, mv, num=bins)
+        y_edges = np.linspace(cy - mv, cy + mv, num=bins)
+    else:
+        x_edges, y_edges = bins
+    summ, hist = eng.spot_stats(res, x_edges, y_edges)
+    return summ, hist, np.asarray(x_edges), np.asarray(y_edges)
+
+
 def trace_grid_spots(opt_model, grid_rng, fld, wvls, foc, image_pt, **kwargs):
     """``trace_grid_spot`` for every wavelength of ``wvls`` in ONE launch
     (rox_trace_pupil_grids): the per-wavelength loop of SequentialModel.trace_grid

@@ -120,3 +120,108 @@ def test_the_global_table_instance_on_the_regular_fixtures():
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1800)
     assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
     assert ' passed' in p.stdout
+
+
+# ---------------------------------------------------------------- rox_spot_stats
+@pytest.mark.parametrize('name,num', [('dblgauss_c2', 300), ('rc_telescope_c4', 128), ('cell_phone', 200)])
+def test_spot_statistics_on_the_device(name, num):
+    """rox_spot_stats over a ROX_OUT_HITS launch == NumPy over the ORACLE's spot of the same grid:
+    the count, min / max (RayGeoPSF.ray_data_bounds, analysisfigure.py:237-248) exactly; the 2-D
+    histogram == numpy.histogram2d(x, y, bins=[x_edges, y_edges]) count for count, for RayGeoPSF's
+    own 'fit' edges (np.linspace over the data's half-extent, 100 samples) and for edges laid ON
+    data values (the closed right edge, values outside the range); centroid and RMS radius to
+    1e-12 (parallel sums).  The packed-pairs layout (ROX_OUT_HITS_COMPACT in HBM) gives the same."""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_opts, make_grid, DeviceResult
+    import torch
+    wl = workloads.load(name)
+    N = wl.n_ifcs
+    eng = TraceEngine(wl.table)
+    fi = len(wl.fields) - 1
+    fld = wl.fields[fi]
+    flags = SPOT if (fld.kind != abi.FLD_EPD_WIDE and fld.z_dir0 != 0.0) else SPOT & ~abi.INTERSECT_OBJ
+    grid = make_grid((-1., -1.), (1., 1.), num)
+    o = make_opts(flags=flags, out_mode=abi.OUT_HITS, first_surf=1, last_surf=N - 2, foc=wl.foc,
+                  image_pt=wl.image_pts[fi])
+    orc = oracle.trace_pupil_grid(wl.table, fld, oracle.make_grid((-1., -1.), (1., 1.), num), wl.ref_wvl_idx, o)
+    ok = orc.status == abi.OK
+    x, y = orc.seg[0][ok], orc.seg[1][ok]
+    assert len(x) > 1000
+    res = DeviceResult(torch, eng.device, 0, num * num, abi.OUT_HITS, want_pupil=False, nan_fill=False)
+    eng.trace_pupil_grid(fld, grid, wl.ref_wvl_idx, o, want_pupil=False, out=res)
+    summ, none = eng.spot_stats(res)
+    assert none is None and summ['n'] == len(x)
+    assert summ['min'] == (x.min(), y.min()) and summ['max'] == (x.max(), y.max())
+    assert abs(summ['centroid'][0] - x.mean()) <= 1e-12 * max(1.0, abs(x.mean()))
+    assert abs(summ['centroid'][1] - y.mean()) <= 1e-12 * max(1.0, abs(y.mean()))
+    rms = np.sqrt(np.mean((x - x.mean()) ** 2 + (y - y.mean()) ** 2))
+    assert abs(summ['rms_radius'] - rms) <= 1e-9 * max(rms, 1e-300) + 1e-15
+    # RayGeoPSF's 'fit' edges (analysisfigure.py:250-262)
+    dx, dy = (x.max() - x.min()) / 2, (y.max() - y.min()) / 2
+    cy = (y.max() + y.min()) / 2
+    mv = max(dx, dy)
+    cases = [(np.linspace(-mv, mv, num=100), np.linspace(cy - mv, cy + mv, num=100)),
+             (np.linspace(-mv, mv, num=257), np.linspace(cy - mv, cy + mv, num=257)),
+             # edges ON data values, a range that drops part of the data, uneven bins
+             (np.sort(np.concatenate([x[::997][:40], [x.max()]])), np.array([y.min(), np.median(y), y.max()])),
+             (np.array([np.median(x), x.max()]), np.linspace(y.min(), np.median(y), 7))]
+    for xe, ye in cases:
+        xe, ye = np.unique(xe), np.unique(ye)
+        want = np.histogram2d(x, y, bins=[xe, ye])[0]
+        s2, hist = eng.spot_stats(res, xe, ye)
+        assert s2['n'] == len(x)
+        np.testing.assert_array_equal(hist.astype(np.float64), want)
+        assert hist.sum() == want.sum() > 0
+    # the packed pairs of a ROX_OUT_HITS_COMPACT launch, device-resident, counted on the device
+    pack = eng.hits_pack(num * num, 1)
+    oc = make_opts(flags=flags | abi.HITS_APPEND, out_mode=abi.OUT_HITS_COMPACT, first_surf=1, last_surf=N - 2,
+                   foc=wl.foc, image_pt=wl.image_pts[fi])
+    eng.trace_pupil_grid_hits_append(fld, grid, wl.ref_wvl_idx, oc, pack)
+    xe, ye = cases[0]
+    s3, h3 = eng._spot_stats(pack.seg_ptr, pack.cap, None, pack.count.data_ptr(), num * num, abi.SPOT_PAIRS, xe, ye)
+    assert s3['n'] == len(x) and s3['min'] == summ['min'] and s3['max'] == summ['max']
+    np.testing.assert_array_equal(h3.astype(np.float64), np.histogram2d(x, y, bins=[xe, ye])[0])
+    eng.close()
+
+
+def test_spot_stats_product_call_and_its_wall_clock():
+    """rayoptics_amd.trace.trace_grid_spot_stats on a table-backed model: 1 048 576 rays -> summary +
+    RayGeoPSF's 100 x 100 'fit' histogram and a 256 x 256 one on the host; == NumPy over the
+    packed spot trace_grid_spot returns (itself the oracle's, bit for bit); the wall-clock of
+    both calls recorded"""
+    import time
+    import torch
+    from rayoptics_amd import workloads, trace as rox_trace
+    wl = workloads.load('dblgauss_c2')
+    model = workloads.TableModel(wl)
+    fi = 0
+    fld = model.fields[fi]
+    num = 1024
+    rng = [np.array([-1., -1.]), np.array([1., 1.]), num]
+    wvl = wl.table.wvls[wl.ref_wvl_idx]
+    xy = np.array(rox_trace.trace_grid_spot(model, rng, fld, wvl, wl.foc, wl.image_pts[fi]))
+    x, y = xy[:, 0], xy[:, 1]
+    for bins in (100, 257):
+        summ, hist, xe, ye = rox_trace.trace_grid_spot_stats(model, rng, fld, wvl, wl.foc, wl.image_pts[fi], bins=bins)
+        assert summ['n'] == len(x) and summ['min'] == (x.min(), y.min()) and summ['max'] == (x.max(), y.max())
+        np.testing.assert_array_equal(hist.astype(np.float64), np.histogram2d(x, y, bins=[xe, ye])[0])
+    t = {}
+    for what, fn in (('spot_to_host_ms', lambda: rox_trace.trace_grid_spot(model, rng, fld, wvl, wl.foc, wl.image_pts[fi])),
+                     ('stats_hist_257_ms', lambda: rox_trace.trace_grid_spot_stats(model, rng, fld, wvl, wl.foc,
+                                                                                   wl.image_pts[fi], bins=257)),
+                     ('stats_hist_given_edges_ms', lambda: rox_trace.trace_grid_spot_stats(
+                         model, rng, fld, wvl, wl.foc, wl.image_pts[fi], bins=(xe, ye))),
+                     ('stats_only_ms', lambda: rox_trace.trace_grid_spot_stats(model, rng, fld, wvl, wl.foc,
+                                                                               wl.image_pts[fi]))):
+        for _ in range(30):
+            fn()
+        ts = []
+        for _ in range(21):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        t[what] = float(np.median(ts))
+    H.record('spot_stats_wallclock_1M_rays', **t)
+    assert t['stats_only_ms'] < t['spot_to_host_ms']
