@@ -208,7 +208,8 @@ extern "C" int rox_spot_stats(const double *seg, int64_t ld, const uint8_t *stat
     const size_t b_copies = ((size_t)kCopies * bins * 4 + 255) & ~size_t(255);
     const size_t b_part = (size_t)blocks * 10 * 8;
     const size_t d_need = (want_hist ? b_edges + b_copies : 0) + b_part;
-    const size_t h_need = 256 + (size_t)bins * 4;
+    const size_t h_hist = (((size_t)bins * 4) + 255) & ~size_t(255);
+    const size_t h_need = 256 + h_hist + (want_hist ? b_edges : 0);
     std::lock_guard<std::mutex> lock(g_scratch.mu);
 #define SPOT_TRY(expr)                                                                   \
     do {                                                                                 \
@@ -242,10 +243,14 @@ extern "C" int rox_spot_stats(const double *seg, int64_t ld, const uint8_t *stat
         a.x = seg; a.y = seg + 1; a.stride = 2; a.status = nullptr;
     }
     if (want_hist) {
+        // the edges: into the pinned block, one stream-ordered DMA from there (a copy from the
+        // caller's pageable arrays would be staged by the runtime, synchronously)
         double *xe = (double *)d;
         double *ye = xe + n_x_edges;
-        SPOT_TRY(hipMemcpyAsync(xe, x_edges, sizeof(double) * n_x_edges, hipMemcpyHostToDevice, st));
-        SPOT_TRY(hipMemcpyAsync(ye, y_edges, sizeof(double) * n_y_edges, hipMemcpyHostToDevice, st));
+        double *he = (double *)(g_scratch.h + 256 + h_hist);
+        memcpy(he, x_edges, sizeof(double) * n_x_edges);
+        memcpy(he + n_x_edges, y_edges, sizeof(double) * n_y_edges);
+        SPOT_TRY(hipMemcpyAsync(xe, he, sizeof(double) * (n_x_edges + n_y_edges), hipMemcpyHostToDevice, st));
         a.xe = xe; a.ye = ye; a.nx = nx; a.ny = ny;
         a.copies = (uint32_t *)(d + b_edges);
         SPOT_TRY(hipMemsetAsync(a.copies, 0, (size_t)kCopies * bins * 4, st));

@@ -400,20 +400,24 @@ class ModelMemo:
     ``obj_coords``  the memo of ``osp.obj_coords(fld)`` (table._obj_coords: the reverse
                     chief-ray iteration of real-image-height fields, once per launch
                     instead of once per ray)
+    ``scratch``     device-resident launch outputs that product calls reduce on the device
+                    (trace.trace_grid_spot_stats)
 
     session.engine_for hands one engine to every thread that traces the same model: writers
     hold ``lock``."""
-    __slots__ = ('lock', 'chief_rays', 'obj_coords')
+    __slots__ = ('lock', 'chief_rays', 'obj_coords', 'scratch')
 
     def __init__(self):
         self.lock = threading.Lock()
         self.chief_rays = {}
         self.obj_coords = {}
+        self.scratch = {}       # device buffers the product calls reuse ({(thread, rays): DeviceResult})
 
     def clear(self):
         with self.lock:
             self.chief_rays.clear()
             self.obj_coords.clear()
+            self.scratch.clear()
 
 
 class TraceEngine:

@@ -22,6 +22,8 @@ the per-ray Python loop replaced by one device launch.
                                    fields aimed in one launch)
 Result filtering follows trace_safe, rayoptics/raytr/trace.py:160-221.
 """
+import threading
+
 import numpy as np
 
 from . import abi, session
@@ -498,7 +500,14 @@ def trace_grid_spot_stats(opt_model, grid_rng, fld, wvl, foc, image_pt, bins=Non
     eng, f, wi, opts = _launch_setup(opt_model, fld, wvl, kwargs, abi.OUT_HITS, foc, image_pt[:2])
     grid = make_grid(grid_rng[0], grid_rng[1], grid_rng[2])
     R = grid_rng[2] * grid_rng[2]
-    res = DeviceResult(eng.torch, eng.device, 0, R, abi.OUT_HITS, want_pupil=False, nan_fill=False)
+    # (the launch's rows stay on the device: one buffer per thread and size, kept on the engine)
+    key = (threading.get_ident(), R)
+    res = eng.memo.scratch.get(key)
+    if res is None:
+        if len(eng.memo.scratch) >= 8:
+            eng.memo.scratch.clear()
+        res = eng.memo.scratch[key] = DeviceResult(eng.torch, eng.device, 0, R, abi.OUT_HITS,
+                                                   want_pupil=False, nan_fill=False)
     eng.trace_pupil_grid(f, grid, wi, opts, want_pupil=False, out=res)
     if bins is None:
         summ, _ = eng.spot_stats(res)

@@ -223,5 +223,26 @@ def test_spot_stats_product_call_and_its_wall_clock():
             fn()
             ts.append((time.perf_counter() - t0) * 1e3)
         t[what] = float(np.median(ts))
+    # ... and with the tolerance-mode kernels behind the same calls (session.set_tolerance_mode)
+    from rayoptics_amd import session
+    was = session.set_tolerance_mode(True)
+    try:
+        for what, fn in (('tolerance_stats_only_ms', lambda: rox_trace.trace_grid_spot_stats(
+                              model, rng, fld, wvl, wl.foc, wl.image_pts[fi])),
+                         ('tolerance_stats_hist_given_edges_ms', lambda: rox_trace.trace_grid_spot_stats(
+                              model, rng, fld, wvl, wl.foc, wl.image_pts[fi], bins=(xe, ye)))):
+            for _ in range(30):
+                fn()
+            ts = []
+            for _ in range(21):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            t[what] = float(np.median(ts))
+        s_f, h_f, _, _ = rox_trace.trace_grid_spot_stats(model, rng, fld, wvl, wl.foc, wl.image_pts[fi], bins=(xe, ye))
+    finally:
+        session.set_tolerance_mode(was)
+    assert s_f['n'] == len(x) and abs(int(h_f.sum()) - int(hist.sum())) <= 2
     H.record('spot_stats_wallclock_1M_rays', **t)
     assert t['stats_only_ms'] < t['spot_to_host_ms']
