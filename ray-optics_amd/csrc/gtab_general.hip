@@ -6,9 +6,15 @@
 #include "rox_device.hpp"
 
 namespace rox {
+#if (ROX_GTAB_EXACT & 1)
+// (the general instance itself reads its table that way in this build: inst_general.hip)
+void launch_general_gtab(const LaunchCfg &k, const TraceArgs &a) { launch_general(k, a); }
+void launch_general_gtab_batch(const LaunchCfg &k, const TraceArgs *items) { launch_general_batch(k, items); }
+#else
 void launch_general_gtab(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_ALL | F_GTAB>(k, a); }
 void launch_general_gtab_batch(const LaunchCfg &k, const TraceArgs *items)
 {
     launch_instance_batch<F_ALL | F_GTAB>(k, items);
 }
+#endif
 }  // namespace rox

