@@ -4,9 +4,9 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_even_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_EVEN) | flavour_of(F_EVEN, true)>(k, a); }
+void launch_even_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_EVEN) | F_FAST>(k, a); }
 void launch_even_fast_batch(const LaunchCfg &k, const TraceArgs *items)
 {
-    launch_instance_batch<(F_EVEN) | flavour_of(F_EVEN, true)>(k, items);
+    launch_instance_batch<(F_EVEN) | F_FAST>(k, items);
 }
 }  // namespace rox

@@ -4,9 +4,9 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_evenap_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_EVEN | F_APLIST) | flavour_of(F_EVEN | F_APLIST, true)>(k, a); }
+void launch_evenap_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_EVEN | F_APLIST) | F_FAST>(k, a); }
 void launch_evenap_fast_batch(const LaunchCfg &k, const TraceArgs *items)
 {
-    launch_instance_batch<(F_EVEN | F_APLIST) | flavour_of(F_EVEN | F_APLIST, true)>(k, items);
+    launch_instance_batch<(F_EVEN | F_APLIST) | F_FAST>(k, items);
 }
 }  // namespace rox

@@ -4,9 +4,9 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_general_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_ALL) | flavour_of(F_ALL, true)>(k, a); }
+void launch_general_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_ALL) | F_FAST>(k, a); }
 void launch_general_fast_batch(const LaunchCfg &k, const TraceArgs *items)
 {
-    launch_instance_batch<(F_ALL) | flavour_of(F_ALL, true)>(k, items);
+    launch_instance_batch<(F_ALL) | F_FAST>(k, items);
 }
 }  // namespace rox

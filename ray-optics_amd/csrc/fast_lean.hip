@@ -4,9 +4,9 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_lean_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(0) | flavour_of(0, true)>(k, a); }
+void launch_lean_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(0) | F_FAST>(k, a); }
 void launch_lean_fast_batch(const LaunchCfg &k, const TraceArgs *items)
 {
-    launch_instance_batch<(0) | flavour_of(0, true)>(k, items);
+    launch_instance_batch<(0) | F_FAST>(k, items);
 }
 }  // namespace rox

@@ -4,9 +4,9 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_poly_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_POLY) | flavour_of(F_POLY, true)>(k, a); }
+void launch_poly_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_POLY) | F_FAST>(k, a); }
 void launch_poly_fast_batch(const LaunchCfg &k, const TraceArgs *items)
 {
-    launch_instance_batch<(F_POLY) | flavour_of(F_POLY, true)>(k, items);
+    launch_instance_batch<(F_POLY) | F_FAST>(k, items);
 }
 }  // namespace rox

@@ -4,9 +4,9 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_radial_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_RADIAL) | flavour_of(F_RADIAL, true)>(k, a); }
+void launch_radial_fast(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_RADIAL) | F_FAST>(k, a); }
 void launch_radial_fast_batch(const LaunchCfg &k, const TraceArgs *items)
 {
-    launch_instance_batch<(F_RADIAL) | flavour_of(F_RADIAL, true)>(k, items);
+    launch_instance_batch<(F_RADIAL) | F_FAST>(k, items);
 }
 }  // namespace rox

@@ -3,6 +3,6 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_aplist(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_APLIST) | flavour_of(F_APLIST, false)>(k, a); }
-void launch_aplist_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<(F_APLIST) | flavour_of(F_APLIST, false)>(k, items); }
+void launch_aplist(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_APLIST>(k, a); }
+void launch_aplist_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<F_APLIST>(k, items); }
 }  // namespace rox

@@ -3,6 +3,6 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_even(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_EVEN) | flavour_of(F_EVEN, false)>(k, a); }
-void launch_even_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<(F_EVEN) | flavour_of(F_EVEN, false)>(k, items); }
+void launch_even(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_EVEN>(k, a); }
+void launch_even_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<F_EVEN>(k, items); }
 }  // namespace rox

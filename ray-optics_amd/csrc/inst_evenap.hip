@@ -4,9 +4,9 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_evenap(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_EVEN | F_APLIST) | flavour_of(F_EVEN | F_APLIST, false)>(k, a); }
+void launch_evenap(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_EVEN | F_APLIST>(k, a); }
 void launch_evenap_batch(const LaunchCfg &k, const TraceArgs *items)
 {
-    launch_instance_batch<(F_EVEN | F_APLIST) | flavour_of(F_EVEN | F_APLIST, false)>(k, items);
+    launch_instance_batch<F_EVEN | F_APLIST>(k, items);
 }
 }  // namespace rox

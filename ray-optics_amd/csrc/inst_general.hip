@@ -3,6 +3,6 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_general(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_ALL) | flavour_of(F_ALL, false)>(k, a); }
-void launch_general_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<(F_ALL) | flavour_of(F_ALL, false)>(k, items); }
+void launch_general(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_ALL>(k, a); }
+void launch_general_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<F_ALL>(k, items); }
 }  // namespace rox

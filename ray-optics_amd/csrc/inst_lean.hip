@@ -3,6 +3,6 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_lean(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(0) | flavour_of(0, false)>(k, a); }
-void launch_lean_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<(0) | flavour_of(0, false)>(k, items); }
+void launch_lean(const LaunchCfg &k, const TraceArgs &a) { launch_instance<0>(k, a); }
+void launch_lean_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<0>(k, items); }
 }  // namespace rox

@@ -3,6 +3,6 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_poly(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_POLY) | flavour_of(F_POLY, false)>(k, a); }
-void launch_poly_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<(F_POLY) | flavour_of(F_POLY, false)>(k, items); }
+void launch_poly(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_POLY>(k, a); }
+void launch_poly_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<F_POLY>(k, items); }
 }  // namespace rox

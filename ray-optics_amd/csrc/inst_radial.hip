@@ -3,6 +3,6 @@
 #include "rox_device.hpp"
 
 namespace rox {
-void launch_radial(const LaunchCfg &k, const TraceArgs &a) { launch_instance<(F_RADIAL) | flavour_of(F_RADIAL, false)>(k, a); }
-void launch_radial_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<(F_RADIAL) | flavour_of(F_RADIAL, false)>(k, items); }
+void launch_radial(const LaunchCfg &k, const TraceArgs &a) { launch_instance<F_RADIAL>(k, a); }
+void launch_radial_batch(const LaunchCfg &k, const TraceArgs *items) { launch_instance_batch<F_RADIAL>(k, items); }
 }  // namespace rox

@@ -222,23 +222,29 @@ constexpr int F_ALL = F_POLY | F_APLIST | F_PHFILT | F_PHASE;
 // loads (ctblp above) -- the instance of tables beyond the LDS (and, ROX_FAST_GTAB, of the
 // tolerance-mode kernels)
 constexpr int F_GTAB = 128;
-// which instances read their table that way (beside the one for tables beyond the LDS):
-//   ROX_GTAB_EXACT / ROX_GTAB_FAST: bit masks over {1: the instances that carry Newton code,
-//   2: the others}.  A value read by a scalar load sits in SGPRs: the Newton instances, whose
-//   asphere coefficients and row constants otherwise occupy vector registers for the whole
-//   evaluation, drop from 91-101 to 72-80 VGPRs (one or two more resident waves per SIMD).
+// Which kernels read their table that way (beside the instance for tables beyond the LDS):
+// ROX_GTAB_EXACT / ROX_GTAB_FAST, bit masks over {1: the reduced-output modes of the instances
+// that carry Newton code, 2: ... of the other instances, 4: FULL packets of the Newton
+// instances, 8: FULL of the others}.  A value read by a scalar load sits in SGPRs: the Newton
+// instances, whose asphere coefficients and row constants otherwise occupy vector registers
+// for the whole evaluation, drop from 91-101 to 72-80 VGPRs -- one or two more resident waves
+// per SIMD.  Measured per 2^20 rays (gpurun r06t): .zmx zoom HITS 134 -> 124 us, tolerance mode
+// 87 -> 76; Nikkor 291 -> 276, 154 -> 143; phone lens 227 -> 226, 151 -> 142; FULL packets gain
+// nothing (bound by their stores; phone lens 267 -> 277): shipped for the reduced-output modes
+// of the Newton instances, exact and tolerance mode.  Bit-identical either way.
 #ifndef ROX_GTAB_EXACT
-#define ROX_GTAB_EXACT 0
+#define ROX_GTAB_EXACT 1
 #endif
 #ifndef ROX_GTAB_FAST
-#define ROX_GTAB_FAST 0
+#define ROX_GTAB_FAST 1
 #endif
-// the flavour bits of the compiled instance that serves feature set `feat`
-constexpr int flavour_of(int feat, bool fast)
+// F_GTAB or 0 for (feature set, tolerance mode, output mode): the kernel the host launches
+constexpr int gtab_of(int feat, bool fast, int out_mode)
 {
     const int mask = fast ? ROX_GTAB_FAST : ROX_GTAB_EXACT;
     const bool newton = (feat & (1 | 2 | 4)) != 0;
-    return (fast ? 64 /* F_FAST */ : 0) | ((mask & (newton ? 1 : 2)) ? F_GTAB : 0);
+    const int bit = (out_mode == ROX_OUT_FULL ? 4 : 1) << (newton ? 0 : 1);
+    return ((feat & F_GTAB) || (mask & bit)) ? F_GTAB : 0;
 }
 
 struct v3 { double x, y, z; };
@@ -2567,19 +2573,24 @@ inline void launch_one(const LaunchCfg &k, const TraceArgs &a)
     launch_with_lds(kern, k.grid, dim3(bs), k.lds, k.stream, a);
 }
 
+// (FEAT: the instance's feature set | F_FAST for a tolerance-mode instance | F_GTAB for the
+// instance of tables beyond the LDS; whether a mode's kernel reads the table through scalar
+// loads is gtab_of()'s per-mode decision)
 template <int GEN, bool PRW, int FEAT>
 inline void launch_mode(const LaunchCfg &k, const TraceArgs &a)
 {
+    constexpr bool kF = (FEAT & F_FAST) != 0;
+    constexpr int FR = FEAT | gtab_of(FEAT, kF, ROX_OUT_HITS), FF = FEAT | gtab_of(FEAT, kF, ROX_OUT_FULL);
     switch (k.out_mode) {
     case ROX_OUT_FULL:
-        if constexpr (!(FEAT & F_FAST))     // (the host never sends FULL to a tolerance-mode instance)
-            launch_one<ROX_OUT_FULL, GEN, PRW, FEAT>(k, a);
+        if constexpr (!kF)                  // (the host never sends FULL to a tolerance-mode instance)
+            launch_one<ROX_OUT_FULL, GEN, PRW, FF>(k, a);
         break;
-    case ROX_OUT_LAST: launch_one<ROX_OUT_LAST, GEN, PRW, FEAT>(k, a); break;
-    case ROX_OUT_OPD: launch_one<ROX_OUT_OPD, GEN, PRW, FEAT>(k, a); break;
-    case ROX_OUT_HITS_COMPACT: launch_one<ROX_OUT_HITS_COMPACT, GEN, PRW, FEAT>(k, a); break;
-    case ROX_OUT_FAN: launch_one<ROX_OUT_FAN, GEN, PRW, FEAT>(k, a); break;
-    default: launch_one<ROX_OUT_HITS, GEN, PRW, FEAT>(k, a); break;
+    case ROX_OUT_LAST: launch_one<ROX_OUT_LAST, GEN, PRW, FR>(k, a); break;
+    case ROX_OUT_OPD: launch_one<ROX_OUT_OPD, GEN, PRW, FR>(k, a); break;
+    case ROX_OUT_HITS_COMPACT: launch_one<ROX_OUT_HITS_COMPACT, GEN, PRW, FR>(k, a); break;
+    case ROX_OUT_FAN: launch_one<ROX_OUT_FAN, GEN, PRW, FR>(k, a); break;
+    default: launch_one<ROX_OUT_HITS, GEN, PRW, FR>(k, a); break;
     }
 }
 
@@ -2625,16 +2636,18 @@ inline void launch_one_batch(const LaunchCfg &k, const TraceArgs *items)
 template <int FEAT>
 inline void launch_instance_batch(const LaunchCfg &k, const TraceArgs *items)
 {
+    constexpr bool kF = (FEAT & F_FAST) != 0;
+    constexpr int FR = FEAT | gtab_of(FEAT, kF, ROX_OUT_HITS), FF = FEAT | gtab_of(FEAT, kF, ROX_OUT_FULL);
     switch (k.out_mode) {
     case ROX_OUT_FULL:
-        if constexpr (!(FEAT & F_FAST))
-            launch_one_batch<ROX_OUT_FULL, FEAT>(k, items);
+        if constexpr (!kF)
+            launch_one_batch<ROX_OUT_FULL, FF>(k, items);
         break;
-    case ROX_OUT_LAST: launch_one_batch<ROX_OUT_LAST, FEAT>(k, items); break;
-    case ROX_OUT_OPD: launch_one_batch<ROX_OUT_OPD, FEAT>(k, items); break;
-    case ROX_OUT_HITS_COMPACT: launch_one_batch<ROX_OUT_HITS_COMPACT, FEAT>(k, items); break;
-    case ROX_OUT_FAN: launch_one_batch<ROX_OUT_FAN, FEAT>(k, items); break;
-    default: launch_one_batch<ROX_OUT_HITS, FEAT>(k, items); break;
+    case ROX_OUT_LAST: launch_one_batch<ROX_OUT_LAST, FR>(k, items); break;
+    case ROX_OUT_OPD: launch_one_batch<ROX_OUT_OPD, FR>(k, items); break;
+    case ROX_OUT_HITS_COMPACT: launch_one_batch<ROX_OUT_HITS_COMPACT, FR>(k, items); break;
+    case ROX_OUT_FAN: launch_one_batch<ROX_OUT_FAN, FR>(k, items); break;
+    default: launch_one_batch<ROX_OUT_HITS, FR>(k, items); break;
     }
 }
 
@@ -2661,8 +2674,7 @@ void launch_general_batch(const LaunchCfg &, const TraceArgs *);
 // the general instance over a table left in global memory (csrc/gtab_general.hip)
 void launch_general_gtab(const LaunchCfg &, const TraceArgs &);
 void launch_general_gtab_batch(const LaunchCfg &, const TraceArgs *);
-// ... and their tolerance-mode twins (csrc/fast_*.hip: kInstances[i] | flavour_of(., true),
-// reduced-output modes)
+// ... and their tolerance-mode twins (csrc/fast_*.hip: kInstances[i] | F_FAST, reduced-output modes)
 void launch_lean_fast(const LaunchCfg &, const TraceArgs &);
 void launch_even_fast(const LaunchCfg &, const TraceArgs &);
 void launch_radial_fast(const LaunchCfg &, const TraceArgs &);

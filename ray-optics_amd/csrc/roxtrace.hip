@@ -713,7 +713,7 @@ int launch_setup(rox_system *sys, TraceArgs &a, int gen, bool prw, hipStream_t s
     // (an instance compiled with F_PHASE stages the phase constants, needed or not)
     const size_t stash = a.opts.out_mode == ROX_OUT_HITS_COMPACT    // two tiles of packed pairs (rox_device.hpp)
                              ? 16 + 2 * 16 * (size_t)block_of(ROX_OUT_HITS_COMPACT, kInstances[inst]) : 0;
-    const bool fast_gtab = (flavour_of(kInstances[inst], k.fast) & F_GTAB) != 0;   // (this instance's own table source)
+    const bool fast_gtab = gtab_of(kInstances[inst], k.fast, a.opts.out_mode) != 0;   // (this kernel's own table source)
     k.gtab = false;
     k.lds = lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0, k.fast, fast_gtab,
                       (kInstances[inst] & F_APLIST) != 0) + stash;
@@ -839,7 +839,7 @@ int launch(rox_system *sys, TraceArgs &a, int gen, hipStream_t st)
             kh.out_mode = ROX_OUT_HITS;
             kh.lds = k.gtab ? lds_bytes(sys, prw, true, false, true, true)
                             : lds_bytes(sys, prw, (kInstances[inst] & F_PHASE) != 0, kh.fast,
-                                        (flavour_of(kInstances[inst], kh.fast) & F_GTAB) != 0,
+                                        gtab_of(kInstances[inst], kh.fast, ROX_OUT_HITS) != 0,
                                         (kInstances[inst] & F_APLIST) != 0);
             const int hb = block_of(ROX_OUT_HITS, kInstances[inst], kh.small);
             int64_t hblocks = (a.n_rays + hb - 1) / hb;
