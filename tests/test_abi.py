@@ -149,3 +149,41 @@ def test_bench_scaling_keys_are_what_they_say():
     k1 = b.scaling_keys(77.0, 77.0, 1)
     assert k1['speedup'] == 1.0 and k1['efficiency'] == 1.0
     assert b.scaling_keys(None, 11.0, 4)['speedup'] is None
+
+
+def test_spot_stats_rejects_bad_arguments_without_a_device(lib):
+    """rox_spot_stats validates before it touches the device: null buffers, an unknown layout,
+    a histogram without edges, edges that do not increase"""
+    import numpy as np
+    abi.declare(lib)
+    summ = abi.SpotSummary()
+    xy = np.zeros(8)
+    hist = np.zeros(4, dtype=np.uint32)
+    good = np.array([0.0, 1.0, 2.0])
+    bad = np.array([0.0, 2.0, 1.0])
+    assert lib.rox_spot_stats(None, 4, None, None, 4, abi.SPOT_ROWS, None, 0, None, 0, C.byref(summ), None, None) == -1
+    assert lib.rox_spot_stats(xy.ctypes.data, 4, None, None, 4, 7, None, 0, None, 0, C.byref(summ), None, None) == -1
+    assert lib.rox_spot_stats(xy.ctypes.data, 2, None, None, 4, abi.SPOT_ROWS, None, 0, None, 0, C.byref(summ), None,
+                              None) == -1          # ld < n
+    assert lib.rox_spot_stats(xy.ctypes.data, 4, None, None, 4, abi.SPOT_ROWS, None, 0, None, 0, C.byref(summ),
+                              hist.ctypes.data, None) == -1     # histogram without edges
+    assert lib.rox_spot_stats(xy.ctypes.data, 4, None, None, 4, abi.SPOT_ROWS, bad.ctypes.data, 3, good.ctypes.data, 3,
+                              C.byref(summ), hist.ctypes.data, None) == -1
+    assert b'monotonically' in lib.rox_last_error()
+
+
+def test_tolerance_mode_is_an_opt_in_of_the_drop_in_layer():
+    """session.set_tolerance_mode / install(tolerance_mode=...): ROX_FAST_FP64 rides on every rox_opts
+    the drop-ins build, and only then"""
+    from rayoptics_amd import session, trace
+    assert session.TOLERANCE_MODE is False
+    o = trace.opts_from_kwargs(13, {'check_apertures': True}, abi.OUT_HITS)
+    assert not (o.flags & abi.FAST_FP64) and (o.flags & abi.CHECK_APERTURES)
+    was = session.set_tolerance_mode(True)
+    try:
+        assert was is False
+        o = trace.opts_from_kwargs(13, {}, abi.OUT_HITS)
+        assert o.flags & abi.FAST_FP64
+    finally:
+        session.set_tolerance_mode(was)
+    assert not (trace.opts_from_kwargs(13, {}, abi.OUT_FULL).flags & abi.FAST_FP64)
