@@ -1230,23 +1230,32 @@ __device__ __forceinline__ int apply_phase(TP ph, TP pc, const v3 &pt, const v3 
 }
 
 // ------------------------------------------------------------------ OPD
+// FAST (the tolerance-mode instances): the quotients and the square root of the wave-aberration
+// formulas through rcp_f / sqrt_f (~1 ulp) instead of the correctly rounded expansions; the
+// operation order is otherwise the reference's.  An OPD is a difference of optical paths of
+// O(100) system units: 1e-16 relative on its terms is 1e-14 absolute.
+template <bool FAST>
+__device__ __forceinline__ double wf_div(double a, double b) { return FAST ? a * rcp_f(b) : a / b; }
+template <bool FAST>
+__device__ __forceinline__ double wf_sqrt(double x) { return FAST ? sqrt_f(x) : sqrt(x); }
+
 // waveabr.py:117-132 eic_distance
-template <class P3>
+template <bool FAST = false, class P3>
 __device__ __forceinline__ double eic_distance(const v3 &p, const v3 &d, P3 p0, P3 d0)
 {
     const v3 sd{d.x + d0[0], d.y + d0[1], d.z + d0[2]};
     const v3 dp{p.x - p0[0], p.y - p0[1], p.z - p0[2]};
-    return dot3(sd, dp) / (1. + dot3(d, v3{d0[0], d0[1], d0[2]}));
+    return wf_div<FAST>(dot3(sd, dp), 1. + dot3(d, v3{d0[0], d0[1], d0[2]}));
 }
 
 // waveabr.py:256-307 wave_abr_full_calc_finite_pup (+ transform.py:234-258)
-template <class WF>      // rox_wavefront, in whatever address space the launch arguments live
+template <bool FAST = false, class WF>      // rox_wavefront, in whatever address space the launch arguments live
 __device__ __forceinline__ double wave_abr_finite_pup(WF &w, const v3 &ray1_p,
                                                       const v3 &ray0_d, const v3 &rayk_p,
                                                       const v3 &rayk_d, double ray_op)
 {
-    const double e1 = eic_distance(ray1_p, ray0_d, w.cr1_p, w.cr0_d);
-    const double ekp = eic_distance(rayk_p, rayk_d, w.crk_p, w.crk_d);
+    const double e1 = eic_distance<FAST>(ray1_p, ray0_d, w.cr1_p, w.cr0_d);
+    const double ekp = eic_distance<FAST>(rayk_p, rayk_d, w.crk_p, w.crk_d);
     v3 b4p = rayk_p, b4d = rayk_d;
     if (w.after_kind != 0) {
         const v3 t{rayk_p.x - w.after_t[0], rayk_p.y - w.after_t[1], rayk_p.z - w.after_t[2]};
@@ -1262,23 +1271,25 @@ __device__ __forceinline__ double wave_abr_finite_pup(WF &w, const v3 &ray1_p,
                 (b4p.z - dst * b4d.z) - w.cr_exp_pt[2]};
     const v3 rd{w.ref_dir[0], w.ref_dir[1], w.ref_dir[2]};
     const double R = w.ref_radius;
-    const double F = dot3(rd, b4d) - dot3(b4d, pc) / R;
-    const double J = dot3(pc, pc) / R - 2.0 * dot3(rd, pc);
-    const double denom = F + w.sign_soln * sqrt(F * F + J / R);
-    const double ep = (denom == 0) ? 0 : J / denom;
+    // (R is a launch constant: the tolerance mode multiplies by its reciprocal, formed once)
+    const double rR = FAST ? rcp_f(R) : 0.0;
+    const double F = dot3(rd, b4d) - (FAST ? dot3(b4d, pc) * rR : dot3(b4d, pc) / R);
+    const double J = (FAST ? dot3(pc, pc) * rR : dot3(pc, pc) / R) - 2.0 * dot3(rd, pc);
+    const double denom = F + w.sign_soln * wf_sqrt<FAST>(F * F + (FAST ? J * rR : J / R));
+    const double ep = (denom == 0) ? 0 : wf_div<FAST>(J, denom);
     return -w.n_obj * e1 - ray_op + w.n_img * ekp + w.cr_op - w.n_img * ep;
 }
 
 // waveabr.py:356-424 wave_abr_full_calc_inf_ref (ROX_WF_INF_FULL) and its pre-calc /
 // calc split :427-488 (ROX_WF_INF_SPLIT); dist_to_shortest_join :178-196,
 // ray_dist_to_perp_from_origin :166-175.  Chief-ray-only terms come from the host.
-template <class WF>
+template <bool FAST = false, class WF>
 __device__ __forceinline__ double wave_abr_inf_ref(WF &w, const v3 &ray1_p,
                                                    const v3 &ray0_d, const v3 &rayk_p,
                                                    const v3 &rayk_d, const v3 &rayl_p,
                                                    const v3 &rayl_d, double ray_op)
 {
-    const double e1 = eic_distance(ray1_p, ray0_d, w.cr1_p, w.cr0_d);
+    const double e1 = eic_distance<FAST>(ray1_p, ray0_d, w.cr1_p, w.cr0_d);
     v3 p_b4 = rayk_p, d_b4 = rayk_d;
     if (w.last_kind) {
         p_b4 = rotate(w.last_rt, w.last_order, v3{rayk_p.x - w.last_t[0], rayk_p.y - w.last_t[1],
@@ -1298,8 +1309,8 @@ __device__ __forceinline__ double wave_abr_inf_ref(WF &w, const v3 &ray1_p,
         P1 = p1;
         P2 = v3{rayl_p.x + t2 * rayl_d.x, rayl_p.y + t2 * rayl_d.y, rayl_p.z + t2 * rayl_d.z};
     } else {
-        const double t1 = dot3(cross3(rayl_d, n), del_p) / nn;
-        const double t2 = dot3(cross3(d1, n), del_p) / nn;
+        const double t1 = wf_div<FAST>(dot3(cross3(rayl_d, n), del_p), nn);
+        const double t2 = wf_div<FAST>(dot3(cross3(d1, n), del_p), nn);
         P1 = v3{p1.x + t1 * d1.x, p1.y + t1 * d1.y, p1.z + t1 * d1.z};
         P2 = v3{rayl_p.x + t2 * rayl_d.x, rayl_p.y + t2 * rayl_d.y, rayl_p.z + t2 * rayl_d.z};
     }
@@ -1314,10 +1325,10 @@ __device__ __forceinline__ double wave_abr_inf_ref(WF &w, const v3 &ray1_p,
     const double denom = 1 + dot3(d_b4, dcr);
     if (w.kind == ROX_WF_INF_SPLIT) {
         const double pre_opd = -w.n_obj * e1 - W0;
-        const double W_inf = w.n_img * numer / denom;
+        const double W_inf = wf_div<FAST>(w.n_img * numer, denom);
         return pre_opd - W_inf;
     }
-    const double W_inf = W0 + w.n_img * numer / denom;
+    const double W_inf = W0 + wf_div<FAST>(w.n_img * numer, denom);
     return -w.n_obj * e1 - W_inf;
 }
 
@@ -1641,6 +1652,9 @@ __device__ __forceinline__ void trace_ray(const CTX &c, const SegOut &so, const 
 #ifndef ROX_REDUCED_STRAIGHT     // 0: the reduced-output modes of the exact instances keep trace_ray()
 #define ROX_REDUCED_STRAIGHT 1
 #endif
+#ifndef ROX_SL_SLIM_DIV          // 1: the two plain quotients of the straight-line loop (cx2 / den, cosI) through
+#define ROX_SL_SLIM_DIV 0        //    slim_div() (bit-identical inside the exponent band, the plain operator outside)
+#endif
 
 // profiles.py:321-336 / 580-593 as quadric_root() / quadric_hit() compute them, without the early exit
 __device__ __forceinline__ bool quadric_hit_sl(bool conic, double cv, double cc, double ec,
@@ -1659,7 +1673,11 @@ __device__ __forceinline__ bool quadric_hit_sl(bool conic, double cv, double cc,
     }
     const double rad = b * b - ax2 * cx2;
     const double den = z_dir * slim_sqrt(rad) - b;      // (NaN where rad < 0: flagged below)
+#if ROX_SL_SLIM_DIV
+    double sq = slim_div(cx2, den);
+#else
     double sq = cx2 / den;
+#endif
     // np.errstate(divide='raise') -> FloatingPointError -> s = 0 only for a finite non-zero
     // numerator; 0/0 and nan/0 stay NaN; all three coefficients zero: s = 0 without dividing
     if (den == 0.0 && cx2 != 0.0 && isfinite(cx2))
@@ -1675,7 +1693,11 @@ __device__ __forceinline__ bool quadric_hit_sl(bool conic, double cv, double cc,
 __device__ __forceinline__ bool refract_sl(const v3 &d, const v3 &nrm, double n_in, double n_out, v3 &out)
 {
     const double nlen = slim_sqrt(dot3(nrm, nrm));
+#if ROX_SL_SLIM_DIV
+    const double cosI = slim_div(dot3(d, nrm), nlen);
+#else
     const double cosI = dot3(d, nrm) / nlen;
+#endif
     const double sin2 = 1.0 - cosI * cosI;
     const double rad = n_out * n_out - n_in * n_in * sin2;
     const double n_cosIp = copysign(slim_sqrt(rad), cosI);
@@ -2424,11 +2446,11 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
                     const double op = e.phs + e.opl;
                     so.put(0, OUT_MODE == ROX_OUT_FAN ? 2 : 0,
                            a.opts.wf.kind == ROX_WF_FINITE            // (wave-uniform)
-                           ? wave_abr_finite_pup(a.opts.wf, e.ray1_p, dir0, e.rayk_p, e.rayk_d, op)
-                           : wave_abr_inf_ref(a.opts.wf, e.ray1_p, dir0, e.rayk_p, e.rayk_d,
-                                              e.inc, e.ad, op));
+                           ? wave_abr_finite_pup<kFast>(a.opts.wf, e.ray1_p, dir0, e.rayk_p, e.rayk_d, op)
+                           : wave_abr_inf_ref<kFast>(a.opts.wf, e.ray1_p, dir0, e.rayk_p, e.rayk_d,
+                                                     e.inc, e.ad, op));
                     if (OUT_MODE == ROX_OUT_FAN) {          // analyses.py:258-262
-                        const double dist = a.opts.foc / e.ad.z;
+                        const double dist = kFast ? a.opts.foc * rcp_f(e.ad.z) : a.opts.foc / e.ad.z;
                         so.put(0, 0, (e.inc.x + dist * e.ad.x) - a.opts.image_pt[0]);
                         so.put(0, 1, (e.inc.y + dist * e.ad.y) - a.opts.image_pt[1]);
                     }
