@@ -132,9 +132,6 @@
 #ifndef ROX_NEWTON_UNROLL     // Spencer-Murty steps spelled straight-line before the residual loop.  Rounds 1-4
 #define ROX_NEWTON_UNROLL 0    // shipped 4 (six inlined evaluations per asphere site); the plain loop -- two --
 #endif                         // is a third of the code and faster: Nikkor HITS 329 -> 314 us, .zmx 143.2 -> 141.5
-#ifndef ROX_COSI_SLIM         // 1: cosI = dot(d, n) / |n| of refract() / mirror() through slim_div():
-#define ROX_COSI_SLIM 0        //    measured, nothing (lean HITS 109.8 us without, 111.4 with): off
-#endif
 #ifndef ROX_IDENT_RT_FULL_POLY   // 1: the identity-rotation short cut also in the FULL mode of those
 #define ROX_IDENT_RT_FULL_POLY 1 //    instances, which are closer to their VALU bound (283 / 473 / 187 us)
 #endif
@@ -506,11 +503,7 @@ __device__ __forceinline__ bool refract(const v3 &d, const v3 &nrm, double n_in,
                                         double n_out, v3 &out)
 {
     const double nlen = slim_sqrt(dot3(nrm, nrm));
-#if ROX_COSI_SLIM
-    const double cosI = slim_div(dot3(d, nrm), nlen);
-#else
     const double cosI = dot3(d, nrm) / nlen;
-#endif
     const double sin2 = 1.0 - cosI * cosI;
     const double rad = n_out * n_out - n_in * n_in * sin2;
     if (rad < 0.0)
@@ -526,11 +519,7 @@ __device__ __forceinline__ bool refract(const v3 &d, const v3 &nrm, double n_in,
 __device__ __forceinline__ v3 mirror(const v3 &d, const v3 &nrm)
 {
     const double nlen = slim_sqrt(dot3(nrm, nrm));
-#if ROX_COSI_SLIM
-    const double cosI = slim_div(dot3(d, nrm), nlen);
-#else
     const double cosI = dot3(d, nrm) / nlen;
-#endif
     const double k = 2.0 * cosI;
     return v3{d.x - k * nrm.x, d.y - k * nrm.y, d.z - k * nrm.z};
 }
@@ -888,7 +877,9 @@ __device__ __forceinline__ v3 rotate_f(P rt, const v3 &v)
 //   d_out = mu d + (sg sign(cosI) sqrt(1 - mu^2 (1 - cosI^2)) - mu cosI) n
 //   transmit  mu = n_in / n_out, sg = +1          (bend)
 //   reflect   mu = 1, sg = -1: the root is |cosI|, d_out = d - 2 cosI n   (reflect)
-//   dummy / phantom  mu = 1, sg = +1: the bracket is |cosI| sign(cosI) - cosI = 0, d_out = d
+//   (mu = 1, sg = +1 would pass the direction through -- the bracket is |cosI| sign(cosI) - cosI
+//   = 0 -- but dummy and phantom interfaces copy it instead, as the reference does: a NaN normal
+//   of a degenerate ray must not reach the direction)
 // (mu, mu^2, sg) are staged per (wavelength, interface) by the workgroup.  Returns false where
 // the radicand is negative (total internal reflection; out is NaN there).
 __device__ __forceinline__ bool interact_f(const v3 &d, const v3 &n, double mu, double mu2, double sg,
@@ -1652,9 +1643,6 @@ __device__ __forceinline__ void trace_ray(const CTX &c, const SegOut &so, const 
 #ifndef ROX_REDUCED_STRAIGHT     // 0: the reduced-output modes of the exact instances keep trace_ray()
 #define ROX_REDUCED_STRAIGHT 1
 #endif
-#ifndef ROX_SL_SLIM_DIV          // 1: the two plain quotients of the straight-line loop (cx2 / den, cosI) through
-#define ROX_SL_SLIM_DIV 0        //    slim_div() (bit-identical inside the exponent band, the plain operator outside)
-#endif
 
 // profiles.py:321-336 / 580-593 as quadric_root() / quadric_hit() compute them, without the early exit
 __device__ __forceinline__ bool quadric_hit_sl(bool conic, double cv, double cc, double ec,
@@ -1673,11 +1661,7 @@ __device__ __forceinline__ bool quadric_hit_sl(bool conic, double cv, double cc,
     }
     const double rad = b * b - ax2 * cx2;
     const double den = z_dir * slim_sqrt(rad) - b;      // (NaN where rad < 0: flagged below)
-#if ROX_SL_SLIM_DIV
-    double sq = slim_div(cx2, den);
-#else
-    double sq = cx2 / den;
-#endif
+    double sq = cx2 / den;      // (through slim_div(): measured slower, EXPERIMENTS.md round 6)
     // np.errstate(divide='raise') -> FloatingPointError -> s = 0 only for a finite non-zero
     // numerator; 0/0 and nan/0 stay NaN; all three coefficients zero: s = 0 without dividing
     if (den == 0.0 && cx2 != 0.0 && isfinite(cx2))
@@ -1693,11 +1677,7 @@ __device__ __forceinline__ bool quadric_hit_sl(bool conic, double cv, double cc,
 __device__ __forceinline__ bool refract_sl(const v3 &d, const v3 &nrm, double n_in, double n_out, v3 &out)
 {
     const double nlen = slim_sqrt(dot3(nrm, nrm));
-#if ROX_SL_SLIM_DIV
-    const double cosI = slim_div(dot3(d, nrm), nlen);
-#else
     const double cosI = dot3(d, nrm) / nlen;
-#endif
     const double sin2 = 1.0 - cosI * cosI;
     const double rad = n_out * n_out - n_in * n_in * sin2;
     const double n_cosIp = copysign(slim_sqrt(rad), cosI);
@@ -2025,8 +2005,10 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
                 else
                     ph_fail = (rc == PHASE_TIR) ? ROX_TIR : ROX_EVANESCENT;       // :253-257
             }
-        } else {
+        } else if (mode == ROX_TRANSMIT || mode == ROX_REFLECT) {                   // (wave-uniform)
             tir = !interact_f(b4d, nrm, muw[surf], muw[N + surf], muw[2 * N + surf], ad);   // :239-245
+        } else {
+            ad = b4d;       // dummy / phantom: the direction as it is, whatever the normal (:215-221)
         }
         // :231-257 the first failure in the reference's order: miss, blocked, TIR / evanescent
         const int st = !hit ? (int)ROX_MISSED_SURFACE
