@@ -248,3 +248,52 @@ def test_spot_stats_product_call_and_its_wall_clock():
     assert s_f['n'] == len(x) and abs(int(h_f.sum()) - int(hist.sum())) <= 16
     H.record('spot_stats_wallclock_1M_rays', **t)
     assert t['stats_only_ms'] < t['spot_to_host_ms']
+
+
+# ---------------------------------------------------------------- degenerate operands
+@pytest.mark.parametrize('name', ['dblgauss', 'nikkor', 'rc_telescope', 'cell_phone', 'tilted_singlet', 'toroid_lens'])
+def test_degenerate_rays_bit_exact(name):
+    """rays whose start points and directions are drawn from {+-0, +-1, 0.5, 1e-17, 1e-300, 1e300, inf,
+    nan} (the reference traces whatever it is given: NaN and infinities flow through its NumPy
+    arithmetic, comparisons with NaN are false) -- FULL, LAST and HITS on the device against the
+    oracle, bit for bit incl. the NaN pattern, status and failing surface.  The straight-line loop
+    of the reduced-output modes (trace_ray_reduced) lets the arithmetic behind a raised failure
+    flag run on: this is where it would show if that changed an outcome."""
+    from oracle import oracle
+    from rayoptics_amd.engine import TraceEngine
+    fx = H.fixture(name)
+    tbl = fx.table
+    N = tbl.n_ifcs
+    rng = np.random.default_rng(606 + len(name))
+    pool = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 1e-17, 1e-300, 1e300, np.inf, -np.inf, np.nan, 3.0, -0.25])
+    R = 6000
+    pt0 = pool[rng.integers(0, len(pool), (3, R))]
+    d = pool[rng.integers(0, len(pool), (3, R))]
+    # half of the rays: a regular ray with ONE degenerate component
+    reg = rng.random(R) < 0.5
+    base_p = np.stack([rng.uniform(-5, 5, R), rng.uniform(-5, 5, R), np.zeros(R)])
+    base_d = np.stack([rng.uniform(-.2, .2, R), rng.uniform(-.2, .2, R), np.ones(R)])
+    base_d /= np.linalg.norm(base_d, axis=0)
+    which = rng.integers(0, 6, R)
+    for k in range(3):
+        pt0[k] = np.where(reg & (which != k), base_p[k], pt0[k])
+        d[k] = np.where(reg & (which != 3 + k), base_d[k], d[k])
+    W = len(tbl.wvls)
+    wi = rng.integers(0, W, R).astype(np.int32)
+    eng = TraceEngine(tbl)
+    n_ok = 0
+    for mode in (abi.OUT_FULL, abi.OUT_LAST, abi.OUT_HITS):
+        for flags in (abi.INTERSECT_OBJ | abi.CHECK_APERTURES, 0):
+            opts = oracle.make_opts(flags=flags, out_mode=mode, first_surf=1, last_surf=N - 2, foc=0.03,
+                                    image_pt=(0.1, -0.2))
+            with np.errstate(all='ignore'):
+                orc = oracle.trace_rays(tbl, pt0, d, wi, opts)
+            dev = eng.trace_rays(pt0, d, wi, opts, nan_fill=True).to_host()
+            np.testing.assert_array_equal(dev.status, orc.status, err_msg=f'{name} mode {mode} flags {flags}')
+            np.testing.assert_array_equal(dev.fail_surf, orc.fail_surf)
+            K = dev.seg.shape[0] if mode == abi.OUT_FULL else None
+            H.bit_equal(dev.seg, orc.seg[:K] if K else orc.seg, f'{name} mode {mode} flags {flags} seg')
+            H.bit_equal(dev.op, orc.op, f'{name} mode {mode} op')
+            n_ok += int((orc.status == abi.OK).sum())
+    eng.close()
+    assert n_ok > 100
