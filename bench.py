@@ -546,6 +546,10 @@ def main():
                         value=c5['intersections'] / (legs[bestx] * 1e-3),
                         what='what a `--gpus N` line reports under value / ms_per_step, at N = 1: draw the '
                              'scaling curve from this and the N > 1 lines, not from this line\'s `value`')
+                    tm = c5.get('rccl_tolerance_mode')
+                    if isinstance(tm, dict) and 'end_to_end_ms' in tm:
+                        # the same problem behind the tolerance-mode kernels (ROX_FAST_FP64; opt-in, not the headline)
+                        line['strong_equiv']['ms_per_step_tolerance_mode'] = tm['end_to_end_ms']
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(wl, fld, wi, opts, num, args.cpu_sample_rows,
@@ -898,12 +902,14 @@ class SpotProblem:
         LIVE_SEGMENTS.add(seg.path)
         return seg
 
-    def run(self, exchange, segment=None, result_on='host', pipeline=True, timings=None):
-        from rayoptics_amd import dist as rdist
+    def run(self, exchange, segment=None, result_on='host', pipeline=True, timings=None, tolerance_mode=False):
+        from rayoptics_amd import abi, dist as rdist
         wl = self.wl
+        flags = (SPOT_FLAGS | abi.FAST_FP64) if tolerance_mode else None
         return rdist.trace_spot_sharded(self.eng, self.fields, self.image_pts, self.nw, self.num, wl.foc,
-                                        by=self.by, exchange=exchange, segment=segment, timings=timings,
-                                        pipeline=pipeline, result_on=result_on, group=self.group)
+                                        flags=flags, by=self.by, exchange=exchange, segment=segment,
+                                        timings=timings, pipeline=pipeline, result_on=result_on,
+                                        group=self.group)
 
     def kernel_ms(self):
         """this rank's launches alone (packed hits appended into HBM), events on the launch stream"""
@@ -1229,7 +1235,10 @@ def strong_scaling(args, torch, dist, multi, world, rank, fence, ranks_seen):
             try:
                 kw = {'rccl': dict(exchange='rccl'), 'host': dict(exchange='host'),
                       'rccl_device': dict(exchange='rccl', result_on='device'),
-                      'rccl_unpipelined': dict(exchange='rccl', pipeline=False)}[key]
+                      'rccl_unpipelined': dict(exchange='rccl', pipeline=False),
+                      # the same exchange behind the tolerance-mode kernels (ROX_FAST_FP64: <= 1e-10
+                      # from the reference, not bit-exact; never the headline)
+                      'rccl_tolerance_mode': dict(exchange='rccl', tolerance_mode=True)}[key]
                 setup_ms = 0.0
                 if key == 'host':
                     t_s = time.perf_counter()
@@ -1272,7 +1281,8 @@ def strong_scaling(args, torch, dist, multi, world, rank, fence, ranks_seen):
                     'grouped send/recv of the packed pairs to rank 0 + copy-engine D2H per piece; host = '
                     'copy-engine D2H of every rank over its own PCIe link into a shared pinned segment, no '
                     'xGMI step',
-            'c5': problem('litho_c5', args.strong_num, 'rows', ('rccl', 'host', 'rccl_device', 'rccl_unpipelined')),
+            'c5': problem('litho_c5', args.strong_num, 'rows', ('rccl', 'host', 'rccl_device', 'rccl_unpipelined',
+                                                                   'rccl_tolerance_mode')),
             'c4': problem('rc_telescope_c4', 256, 'field', ('rccl', 'host')),
             # the N = 1 main line's lens and grid (one field, one wavelength), by pupil rows
             'c2_sharded': problem('dblgauss_c2', args.num, 'rows', ('rccl', 'rccl_device'),
