@@ -36,6 +36,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <type_traits>
 
 #include "../../include/roxtrace.h"
@@ -2525,12 +2526,27 @@ ROX_KERNEL_ALIGNED trace_kernel(const TraceArgs a)
 // the figures that call them per field: blockIdx.y picks the item, blockIdx.x strides over
 // that item's tiles.  The items sit in device memory and are read through the constant
 // address space, i.e. with the same scalar loads that read a kernel argument.
+// A batch of up to kInlineItems items travels IN the kernel argument (`inl`, `items` null): no
+// upload in front of the kernel -- a copy-engine transfer and its cross-queue signal, ~6 us
+// before an 18-30 us kernel of a figure's or BASELINE configs[3]'s few small grids.  (gfx950
+// takes kernel arguments of 31 KiB and more; tools/kernarg_probe.hip: a launch with 16 items
+// inline 4.6 us against 7.0 us for upload + launch, back to back.)
 typedef const __attribute__((address_space(4))) TraceArgs *ConstTraceArgs;
+constexpr int kInlineItems = 16;
+struct BatchArgs {
+    const TraceArgs *items;             // device array [gridDim.y], or nullptr: the items are inl[]
+    TraceArgs inl[kInlineItems];
+};
 template <int OUT_MODE, int FEAT, bool SMALL = false>
 __global__ void __launch_bounds__(block_of(OUT_MODE, FEAT, SMALL), min_waves_of(OUT_MODE, FEAT, SMALL))
-ROX_KERNEL_ALIGNED trace_kernel_batch(const TraceArgs *items)
+ROX_KERNEL_ALIGNED trace_kernel_batch(const BatchArgs b)
 {
-    trace_tiles<OUT_MODE, GEN_PUPIL, false, FEAT, SMALL>(*(ConstTraceArgs)(items + blockIdx.y));
+    // (the argument block read in place, with a wave-uniform index: scalar loads either way)
+    typedef const __attribute__((address_space(4))) char *cbytes;
+    const ConstTraceArgs inl =
+        (ConstTraceArgs)((cbytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(BatchArgs, inl));
+    const ConstTraceArgs items = b.items ? (ConstTraceArgs)b.items : inl;
+    trace_tiles<OUT_MODE, GEN_PUPIL, false, FEAT, SMALL>(items[blockIdx.y]);
 }
 
 // ------------------------------------------------------------------ launching
@@ -2540,6 +2556,7 @@ struct LaunchCfg {
     bool small;         // workgroups of ROX_BLOCK_SMALL threads (pupil launches; see block_of())
     bool fast;          // the tolerance-mode instance (ROX_FAST_FP64 on a reduced-output mode)
     bool gtab;          // the table does not fit the LDS: the general instance over global memory
+    int n_inline;       // batches: > 0 = `items` is a HOST array of this many items for the kernel argument
     int out_mode;       // ROX_OUT_*
     dim3 grid;
     size_t lds;
@@ -2613,12 +2630,16 @@ inline void launch_instance(const LaunchCfg &k, const TraceArgs &a)
 // the batched form (trace_kernel_batch): pupil grids, one wavelength per item
 template <class K>
 inline void launch_batch_with_lds(K kernel, const dim3 &grid, const dim3 &block, size_t lds,
-                                  hipStream_t st, const TraceArgs *items)
+                                  hipStream_t st, const TraceArgs *items, int n_inline)
 {
     if (lds > kDefaultDynLds)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, grid, block, lds, st, items);
+    BatchArgs b;                        // (inl beyond n_inline is never read: left as it is)
+    b.items = n_inline > 0 ? nullptr : items;
+    if (n_inline > 0)
+        memcpy(b.inl, items, sizeof(TraceArgs) * (size_t)n_inline);
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, b);
 }
 
 template <int OUT_MODE, int FEAT>
@@ -2628,13 +2649,13 @@ inline void launch_one_batch(const LaunchCfg &k, const TraceArgs *items)
         if (k.small) {
             constexpr int bs = block_of(OUT_MODE, FEAT, true);
             auto kern = trace_kernel_batch<OUT_MODE, FEAT, true>;
-            launch_batch_with_lds(kern, k.grid, dim3(bs), k.lds, k.stream, items);
+            launch_batch_with_lds(kern, k.grid, dim3(bs), k.lds, k.stream, items, k.n_inline);
             return;
         }
     }
     constexpr int bs = block_of(OUT_MODE, FEAT);
     auto kern = trace_kernel_batch<OUT_MODE, FEAT, false>;
-    launch_batch_with_lds(kern, k.grid, dim3(bs), k.lds, k.stream, items);
+    launch_batch_with_lds(kern, k.grid, dim3(bs), k.lds, k.stream, items, k.n_inline);
 }
 
 template <int FEAT>

@@ -203,7 +203,8 @@ struct StreamCtx {
     // block for small ones (grow-only)
     char *d_stage = nullptr, *h_stage = nullptr;
     size_t d_stage_cap = 0, h_stage_cap = 0;
-    // rox_trace_pupil_grids: the launch items of a batch.  Written into one of kItemSlots
+    // rox_trace_pupil_grids: the launch items of a batch of MORE than kInlineItems items (smaller
+    // batches travel in the kernel argument, rox_device.hpp BatchArgs).  Written into one of kItemSlots
     // pinned slots (a slot is reused only after the copy that read it has completed),
     // copied to d_items in stream order, read by the kernel through scalar loads.
     static constexpr int kItemSlots = 4;
@@ -706,6 +707,7 @@ int launch_setup(rox_system *sys, TraceArgs &a, int gen, bool prw, hipStream_t s
     k.gen = gen;
     k.per_ray_wvl = prw;
     k.small = false;
+    k.n_inline = 0;
     k.fast = use_fast(a.opts);
     k.out_mode = a.opts.out_mode;
     k.stream = st;
@@ -1534,6 +1536,18 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
     const int64_t cap = (int64_t)sys->num_cus * (compact ? compact_blocks_per_cu() : blocks_per_cu(bs));
     if (blocks > cap)
         blocks = cap;
+    k.grid = dim3((unsigned)blocks, (unsigned)n_grids);
+    // a few items: in the kernel argument itself (rox_device.hpp BatchArgs) -- nothing to upload
+    static const bool no_inline = [] {
+        const char *e = getenv("ROX_BATCH_NO_INLINE");      // (the A/B switch of tools/ab_bench.py)
+        return e && *e && atoi(e) != 0;
+    }();
+    if (n_grids <= kInlineItems && !no_inline) {
+        k.n_inline = n_grids;
+        launch_feat_batch(inst, k, items.data());
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     // items -> pinned slot -> device, in stream order
     if (n_grids > cx->items_cap) {
         if (cx->d_items)
@@ -1553,7 +1567,7 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
     }
     // The items of a batch that repeats the previous one of this stream byte for byte (a figure
     // refreshed with unchanged arguments, a timing loop) are already in d_items: the upload -- a
-    // copy-engine transfer in front of the kernel, ~6 us of a 24 us configs[3] pass -- is skipped.
+    // copy-engine transfer in front of the kernel, ~6 us -- is skipped.
     const size_t items_bytes = sizeof(TraceArgs) * (size_t)n_grids;
     // ROX_BATCH_ALWAYS_UPLOAD=1 (read once) switches the short cut off: bench.py times the
     // BASELINE configurations that way, so that its figures are those of a call whose fields or
@@ -1579,7 +1593,6 @@ int rox_trace_pupil_grids(rox_system *sys, int32_t n_grids, const rox_field *fld
         cx->items_last.assign(reinterpret_cast<const char *>(items.data()),
                               reinterpret_cast<const char *>(items.data()) + items_bytes);
     }
-    k.grid = dim3((unsigned)blocks, (unsigned)n_grids);
     launch_feat_batch(inst, k, cx->d_items);
     HIP_TRY(hipGetLastError());
     return 0;

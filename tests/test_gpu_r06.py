@@ -297,3 +297,51 @@ def test_degenerate_rays_bit_exact(name):
             n_ok += int((orc.status == abi.OK).sum())
     eng.close()
     assert n_ok > 100
+
+
+# ---- batches whose items travel in the kernel argument (<= 16) and batches that are uploaded
+@pytest.mark.parametrize('n_items', [1, 2, 15, 16, 17, 40])
+@pytest.mark.parametrize('mode', [abi.OUT_FULL, abi.OUT_HITS, abi.OUT_HITS_COMPACT])
+def test_batches_either_side_of_the_inline_limit(n_items, mode):
+    """rox_trace_pupil_grids hands up to 16 items to the kernel inside its argument block and
+    uploads larger batches to device memory (csrc/rox_device.hpp BatchArgs): item for item the
+    same bits as the single-grid entry, on both sides of the limit and in a sequence that
+    alternates between the two on one stream"""
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_grid, make_opts
+    wl = workloads.load('dblgauss_c2')
+    eng = TraceEngine(wl.table)
+    N = wl.n_ifcs
+    W = len(wl.table.wvls)
+    base = [(fi, wi) for fi in range(len(wl.fields)) for wi in range(W)]
+    pairs = [base[i % len(base)] for i in range(n_items)]
+    grid = make_grid((-1., -1.), (1., 1.), 37)
+    flags = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
+    opts = [make_opts(flags=flags, out_mode=mode, first_surf=1, last_surf=N - 2, foc=wl.foc,
+                      image_pt=wl.image_pts[fi]) for fi, _ in pairs]
+    flds = [wl.fields[fi] for fi, _ in pairs]
+    wis = [wi for _, wi in pairs]
+    single = {}
+    for (fi, wi), o in zip(pairs, opts):
+        if (fi, wi) not in single:
+            if mode == abi.OUT_HITS_COMPACT:
+                single[fi, wi] = eng.trace_pupil_grids_hits([wl.fields[fi]], [wi], grid, [o])[0].copy()
+            else:
+                single[fi, wi] = eng.trace_pupil_grid(wl.fields[fi], grid, wi, o, nan_fill=True).to_host()
+    for rep in range(2):
+        if mode == abi.OUT_HITS_COMPACT:
+            got = eng.trace_pupil_grids_hits(flds, wis, grid, opts)
+            for p, g in zip(pairs, got):
+                assert np.array_equal(g, single[p]), (n_items, p, rep)
+            # ... a small batch in between (the other path on the same stream context)
+            other = eng.trace_pupil_grids_hits(flds[:3], wis[:3], grid, opts[:3])
+            for p, g in zip(pairs[:3], other):
+                assert np.array_equal(g, single[p])
+        else:
+            res = eng.trace_pupil_grids(flds, wis, grid, opts, nan_fill=True)
+            for p, r in zip(pairs, res):
+                dev = r.to_host()
+                np.testing.assert_array_equal(dev.status, single[p].status)
+                H.bit_equal(dev.seg, single[p].seg, f'{n_items} items, item {p}, pass {rep}')
+                H.bit_equal(dev.op, single[p].op, 'op')
+    eng.close()
