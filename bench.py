@@ -311,6 +311,23 @@ def main():
         xy = rox_trace.trace_grid_spot(model, grid_rng, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
         spot_ms.append((time.perf_counter() - t1) * 1e3)
     n_through = int(xy.shape[0])
+    # ... and behind the opt-in tolerance-mode kernels (session.set_tolerance_mode: ROX_FAST_FP64 on
+    # every reduced-output launch of the drop-ins; <= 1e-10 from the reference, not its bits)
+    from rayoptics_amd import session as rox_session
+    spot_tol_ms, n_through_tol = [], None
+    rox_session.set_tolerance_mode(True)
+    try:
+        for _ in range(20):
+            xy_t = rox_trace.trace_grid_spot(model, grid_rng, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
+        for _ in range(41):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            xy_t = rox_trace.trace_grid_spot(model, grid_rng, mfld, wvl_nm, wl.foc, wl.image_pts[fi])
+            spot_tol_ms.append((time.perf_counter() - t1) * 1e3)
+        n_through_tol = int(xy_t.shape[0])
+        spot_tol_dev = (float(np.max(np.abs(xy_t - xy))) if xy_t.shape == xy.shape else None)
+    finally:
+        rox_session.set_tolerance_mode(False)
     # what an interactive caller meets: the same call after the GPU has idled for a second (the
     # clocks have dropped), at the 1M-ray grid and at the 64 x 64 grid figures default to
     cold_spot = {}
@@ -406,6 +423,12 @@ def main():
             'spot_diagram': {'wallclock_ms': float(np.median(spot_ms)),
                              'wallclock_min_ms': float(np.min(spot_ms)), 'rays': R,
                              'rays_through': n_through, 'kernel_hits_ms': hits_kern_ms,
+                             'tolerance_mode': {'wallclock_ms': float(np.median(spot_tol_ms)),
+                                                'wallclock_min_ms': float(np.min(spot_tol_ms)),
+                                                'rays_through': n_through_tol,
+                                                'max_abs_deviation_from_exact': spot_tol_dev,
+                                                'what': 'the same call after session.set_tolerance_mode(True): '
+                                                        'opt-in, never the figure above'},
                              'pcie_floor_ms': n_through * 16 / 54.7e9 * 1e3,
                              'after_idle': cold_spot,
                              'what': 'rayoptics_amd.trace.trace_grid_spot(model, grid_rng, fld, wvl, '
