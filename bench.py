@@ -129,6 +129,7 @@ def self_launch(args):
 
 def main():
     global SPOT_FLAGS
+    t_process = time.perf_counter()
     args = parse()
     if args.ref_worker:                 # a process of cpu_reference_fanned(): no torch, no GPU
         return ref_worker(args.ref_worker)
@@ -438,6 +439,7 @@ def main():
                                      'is the floor)'},
             'configs': configs,
             'configs_batch_items_uploaded_every_pass': os.environ.get('ROX_BATCH_ALWAYS_UPLOAD') == '1',
+            'configs_batch_items_in_kernel_argument_up_to': 16,
             'psf': psf,
             'cpu_baseline': None,
             'strong_scaling': None,
@@ -454,6 +456,9 @@ def main():
         if rank != 0 or emitted.is_set():
             return
         emitted.set()
+        # (this process, from its start to the line: imports, build check, every leg -- what a
+        # driver's clock around the command sees, less the interpreter's own start-up)
+        line['bench_wall_s'] = round(time.perf_counter() - t_process, 2)
         sys.stdout.flush()
         if saved_stdout is not None:
             os.dup2(saved_stdout, 1)
