@@ -751,6 +751,9 @@ def configs_leg(torch, abi, workloads):
         for mode, label in ((abi.OUT_HITS, 'hits'), (abi.OUT_HITS, 'hits_fast'), (abi.OUT_FULL, 'full')):
             if mode == abi.OUT_FULL and not do_full:
                 continue
+            # (hits_fast: the opt-in tolerance-mode kernels, ROX_FAST_FP64 -- never a headline figure.
+            # FULL launches of these configurations keep the exact kernels under the flag too: none
+            # of them is made mostly of aspheres, roxtrace.hip use_fast())
             fast = abi.FAST_FP64 if label == 'hits_fast' else 0
             # every grid of the configuration has its own output buffers (a pass leaves the
             # whole configuration's result in HBM)

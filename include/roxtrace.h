@@ -156,10 +156,14 @@ enum { ROX_CHECK_APERTURES = 1u,     /* raytrace.py:198-202                    *
  * reciprocal-square-root seeds with Newton-Raphson refinement, fused multiply-adds and Horner
  * series instead of NumPy's operation order (csrc/rox_device.hpp, "tolerance mode"; observed
  * deviation <= 1e-12).  A ray whose miss / total-internal-reflection radicand or aperture margin
- * lies within rounding of zero may be classified the other way.  ROX_OUT_FULL ignores the flag
- * (FULL packets are bound by their stores and stay bit-exact), as do the search entries
- * (rox_aim_chief_rays, rox_find_real_enp, rox_calc_vignetting, rox_iterate_*).  In a
- * rox_trace_pupil_grids call every item must carry the same setting.             */
+ * lies within rounding of zero may be classified the other way.  The flag is a permission: the
+ * library takes it where it buys time and answers bit-exactly (which is within any tolerance)
+ * elsewhere -- ROX_OUT_FULL packets come from the tolerance-mode kernels only for systems
+ * made mostly of aspheres, whose FULL launches are bound by arithmetic too (every segment
+ * within the same bar, partial records of failed rays included); FULL launches of other
+ * systems (bound by their stores), FULL with ROX_FILTER_PHANTOMS and the search entries
+ * (rox_aim_chief_rays, rox_find_real_enp, rox_calc_vignetting, rox_iterate_*) stay
+ * bit-exact.  In a rox_trace_pupil_grids call every item must carry the same setting.   */
 #define ROX_FAST_FP64 64u
 /* rox_surface.rt_order: NumPy hands `rt.dot(v)` to OpenBLAS dgemv, whose FMA
  * chain runs over the columns in a different order for an F-ordered rt (the

@@ -167,7 +167,7 @@ constexpr int min_waves_of(int out_mode, int feat, bool small = false)
 {
     // (the small-workgroup kernels serve launches that fit the chip once: latency, where the
     // scratch of the tighter budget costs -- configs[3] HITS 18 -> 20 us -- instead of paying)
-    return (feat & kFeatFast) ? ROX_MIN_WAVES_FAST
+    return ((feat & kFeatFast) && out_mode != ROX_OUT_FULL) ? ROX_MIN_WAVES_FAST
          : (feat == 8 /* F_APLIST */ && out_mode == ROX_OUT_HITS && !small) ? ROX_MIN_WAVES_APLIST_REDUCED
          : (out_mode == ROX_OUT_FULL && (feat & kFeatNewton)) ? ROX_MIN_WAVES_FULL_POLY
          : (out_mode == ROX_OUT_HITS_COMPACT && !(feat & ~8)) ? ROX_MIN_WAVES_COMPACT_LEAN
@@ -1863,10 +1863,17 @@ __device__ __forceinline__ void trace_ray_reduced(const CTX &c, const v3 &pt0, c
 // arithmetic of the section "tolerance mode" above.  c.mu / c.mu2 = n_in / n_out and its square
 // per interface, staged by the workgroup.
 template <int OUT_MODE, bool PER_RAY_WVL, int FEAT, class CTX>
-__device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, const v3 &dir0, int wi,
-                                               bool live, RayEnd &e)
+__device__ __forceinline__ void trace_ray_fast(const CTX &c, const SegOut &so, const v3 &pt0,
+                                               const v3 &dir0, int wi, bool live, RayEnd &e)
 {
-    static_assert(OUT_MODE != ROX_OUT_FULL && OUT_MODE != MODE_PROBE, "reduced-output modes only");
+    static_assert(OUT_MODE != MODE_PROBE, "the searches keep the exact arithmetic");
+    // FULL packets (round 6): the segment stores of trace_ray() -- [p, d, dst, normal] per
+    // interface, the distance of a segment known only at the next intersection, the partial
+    // record [inc_pt, before_dir, 0.0, normal] where a ray is blocked or totally reflected -- in
+    // this loop.  Without phantom filtering (the host sends ROX_FILTER_PHANTOMS launches to the
+    // exact kernels): segment k is interface k.  The workgroup's waves meet at a barrier before
+    // every interface as in trace_ray(), so every wave runs every iteration.
+    constexpr bool kFull = OUT_MODE == ROX_OUT_FULL;
     constexpr int O_CV = offsetof(rox_surface, cv) / 8, O_CC = offsetof(rox_surface, cc) / 8,
                   O_EC = offsetof(rox_surface, ec) / 8, O_CR = offsetof(rox_surface, cR) / 8,
                   O_COEF = offsetof(rox_surface, coefs) / 8,
@@ -1874,6 +1881,7 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
                   O_ZDIR = offsetof(rox_surface, z_dir) / 8,
                   O_PH = offsetof(rox_surface, ph) / 8;
     constexpr bool kPoly = (FEAT & F_POLY) != 0;
+    constexpr bool kSync = kFull && (kPoly ? ROX_WG_SYNC_POLY : ROX_WG_SYNC);
     const int N = c.N;
     const auto tbl = c.tbl;
     tblp nwl = PER_RAY_WVL ? c.ntab + (size_t)wi * N : c.ntab;
@@ -1891,10 +1899,11 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
     double pp_dst1 = 0.0;
     if (live) {
         const auto row = tbl;
-        if (c.intersect_obj) {                  // raytrace.py:145-158 (the normal is not needed)
+        v3 bn{0., 0., 1.};
+        if (c.intersect_obj) {                  // raytrace.py:145-158 (the normal: FULL packets only)
             const int prof = ints_of(row)[1];
             double s_;
-            v3 df;
+            v3 df{0., 0., 1.};
             bool ok;
             if ((FEAT & F_PHASE) && prof == ROX_THINLENS) {
                 s_ = -pt0.z / dir0.z;
@@ -1903,6 +1912,10 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
             } else if (!kPoly || prof <= ROX_CONIC) {
                 ok = quadric_hit(prof == ROX_CONIC, row[O_CV], row[O_CC], row[O_EC], pt0, dir0,
                                  row[O_ZDIR], s_, bp);
+                if (kFull) {
+                    const double k = (prof == ROX_CONIC) ? (row[O_CC] + 1.0) * row[O_CV] : row[O_CV];
+                    df = v3{row[O_CR] * bp.x, row[O_CR] * bp.y, 1.0 - k * bp.z};
+                }
             } else {
                 // (an aspheric OBJECT surface -- never at infinity -- takes the tolerance-mode
                 // iteration: the exact one would set the register budget of the whole kernel)
@@ -1912,8 +1925,12 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
             if (!ok) {
                 status = ROX_MISSED_SURFACE;
                 fail_surf = 0;
+            } else if (kFull && !((FEAT & F_PHASE) && prof == ROX_THINLENS)) {
+                bn = unit_f(df);
             }
         }
+        if (kFull && status == ROX_OK)
+            so.pdn(0, bp, bd, bn);
         const v3 dp{bp.x - row[O_T], bp.y - row[O_T + 1], bp.z - row[O_T + 2]};
         const v3 b4p = rotate(row + O_RT, ints_of(row)[4], dp);
         b4d1 = rotate(row + O_RT, ints_of(row)[4], bd);
@@ -1941,6 +1958,7 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
         const int mode = ints_of(row)[0], prof = ints_of(row)[1];
         const double cv = row[O_CV];
         const bool thin = (FEAT & F_PHASE) && prof == ROX_THINLENS;
+        const v3 bd0 = ad;          // before_dir in the previous frame (FULL: a partial record stores it)
 
         // :181-183 intersect
         double s;
@@ -1966,6 +1984,10 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
                 opl = hit ? opl_new : opl;
             }
         }
+        // :185-191 the previous segment is completed only now (:231-237: up to the closest
+        // approach where the surface was missed)
+        if (kFull)
+            so.dst(surf - 1, hit ? pp_dst + s : pp_dst);
 
         // :196 normal = normalize(df(inc_pt)); a sphere's gradient has unit length on the sphere
         if (thin) {
@@ -2018,8 +2040,14 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
         if (st != ROX_OK) {
             status = st;
             fail_surf = surf;
+            if (kFull && hit) {         // :239-257 partial record: [inc_pt, before_dir, 0.0, normal]
+                so.pdn(surf, inc, bd0, nrm);
+                so.dst(surf, 0.0);
+            }
             return false;
         }
+        if (kFull)
+            so.pdn(surf, inc, ad, nrm);
         if (OUT_MODE == ROX_OUT_OPD || OUT_MODE == ROX_OUT_FAN) {
             if (surf == 1)
                 e.ray1_p = inc;
@@ -2032,7 +2060,30 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
         return true;
     };
 
-    if (status == ROX_OK && N > 1 && interface(1, pp1, b4d1, pp_dst1)) {
+    if constexpr (kSync) {
+        // every wave of the workgroup reaches every barrier; lanes whose ray has ended idle
+        bool alive = false;
+        if (N > 1) {
+            __builtin_amdgcn_s_barrier();
+            if (status == ROX_OK)
+                alive = interface(1, pp1, b4d1, pp_dst1);
+        }
+        for (int surf = 2; surf < N; ++surf) {
+            __builtin_amdgcn_s_barrier();
+            if (!alive)
+                continue;
+            const auto prow = tbl + (size_t)(surf - 1) * kRowDoubles;
+            v3 b4p{inc.x - prow[O_T], inc.y - prow[O_T + 1], inc.z - prow[O_T + 2]};
+            v3 b4d = ad;
+            if ((ints_of(prow)[5] & 2) == 0) {
+                b4p = rotate_f(prow + O_RT, b4p);
+                b4d = rotate_f(prow + O_RT, ad);
+            }
+            const double pp_dst = -dot3_f(b4p, b4d);
+            const v3 pp{fma(pp_dst, b4d.x, b4p.x), fma(pp_dst, b4d.y, b4p.y), fma(pp_dst, b4d.z, b4p.z)};
+            alive = interface(surf, pp, b4d, pp_dst);
+        }
+    } else if (status == ROX_OK && N > 1 && interface(1, pp1, b4d1, pp_dst1)) {
         for (int surf = 2; surf < N; ++surf) {
             // :170-174 transform to the new vertex frame, closest approach to its origin
             const auto prow = tbl + (size_t)(surf - 1) * kRowDoubles;
@@ -2048,6 +2099,8 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const v3 &pt0, cons
                 break;
         }
     }
+    if (kFull && status == ROX_OK)      // :259-262
+        so.dst(N - 1, 0.0);
     e.status = status;
     e.fail_surf = fail_surf;
     e.opl = opl;
@@ -2407,7 +2460,7 @@ __device__ __forceinline__ void trace_tiles(ARGS &a)
             }
         }
         if constexpr (kFast)
-            trace_ray_fast<OUT_MODE, PER_RAY_WVL, FEAT>(c, pt0, dir0, wi, active, e);
+            trace_ray_fast<OUT_MODE, PER_RAY_WVL, FEAT>(c, so, pt0, dir0, wi, active, e);
         else if constexpr (ROX_REDUCED_STRAIGHT && OUT_MODE != ROX_OUT_FULL)
             trace_ray_reduced<OUT_MODE, PER_RAY_WVL, FEAT>(c, pt0, dir0, wi, active, e);
         else
@@ -2603,10 +2656,7 @@ inline void launch_mode(const LaunchCfg &k, const TraceArgs &a)
     constexpr bool kF = (FEAT & F_FAST) != 0;
     constexpr int FR = FEAT | gtab_of(FEAT, kF, ROX_OUT_HITS), FF = FEAT | gtab_of(FEAT, kF, ROX_OUT_FULL);
     switch (k.out_mode) {
-    case ROX_OUT_FULL:
-        if constexpr (!kF)                  // (the host never sends FULL to a tolerance-mode instance)
-            launch_one<ROX_OUT_FULL, GEN, PRW, FF>(k, a);
-        break;
+    case ROX_OUT_FULL: launch_one<ROX_OUT_FULL, GEN, PRW, FF>(k, a); break;
     case ROX_OUT_LAST: launch_one<ROX_OUT_LAST, GEN, PRW, FR>(k, a); break;
     case ROX_OUT_OPD: launch_one<ROX_OUT_OPD, GEN, PRW, FR>(k, a); break;
     case ROX_OUT_HITS_COMPACT: launch_one<ROX_OUT_HITS_COMPACT, GEN, PRW, FR>(k, a); break;
@@ -2664,10 +2714,7 @@ inline void launch_instance_batch(const LaunchCfg &k, const TraceArgs *items)
     constexpr bool kF = (FEAT & F_FAST) != 0;
     constexpr int FR = FEAT | gtab_of(FEAT, kF, ROX_OUT_HITS), FF = FEAT | gtab_of(FEAT, kF, ROX_OUT_FULL);
     switch (k.out_mode) {
-    case ROX_OUT_FULL:
-        if constexpr (!kF)
-            launch_one_batch<ROX_OUT_FULL, FF>(k, items);
-        break;
+    case ROX_OUT_FULL: launch_one_batch<ROX_OUT_FULL, FF>(k, items); break;
     case ROX_OUT_LAST: launch_one_batch<ROX_OUT_LAST, FR>(k, items); break;
     case ROX_OUT_OPD: launch_one_batch<ROX_OUT_OPD, FR>(k, items); break;
     case ROX_OUT_HITS_COMPACT: launch_one_batch<ROX_OUT_HITS_COMPACT, FR>(k, items); break;

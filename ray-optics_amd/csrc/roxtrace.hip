@@ -336,16 +336,35 @@ size_t lds_bytes(const rox_system *s, bool per_ray_wvl, bool phase, bool fast, b
 }
 
 // ROX_FAST_FP64 is a permission, taken where it buys something: the reduced-output modes (bound
-// by VALU issue).  FULL packets are bound by their stores and stay bit-exact.
+// by VALU issue) always, FULL packets where the system makes them VALU-bound too (below).
 // ROX_FAST_FP64_DISABLE=1 (read once) ignores the flag everywhere: an A/B switch for callers
 // that set it by default.
-bool use_fast(const rox_opts &o)
+bool use_fast(const rox_system *sys, const rox_opts &o)
 {
     static const bool off = [] {
         const char *e = getenv("ROX_FAST_FP64_DISABLE");
         return e && *e && atoi(e) != 0;
     }();
-    return (o.flags & ROX_FAST_FP64) != 0 && o.out_mode != ROX_OUT_FULL && !off;
+    // FULL packets: the tolerance-mode kernels write them too (trace_ray_fast), and the host sends
+    // a launch there where that pays -- systems whose interfaces are mostly aspheres (the same
+    // test that picks their FULL workgroup, want_small()): there the FULL kernel is bound by the
+    // Spencer-Murty arithmetic (phone lens, 8 aspheres in 12: 265 -> 208-212 us per 2^20 rays).
+    // Everywhere else FULL is bound by its stores, which the shorter arithmetic only bunches up
+    // (double Gauss 190.9 -> 200.1, .zmx zoom 191.9 -> 197.3; Nikkor 447.7 -> 440.6, lithography
+    // lens 675.6 -> 670.2): those launches keep the exact kernels -- bit-exact is within any
+    // tolerance.  Never under ROX_FILTER_PHANTOMS (the late append of a filtered segment is not
+    // in trace_ray_fast).  ROX_FAST_FP64_FULL=0 / 1 (read once): never / wherever possible (A/B).
+    static const int full_env = [] {
+        const char *e = getenv("ROX_FAST_FP64_FULL");
+        return (e && *e) ? (atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    if (!(o.flags & ROX_FAST_FP64) || off)
+        return false;
+    if (o.out_mode != ROX_OUT_FULL)
+        return true;
+    if ((o.flags & ROX_FILTER_PHANTOMS) || full_env == 0)
+        return false;
+    return full_env == 1 || sys->n_newton * 4 > sys->n_ifcs - 1;
 }
 
 int check_opts(const rox_system *sys, const rox_opts *o, const rox_out *out, int64_t n_rays)
@@ -708,7 +727,7 @@ int launch_setup(rox_system *sys, TraceArgs &a, int gen, bool prw, hipStream_t s
     k.per_ray_wvl = prw;
     k.small = false;
     k.n_inline = 0;
-    k.fast = use_fast(a.opts);
+    k.fast = use_fast(sys, a.opts);
     k.out_mode = a.opts.out_mode;
     k.stream = st;
     inst = pick_instance(need);

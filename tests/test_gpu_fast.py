@@ -11,7 +11,9 @@ asserted directly:
     TIR limit / miss boundary it was decided at (helpers.boundary_margin, computed from the
     ORACLE's FULL packet of that ray); rays laid within a few ulp of aperture edges and of the
     critical angle make sure the accounting is exercised;
-  * ROX_OUT_FULL ignores the flag (bit-exact), a batch must agree on it."""
+  * ROX_OUT_FULL packets in tolerance mode: every segment of every ray, partial records
+    included, within the same bar; under ROX_FILTER_PHANTOMS they stay bit-exact; a batch must
+    agree on the flag."""
 import numpy as np
 import pytest
 
@@ -192,19 +194,111 @@ def test_fast_opd_and_fan(name, case):
     H.record('fast_opd_fan_vs_oracle', fixture=name, case=case, worst_scaled_error=worst)
 
 
-def test_full_packets_ignore_the_flag_and_batches_must_agree():
+def check_full_packets(tbl, wi, opts, ref, got, what):
+    """FULL packets in tolerance mode against the exact ones: every ray both paths end alike --
+    through, or stopped at the same interface for the same reason -- has the same segments written
+    (the NaN pattern of a NaN-filled buffer) and every value of them within TOL, the partial
+    record of a blocked / reflected ray included; flips are accounted for as check_flips does"""
+    def full_of(r):
+        return ref.seg[:, :, r]
+    flips, err = check_flips(tbl, wi, opts, ref, got, full_of, what)
+    same = (ref.status == got.status) & (ref.fail_surf == got.fail_surf)
+    if same.any():
+        err = max(err, H.scaled_err(ref.seg[..., same], got.seg[..., same]))
+        if ref.pupil is not None and got.pupil is not None:
+            H.bit_equal(ref.pupil, got.pupil, what + ' pupil')
+    assert err <= TOL, f'{what}: scaled error {err:.3e} (partial packets included)'
+    return flips, err
+
+
+@pytest.mark.parametrize('name', WORKLOADS)
+def test_full_packets_in_tolerance_mode_against_the_oracle(name):
+    """ROX_OUT_FULL with ROX_FAST_FP64: 48 x 48 grids of every field (first and last wavelength),
+    apertures checked -- so that blocked rays leave their partial records -- against the oracle's
+    packets; the single launch and the batched one give the same bits"""
     from oracle import oracle
     from rayoptics_amd import workloads
-    from rayoptics_amd.engine import TraceEngine, make_grid, EngineError
-    wl = workloads.load('dblgauss_c2')
+    from rayoptics_amd.engine import TraceEngine, make_grid
+    wl = workloads.load(name)
     eng = TraceEngine(wl.table)
+    num = 48
+    grid = make_grid((-1., -1.), (1., 1.), num)
+    W = len(wl.table.wvls)
+    worst, flips, n_ok, n_part = 0.0, 0, 0, 0
+    pairs = [(fi, wi) for fi in range(len(wl.fields)) for wi in sorted({0, W - 1})]
+    ol = [_opts(wl, fi, abi.OUT_FULL, True) for fi, _ in pairs]
+    batch = eng.trace_pupil_grids([wl.fields[fi] for fi, _ in pairs], [wi for _, wi in pairs], grid, ol,
+                                  nan_fill=True)
+    for (fi, wi), o, rb in zip(pairs, ol, batch):
+        orc = oracle.trace_pupil_grid(wl.table, wl.fields[fi], grid, wi, o)
+        dev = eng.trace_pupil_grid(wl.fields[fi], grid, wi, o, nan_fill=True).to_host()
+        f, e = check_full_packets(wl.table, wi, o, orc, dev, f'{name} f{fi} w{wi} FULL')
+        flips += f
+        worst = max(worst, e)
+        n_ok += int((orc.status == abi.OK).sum())
+        n_part += int(((orc.status == abi.BLOCKED) | (orc.status == abi.TIR)).sum())
+        b = rb.to_host()
+        np.testing.assert_array_equal(dev.status, b.status)
+        H.bit_equal(dev.seg, b.seg, f'{name} f{fi} w{wi}: batched vs single, tolerance-mode FULL')
+    eng.close()
+    assert n_ok > 300
+    H.record('fast_full_vs_oracle', workload=name, grid=num, worst_scaled_error=worst, status_flips=flips,
+             rays_through=n_ok, partial_records=n_part)
+
+
+def test_full_tolerance_kernels_on_every_workload():
+    """The host sends a FULL launch to the tolerance-mode kernels only for systems made mostly of
+    aspheres (roxtrace.hip use_fast(); of the workloads above: the phone lens) -- elsewhere they
+    are slower than the store-bound exact kernels.  ROX_FAST_FP64_FULL=1 (read once by the
+    library: a subprocess) sends every FULL launch with the flag there: the test above, on every
+    workload, against the same bar; and the phone lens indeed runs on them by default (its
+    packets differ from the exact ones in the last bits; the double Gauss's do not)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ROX_FAST_FP64_FULL='1')
+    p = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        'tests/test_gpu_fast.py', '-k', 'full_packets_in_tolerance_mode'],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
+    assert f'{len(WORKLOADS)} passed' in p.stdout, p.stdout[-500:]
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_grid
+    grid = make_grid((-1., -1.), (1., 1.), 40)
+    differs = {}
+    for name in ('cell_phone', 'dblgauss_c2'):
+        wl = workloads.load(name)
+        eng = TraceEngine(wl.table)
+        a = eng.trace_pupil_grid(wl.fields[0], grid, 0, _opts(wl, 0, abi.OUT_FULL, True), nan_fill=True).to_host()
+        b = eng.trace_pupil_grid(wl.fields[0], grid, 0, _opts(wl, 0, abi.OUT_FULL, False), nan_fill=True).to_host()
+        differs[name] = not np.array_equal(a.seg, b.seg, equal_nan=True)
+        assert H.scaled_err(b.seg[..., b.status == abi.OK], a.seg[..., b.status == abi.OK]) <= TOL
+        eng.close()
+    assert differs == {'cell_phone': True, 'dblgauss_c2': False}
+
+
+def test_full_packets_under_phantom_filtering_stay_exact_and_batches_must_agree():
+    """ROX_FILTER_PHANTOMS + ROX_OUT_FULL keeps the exact kernels whatever ROX_FAST_FP64 says (the
+    late append of a filtered segment, raytrace.py:185-191, is not in trace_ray_fast); a batch must
+    agree on the flag"""
+    from oracle import oracle
+    from rayoptics_amd import workloads
+    from rayoptics_amd.engine import TraceEngine, make_grid, EngineError, make_opts
     grid = make_grid((-1., -1.), (1., 1.), 96)
-    o = _opts(wl, 1, abi.OUT_FULL, True)
+    # (the phone lens: the system whose FULL launches the flag would otherwise move)
+    wl = workloads.load('cell_phone')
+    eng = TraceEngine(wl.table)
+    o = make_opts(flags=_flags(wl, 1) | abi.FAST_FP64 | abi.FILTER_PHANTOMS, out_mode=abi.OUT_FULL,
+                  first_surf=1, last_surf=wl.n_ifcs - 2, foc=wl.foc, image_pt=wl.image_pts[1])
     dev = eng.trace_pupil_grid(wl.fields[1], grid, 1, o, nan_fill=True).to_host()
     orc = oracle.trace_pupil_grid(wl.table, wl.fields[1], grid, 1, o)
     np.testing.assert_array_equal(dev.status, orc.status)
-    H.bit_equal(dev.seg, orc.seg, 'FULL with ROX_FAST_FP64')
+    H.bit_equal(dev.seg, orc.seg, 'FULL with ROX_FAST_FP64 | ROX_FILTER_PHANTOMS')
     H.bit_equal(dev.op, orc.op, 'op')
+    eng.close()
+    wl = workloads.load('dblgauss_c2')
+    eng = TraceEngine(wl.table)
     with pytest.raises(EngineError, match='ROX_FAST_FP64'):
         eng.trace_pupil_grids([wl.fields[0], wl.fields[1]], [0, 0], grid,
                               [_opts(wl, 0, abi.OUT_HITS, True), _opts(wl, 1, abi.OUT_HITS, False)])

@@ -5,6 +5,11 @@ rays incl. steep, backward and degenerate ones, objects 20 ... 1e10 away): LAST 
 tolerance mode against the oracle.
 
     python tools/fast_soak.py [first_seed] [count]
+    ROX_FAST_FP64_FULL=1 python tools/fast_soak.py [first_seed] [count] full     (FULL packets too)
+
+`full`: ROX_OUT_FULL as a third mode -- every segment of every ray, partial records of failed rays
+included.  The library sends FULL launches to the tolerance-mode kernels only for systems made
+mostly of aspheres; ROX_FAST_FP64_FULL=1 (read once by the library) sends all of them there.
 
 A ray DEVIATES when its status / failing surface differs from the oracle's, or a value differs by
 more than 1e-10 * max(1, magnitude of the vector it belongs to).  Random prescriptions traced by
@@ -64,6 +69,8 @@ def main():
     import test_gpu_fuzz as t
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+    with_full = len(sys.argv) > 3 and sys.argv[3] == 'full'
+    modes = (abi.OUT_LAST, abi.OUT_HITS) + ((abi.OUT_FULL,) if with_full else ())
     t0 = time.time()
     tot = dict(systems=0, rays=0, agree=0, deviating=0, deviating_status=0, deviating_value=0,
                ill_conditioned=0, wandering_iteration=0, unexplained_deviations=0, worst_agreeing=0.0)
@@ -83,7 +90,7 @@ def main():
         W = len(tbl.wvls)
         wi = rng.integers(0, W, R).astype(np.int32) if seed % 2 else int(rng.integers(0, W))
         eng = TraceEngine(tbl)
-        for mode in (abi.OUT_LAST, abi.OUT_HITS):
+        for mode in modes:
             flags = (abi.INTERSECT_OBJ if seed % 5 else 0) | (abi.CHECK_APERTURES if seed % 3 else 0)
             kw = dict(out_mode=mode, first_surf=int(seed % 2), last_surf=(N - 2) if seed % 7 else -1,
                       foc=0.01 * (seed % 50), image_pt=(0.1, -0.2))
@@ -95,7 +102,16 @@ def main():
             same = (orc.status == dev.status) & (orc.fail_surf == dev.fail_surf)
             ok = same & (orc.status == abi.OK)
             err = np.zeros(R)
-            if ok.any():
+            if mode == abi.OUT_FULL:
+                # every ray both end alike: the segments written (same NaN pattern), value by value
+                ns = orc.seg.shape[0]
+                g_full = tuple(slice(10 * k + a0, 10 * k + a1) for k in range(ns)
+                               for a0, a1 in ((0, 3), (3, 6), (6, 7), (7, 10)))
+                if same.any():
+                    err[same] = scaled(orc.seg.reshape(ns * 10, -1)[:, same],
+                                       dev.seg.reshape(ns * 10, -1)[:, same], g_full).max(axis=0)
+                    err[ok] = np.maximum(err[ok], scaled(orc.op[ok], dev.op[ok]))
+            elif ok.any():
                 err[ok] = scaled(orc.seg[:, ok], dev.seg[:, ok], GROUPS[int(mode)]).max(axis=0)
                 err[ok] = np.maximum(err[ok], scaled(orc.op[ok], dev.op[ok]))
             dev_mask = ~same | (err > TOL)
@@ -133,10 +149,11 @@ def main():
                 moved = np.maximum(moved, scaled(base.op, pert.op))
                 ill |= (pert.status != base.status) | (pert.fail_surf != base.fail_surf) | (moved > TOL / 16)
                 # ... and what the output mode makes of it (HITS: inc + (foc / ad.z) ad)
-                with np.errstate(all='ignore'):
-                    pm = oracle.trace_rays(tbl, p2, d2, w_b, o_ref)
-                mm = scaled(orc.seg[:, bad], pm.seg, GROUPS[int(mode)]).max(axis=0)
-                ill |= (orc.status[bad] == abi.OK) & (pm.status == abi.OK) & (mm > TOL / 16)
+                if mode != abi.OUT_FULL:
+                    with np.errstate(all='ignore'):
+                        pm = oracle.trace_rays(tbl, p2, d2, w_b, o_ref)
+                    mm = scaled(orc.seg[:, bad], pm.seg, GROUPS[int(mode)]).max(axis=0)
+                    ill |= (orc.status[bad] == abi.OK) & (pm.status == abi.OK) & (mm > TOL / 16)
             tot['ill_conditioned'] += int(ill.sum())
             for j in np.flatnonzero(~ill):
                 # the reference's own Spencer-Murty step counts along this ray
@@ -162,7 +179,8 @@ def main():
                                    'newton_steps': [int(x) for x in steps[:8]]})
         eng.close()
         tot['systems'] += 1
-    tot.update(first_seed=first, modes=2, seconds=round(time.time() - t0, 1), tolerance=TOL,
+    tot.update(first_seed=first, modes=len(modes), full_packets=with_full,
+               full_tolerance_kernels_forced=os.environ.get('ROX_FAST_FP64_FULL') == '1', seconds=round(time.time() - t0, 1), tolerance=TOL,
                unexplained_deviations_listed=listed)
     print(json.dumps(tot))
 

@@ -7,6 +7,7 @@ O=gpurun_out/r06soak
 mkdir -p $O
 timeout 1500 python tools/fuzz_soak.py 700000 30000 > $O/fuzz_soak.json 2> $O/fuzz_soak.err; echo "fuzz rc=$?"
 timeout 1500 python tools/fast_soak.py 800000 8000 > $O/fast_soak.json 2> $O/fast_soak.err; echo "fast rc=$?"
+ROX_FAST_FP64_FULL=1 timeout 1500 python tools/fast_soak.py 1700000 4000 full > $O/fast_soak_full_packets.json 2> $O/fast_soak_full.err; echo "fast full rc=$?"
 timeout 900 python tools/phase_soak.py 200 > $O/phase_soak.json 2> $O/phase_soak.err; echo "phase rc=$?"
 timeout 900 python tools/opd_soak.py 60 > $O/opd_soak.json 2> $O/opd_soak.err; echo "opd rc=$?"
 timeout 900 python tools/entry_soak.py > $O/entry_soak.json 2> $O/entry_soak.err; echo "entry rc=$?"

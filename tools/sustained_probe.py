@@ -3,7 +3,7 @@
 back-to-back launches over a few seconds, with clocks / power sampled from
 rocm-smi meanwhile (is the FULL kernel power-capped when launched continuously?).
 
-    [ROX_LIB=variant.so] python tools/sustained_probe.py [--mode full|hits|hits_fast] [--seconds 3]"""
+    [ROX_LIB=variant.so] python tools/sustained_probe.py [--mode full|hits|hits_fast|full_fast] [--seconds 3]"""
 import argparse
 import json
 import os
@@ -50,8 +50,8 @@ def main():
     flags = abi.INTERSECT_OBJ | abi.CHECK_APERTURES | abi.APPLY_VIGNETTING
     if fld.kind == abi.FLD_EPD_WIDE or fld.z_dir0 == 0.0:
         flags &= ~abi.INTERSECT_OBJ
-    mode = abi.OUT_FULL if args.mode == 'full' else abi.OUT_HITS
-    if args.mode == 'hits_fast':           # the tolerance-mode twin (ROX_FAST_FP64)
+    mode = abi.OUT_FULL if args.mode in ('full', 'full_fast') else abi.OUT_HITS
+    if args.mode in ('hits_fast', 'full_fast'):           # the tolerance-mode twin (ROX_FAST_FP64)
         flags |= abi.FAST_FP64
     o = make_opts(flags=flags, out_mode=mode, first_surf=1, last_surf=N - 2, foc=wl.foc,
                   image_pt=wl.image_pts[args.field])
