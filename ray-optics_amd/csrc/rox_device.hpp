@@ -102,6 +102,12 @@
 #ifndef ROX_BLOCK_FULL       // workgroup size of FULL mode: with the per-surface barrier the whole
 #define ROX_BLOCK_FULL 1024   // workgroup writes its packet rows together (sustained 256 -> 215 us,
 #endif                        // 512 -> 198 us, 1024 -> 192.5 us; without the barrier 217 us)
+#ifndef ROX_FULL_EARLY_STORES    // 1: FULL packets: a segment's point and normal are stored as soon as they
+#define ROX_FULL_EARLY_STORES 1  //    are known (after the intersection / the normalisation) instead of with the
+#endif                           //    direction at the end of the iteration: the workgroup's ten row pieces per
+                                 //    surface leave in three bursts instead of one -- the store-bound double Gauss
+                                 //    192.0 -> 188.2 us per 2^20 rays (5.24 -> 5.34 TB/s), .zmx zoom and phone lens
+                                 //    unchanged, lithography lens 669 -> 666 (gpurun_out ab_full, two rounds)
 #ifndef ROX_WG_SYNC          // 1: FULL mode: a workgroup barrier per surface keeps the waves of a
 #define ROX_WG_SYNC 1         //    workgroup on the same packet rows (218 -> 202 us)
 #endif
@@ -1532,6 +1538,12 @@ __device__ __forceinline__ void trace_ray(const CTX &c, const SegOut &so, const 
         }
         if (OUT_MODE == ROX_OUT_FULL)
             so.dst(acc_slot, acc_dst);
+        // (without phantom filtering the record of this interface -- complete or partial -- holds
+        // inc_pt and the normal in slot `surf` whatever happens next: stored as they become known)
+        constexpr bool kEarly = OUT_MODE == ROX_OUT_FULL && ROX_FULL_EARLY_STORES && !(FEAT & F_PHFILT);
+        if (kEarly) {
+            so.put(surf, 0, inc.x); so.put(surf, 1, inc.y); so.put(surf, 2, inc.z);
+        }
 
         // :193-194 (in_gap_range, :123-132)
         {
@@ -1552,6 +1564,9 @@ __device__ __forceinline__ void trace_ray(const CTX &c, const SegOut &so, const 
                 df = v3{ncv * inc.x, ncv * inc.y, 1.0 - k * inc.z};
             }
             nrm = unit(df);
+        }
+        if (kEarly) {
+            so.put(surf, 7, nrm.x); so.put(surf, 8, nrm.y); so.put(surf, 9, nrm.z);
         }
 
         // :198-202 aperture test (in_surface_range, :134-142)
@@ -1591,7 +1606,11 @@ __device__ __forceinline__ void trace_ray(const CTX &c, const SegOut &so, const 
             fail_surf = surf;
             if (OUT_MODE == ROX_OUT_FULL) {
                 const int sl = NSLOTS_BEFORE(surf);
-                so.pdn(sl, inc, bd, nrm);
+                if (kEarly) {
+                    so.put(sl, 3, bd.x); so.put(sl, 4, bd.y); so.put(sl, 5, bd.z);
+                } else {
+                    so.pdn(sl, inc, bd, nrm);
+                }
                 so.dst(sl, 0.0);
             }
             ROX_LEAVE;
@@ -1615,8 +1634,11 @@ __device__ __forceinline__ void trace_ray(const CTX &c, const SegOut &so, const 
         b4_mode = mode;
         if (OUT_MODE == ROX_OUT_FULL) {
             const bool cur_filtered = c.filter_ph && (mode == ROX_PHANTOM) && surf < N - 1;
-            if (!cur_filtered)
+            if (kEarly) {
+                so.put(surf, 3, ad.x); so.put(surf, 4, ad.y); so.put(surf, 5, ad.z);
+            } else if (!cur_filtered) {
                 so.pdn(SLOT(surf), inc, ad, nrm);
+            }
         }
     }
     if (OUT_MODE == ROX_OUT_FULL && status == ROX_OK)   // :259-262
@@ -1986,8 +2008,12 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const SegOut &so, c
         }
         // :185-191 the previous segment is completed only now (:231-237: up to the closest
         // approach where the surface was missed)
+        constexpr bool kEarly = kFull && ROX_FULL_EARLY_STORES;
         if (kFull)
             so.dst(surf - 1, hit ? pp_dst + s : pp_dst);
+        if (kEarly && hit) {
+            so.put(surf, 0, inc.x); so.put(surf, 1, inc.y); so.put(surf, 2, inc.z);
+        }
 
         // :196 normal = normalize(df(inc_pt)); a sphere's gradient has unit length on the sphere
         if (thin) {
@@ -1999,6 +2025,10 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const SegOut &so, c
                 nrm = unit_f(nrm);
         } else {
             nrm = unit_f(df);
+        }
+
+        if (kEarly && hit) {
+            so.put(surf, 7, nrm.x); so.put(surf, 8, nrm.y); so.put(surf, 9, nrm.z);
         }
 
         // :198-202 aperture test (in_surface_range, :134-142)
@@ -2041,13 +2071,20 @@ __device__ __forceinline__ void trace_ray_fast(const CTX &c, const SegOut &so, c
             status = st;
             fail_surf = surf;
             if (kFull && hit) {         // :239-257 partial record: [inc_pt, before_dir, 0.0, normal]
-                so.pdn(surf, inc, bd0, nrm);
+                if (kEarly) {
+                    so.put(surf, 3, bd0.x); so.put(surf, 4, bd0.y); so.put(surf, 5, bd0.z);
+                } else {
+                    so.pdn(surf, inc, bd0, nrm);
+                }
                 so.dst(surf, 0.0);
             }
             return false;
         }
-        if (kFull)
+        if (kEarly) {
+            so.put(surf, 3, ad.x); so.put(surf, 4, ad.y); so.put(surf, 5, ad.z);
+        } else if (kFull) {
             so.pdn(surf, inc, ad, nrm);
+        }
         if (OUT_MODE == ROX_OUT_OPD || OUT_MODE == ROX_OUT_FAN) {
             if (surf == 1)
                 e.ray1_p = inc;
