@@ -1,5 +1,5 @@
 // fast_poly.hip -- the tolerance-mode (ROX_FAST_FP64) trace kernels of feature instance
-// F_POLY (rox_device.hpp, "tolerance mode"): reduced-output modes only.  One translation unit per
+// F_POLY (rox_device.hpp, "tolerance mode"): every output mode (FULL packets: taken by the host where they pay).  One translation unit per
 // instance so that the instances compile in parallel.
 #include "rox_device.hpp"
 

@@ -2715,6 +2715,15 @@ inline void launch_instance(const LaunchCfg &k, const TraceArgs &a)
 }
 
 // the batched form (trace_kernel_batch): pupil grids, one wavelength per item
+// the host-side argument block of a batched launch: one zero-initialised 16 KB block per host
+// thread (the launch copies its argument before it returns; inl beyond n_inline is never read by
+// the kernel and keeps what an earlier launch left there)
+inline BatchArgs &batch_args_block()
+{
+    static thread_local BatchArgs b{};
+    return b;
+}
+
 template <class K>
 inline void launch_batch_with_lds(K kernel, const dim3 &grid, const dim3 &block, size_t lds,
                                   hipStream_t st, const TraceArgs *items, int n_inline)
@@ -2722,7 +2731,7 @@ inline void launch_batch_with_lds(K kernel, const dim3 &grid, const dim3 &block,
     if (lds > kDefaultDynLds)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    BatchArgs b;                        // (inl beyond n_inline is never read: left as it is)
+    BatchArgs &b = batch_args_block();
     b.items = n_inline > 0 ? nullptr : items;
     if (n_inline > 0)
         memcpy(b.inl, items, sizeof(TraceArgs) * (size_t)n_inline);
@@ -2783,7 +2792,7 @@ void launch_general_batch(const LaunchCfg &, const TraceArgs *);
 // the general instance over a table left in global memory (csrc/gtab_general.hip)
 void launch_general_gtab(const LaunchCfg &, const TraceArgs &);
 void launch_general_gtab_batch(const LaunchCfg &, const TraceArgs *);
-// ... and their tolerance-mode twins (csrc/fast_*.hip: kInstances[i] | F_FAST, reduced-output modes)
+// ... and their tolerance-mode twins (csrc/fast_*.hip: kInstances[i] | F_FAST)
 void launch_lean_fast(const LaunchCfg &, const TraceArgs &);
 void launch_even_fast(const LaunchCfg &, const TraceArgs &);
 void launch_radial_fast(const LaunchCfg &, const TraceArgs &);
