@@ -396,7 +396,8 @@ def test_decentered_roa_parsed_here_traces_like_the_oracle():
 
 
 @pytest.mark.parametrize('script,args,expect', [('spot_diagram.py', ['96'], 'rms spot radius'),
-                                                 ('wavefront_psf.py', ['32', '128'], 'Strehl')])
+                                                 ('wavefront_psf.py', ['32', '128'], 'Strehl'),
+                                                 ('spot_stats.py', ['128'], 'rms spot radius')])
 def test_examples_run(script, args, expect):
     """the stand-alone examples run as written (subprocess, from the repo root)"""
     import os
